@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixels/s of the descriptor hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json north_star): TPI at scale 2000 m (disc of 67 px on a 30 m grid) over a
+32768 x 32768 synthetic float32 DEM.  One "step" = one pass of the TPI kernel over the whole
+DEM.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the DEM is split into
+N contiguous row blocks - the total work is fixed (strong scaling) - and every step first
+refreshes the 33 ghost rows from the neighbours over RCCL, overlapped with the interior rows.
+Inputs are generated on the device and are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the TPI kernel at SURVEY.md 8(d)'s 8 B/pixel
+(4 read + 4 written) against 8 TB/s; `cpu_baseline` times the oracle's scipy restatement of
+the reference path on one host core for a bounded sample.  torch is used for rendezvous,
+barriers and the max-over-ranks only; it never touches the GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
+BYTES_PER_PIXEL = {"tpi": 8, "std": 8, "tpi_std": 12, "gradient": 20, "sx": 8, "gaussian": 8}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ny", type=int, default=32768)
+    ap.add_argument("--nx", type=int, default=32768)
+    ap.add_argument("--size", type=int, default=67, help="disc diameter in pixels (2000 m / 30 m)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-descriptor side table")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    return ap.parse_args()
+
+
+class Rendezvous:
+    """Barrier / broadcast / max over ranks.  Single process: no torch at all."""
+
+    def __init__(self, world):
+        self.world = world
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.dist = None
+        if world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=self.rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def bcast_bytes(self, payload):
+        if not self.dist:
+            return payload
+        box = [payload]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def max(self, value):
+        if not self.dist:
+            return value
+        import torch
+
+        t = torch.tensor([value], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def time_kernel(fn, reps, dev):
+    """Average HIP-event duration (ms) of `fn` over `reps` back-to-back launches."""
+    fn()
+    dev.sync()
+    dev.timer_start()
+    for _ in range(reps):
+        fn()
+    return dev.timer_stop() / reps
+
+
+def cpu_baseline(size, sample_rows, sample_cols, dem_sample):
+    from oracle import topo_oracle as orc
+
+    t0 = time.perf_counter()
+    orc.tpi_scipy(dem_sample, size)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(sample_rows * sample_cols / dt / 1e6, 3),
+        "unit": "Mpixels/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle.tpi_scipy (scipy.signal.convolve FFT path of the reference) on a "
+                  f"{sample_rows}x{sample_cols} window of the same DEM, size {size}, "
+                  f"{dt:.1f} s wall",
+    }
+
+
+def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
+    """Per-descriptor throughput on the resident DEM (N = 1 only): not the headline."""
+    from topo_descriptors_amd import device as d
+
+    out = {}
+    o1 = d.DeviceArray(ny, nx)
+    o2 = d.DeviceArray(ny, nx)
+    blk = block_cls(dem)
+    px = ny * nx
+
+    def entry(key, ms, bpp):
+        out[key] = {"ms": round(ms, 4), "Mpixels_per_s": round(px / ms / 1e3, 1),
+                    "hbm_frac": round(px * bpp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    for size in (7, 65, 67):
+        entry(f"tpi_s{size}", time_kernel(lambda: blk.tpi_std(size, tpi=o1), 3, d), 8)
+        entry(f"std_s{size}", time_kernel(lambda: blk.tpi_std(size, std=o2), 3, d), 8)
+        entry(f"tpi_std_s{size}", time_kernel(lambda: blk.tpi_std(size, tpi=o1, std=o2), 3, d), 12)
+    o3 = d.DeviceArray(ny, nx)
+    o4 = d.DeviceArray(ny, nx)
+    for sigma in (3.25, 30.25):
+        fn = lambda: blk.gradient(sigma, [30.0], [-30.0], dx=o1, dy=o2, slope=o3, aspect=o4)  # noqa: E731
+        entry(f"gradient_sigma{sigma}", time_kernel(fn, 2, d), 20)
+        fn = lambda: blk.gradient(sigma, [30.0], [-30.0], slope=o3, aspect=o4)  # noqa: E731
+        entry(f"slope_aspect_sigma{sigma}", time_kernel(fn, 2, d), 12)
+    for radius in (500.0, 2000.0):
+        window, dj, di, dist = d.sx_offsets(0.0, radius, 30.0, -30.0)
+        fn = lambda: blk.sx(dj, di, dist, window, 10.0, o1)  # noqa: E731
+        entry(f"sx_az0_r{int(radius)}", time_kernel(fn, 3, d), 8)
+    for a in (o1, o2, o3, o4):
+        a.free()
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run "
+                     "(one rank per GPU)")
+        args.gpus = world
+    rdv = Rendezvous(world)
+    rank = rdv.rank
+    os.environ.setdefault("TOPO_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+
+    import ctypes
+
+    from topo_descriptors_amd import _lib, device as d
+
+    lib = _lib.lib()  # binds this process to its GPU; raises when the HIP library is missing
+    ny, nx, size = args.ny, args.nx, args.size
+
+    # ---- row shard of this rank ---------------------------------------------------------------
+    base, extra = divmod(ny, world)
+    rows_local = base + (1 if rank < extra else 0)
+    row0 = rank * base + min(rank, extra)
+    up, down = ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(lib.topo_amd_halo_rows(_lib.DESC_TPI, float(size), 0.0, ctypes.byref(up),
+                                      ctypes.byref(down)), "halo_rows")
+    halo_up, halo_dn = (up.value, down.value) if world > 1 else (0, 0)
+    if world > 1:
+        uid = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        if rank == 0:
+            _lib.check(lib.topo_amd_comm_unique_id(uid), "comm_unique_id")
+        payload = rdv.bcast_bytes(uid.raw)
+        _lib.check(lib.topo_amd_comm_init(rank, world, payload), "comm_init")
+
+    block = d.DeviceArray(halo_up + rows_local + halo_dn, nx)
+    d.synth_dem(rows_local, nx, row0=row0, seed=0, out=block, out_row=halo_up)
+    out = d.DeviceArray(rows_local, nx)
+    d.sync()
+
+    if world == 1:
+        blk = d.Block(block)
+
+        def step():
+            blk.tpi_std(size, tpi=out)
+    else:
+        def step():
+            _lib.check(lib.topo_amd_shard_tpi_std(block.ptr, rows_local, row0, ny, nx, size, out.ptr,
+                                                  None), "shard_tpi_std")
+
+    for _ in range(args.warmup):
+        step()
+    d.sync()
+    rdv.barrier()
+    d.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    event_ms = d.timer_stop()  # HIP events on the compute stream around the K launches
+    d.sync()
+    rdv.barrier()
+    wall = time.perf_counter() - t0
+    wall = rdv.max(wall)
+    kernel_ms = rdv.max(event_ms / args.steps)
+
+    px_total = ny * nx
+    value = px_total * args.steps / wall / 1e6
+    result = None
+    if rank == 0:
+        px_launch = rows_local * nx  # what one rank's launch covers
+        achieved = px_launch * BYTES_PER_PIXEL["tpi"] / (kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "Mpixels/s (and % HBM roofline) per descriptor, 1/2/4/8 MI355X",
+            "value": round(value, 1),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"topo.tpi size={size}px (2000 m @ 30 m) on a {ny}x{nx} f32 DEM, "
+                            f"row-sharded over {world} GPU(s)",
+                "descriptor": "tpi", "disc_px": size, "dem": [ny, nx],
+                "rows_per_gpu": rows_local, "halo_rows": [halo_up, halo_dn],
+                "parallelism": f"rows{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "disc TPI kernel, per-rank launch",
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL["tpi"],
+            },
+        }
+        if not args.no_cpu and world == 1:
+            rows_s = min(ny, 8192)
+            cols_s = min(nx, 8192)
+            sample = block.to_host(halo_up, rows_s)[:, :cols_s].copy()
+            result["cpu_baseline"] = cpu_baseline(size, rows_s, cols_s, sample)
+            # spot parity at full size: TPI of the same window vs the oracle, interior only
+            got = out.to_host(0, rows_s)[:, :cols_s]
+            from oracle import topo_oracle as orc
+
+            r = size
+            want = orc.tpi_scipy(sample, size)
+            result["parity_spot"] = {
+                "max_abs_err_m": float(np.max(np.abs(got[: rows_s - r, : cols_s - r] -
+                                                      want[: rows_s - r, : cols_s - r]))),
+                "window": [rows_s - r, cols_s - r],
+            }
+        if not args.no_extras and world == 1:
+            result["descriptors"] = extras(d, _lib, args, d.Block, block, ny, nx)
+    out.free()
+    block.free()
+    if world > 1:
+        _lib.check(lib.topo_amd_comm_destroy(), "comm_destroy")
+    rdv.close()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+/*
+ * topo_amd.h - C ABI of libtopo_amd.so, the MI355X (gfx950) implementation of the
+ * per-pixel descriptor hot path of MeteoSwiss/topo-descriptors.
+ *
+ * The reference has no FFI of its own (it is pure Python on scipy/numba wheels); the
+ * boundary this library replaces is the set of Python call sites listed next to each
+ * entry point (file:line into the reference).  INTEGRATION.md shows the ctypes stub a
+ * maintainer adds to `topo_descriptors/topo.py` to route those calls here.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative TOPO_AMD_E* code otherwise; the
+ *     message is available from topo_amd_last_error() (thread-local).
+ *   - arrays are C-contiguous float32, ny rows x nx columns, row pitch == nx.
+ *   - *_f32 entry points take HOST pointers, do upload -> kernels -> download and return
+ *     when the result is in the caller's buffer.  Nothing is retained after return.
+ *   - *_dev entry points take DEVICE pointers obtained from topo_amd_malloc, enqueue on the
+ *     library's compute stream and return immediately; call topo_amd_sync() before reading.
+ *   - row-block form: a device block holds `in_rows` consecutive rows of a global
+ *     `gny x nx` DEM starting at global row `in_row0`.  Output rows are
+ *     [out_row0, out_row0+out_rows) in global numbering and `out` points at the first of
+ *     them.  The boundary rule of each descriptor (zero padding, reflection, one-sided
+ *     difference, zero frame) is applied at the GLOBAL edges only, so that a row shard
+ *     plus its ghost rows gives results bit-identical to the single-block run.  The block
+ *     must contain every row the requested output rows depend on (see topo_amd_halo_rows).
+ *   - one process drives one GPU (topo_amd_init(device)); entry points are serialised on
+ *     that device's compute stream.
+ */
+#ifndef TOPO_AMD_H
+#define TOPO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOPO_AMD_OK 0
+#define TOPO_AMD_EINVAL (-1)   /* bad argument                                   */
+#define TOPO_AMD_EHIP (-2)     /* a HIP runtime call failed                      */
+#define TOPO_AMD_ENODEV (-3)   /* no usable GPU / library not initialised        */
+#define TOPO_AMD_ERCCL (-4)    /* an RCCL call failed                            */
+#define TOPO_AMD_EUNSUP (-5)   /* valid request the kernels do not cover (yet)   */
+
+/* descriptor ids for topo_amd_halo_rows */
+#define TOPO_AMD_DESC_TPI 0
+#define TOPO_AMD_DESC_STD 1
+#define TOPO_AMD_DESC_GAUSS 2
+#define TOPO_AMD_DESC_GRADIENT 3
+#define TOPO_AMD_DESC_SOBEL 4
+#define TOPO_AMD_DESC_SX 5
+
+/* resolution layout for the gradient normalisation (reference topo.py:688-712) */
+#define TOPO_AMD_RES_SCALAR 0 /* res_x[0], res_y[0]                                   */
+#define TOPO_AMD_RES_1D 1     /* res_x[nx] per column, res_y[gny] per GLOBAL row      */
+#define TOPO_AMD_RES_2D 2     /* res_x, res_y: [out_rows x nx] aligned with `out`     */
+
+/* ---- runtime ------------------------------------------------------------------------ */
+const char* topo_amd_version(void);
+const char* topo_amd_last_error(void);
+int topo_amd_device_count(void);
+int topo_amd_init(int device);            /* idempotent for the same device           */
+int topo_amd_shutdown(void);
+int topo_amd_device_name(char* buf, int buflen);
+
+int topo_amd_malloc(void** dptr, size_t bytes);
+int topo_amd_free(void* dptr);
+int topo_amd_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int topo_amd_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int topo_amd_memcpy_d2d(void* dst, const void* src, size_t bytes);
+int topo_amd_memset(void* dst, int value, size_t bytes);
+int topo_amd_sync(void);
+
+/* HIP-event stopwatch on the compute stream (what bench.py times kernels with). */
+int topo_amd_timer_start(void);
+int topo_amd_timer_stop(float* elapsed_ms); /* records, synchronises, returns ms        */
+
+/* Deterministic synthetic terrain (integer-valued metres, float32) written on the device:
+ * value depends only on (global row, column, seed), so shards agree on overlaps.        */
+int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed);
+
+/* ---- geometry helpers (host) -------------------------------------------------------- */
+/* Tap count of the reference's circular_kernel(size) (topo.py:191-213).               */
+int topo_amd_disc_tap_count(int size);
+/* Writes the size x size 0/1 mask (row-major float32).                                 */
+int topo_amd_disc_mask(int size, float* mask);
+/* Ghost rows a row block needs above / below its output rows for one descriptor.
+ * p0: size (TPI/STD) | sigma_axis0 (GAUSS/GRADIENT: max of the two axis-0 sigmas)
+ * p1: pre-smoothing sigma (TPI/STD, 0 = none) | unused
+ * For SX pass the extremes of the offset table instead: p0 = -min(dj), p1 = max(dj).   */
+int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* below);
+
+/* ---- descriptors, device row-block form --------------------------------------------- */
+/* TPI and/or STD over the reference's disc (replaces topo.tpi topo.py:144-181 and topo.std
+ * topo.py:272-307, called from topo.py:138 and :266).  Either output may be NULL.  STD is
+ * float32 on the device (the Python wrapper widens to float64 like the reference).       */
+int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int size,
+                         int out_row0, int out_rows, float* tpi_out, float* std_out);
+
+/* ndimage.gaussian_filter(dem, (sigma_y, sigma_x)), reflect boundary, truncate 4 sigma
+ * (replaces topo.dem topo.py:62-80 and the pre-smoothing at topo.py:173, :298).  A sigma of
+ * 0 skips that axis.  `scratch` must hold (out_rows) x nx floats or be NULL (then the
+ * library uses its own workspace).                                                       */
+int topo_amd_gaussian_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
+                          double sigma_y, double sigma_x, int out_row0, int out_rows,
+                          float* out);
+
+/* 3x3 Sobel pair / 8, true convolution, reflect (replaces topo.sobel topo.py:658-685).  */
+int topo_amd_sobel_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
+                       int out_row0, int out_rows, float* dx_out, float* dy_out);
+
+/* [dx, dy, slope, aspect] (replaces topo.gradient topo.py:597-644, called from :583).
+ * sigma <= 1 -> Sobel; sig_ratio == 1 -> one isotropic smooth; otherwise the two
+ * anisotropic smooths.  res_x / res_y are HOST double arrays for RES_SCALAR / RES_1D and
+ * DEVICE float arrays for RES_2D.  Any output may be NULL.                                */
+int topo_amd_gradient_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
+                          double sigma, double sig_ratio, int res_mode, const void* res_x,
+                          const void* res_y, int out_row0, int out_rows, float* dx_out,
+                          float* dy_out, float* slope_out, float* aspect_out);
+
+/* Sx max-elevation-angle scan (replaces topo._sx_rolling topo.py:928-953, called from :856).
+ * dj/di: offsets of the ray pixels relative to the target (host int32, n_off entries,
+ * duplicates allowed); dist: metric distance of each (host double, NaN = skip, as left by
+ * radius_min at topo.py:845); window: zero-frame width int(W/2); height: topo.py:947.     */
+int topo_amd_sx_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
+                    const int32_t* dj, const int32_t* di, const double* dist, int n_off,
+                    int window, double height, int out_row0, int out_rows, float* out);
+
+/* ---- descriptors, host-buffer form (single block, whole DEM) -------------------------- */
+int topo_amd_tpi_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
+int topo_amd_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
+int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigma,
+                         float* tpi_out, float* std_out);
+int topo_amd_gauss_f32(const float* dem, int ny, int nx, double sigma_y, double sigma_x,
+                       float* out);
+int topo_amd_sobel_f32(const float* dem, int ny, int nx, float* dx_out, float* dy_out);
+/* res_mode RES_2D here takes HOST float arrays [ny x nx].                                 */
+int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double sig_ratio,
+                          int res_mode, const void* res_x, const void* res_y, float* dx_out,
+                          float* dy_out, float* slope_out, float* aspect_out);
+int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const int32_t* di,
+                    const double* dist, int n_off, int window, double height, float* out);
+
+/* ---- row sharding over the GPUs of one node (RCCL over xGMI) -------------------------- */
+/* The reference's only precedent is dask map_overlap(depth, boundary="none") for TPI
+ * (topo.py:177-178): independent blocks plus ghost rows.  Rank r owns a contiguous row
+ * block; ghost rows travel with one ncclSend/ncclRecv pair per neighbour.                */
+#define TOPO_AMD_UNIQUE_ID_BYTES 128
+int topo_amd_comm_unique_id(char id[TOPO_AMD_UNIQUE_ID_BYTES]); /* rank 0, then broadcast */
+int topo_amd_comm_init(int rank, int nranks, const char id[TOPO_AMD_UNIQUE_ID_BYTES]);
+int topo_amd_comm_rank(void);
+int topo_amd_comm_size(void);
+int topo_amd_comm_destroy(void);
+
+/* `block` holds [halo_above | rows_local | halo_below] rows of nx floats.  Fills the ghost
+ * rows from the neighbours on the communication stream (ranks at the global edge skip the
+ * missing side) and records an event; topo_amd_halo_wait() makes the compute stream wait
+ * for it.  Every rank must call with the same halo depths.  Requires rows_local >= both.  */
+int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_above,
+                                 int halo_below);
+int topo_amd_halo_wait(void);
+
+/* Sharded TPI/STD step: ghost exchange overlapped with the interior rows, then the two
+ * seam strips.  `block` as above with halo_above == halo_below == topo_amd_halo_rows(TPI).
+ * row0 = global index of the first local row.  Outputs are rows_local x nx.               */
+int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int nx, int size,
+                           float* tpi_out, float* std_out);
+int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int nx,
+                            double sigma, double sig_ratio, int res_mode, const void* res_x,
+                            const void* res_y, float* dx_out, float* dy_out, float* slope_out,
+                            float* aspect_out);
+int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx,
+                      const int32_t* dj, const int32_t* di, const double* dist, int n_off,
+                      int window, double height, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPO_AMD_H */

@@ -1,0 +1,226 @@
+"""Parity of the HIP path against the golden vectors of the real reference and against the
+oracle's exact float64 evaluation.  Every call goes through the C ABI of libtopo_amd.so.
+
+Tolerance contract (written out here):
+  * TPI, dx, dy, slope, Sx:  max|gpu - ref| / max|ref| <= 1e-4 over the whole array; on top of
+    that a tighter bound against the exact evaluation, because the zero-padded borders inflate
+    max|ref| for TPI.
+  * aspect: wrapped difference <= 1e-4 * 360 deg where slope > 0.1 deg; dx, dy compared everywhere.
+  * STD: (i) |gpu - exact| <= 1e-4 * max|ref|; (ii) |gpu - ref| <= |ref - exact|_max + 1e-4 * max|ref|
+    (the reference's own float32-FFT noise floor is stored with each fixture).
+"""
+import numpy as np
+import pytest
+
+from oracle import topo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+from topo_descriptors_amd import topo  # noqa: E402
+
+REL = 1e-4
+
+
+def rel_range(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.nanmax(np.abs(a - b)) / max(np.nanmax(np.abs(b)), 1e-30))
+
+
+class FakeVar:
+    def __init__(self, values, dims):
+        self.values, self.dims = values, dims
+
+
+class FakeDataset:
+    def __init__(self, dem, x, y, crs="epsg:2056"):
+        self._v = {"dem": FakeVar(dem, ("y", "x")), "x": FakeVar(x, ("x",)), "y": FakeVar(y, ("y",))}
+        self.attrs = {"crs": crs}
+
+    def __getitem__(self, k):
+        return self._v[k]
+
+    def __iter__(self):
+        return iter(["dem"])
+
+
+SIZES = (3, 5, 6, 7, 17, 65)
+
+
+@pytest.mark.parametrize("tag", ["int", "frac"])
+@pytest.mark.parametrize("size", SIZES)
+def test_tpi_vs_reference(golden, tag, size):
+    g = golden("tpi_std")
+    dem = g["dem_" + tag]
+    ref = g[f"tpi_{tag}_s{size}"]
+    got = topo.tpi(dem, size)
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    assert rel_range(got, ref) <= REL
+    exact = orc.tpi_exact(dem, size)
+    # float32 sums around a tile offset: a few 1e-4 m on 2000 m terrain
+    assert np.max(np.abs(got - exact)) <= 2e-3
+    inner = (slice(size, -size), slice(size, -size))
+    if exact[inner].size:
+        assert np.max(np.abs(got[inner] - exact[inner])) <= REL * np.max(np.abs(exact[inner]))
+
+
+@pytest.mark.parametrize("tag", ["int", "frac"])
+@pytest.mark.parametrize("size", SIZES)
+def test_std_vs_reference(golden, tag, size):
+    g = golden("tpi_std")
+    dem = g["dem_" + tag]
+    ref = g[f"std_{tag}_s{size}"]
+    floor = float(g[f"std_{tag}_s{size}_floor"])
+    got = topo.std(dem, size)
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    exact = orc.std_exact(dem, size)
+    scale = np.max(np.abs(ref))
+    assert np.max(np.abs(got - exact)) <= REL * scale            # (i)
+    assert np.max(np.abs(got - ref)) <= floor + REL * scale        # (ii)
+
+
+def test_tpi_std_fused_equals_separate(golden):
+    g = golden("tpi_std")
+    for tag in ("int", "frac"):
+        dem = g["dem_" + tag]
+        t, s = topo.tpi_std(dem, 17)
+        assert np.array_equal(t, topo.tpi(dem, 17))
+        assert np.array_equal(s, topo.std(dem, 17))
+
+
+def test_tpi_std_with_presmoothing(golden):
+    g = golden("tpi_std")
+    for tag in ("int", "frac"):
+        dem = g["dem_" + tag]
+        assert rel_range(topo.tpi(dem, 7, sigma=1.75), g[f"tpi_{tag}_s7_sig1p75"]) <= REL
+        ref = g[f"std_{tag}_s17_sig2p125"]
+        floor = float(g[f"std_{tag}_s17_sig2p125_floor"])
+        got = topo.std(dem, 17, sigma=2.125)
+        assert np.max(np.abs(got - ref)) <= floor + REL * np.max(ref)
+
+
+def test_tpi_size_one_non_finite():
+    dem = orc.synthetic_dem(8, 9, seed=7)
+    assert not np.any(np.isfinite(topo.tpi(dem, 1)))
+
+
+@pytest.mark.parametrize("key,src", [("gauss_int_0.75", "dem_int"), ("gauss_int_2.25", "dem_int"),
+                                     ("gauss_int_3.25", "dem_int"), ("gauss_big_30.25", "dem_big"),
+                                     ("gauss_small_8.0", "dem_small")])
+def test_gaussian_vs_reference(golden, key, src):
+    g = golden("gaussian")
+    sigma = float(key.rsplit("_", 1)[1])
+    ref = g[key]
+    got = topo.dem(g[src], sigma)
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    assert rel_range(got, ref) <= REL
+    # much tighter in practice: a couple of float32 ulps of a ~2000 m field
+    assert np.max(np.abs(got.astype(np.float64) - orc.gaussian_exact(g[src], sigma))) <= 1e-3
+
+
+def test_gaussian_anisotropic_and_identity(golden):
+    g = golden("gaussian")
+    dem = g["dem_int"]
+    got = topo.dem(dem, (3.25, 0.0))
+    from scipy import ndimage
+    assert np.max(np.abs(got - ndimage.gaussian_filter(dem, (3.25, 0.0)))) <= 1e-3
+    got = topo.dem(dem, (0.0, 2.25))
+    assert np.max(np.abs(got - ndimage.gaussian_filter(dem, (0.0, 2.25)))) <= 1e-3
+    assert np.array_equal(topo.dem(dem, 0.0), dem)
+    assert np.array_equal(topo.dem(dem, 0.1), ndimage.gaussian_filter(dem, 0.1))  # radius 0
+
+
+def check_gradient(got, ref_by_name, exact=None):
+    dx, dy, slope, aspect = got
+    for a in got:
+        assert a.dtype == np.float32
+    assert rel_range(dx, ref_by_name["dx"]) <= REL
+    assert rel_range(dy, ref_by_name["dy"]) <= REL
+    assert rel_range(slope, ref_by_name["slope"]) <= REL
+    steep = ref_by_name["slope"] > 0.1
+    if np.any(steep):
+        d = orc.wrapped_angle_diff(aspect, ref_by_name["aspect"])
+        assert np.max(d[steep]) <= REL * 360.0
+    assert np.all((aspect >= 0) & (aspect < 360))
+
+
+GRAD_CASES = [("sob_n", 0.75, "n", 1), ("g3_n", 3.25, "n", 1), ("g3_s", 3.25, "s", 1),
+              ("g3_2d", 3.25, "2d", 1), ("g3_r2_n", 3.25, "n", 2), ("g2_r05_n", 2.25, "n", 0.5)]
+
+
+@pytest.mark.parametrize("tag,sigma,res_tag,ratio", GRAD_CASES)
+def test_gradient_vs_reference(golden, tag, sigma, res_tag, ratio):
+    g = golden("gradient")
+    res = {"x": g[f"res_{res_tag}_x"], "y": g[f"res_{res_tag}_y"]}
+    dem = g["dem_int"].copy()
+    got = topo.gradient(dem, sigma, res, sig_ratio=ratio)
+    assert np.array_equal(dem, g["dem_int"])  # input not mutated
+    check_gradient(got, {n: g[f"{tag}_{n}"] for n in ("dx", "dy", "slope", "aspect")})
+
+
+def test_gradient_large_sigma(golden):
+    g = golden("gradient")
+    res = {"x": g["res_b_x"], "y": g["res_b_y"]}
+    got = topo.gradient(g["dem_big"], 30.25, res)
+    check_gradient(got, {n: g[f"g30_big_{n}"] for n in ("dx", "dy", "slope", "aspect")})
+
+
+def test_sobel_vs_reference(golden):
+    g = golden("gradient")
+    dx, dy = topo.sobel(g["dem_int"])
+    assert rel_range(dx, g["sobel_dx"]) <= 1e-6 and rel_range(dy, g["sobel_dy"]) <= 1e-6
+
+
+def test_aspect_conventions(golden):
+    g = golden("gradient")
+    res = {"x": g["res_f_x"], "y": g["res_f_y"]}
+    flat = topo.gradient(g["plane_flat_in"], 2.0, res)
+    assert np.all(flat[2] == 0) and np.all(flat[3] == 0)      # -0.0 dy keeps aspect at 0
+    north = topo.gradient(g["plane_northf_in"], 2.0, res)
+    assert np.max(orc.wrapped_angle_diff(north[3], g["plane_northf_aspect"])) <= 1e-3
+    east = topo.gradient(g["plane_eastf_in"], 2.0, res)
+    assert np.max(np.abs(east[3] - g["plane_eastf_aspect"])) <= 1e-3
+    for got, tag in ((north, "northf"), (east, "eastf")):
+        assert rel_range(got[2], g[f"plane_{tag}_slope"]) <= REL
+
+
+SX_TAGS = ["az0", "az90", "az225", "arc0", "rmin", "south_up", "aniso"]
+
+
+@pytest.mark.parametrize("tag", SX_TAGS)
+def test_sx_vs_reference(golden, tag):
+    g = golden("sx")
+    az, radius, height, arc, steps, rmin = g[f"{tag}_params"]
+    ds = FakeDataset(g["dem"], g[f"{tag}_x"], g[f"{tag}_y"])
+    got = topo.sx(ds, az, radius, height=height, azimuth_arc=arc, azimuth_steps=int(steps),
+                  radius_min=rmin)
+    ref = g[f"{tag}_out"]
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    assert rel_range(got, ref) <= REL
+    assert np.array_equal(got == 0, ref == 0)  # the zero frame
+
+
+def test_sx_nan_handling():
+    dem = orc.synthetic_dem(64, 72, seed=11)
+    dem[30, 40] = np.nan
+    x = 2600000.0 + 30.0 * np.arange(72)
+    y = 1200000.0 - 30.0 * np.arange(64)
+    got = topo.sx(FakeDataset(dem, x, y), 0, 300.0)
+    want = orc.sx(dem, x, y, 0, 300.0)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.max(np.abs(got[ok] - want[ok])) <= REL * np.max(np.abs(want[ok]))
+
+
+def test_ragged_shapes_and_tiny_inputs():
+    # shapes that are not multiples of any tile, down to a single row / column
+    for ny, nx in ((1, 1), (1, 37), (53, 1), (33, 129), (97, 257), (130, 64)):
+        dem = orc.synthetic_dem(ny, nx, seed=ny * 1000 + nx)
+        for size in (3, 7, 17):
+            got = topo.tpi(dem, size)
+            assert np.max(np.abs(got - orc.tpi_exact(dem, size))) <= 2e-3, (ny, nx, size)
+            s = topo.std(dem, size)
+            e = orc.std_exact(dem, size)
+            assert np.max(np.abs(s - e)) <= REL * max(np.max(e), 1.0), (ny, nx, size)
+        sm = topo.dem(dem, 2.25)
+        assert np.max(np.abs(sm - orc.gaussian_exact(dem, 2.25))) <= 1e-3, (ny, nx)

@@ -1,0 +1,166 @@
+"""Host-side logic of the product package and the shape of the C ABI.  No GPU needed:
+nothing here launches a kernel."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from topo_descriptors_amd import _lib, helpers as hlp, topo
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeVar:
+    def __init__(self, values, dims):
+        self.values = values
+        self.dims = dims
+
+
+class FakeDataset:
+    """Duck-typed stand-in for xarray.Dataset (xarray is not installed in this image)."""
+
+    def __init__(self, dem, x, y, crs="epsg:2056", dims=("y", "x")):
+        self._v = {"dem": FakeVar(dem, dims), "x": FakeVar(x, ("x",)), "y": FakeVar(y, ("y",))}
+        self.attrs = {} if crs is None else {"crs": crs}
+
+    def __getitem__(self, k):
+        return self._v[k]
+
+    def __iter__(self):
+        return iter(["dem"])
+
+
+# ---- the reference's four known-answer tests against the PRODUCT helpers ------------------------
+def test_sx_distance():  # reference test/test_topo.py:6-28
+    out = topo._sx_distance(150.0, 50.0, 40.0)
+    first = np.array([256.1249695, 219.31712199, 188.67962264, 167.63054614, 160.0,
+                      167.63054614, 188.67962264, 219.31712199, 256.1249695])
+    assert np.all(np.isclose(out[0, :], first))
+    assert out.dtype == np.float64
+
+
+def test_sx_bresenhamlines():  # reference test/test_topo.py:31-54
+    out = topo._sx_bresenhamlines(np.array([[8, 9], [17, 22]]), np.array([15, 15]))
+    expected = np.array([[9, 10], [10, 11], [11, 12], [12, 12], [13, 13], [14, 14],
+                         [17, 21], [16, 20], [16, 19], [16, 18], [16, 17], [15, 16]])
+    assert np.all(out == expected)
+    assert out.dtype == np.int64
+
+
+def test_sx_source_idx_delta():  # reference test/test_topo.py:57-67
+    out = topo._sx_source_idx_delta(np.array([3.0, 4.0, 5.0, 6.0]), 500, 20, 30)
+    assert np.all(out == np.array([[17, 1], [17, 2], [17, 2], [17, 3]]))
+    assert out.dtype == np.int64
+
+
+def test_round_up_to_odd():  # reference test/test_helpers.py:6-11
+    outputs = hlp.round_up_to_odd(np.arange(0.1, 10, 0.7))
+    assert outputs.dtype == np.int64
+    assert list(outputs) == [1, 1, 1, 3, 3, 3, 5, 5, 5, 7, 7, 7, 9, 9, 9]
+
+
+# ---- golden vectors ---------------------------------------------------------------------------
+def test_geometry_helpers_golden(golden):
+    g = golden("sx_geometry")
+    n_geo = sum(1 for k in g if k.startswith("dist") and k.endswith("_args"))
+    n_az = sum(1 for k in g if k.startswith("az"))
+    for m in range(n_geo):
+        radius, dx, dy = g[f"dist{m}_args"]
+        dist = topo._sx_distance(radius, dx, dy)
+        assert dist.shape == g[f"dist{m}"].shape
+        assert np.allclose(dist, g[f"dist{m}"], rtol=1e-15, atol=1e-12)
+        centre = np.floor(np.array(dist.shape) / 2)
+        for n in range(n_az):
+            delta = topo._sx_source_idx_delta(g[f"az{n}"], radius, dx, dy)
+            assert np.array_equal(delta, g[f"delta_a{n}_g{m}"])
+            lines = topo._sx_bresenhamlines((centre + delta).astype(int), centre)
+            assert np.array_equal(lines, g[f"lines_a{n}_g{m}"])
+
+
+def test_circular_kernel_golden(golden):
+    g = golden("circular_kernel")
+    for key, ref in g.items():
+        got = topo.circular_kernel(int(key[1:]))
+        assert got.dtype == np.float32 and np.array_equal(got, ref), key
+    lib = _lib.load()
+    for size, taps in ((3, 9), (5, 13), (7, 29), (17, 197), (65, 3209), (67, 3409), (81, 5025)):
+        assert lib.topo_amd_disc_tap_count(size) == taps
+
+
+def test_scale_to_pixel_and_sigmas_golden(golden):
+    g = golden("helpers")
+    for tag in ("30", "25"):
+        ds = FakeDataset(np.zeros((40, 50), np.float32), g["x" + tag], g["y" + tag])
+        px, res = hlp.scale_to_pixel([2000, 200, 500], ds)
+        assert np.array_equal(px, g["px" + tag]) and px.dtype == np.int64
+        assert np.array_equal(res["x"], g[f"res{tag}_x"]) and np.array_equal(res["y"], g[f"res{tag}_y"])
+    sig = hlp.get_sigmas([None, 0.5, 1, 0], np.array([67, 7, 17, 9]))
+    for s, w in zip(sig, g["sigmas"]):
+        assert (s is None and np.isnan(w)) or s == w
+
+
+# ---- error behaviour of the boundary ------------------------------------------------------------
+def test_check_dem_errors():
+    x, y = np.arange(5.0), np.arange(4.0)
+    dem = np.zeros((4, 5), np.float32)
+    with pytest.raises(ValueError):
+        hlp.check_dem(dem)                                  # not a Dataset
+    with pytest.raises(ValueError):
+        hlp.check_dem(FakeDataset(dem, x, y, dims=("x", "y")))
+    with pytest.raises(KeyError):
+        hlp.check_dem(FakeDataset(dem, x, y, crs=None))
+    with pytest.raises(ValueError):
+        hlp.check_dem(FakeDataset(dem, x, y, crs="swiss grid"))
+    hlp.check_dem(FakeDataset(dem, x, y, crs="EPSG:2056"))
+    assert hlp.get_da(FakeDataset(dem, x, y)).values is dem
+
+
+def test_sx_requires_dataset():
+    with pytest.raises(TypeError):
+        topo.sx(np.zeros((8, 8), np.float32), 0, 500.0)
+
+
+def test_halo_rows_contract():
+    lib = _lib.load()
+    up, down = ctypes.c_int32(), ctypes.c_int32()
+    cases = [(_lib.DESC_TPI, 67, 0, 33, 33), (_lib.DESC_TPI, 6, 0, 3, 2), (_lib.DESC_STD, 7, 1.75, 10, 10),
+             (_lib.DESC_GAUSS, 30.25, 0, 121, 121), (_lib.DESC_GRADIENT, 30.25, 0, 122, 122),
+             (_lib.DESC_GRADIENT, 0.75, 0, 1, 1), (_lib.DESC_SOBEL, 0, 0, 1, 1),
+             (_lib.DESC_SX, 17, 0, 17, 0)]
+    for desc, p0, p1, a, b in cases:
+        assert lib.topo_amd_halo_rows(desc, p0, p1, ctypes.byref(up), ctypes.byref(down)) == 0
+        assert (up.value, down.value) == (a, b), (desc, p0, p1)
+
+
+# ---- the C ABI: library loads and exports every declared symbol ----------------------------
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "topo_amd.h")).read()
+    declared = set(re.findall(r"\b(topo_amd_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 40
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/topo_amd.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in _lib.load().topo_amd_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    lib = _lib.load()
+    if lib.topo_amd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.TopoAmdError):
+        topo.tpi(np.zeros((8, 8), np.float32), 3)
+    # entry points refuse to run before topo_amd_init
+    assert lib.topo_amd_sync() != 0
+    assert b"topo_amd_init" in lib.topo_amd_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "topo_descriptors_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "oracle" not in text.lower() or f == "__init__.py" and False, os.path.join(root, f)

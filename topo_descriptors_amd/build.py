@@ -1,0 +1,60 @@
+"""Builds libtopo_amd.so in-tree with hipcc for gfx950 (no JIT cache, no pip install)."""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtopo_amd.so")
+SOURCES = ["disc.hip", "gauss.hip", "sx.hip", "capi.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (looked on PATH and in /opt/rocm/bin)")
+    return exe
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build_library(force=False, verbose=True):
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
+    headers = [os.path.join(CSRC, "common.hpp"),
+               os.path.join(os.path.dirname(HERE), "include", "topo_amd.h")]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if not force and _newer(LIB, srcs + headers):
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
+        cmd = [cc, f"--offload-arch={ARCH}", *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs,
+           "-L/opt/rocm/lib", "-lrccl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv))

@@ -1,0 +1,738 @@
+// C ABI of libtopo_amd.so (declared in include/topo_amd.h): context, memory, the row-block
+// and host-buffer descriptor entry points, and RCCL ghost-row exchange for row shards.
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "common.hpp"
+
+namespace topo {
+
+static thread_local std::string g_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+Context& ctx() {
+    static Context c;
+    return c;
+}
+
+int require_ready() {
+    if (!ctx().ready) {
+        set_error("libtopo_amd: call topo_amd_init(device) first");
+        return TOPO_AMD_ENODEV;
+    }
+    return TOPO_AMD_OK;
+}
+
+int workspace(int slot, size_t bytes, void** out) {
+    Context& c = ctx();
+    if (c.ws_bytes[slot] < bytes) {
+        if (c.ws[slot]) {
+            TOPO_HIP(hipStreamSynchronize(c.compute));
+            TOPO_HIP(hipFree(c.ws[slot]));
+            c.ws[slot] = nullptr;
+            c.ws_bytes[slot] = 0;
+        }
+        TOPO_HIP(hipMalloc(&c.ws[slot], bytes));
+        c.ws_bytes[slot] = bytes;
+    }
+    *out = c.ws[slot];
+    return TOPO_AMD_OK;
+}
+
+// Small parameter tables: pinned staging + async copy on the compute stream.  The previous
+// content is remembered so a loop over the same parameters uploads nothing.
+namespace {
+struct TableSlot {
+    void* pinned = nullptr;
+    size_t cap = 0;
+    std::vector<char> last;
+    hipEvent_t copied = nullptr;
+};
+TableSlot g_slots[6];
+}  // namespace
+
+int upload_table(int slot, const void* host, size_t bytes, void** out) {
+    Context& c = ctx();
+    TableSlot& s = g_slots[slot];
+    if (bytes == 0) bytes = 4;
+    if (c.tab_bytes[slot] < bytes || s.cap < bytes) {
+        const size_t cap = bytes * 2 + 256;
+        TOPO_HIP(hipStreamSynchronize(c.compute));
+        if (c.tab[slot]) TOPO_HIP(hipFree(c.tab[slot]));
+        if (s.pinned) TOPO_HIP(hipHostFree(s.pinned));
+        TOPO_HIP(hipMalloc(&c.tab[slot], cap));
+        TOPO_HIP(hipHostMalloc(&s.pinned, cap, hipHostMallocDefault));
+        c.tab_bytes[slot] = cap;
+        s.cap = cap;
+        s.last.clear();
+        if (!s.copied) TOPO_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+    }
+    if (s.last.size() != bytes || std::memcmp(s.last.data(), host, bytes) != 0) {
+        if (!s.last.empty()) TOPO_HIP(hipEventSynchronize(s.copied));  // staging still in use?
+        std::memcpy(s.pinned, host, bytes);
+        TOPO_HIP(hipMemcpyAsync(c.tab[slot], s.pinned, bytes, hipMemcpyHostToDevice, c.compute));
+        TOPO_HIP(hipEventRecord(s.copied, c.compute));
+        s.last.assign((const char*)host, (const char*)host + bytes);
+    }
+    *out = c.tab[slot];
+    return TOPO_AMD_OK;
+}
+
+int check_block(const Block& b, int need_above, int need_below, const char* who) {
+    TOPO_REQUIRE(b.in != nullptr, "%s: input pointer is NULL", who);
+    TOPO_REQUIRE(b.gny >= 1 && b.nx >= 1, "%s: empty DEM %d x %d", who, b.gny, b.nx);
+    TOPO_REQUIRE(b.in_rows >= 1 && b.in_row0 >= 0 && b.in_row0 + b.in_rows <= b.gny,
+                 "%s: block rows [%d, %d) outside the DEM of %d rows", who, b.in_row0,
+                 b.in_row0 + b.in_rows, b.gny);
+    TOPO_REQUIRE(b.out_rows >= 1 && b.out_row0 >= 0 && b.out_row0 + b.out_rows <= b.gny,
+                 "%s: output rows [%d, %d) outside the DEM of %d rows", who, b.out_row0,
+                 b.out_row0 + b.out_rows, b.gny);
+    const int first = std::max(0, b.out_row0 - need_above);
+    const int last = std::min(b.gny, b.out_row0 + b.out_rows + need_below);
+    TOPO_REQUIRE(b.in_row0 <= first && b.in_row0 + b.in_rows >= last,
+                 "%s: block rows [%d, %d) do not cover the %d/%d ghost rows needed by output rows "
+                 "[%d, %d)", who, b.in_row0, b.in_row0 + b.in_rows, need_above, need_below,
+                 b.out_row0, b.out_row0 + b.out_rows);
+    return TOPO_AMD_OK;
+}
+
+// ---- RCCL state -----------------------------------------------------------------------------
+namespace {
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, size = 1;
+    bool halo_pending = false;
+} g_comm;
+
+#define TOPO_NCCL(call)                                                                    \
+    do {                                                                                   \
+        ncclResult_t r_ = (call);                                                          \
+        if (r_ != ncclSuccess) {                                                           \
+            ::topo::set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_),      \
+                              __FILE__, __LINE__);                                         \
+            return TOPO_AMD_ERCCL;                                                         \
+        }                                                                                  \
+    } while (0)
+
+// compose pre-smoothing + disc: TPI/STD with sigma (topo.py:172-173, :297-298)
+int tpi_std_block(const Block& b, int size, double sigma, float* tpi_out, float* std_out) {
+    DiscRuns disc;
+    TOPO_TRY(build_disc(size, &disc));
+    const int above = -disc.dj_min, below = disc.dj_max;
+    if (!(sigma > 0.0)) {
+        TOPO_TRY(check_block(b, above, below, "tpi_std"));
+        return launch_tpi_std(b, disc, tpi_out, std_out);
+    }
+    const int R = gaussian_radius(sigma);
+    TOPO_TRY(check_block(b, above + R, below + R, "tpi_std(sigma)"));
+    // smooth exactly the rows the disc will read, then run the disc on that plane
+    const int s0 = std::max(0, b.out_row0 - above);
+    const int s1 = std::min(b.gny, b.out_row0 + b.out_rows + below);
+    void* plane = nullptr;
+    TOPO_TRY(workspace(3, (size_t)(s1 - s0) * b.nx * sizeof(float), &plane));
+    Block g = b;
+    g.out_row0 = s0;
+    g.out_rows = s1 - s0;
+    TOPO_TRY(launch_gaussian(g, sigma, sigma, (float*)plane));
+    Block d = b;
+    d.in = (const float*)plane;
+    d.in_row0 = s0;
+    d.in_rows = s1 - s0;
+    return launch_tpi_std(d, disc, tpi_out, std_out);
+}
+
+int gradient_halo(double sigma, double sig_ratio) {
+    if (sigma <= 1.0) return 1;
+    const double s_max = sig_ratio == 1.0 ? sigma : std::max(sigma, sigma * sig_ratio);
+    return gaussian_radius(s_max) + 1;
+}
+
+// RAII-less helper for the host-buffer entry points
+struct HostRun {
+    std::vector<void*> bufs;
+    ~HostRun() {
+        for (void* p : bufs) (void)hipFree(p);
+    }
+    int alloc(void** p, size_t bytes) {
+        TOPO_HIP(hipMalloc(p, bytes));
+        bufs.push_back(*p);
+        return TOPO_AMD_OK;
+    }
+};
+
+int download(void* host, const void* dev, size_t bytes) {
+    if (!host) return TOPO_AMD_OK;
+    TOPO_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+}  // namespace
+}  // namespace topo
+
+using namespace topo;
+
+extern "C" {
+
+const char* topo_amd_version(void) { return "topo_amd 0.1.0 (gfx950)"; }
+const char* topo_amd_last_error(void) { return g_error.c_str(); }
+
+int topo_amd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int topo_amd_init(int device) {
+    Context& c = ctx();
+    if (c.ready && c.device == device) return TOPO_AMD_OK;
+    if (c.ready) {
+        set_error("topo_amd_init: already bound to device %d (one process drives one GPU)", c.device);
+        return TOPO_AMD_EINVAL;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        set_error("topo_amd_init: no HIP device visible");
+        return TOPO_AMD_ENODEV;
+    }
+    TOPO_REQUIRE(device >= 0 && device < n, "topo_amd_init: device %d not in [0, %d)", device, n);
+    TOPO_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    TOPO_HIP(hipGetDeviceProperties(&prop, device));
+    c.num_cu = prop.multiProcessorCount;
+    TOPO_HIP(hipStreamCreateWithFlags(&c.compute, hipStreamNonBlocking));
+    TOPO_HIP(hipStreamCreateWithFlags(&c.comm, hipStreamNonBlocking));
+    TOPO_HIP(hipEventCreateWithFlags(&c.halo_done, hipEventDisableTiming));
+    TOPO_HIP(hipEventCreateWithFlags(&c.input_ready, hipEventDisableTiming));
+    TOPO_HIP(hipEventCreate(&c.t0));
+    TOPO_HIP(hipEventCreate(&c.t1));
+    c.device = device;
+    c.ready = true;
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_shutdown(void) {
+    Context& c = ctx();
+    if (!c.ready) return TOPO_AMD_OK;
+    (void)hipDeviceSynchronize();
+    if (g_comm.comm) {
+        (void)ncclCommDestroy(g_comm.comm);
+        g_comm = Comm();
+    }
+    for (int i = 0; i < 4; ++i)
+        if (c.ws[i]) (void)hipFree(c.ws[i]);
+    for (int i = 0; i < 6; ++i) {
+        if (c.tab[i]) (void)hipFree(c.tab[i]);
+        if (g_slots[i].pinned) (void)hipHostFree(g_slots[i].pinned);
+        if (g_slots[i].copied) (void)hipEventDestroy(g_slots[i].copied);
+        g_slots[i] = TableSlot();
+    }
+    (void)hipEventDestroy(c.halo_done);
+    (void)hipEventDestroy(c.input_ready);
+    (void)hipEventDestroy(c.t0);
+    (void)hipEventDestroy(c.t1);
+    (void)hipStreamDestroy(c.compute);
+    (void)hipStreamDestroy(c.comm);
+    c = Context();
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_device_name(char* buf, int buflen) {
+    TOPO_TRY(require_ready());
+    hipDeviceProp_t prop;
+    TOPO_HIP(hipGetDeviceProperties(&prop, ctx().device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_malloc(void** dptr, size_t bytes) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dptr != nullptr, "topo_amd_malloc: NULL result pointer");
+    TOPO_HIP(hipMalloc(dptr, bytes ? bytes : 4));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_free(void* dptr) {
+    TOPO_TRY(require_ready());
+    if (dptr) {
+        TOPO_HIP(hipStreamSynchronize(ctx().compute));
+        TOPO_HIP(hipFree(dptr));
+    }
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    TOPO_TRY(require_ready());
+    TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().compute));
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    TOPO_TRY(require_ready());
+    TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().compute));
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+    TOPO_TRY(require_ready());
+    TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_memset(void* dst, int value, size_t bytes) {
+    TOPO_TRY(require_ready());
+    TOPO_HIP(hipMemsetAsync(dst, value, bytes, ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_sync(void) {
+    TOPO_TRY(require_ready());
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    TOPO_HIP(hipStreamSynchronize(ctx().comm));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_timer_start(void) {
+    TOPO_TRY(require_ready());
+    TOPO_HIP(hipEventRecord(ctx().t0, ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_timer_stop(float* elapsed_ms) {
+    TOPO_TRY(require_ready());
+    TOPO_HIP(hipEventRecord(ctx().t1, ctx().compute));
+    TOPO_HIP(hipEventSynchronize(ctx().t1));
+    TOPO_HIP(hipEventElapsedTime(elapsed_ms, ctx().t0, ctx().t1));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(out && rows >= 1 && nx >= 1, "synth_dem: bad arguments");
+    return launch_synth(out, rows, row0, nx, seed);
+}
+
+// ---- geometry helpers ---------------------------------------------------------------------
+int topo_amd_disc_tap_count(int size) {
+    DiscRuns d;
+    if (build_disc(size, &d) != TOPO_AMD_OK) return TOPO_AMD_EINVAL;
+    return d.taps;
+}
+
+int topo_amd_disc_mask(int size, float* mask) {
+    TOPO_REQUIRE(mask != nullptr, "disc_mask: NULL output");
+    DiscRuns d;
+    TOPO_TRY(build_disc(size, &d));
+    const int c = (size - 1) / 2;
+    for (int a = 0; a < size; ++a) {
+        const int row = (c - a) - d.dj_min;
+        for (int b = 0; b < size; ++b) {
+            const int di = c - b;
+            mask[a * size + b] = (di >= d.lo[row] && di <= d.hi[row]) ? 1.0f : 0.0f;
+        }
+    }
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* below) {
+    TOPO_REQUIRE(above && below, "halo_rows: NULL output");
+    switch (descriptor) {
+        case TOPO_AMD_DESC_TPI:
+        case TOPO_AMD_DESC_STD: {
+            DiscRuns d;
+            TOPO_TRY(build_disc((int)p0, &d));
+            const int R = p1 > 0.0 ? gaussian_radius(p1) : 0;
+            *above = -d.dj_min + R;
+            *below = d.dj_max + R;
+            return TOPO_AMD_OK;
+        }
+        case TOPO_AMD_DESC_GAUSS:
+            *above = *below = gaussian_radius(p0);
+            return TOPO_AMD_OK;
+        case TOPO_AMD_DESC_GRADIENT:
+            *above = *below = p0 <= 1.0 ? 1 : gaussian_radius(p0) + 1;
+            return TOPO_AMD_OK;
+        case TOPO_AMD_DESC_SOBEL:
+            *above = *below = 1;
+            return TOPO_AMD_OK;
+        case TOPO_AMD_DESC_SX:
+            *above = p0 > 0 ? (int)p0 : 0;
+            *below = p1 > 0 ? (int)p1 : 0;
+            return TOPO_AMD_OK;
+        default:
+            set_error("halo_rows: unknown descriptor %d", descriptor);
+            return TOPO_AMD_EINVAL;
+    }
+}
+
+// ---- device row-block entry points ------------------------------------------------------------
+int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int size,
+                         int out_row0, int out_rows, float* tpi_out, float* std_out) {
+    TOPO_TRY(require_ready());
+    Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    return tpi_std_block(b, size, 0.0, tpi_out, std_out);
+}
+
+int topo_amd_gaussian_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
+                          double sigma_y, double sigma_x, int out_row0, int out_rows, float* out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(out != nullptr, "gaussian: NULL output");
+    TOPO_REQUIRE(sigma_y >= 0.0 && sigma_x >= 0.0, "gaussian: negative sigma");
+    Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    const int R = gaussian_radius(sigma_y);
+    TOPO_TRY(check_block(b, R, R, "gaussian"));
+    return launch_gaussian(b, sigma_y, sigma_x, out);
+}
+
+int topo_amd_sobel_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int out_row0,
+                       int out_rows, float* dx_out, float* dy_out) {
+    TOPO_TRY(require_ready());
+    Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    TOPO_TRY(check_block(b, 1, 1, "sobel"));
+    return launch_sobel(b, dx_out, dy_out);
+}
+
+int topo_amd_gradient_dev(const float* in, int in_rows, int in_row0, int gny, int nx, double sigma,
+                          double sig_ratio, int res_mode, const void* res_x, const void* res_y,
+                          int out_row0, int out_rows, float* dx_out, float* dy_out,
+                          float* slope_out, float* aspect_out) {
+    TOPO_TRY(require_ready());
+    Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    const int h = gradient_halo(sigma, sig_ratio);
+    TOPO_TRY(check_block(b, h, h, "gradient"));
+    return launch_gradient(b, sigma, sig_ratio, res_mode, res_x, res_y, dx_out, dy_out, slope_out,
+                           aspect_out);
+}
+
+int topo_amd_sx_dev(const float* in, int in_rows, int in_row0, int gny, int nx, const int32_t* dj,
+                    const int32_t* di, const double* dist, int n_off, int window, double height,
+                    int out_row0, int out_rows, float* out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(out && dj && di && dist && n_off >= 0, "sx: NULL argument");
+    int up = 0, down = 0;
+    for (int n = 0; n < n_off; ++n) {
+        if (std::isnan(dist[n])) continue;
+        up = std::max(up, -dj[n]);
+        down = std::max(down, dj[n]);
+    }
+    Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    // rows of the zero frame need no neighbours, interior rows never reach outside the DEM
+    TOPO_TRY(check_block(b, up, down, "sx"));
+    return launch_sx(b, dj, di, dist, n_off, window, height, out);
+}
+
+// ---- host-buffer entry points ----------------------------------------------------------------
+int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* tpi_out,
+                         float* std_out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dem && ny >= 1 && nx >= 1, "tpi_std: bad DEM");
+    TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
+    const size_t bytes = (size_t)ny * nx * sizeof(float);
+    HostRun run;
+    void *d_in = nullptr, *d_tpi = nullptr, *d_std = nullptr;
+    TOPO_TRY(run.alloc(&d_in, bytes));
+    if (tpi_out) TOPO_TRY(run.alloc(&d_tpi, bytes));
+    if (std_out) TOPO_TRY(run.alloc(&d_std, bytes));
+    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
+    Block b{(const float*)d_in, ny, 0, ny, nx, 0, ny};
+    TOPO_TRY(tpi_std_block(b, size, sigma, (float*)d_tpi, (float*)d_std));
+    TOPO_TRY(download(tpi_out, d_tpi, bytes));
+    TOPO_TRY(download(std_out, d_std, bytes));
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_tpi_f32(const float* dem, int ny, int nx, int size, double sigma, float* out) {
+    TOPO_REQUIRE(out != nullptr, "tpi: NULL output");
+    return topo_amd_tpi_std_f32(dem, ny, nx, size, sigma, out, nullptr);
+}
+
+int topo_amd_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* out) {
+    TOPO_REQUIRE(out != nullptr, "std: NULL output");
+    return topo_amd_tpi_std_f32(dem, ny, nx, size, sigma, nullptr, out);
+}
+
+int topo_amd_gauss_f32(const float* dem, int ny, int nx, double sigma_y, double sigma_x, float* out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dem && out && ny >= 1 && nx >= 1, "gauss: bad arguments");
+    const size_t bytes = (size_t)ny * nx * sizeof(float);
+    HostRun run;
+    void *d_in = nullptr, *d_out = nullptr;
+    TOPO_TRY(run.alloc(&d_in, bytes));
+    TOPO_TRY(run.alloc(&d_out, bytes));
+    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
+    TOPO_TRY(topo_amd_gaussian_dev((const float*)d_in, ny, 0, ny, nx, sigma_y, sigma_x, 0, ny,
+                                   (float*)d_out));
+    TOPO_TRY(download(out, d_out, bytes));
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_sobel_f32(const float* dem, int ny, int nx, float* dx_out, float* dy_out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dem && dx_out && dy_out && ny >= 1 && nx >= 1, "sobel: bad arguments");
+    const size_t bytes = (size_t)ny * nx * sizeof(float);
+    HostRun run;
+    void *d_in = nullptr, *d_dx = nullptr, *d_dy = nullptr;
+    TOPO_TRY(run.alloc(&d_in, bytes));
+    TOPO_TRY(run.alloc(&d_dx, bytes));
+    TOPO_TRY(run.alloc(&d_dy, bytes));
+    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
+    TOPO_TRY(topo_amd_sobel_dev((const float*)d_in, ny, 0, ny, nx, 0, ny, (float*)d_dx, (float*)d_dy));
+    TOPO_TRY(download(dx_out, d_dx, bytes));
+    TOPO_TRY(download(dy_out, d_dy, bytes));
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double sig_ratio,
+                          int res_mode, const void* res_x, const void* res_y, float* dx_out,
+                          float* dy_out, float* slope_out, float* aspect_out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dem && ny >= 1 && nx >= 1, "gradient: bad DEM");
+    const size_t bytes = (size_t)ny * nx * sizeof(float);
+    HostRun run;
+    void *d_in = nullptr, *d_o[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* host_out[4] = {dx_out, dy_out, slope_out, aspect_out};
+    TOPO_TRY(run.alloc(&d_in, bytes));
+    for (int k = 0; k < 4; ++k)
+        if (host_out[k]) TOPO_TRY(run.alloc(&d_o[k], bytes));
+    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
+    const void *rx = res_x, *ry = res_y;
+    if (res_mode == TOPO_AMD_RES_2D) {
+        void *d_rx = nullptr, *d_ry = nullptr;
+        TOPO_TRY(run.alloc(&d_rx, bytes));
+        TOPO_TRY(run.alloc(&d_ry, bytes));
+        TOPO_HIP(hipMemcpyAsync(d_rx, res_x, bytes, hipMemcpyHostToDevice, ctx().compute));
+        TOPO_HIP(hipMemcpyAsync(d_ry, res_y, bytes, hipMemcpyHostToDevice, ctx().compute));
+        rx = d_rx;
+        ry = d_ry;
+    }
+    TOPO_TRY(topo_amd_gradient_dev((const float*)d_in, ny, 0, ny, nx, sigma, sig_ratio, res_mode, rx,
+                                   ry, 0, ny, (float*)d_o[0], (float*)d_o[1], (float*)d_o[2],
+                                   (float*)d_o[3]));
+    for (int k = 0; k < 4; ++k) TOPO_TRY(download(host_out[k], d_o[k], bytes));
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const int32_t* di,
+                    const double* dist, int n_off, int window, double height, float* out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dem && out && ny >= 1 && nx >= 1, "sx: bad arguments");
+    const size_t bytes = (size_t)ny * nx * sizeof(float);
+    HostRun run;
+    void *d_in = nullptr, *d_out = nullptr;
+    TOPO_TRY(run.alloc(&d_in, bytes));
+    TOPO_TRY(run.alloc(&d_out, bytes));
+    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
+    TOPO_TRY(topo_amd_sx_dev((const float*)d_in, ny, 0, ny, nx, dj, di, dist, n_off, window, height,
+                             0, ny, (float*)d_out));
+    TOPO_TRY(download(out, d_out, bytes));
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+// ---- RCCL row sharding ------------------------------------------------------------------------
+int topo_amd_comm_unique_id(char id[TOPO_AMD_UNIQUE_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) <= TOPO_AMD_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId uid;
+    TOPO_NCCL(ncclGetUniqueId(&uid));
+    std::memset(id, 0, TOPO_AMD_UNIQUE_ID_BYTES);
+    std::memcpy(id, &uid, sizeof(uid));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_comm_init(int rank, int nranks, const char id[TOPO_AMD_UNIQUE_ID_BYTES]) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_init: rank %d of %d", rank, nranks);
+    TOPO_REQUIRE(g_comm.comm == nullptr, "comm_init: communicator already exists");
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    TOPO_NCCL(ncclCommInitRank(&g_comm.comm, nranks, uid, rank));
+    g_comm.rank = rank;
+    g_comm.size = nranks;
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_comm_rank(void) { return g_comm.rank; }
+int topo_amd_comm_size(void) { return g_comm.size; }
+
+int topo_amd_comm_destroy(void) {
+    if (g_comm.comm) {
+        (void)hipDeviceSynchronize();
+        TOPO_NCCL(ncclCommDestroy(g_comm.comm));
+    }
+    g_comm = Comm();
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_above,
+                                 int halo_below) {
+    TOPO_TRY(require_ready());
+    Context& c = ctx();
+    TOPO_REQUIRE(block && rows_local >= 1 && nx >= 1 && halo_above >= 0 && halo_below >= 0,
+                 "halo_exchange: bad arguments");
+    TOPO_REQUIRE(rows_local >= halo_above && rows_local >= halo_below,
+                 "halo_exchange: %d local rows cannot feed ghost depths %d/%d (shard too thin)",
+                 rows_local, halo_above, halo_below);
+    // the local rows must be final before neighbours read them
+    TOPO_HIP(hipEventRecord(c.input_ready, c.compute));
+    TOPO_HIP(hipStreamWaitEvent(c.comm, c.input_ready, 0));
+    if (g_comm.size > 1) {
+        TOPO_REQUIRE(g_comm.comm != nullptr, "halo_exchange: call topo_amd_comm_init first");
+        const int up = g_comm.rank - 1, down = g_comm.rank + 1;
+        float* ghost_top = block;
+        float* local = block + (size_t)halo_above * nx;
+        float* ghost_bot = local + (size_t)rows_local * nx;
+        TOPO_NCCL(ncclGroupStart());
+        if (up >= 0) {
+            // my first halo_below rows become the upper neighbour's bottom ghost rows
+            if (halo_below > 0)
+                TOPO_NCCL(ncclSend(local, (size_t)halo_below * nx, ncclFloat, up, g_comm.comm, c.comm));
+            if (halo_above > 0)
+                TOPO_NCCL(ncclRecv(ghost_top, (size_t)halo_above * nx, ncclFloat, up, g_comm.comm, c.comm));
+        }
+        if (down < g_comm.size) {
+            if (halo_above > 0)
+                TOPO_NCCL(ncclSend(local + (size_t)(rows_local - halo_above) * nx,
+                                   (size_t)halo_above * nx, ncclFloat, down, g_comm.comm, c.comm));
+            if (halo_below > 0)
+                TOPO_NCCL(ncclRecv(ghost_bot, (size_t)halo_below * nx, ncclFloat, down, g_comm.comm, c.comm));
+        }
+        TOPO_NCCL(ncclGroupEnd());
+    }
+    TOPO_HIP(hipEventRecord(c.halo_done, c.comm));
+    g_comm.halo_pending = true;
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_halo_wait(void) {
+    TOPO_TRY(require_ready());
+    if (g_comm.halo_pending) {
+        TOPO_HIP(hipStreamWaitEvent(ctx().compute, ctx().halo_done, 0));
+        g_comm.halo_pending = false;
+    }
+    return TOPO_AMD_OK;
+}
+
+}  // extern "C"
+
+namespace topo {
+namespace {
+
+// Geometry of one rank's haloed block inside the global DEM.
+struct Shard {
+    Block whole;           // block including the ghost rows that exist
+    int row0, rows_local;  // owned rows
+    int interior0, interior1;  // owned rows whose stencil stays inside the owned rows
+};
+
+Shard make_shard(float* block, int rows_local, int row0, int gny, int nx, int above, int below) {
+    Shard s;
+    const bool has_up = row0 > 0, has_down = row0 + rows_local < gny;
+    // the buffer always reserves `above` ghost rows on top; at the global edge they are unused
+    s.whole.in = block + (size_t)(has_up ? 0 : above) * nx;
+    s.whole.in_row0 = has_up ? row0 - above : row0;
+    s.whole.in_rows = rows_local + (has_up ? above : 0) + (has_down ? below : 0);
+    s.whole.gny = gny;
+    s.whole.nx = nx;
+    s.row0 = row0;
+    s.rows_local = rows_local;
+    s.interior0 = has_up ? std::min(row0 + above, row0 + rows_local) : row0;
+    s.interior1 = has_down ? std::max(row0 + rows_local - below, s.interior0) : row0 + rows_local;
+    return s;
+}
+
+// Runs `fn(out_row0, out_rows)` for the interior first, then (after the ghost rows landed)
+// for the seam strips: the exchange overlaps the interior compute.
+template <class Fn>
+int run_overlapped(float* block, const Shard& s, int above, int below, Fn fn) {
+    TOPO_TRY(topo_amd_halo_exchange_start(block, s.rows_local, s.whole.nx, above, below));
+    if (s.interior1 > s.interior0) TOPO_TRY(fn(s.interior0, s.interior1 - s.interior0));
+    TOPO_TRY(topo_amd_halo_wait());
+    if (s.interior0 > s.row0) TOPO_TRY(fn(s.row0, s.interior0 - s.row0));
+    const int end = s.row0 + s.rows_local;
+    if (end > s.interior1) TOPO_TRY(fn(s.interior1, end - s.interior1));
+    return TOPO_AMD_OK;
+}
+
+float* shift(float* p, int rows, int nx) { return p ? p + (size_t)rows * nx : nullptr; }
+
+}  // namespace
+}  // namespace topo
+
+extern "C" {
+
+int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int nx, int size,
+                           float* tpi_out, float* std_out) {
+    TOPO_TRY(require_ready());
+    DiscRuns disc;
+    TOPO_TRY(build_disc(size, &disc));
+    const int above = -disc.dj_min, below = disc.dj_max;
+    Shard s = make_shard(block, rows_local, row0, gny, nx, above, below);
+    return run_overlapped(block, s, above, below, [&](int o0, int on) {
+        Block b = s.whole;
+        b.out_row0 = o0;
+        b.out_rows = on;
+        TOPO_TRY(check_block(b, above, below, "shard_tpi_std"));
+        return launch_tpi_std(b, disc, shift(tpi_out, o0 - row0, nx), shift(std_out, o0 - row0, nx));
+    });
+}
+
+int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int nx, double sigma,
+                            double sig_ratio, int res_mode, const void* res_x, const void* res_y,
+                            float* dx_out, float* dy_out, float* slope_out, float* aspect_out) {
+    TOPO_TRY(require_ready());
+    const int h = gradient_halo(sigma, sig_ratio);
+    Shard s = make_shard(block, rows_local, row0, gny, nx, h, h);
+    return run_overlapped(block, s, h, h, [&](int o0, int on) {
+        Block b = s.whole;
+        b.out_row0 = o0;
+        b.out_rows = on;
+        TOPO_TRY(check_block(b, h, h, "shard_gradient"));
+        const void *rx = res_x, *ry = res_y;
+        if (res_mode == TOPO_AMD_RES_2D) {
+            rx = (const float*)res_x + (size_t)(o0 - row0) * nx;
+            ry = (const float*)res_y + (size_t)(o0 - row0) * nx;
+        }
+        return launch_gradient(b, sigma, sig_ratio, res_mode, rx, ry, shift(dx_out, o0 - row0, nx),
+                               shift(dy_out, o0 - row0, nx), shift(slope_out, o0 - row0, nx),
+                               shift(aspect_out, o0 - row0, nx));
+    });
+}
+
+int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx, const int32_t* dj,
+                      const int32_t* di, const double* dist, int n_off, int window, double height,
+                      float* out) {
+    TOPO_TRY(require_ready());
+    int up = 0, down = 0;
+    for (int n = 0; n < n_off; ++n) {
+        if (std::isnan(dist[n])) continue;
+        up = std::max(up, -dj[n]);
+        down = std::max(down, dj[n]);
+    }
+    Shard s = make_shard(block, rows_local, row0, gny, nx, up, down);
+    return run_overlapped(block, s, up, down, [&](int o0, int on) {
+        Block b = s.whole;
+        b.out_row0 = o0;
+        b.out_rows = on;
+        TOPO_TRY(check_block(b, up, down, "shard_sx"));
+        return launch_sx(b, dj, di, dist, n_off, window, height, shift(out, o0 - row0, nx));
+    });
+}
+
+}  // extern "C"

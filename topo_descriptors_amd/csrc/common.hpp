@@ -1,0 +1,99 @@
+// Shared declarations of libtopo_amd: context, error plumbing, launch helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/topo_amd.h"
+
+namespace topo {
+
+// ---- error plumbing ---------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define TOPO_HIP(call)                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            ::topo::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),       \
+                              __FILE__, __LINE__);                                         \
+            return TOPO_AMD_EHIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+#define TOPO_REQUIRE(cond, ...)                                                            \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            ::topo::set_error(__VA_ARGS__);                                                \
+            return TOPO_AMD_EINVAL;                                                        \
+        }                                                                                  \
+    } while (0)
+
+#define TOPO_TRY(call)                                                                     \
+    do {                                                                                   \
+        int r_ = (call);                                                                   \
+        if (r_ != TOPO_AMD_OK) return r_;                                                  \
+    } while (0)
+
+// ---- per-process context (one process drives one GPU) -------------------------------------
+struct Context {
+    bool ready = false;
+    int device = -1;
+    int num_cu = 256;
+    size_t lds_per_block = 65536;
+    hipStream_t compute = nullptr;   // every kernel goes here
+    hipStream_t comm = nullptr;      // RCCL ghost-row traffic
+    hipEvent_t halo_done = nullptr;  // comm -> compute dependency
+    hipEvent_t input_ready = nullptr;  // compute -> comm dependency
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // grow-only device workspaces (never freed between calls: no hipMalloc in the hot path)
+    void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[4] = {0, 0, 0, 0};
+    // small parameter tables (disc runs, gaussian taps, sx offsets, resolutions)
+    void* tab[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t tab_bytes[6] = {0, 0, 0, 0, 0, 0};
+};
+
+Context& ctx();
+int require_ready();
+int workspace(int slot, size_t bytes, void** out);       // device scratch, grow-only
+int upload_table(int slot, const void* host, size_t bytes, void** out);  // async on compute
+
+// Geometry of a row block inside the global DEM (see include/topo_amd.h).
+struct Block {
+    const float* in;
+    int in_rows, in_row0, gny, nx;
+    int out_row0, out_rows;
+};
+int check_block(const Block& b, int need_above, int need_below, const char* who);
+
+// ---- disc geometry (host) ---------------------------------------------------------------
+struct DiscRuns {
+    int size = 0;
+    int taps = 0;             // number of ones in the mask (centre included)
+    int dj_min = 0, dj_max = 0;
+    int di_min = 0, di_max = 0;
+    int centre_dj = 0, centre_di = 0;      // offset of the tap TPI zeroes (topo.py:170)
+    std::vector<int16_t> lo, hi;           // per dj in [dj_min, dj_max]: di run [lo, hi]
+};
+int build_disc(int size, DiscRuns* out);
+
+// ---- kernel launchers (defined in the .hip files) -------------------------------------------
+int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out);
+int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out);
+int launch_sobel(const Block& b, float* dx_out, float* dy_out);
+int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode,
+                    const void* res_x, const void* res_y, float* dx, float* dy, float* slope,
+                    float* aspect);
+int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double* dist,
+              int n_off, int window, double height, float* out);
+int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed);
+
+int gaussian_radius(double sigma);
+
+}  // namespace topo

@@ -1,0 +1,419 @@
+// K3/K4/K5: separable Gaussian, Sobel, and the gradient -> slope/aspect epilogue.
+//
+// Replaces scipy.ndimage.gaussian_filter (topo.py:80, :173, :298, :631-635), numpy.gradient
+// plus the normalisation / slope / aspect arithmetic (topo.py:631-642, :707-712) and
+// scipy.ndimage.convolve with the Sobel pair (topo.py:679-683).
+//
+// Gaussian = two 1-D passes like scipy (axis 0, then axis 1), radius int(4 sigma + 0.5),
+// float64-normalised taps rounded to float32, reflect ("symmetric") boundary at the GLOBAL
+// DEM edges, and the intermediate rounded to float32 between the passes exactly as the
+// reference does.  Each thread register-blocks TB consecutive outputs along the filter
+// axis so that one loaded sample feeds TB FMAs; samples are taken relative to a per-thread
+// offset so float32 accumulation keeps its digits on 2000 m terrain.
+#include "common.hpp"
+
+#include <cmath>
+
+namespace topo {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ int reflect_index(int i, int n) {
+    // scipy mode="reflect": (d c b a | a b c d | d c b a), period 2n
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+struct GaussArgs {
+    const float* in;
+    float* out;
+    const float* wpad;  // taps padded with TB-1 zeros on both sides
+    int in_rows, in_row0, gny, nx;
+    int out_row0, out_rows;
+    int radius;
+};
+
+// ---- axis 0 (down the columns): lanes run along x, plain coalesced global loads ------------
+template <int TB>
+__global__ __launch_bounds__(kThreads) void gauss_axis0_kernel(GaussArgs p) {
+    const int x = blockIdx.x * kThreads + threadIdx.x;
+    if (x >= p.nx) return;
+    const int y0 = p.out_row0 + blockIdx.y * TB;
+    const int R = p.radius;
+    const float* col = p.in + x;
+
+    float acc[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) acc[t] = 0.0f;
+    const float c = col[(size_t)(reflect_index(min(y0, p.gny - 1), p.gny) - p.in_row0) * p.nx];
+
+    const int n_in = TB + 2 * R;
+    for (int r = 0; r < n_in; ++r) {
+        int gy = reflect_index(y0 - R + r, p.gny);
+        // rows past the block only feed outputs past out_rows (partial last tile)
+        int by = min(max(gy - p.in_row0, 0), p.in_rows - 1);
+        const float v = col[(size_t)by * p.nx] - c;
+        const float* w = p.wpad + r;  // wpad[r - t + TB - 1], t = 0..TB-1
+#pragma unroll
+        for (int t = 0; t < TB; ++t) acc[t] = fmaf(w[TB - 1 - t], v, acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+        const int oy = y0 + t;
+        if (oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + x] = c + acc[t];
+    }
+}
+
+// ---- axis 1 (along the rows): tile staged in LDS, lanes run along y ------------------------
+// block = 64 rows x (4 * TB) output columns; wave w owns TB consecutive columns of every row.
+template <int TB>
+__global__ __launch_bounds__(kThreads) void gauss_axis1_kernel(GaussArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    constexpr int TR = 64;
+    constexpr int TC = 4 * TB;
+    const int R = p.radius;
+    const int cols_l = TC + 2 * R;
+    const int stride = cols_l | 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ox0 = blockIdx.x * TC;
+    const int oy0 = blockIdx.y * TR;  // relative to out_row0; rows here need no halo
+
+    // stage: wave per row, lanes along x (coalesced), reflect at the left/right DEM edges
+    for (int r = wave; r < TR; r += kThreads / 64) {
+        const int row = min(oy0 + r, p.out_rows - 1);
+        const float* src = p.in + (size_t)(row + p.out_row0 - p.in_row0) * p.nx;
+        float* dst = L + r * stride;
+        for (int k = lane; k < cols_l; k += 64) dst[k] = src[reflect_index(ox0 - R + k, p.nx)];
+    }
+    __syncthreads();
+
+    float acc[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) acc[t] = 0.0f;
+    const float* rowp = L + lane * stride + wave * TB;
+    const float c = rowp[R];
+    const int n_in = TB + 2 * R;
+    for (int r = 0; r < n_in; ++r) {
+        const float v = rowp[r] - c;
+        const float* w = p.wpad + r;
+#pragma unroll
+        for (int t = 0; t < TB; ++t) acc[t] = fmaf(w[TB - 1 - t], v, acc[t]);
+    }
+    __syncthreads();
+    // transpose back through LDS so the stores are row-coalesced
+    constexpr int ostride = TC + 1;
+    float* O = L;
+#pragma unroll
+    for (int t = 0; t < TB; ++t) O[lane * ostride + wave * TB + t] = c + acc[t];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TR * TC; idx += kThreads) {
+        const int r = idx / TC, k = idx % TC;
+        const int oy = oy0 + r, ox = ox0 + k;
+        if (oy < p.out_rows && ox < p.nx) p.out[(size_t)oy * p.nx + ox] = O[r * ostride + k];
+    }
+}
+
+// ---- gradient epilogue ---------------------------------------------------------------------
+struct GradArgs {
+    const float* gx_src;  // smoothed field differenced along x (rows start at s_row0)
+    const float* gy_src;  // smoothed field differenced along y
+    const float* raw;     // Sobel branch: the DEM block itself
+    int raw_rows, raw_row0;
+    int s_row0, s_rows;
+    int gny, nx, out_row0, out_rows;
+    int res_mode;
+    const float* res_x;   // device: 1 value, nx values, or out_rows*nx values
+    const float* res_y;   // device: 1 value, gny values, or out_rows*nx values
+    float *dx, *dy, *slope, *aspect;
+};
+
+__device__ __forceinline__ void finish_gradient(const GradArgs& p, int oy, int ox, float dx,
+                                                float dy) {
+    const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
+    float rx, ry;
+    if (p.res_mode == TOPO_AMD_RES_SCALAR) {
+        rx = p.res_x[0];
+        ry = p.res_y[0];
+    } else if (p.res_mode == TOPO_AMD_RES_1D) {
+        rx = p.res_x[ox];
+        ry = p.res_y[oy];
+    } else {
+        rx = p.res_x[o];
+        ry = p.res_y[o];
+    }
+    dx = dx / rx;  // signed resolutions: -0.0 must survive (aspect of flat terrain)
+    dy = dy / ry;
+    if (p.dx) p.dx[o] = dx;
+    if (p.dy) p.dy[o] = dy;
+    const float rad2deg = 57.29577951308232f;
+    if (p.slope) {
+        const float d2 = dx * dx;
+        const float e2 = dy * dy;
+        p.slope[o] = atanf(sqrtf(d2 + e2)) * rad2deg;
+    }
+    if (p.aspect) {
+        float a = 180.0f + atan2f(dx, dy) * rad2deg;
+        if (a >= 360.0f) a -= 360.0f;  // float32 "% 360" of a value in [0, 360]
+        p.aspect[o] = a;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void gradient_epilogue_kernel(GradArgs p) {
+    const int ox = blockIdx.x * kThreads + threadIdx.x;
+    const int oy = p.out_row0 + blockIdx.y;
+    if (ox >= p.nx) return;
+    // numpy.gradient: central difference / 2 inside, first-order one-sided at the edges
+    const float* rowx = p.gx_src + (size_t)(oy - p.s_row0) * p.nx;
+    float dx;
+    if (ox == 0) dx = rowx[1] - rowx[0];
+    else if (ox == p.nx - 1) dx = rowx[ox] - rowx[ox - 1];
+    else dx = (rowx[ox + 1] - rowx[ox - 1]) * 0.5f;
+    const float* coly = p.gy_src + (size_t)(oy - p.s_row0) * p.nx + ox;
+    float dy;
+    if (oy == 0) dy = coly[p.nx] - coly[0];
+    else if (oy == p.gny - 1) dy = coly[0] - coly[-p.nx];
+    else dy = (coly[p.nx] - coly[-p.nx]) * 0.5f;
+    finish_gradient(p, oy, ox, dx, dy);
+}
+
+__device__ __forceinline__ double raw_reflect(const GradArgs& p, int gy, int gx) {
+    gy = reflect_index(gy, p.gny);
+    gx = reflect_index(gx, p.nx);
+    return (double)p.raw[(size_t)(gy - p.raw_row0) * p.nx + gx];
+}
+
+// Sobel pair / 8, true convolution (kernel flipped), evaluated in float64 like ndimage.
+template <bool FINISH>
+__global__ __launch_bounds__(kThreads) void sobel_kernel(GradArgs p) {
+    const int ox = blockIdx.x * kThreads + threadIdx.x;
+    const int oy = p.out_row0 + blockIdx.y;
+    if (ox >= p.nx) return;
+    const double nw = raw_reflect(p, oy - 1, ox - 1), n = raw_reflect(p, oy - 1, ox),
+                 ne = raw_reflect(p, oy - 1, ox + 1);
+    const double w = raw_reflect(p, oy, ox - 1), e = raw_reflect(p, oy, ox + 1);
+    const double sw = raw_reflect(p, oy + 1, ox - 1), s = raw_reflect(p, oy + 1, ox),
+                 se = raw_reflect(p, oy + 1, ox + 1);
+    // float32 taps 1/8, 2/8 are exact; accumulate in double, round once
+    const float dx = (float)(0.125 * (ne - nw) + 0.25 * (e - w) + 0.125 * (se - sw));
+    const float dy = (float)(0.125 * (sw - nw) + 0.25 * (s - n) + 0.125 * (se - ne));
+    if (FINISH) {
+        finish_gradient(p, oy, ox, dx, dy);
+    } else {
+        const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
+        if (p.dx) p.dx[o] = dx;
+        if (p.dy) p.dy[o] = dy;
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------
+int upload_weights(int slot, double sigma, int tb, const float** d_w, int* radius) {
+    const int R = gaussian_radius(sigma);
+    std::vector<double> w(2 * R + 1);
+    double sum = 0.0;
+    for (int k = -R; k <= R; ++k) {
+        w[k + R] = std::exp(-0.5 / (sigma * sigma) * (double)k * (double)k);
+        sum += w[k + R];
+    }
+    std::vector<float> padded(2 * R + 1 + 2 * (tb - 1), 0.0f);
+    for (int k = 0; k <= 2 * R; ++k) padded[k + tb - 1] = (float)(w[k] / sum);
+    void* d = nullptr;
+    TOPO_TRY(upload_table(slot, padded.data(), padded.size() * sizeof(float), &d));
+    *d_w = (const float*)d;
+    *radius = R;
+    return TOPO_AMD_OK;
+}
+
+int pick_tb(int radius) { return radius >= 32 ? 16 : 4; }
+
+int run_axis0(const Block& b, double sigma, float* out, int table_slot) {
+    Context& c = ctx();
+    const int tb = pick_tb(gaussian_radius(sigma));
+    GaussArgs a;
+    TOPO_TRY(upload_weights(table_slot, sigma, tb, &a.wpad, &a.radius));
+    a.in = b.in;
+    a.out = out;
+    a.in_rows = b.in_rows;
+    a.in_row0 = b.in_row0;
+    a.gny = b.gny;
+    a.nx = b.nx;
+    a.out_row0 = b.out_row0;
+    a.out_rows = b.out_rows;
+    dim3 grid((b.nx + kThreads - 1) / kThreads, (b.out_rows + tb - 1) / tb);
+    if (tb == 16) hipLaunchKernelGGL(gauss_axis0_kernel<16>, grid, dim3(kThreads), 0, c.compute, a);
+    else hipLaunchKernelGGL(gauss_axis0_kernel<4>, grid, dim3(kThreads), 0, c.compute, a);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+// `in` holds exactly the rows [out_row0, out_row0 + out_rows) starting at in_row0 == out_row0
+int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int table_slot) {
+    Context& c = ctx();
+    int tb = pick_tb(gaussian_radius(sigma));
+    GaussArgs a;
+    TOPO_TRY(upload_weights(table_slot, sigma, tb, &a.wpad, &a.radius));
+    a.in = in;
+    a.out = out;
+    a.in_rows = rows;
+    a.in_row0 = 0;
+    a.gny = rows;
+    a.nx = nx;
+    a.out_row0 = 0;
+    a.out_rows = rows;
+    const int tc = 4 * tb;
+    const int cols_l = tc + 2 * a.radius;
+    const size_t lds_in = (size_t)64 * (cols_l | 1) * sizeof(float);
+    const size_t lds_out = (size_t)64 * (tc + 1) * sizeof(float);
+    const size_t lds = lds_in > lds_out ? lds_in : lds_out;
+    if (lds > 160 * 1024) {
+        set_error("gaussian: sigma %.3f (radius %d) needs %zu B of LDS per tile; the "
+                  "large-sigma path is not built yet", sigma, a.radius, lds);
+        return TOPO_AMD_EUNSUP;
+    }
+    dim3 grid((nx + tc - 1) / tc, (rows + 63) / 64);
+    if (tb == 16) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_kernel<16>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gauss_axis1_kernel<16>, grid, dim3(kThreads), lds, c.compute, a);
+    } else {
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_kernel<4>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gauss_axis1_kernel<4>, grid, dim3(kThreads), lds, c.compute, a);
+    }
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+// Full 2-D smooth of rows [row0, row0+rows) into `out`; ws_slot names the scratch plane.
+int smooth_rows(const Block& src, double sigma_y, double sigma_x, int row0, int rows, float* out,
+                int ws_slot, int table_slot) {
+    Context& c = ctx();
+    const bool do_y = sigma_y > 1e-15, do_x = sigma_x > 1e-15;
+    Block b = src;
+    b.out_row0 = row0;
+    b.out_rows = rows;
+    const size_t bytes = (size_t)rows * src.nx * sizeof(float);
+    if (do_y && do_x) {
+        void* tmp = nullptr;
+        TOPO_TRY(workspace(ws_slot, bytes, &tmp));
+        TOPO_TRY(run_axis0(b, sigma_y, (float*)tmp, table_slot));
+        TOPO_TRY(run_axis1((const float*)tmp, rows, src.nx, sigma_x, out, table_slot + 1));
+    } else if (do_y) {
+        TOPO_TRY(run_axis0(b, sigma_y, out, table_slot));
+    } else if (do_x) {
+        const float* first = src.in + (size_t)(row0 - src.in_row0) * src.nx;
+        TOPO_TRY(run_axis1(first, rows, src.nx, sigma_x, out, table_slot + 1));
+    } else {
+        const float* first = src.in + (size_t)(row0 - src.in_row0) * src.nx;
+        TOPO_HIP(hipMemcpyAsync(out, first, bytes, hipMemcpyDeviceToDevice, c.compute));
+    }
+    return TOPO_AMD_OK;
+}
+
+int upload_resolution(int res_mode, const void* res_x, const void* res_y, int nx, int gny,
+                      const float** dx, const float** dy) {
+    if (res_mode == TOPO_AMD_RES_2D) {
+        *dx = (const float*)res_x;
+        *dy = (const float*)res_y;
+        return TOPO_AMD_OK;
+    }
+    const int n_x = res_mode == TOPO_AMD_RES_SCALAR ? 1 : nx;
+    const int n_y = res_mode == TOPO_AMD_RES_SCALAR ? 1 : gny;
+    std::vector<float> fx(n_x), fy(n_y);
+    const double* hx = (const double*)res_x;
+    const double* hy = (const double*)res_y;
+    for (int i = 0; i < n_x; ++i) fx[i] = (float)hx[i];
+    for (int i = 0; i < n_y; ++i) fy[i] = (float)hy[i];
+    void *d0 = nullptr, *d1 = nullptr;
+    TOPO_TRY(upload_table(4, fx.data(), fx.size() * sizeof(float), &d0));
+    TOPO_TRY(upload_table(5, fy.data(), fy.size() * sizeof(float), &d1));
+    *dx = (const float*)d0;
+    *dy = (const float*)d1;
+    return TOPO_AMD_OK;
+}
+
+}  // namespace
+
+int gaussian_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
+
+int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out) {
+    return smooth_rows(b, sigma_y, sigma_x, b.out_row0, b.out_rows, out, 0, 1);
+}
+
+int launch_sobel(const Block& b, float* dx_out, float* dy_out) {
+    Context& c = ctx();
+    GradArgs g{};
+    g.raw = b.in;
+    g.raw_rows = b.in_rows;
+    g.raw_row0 = b.in_row0;
+    g.gny = b.gny;
+    g.nx = b.nx;
+    g.out_row0 = b.out_row0;
+    g.out_rows = b.out_rows;
+    g.dx = dx_out;
+    g.dy = dy_out;
+    dim3 grid((b.nx + kThreads - 1) / kThreads, b.out_rows);
+    hipLaunchKernelGGL(sobel_kernel<false>, grid, dim3(kThreads), 0, c.compute, g);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode,
+                    const void* res_x, const void* res_y, float* dx, float* dy, float* slope,
+                    float* aspect) {
+    Context& c = ctx();
+    TOPO_REQUIRE(res_mode >= 0 && res_mode <= 2, "gradient: bad res_mode %d", res_mode);
+    TOPO_REQUIRE(res_x && res_y, "gradient: resolution arrays are NULL");
+    GradArgs g{};
+    TOPO_TRY(upload_resolution(res_mode, res_x, res_y, b.nx, b.gny, &g.res_x, &g.res_y));
+    g.res_mode = res_mode;
+    g.gny = b.gny;
+    g.nx = b.nx;
+    g.out_row0 = b.out_row0;
+    g.out_rows = b.out_rows;
+    g.dx = dx;
+    g.dy = dy;
+    g.slope = slope;
+    g.aspect = aspect;
+    dim3 grid((b.nx + kThreads - 1) / kThreads, b.out_rows);
+    if (sigma <= 1.0) {  // topo.py:628-629
+        g.raw = b.in;
+        g.raw_rows = b.in_rows;
+        g.raw_row0 = b.in_row0;
+        hipLaunchKernelGGL(sobel_kernel<true>, grid, dim3(kThreads), 0, c.compute, g);
+        TOPO_HIP(hipGetLastError());
+        return TOPO_AMD_OK;
+    }
+    TOPO_REQUIRE(b.gny >= 2 && b.nx >= 2,
+                 "gradient: numpy.gradient needs at least 2 samples per axis (got %d x %d)",
+                 b.gny, b.nx);
+    // smoothed rows needed: the output rows plus one neighbour row inside the DEM
+    const int s0 = b.out_row0 > 0 ? b.out_row0 - 1 : 0;
+    const int s1 = (b.out_row0 + b.out_rows + 1 < b.gny) ? b.out_row0 + b.out_rows + 1 : b.gny;
+    const int s_rows = s1 - s0;
+    const size_t bytes = (size_t)s_rows * b.nx * sizeof(float);
+    void *plane_a = nullptr, *plane_b = nullptr;
+    TOPO_TRY(workspace(1, bytes, &plane_a));
+    if (sig_ratio == 1.0) {  // topo.py:630-631
+        TOPO_TRY(smooth_rows(b, sigma, sigma, s0, s_rows, (float*)plane_a, 0, 1));
+        plane_b = plane_a;
+    } else {  // topo.py:633-635
+        const double perp = sigma * sig_ratio;
+        TOPO_TRY(workspace(2, bytes, &plane_b));
+        TOPO_TRY(smooth_rows(b, perp, sigma, s0, s_rows, (float*)plane_a, 0, 1));
+        TOPO_TRY(smooth_rows(b, sigma, perp, s0, s_rows, (float*)plane_b, 0, 1));
+    }
+    g.gx_src = (const float*)plane_a;
+    g.gy_src = (const float*)plane_b;
+    g.s_row0 = s0;
+    g.s_rows = s_rows;
+    hipLaunchKernelGGL(gradient_epilogue_kernel, grid, dim3(kThreads), 0, c.compute, g);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+}  // namespace topo

@@ -1,0 +1,146 @@
+"""Device-resident DEM blocks: upload once, run many descriptors, download what you need.
+
+Thin Python over the ``*_dev`` entry points of the C ABI (include/topo_amd.h).  This is what
+``bench.py`` times (inputs already in HBM) and what the batch wrappers of the reference
+(``compute_tpi`` ... topo.py:88-141) would use to keep the DEM on the GPU across scales.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceArray:
+    """rows x nx float32 plane in HBM owned by libtopo_amd."""
+
+    def __init__(self, rows, nx):
+        self.rows, self.nx = int(rows), int(nx)
+        self.nbytes = self.rows * self.nx * 4
+        p = C.c_void_p()
+        _lib.check(_lib.lib().topo_amd_malloc(C.byref(p), self.nbytes), "topo_amd_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, array):
+        a = _lib.as_f32(array)
+        d = cls(a.shape[0], a.shape[1])
+        _lib.check(_lib.lib().topo_amd_memcpy_h2d(d.ptr, _lib.ptr(a), d.nbytes), "memcpy_h2d")
+        return d
+
+    def row_ptr(self, row):
+        return self.ptr + int(row) * self.nx * 4
+
+    def to_host(self, row0=0, rows=None):
+        rows = self.rows - row0 if rows is None else rows
+        out = np.empty((rows, self.nx), dtype=np.float32)
+        _lib.check(_lib.lib().topo_amd_memcpy_d2h(_lib.ptr(out), self.row_ptr(row0), out.nbytes),
+                   "memcpy_d2h")
+        return out
+
+    def upload_rows(self, array, row0=0):
+        a = _lib.as_f32(array)
+        _lib.check(_lib.lib().topo_amd_memcpy_h2d(self.row_ptr(row0), _lib.ptr(a), a.nbytes),
+                   "memcpy_h2d")
+
+    def free(self):
+        if self.ptr:
+            _lib.check(_lib.lib().topo_amd_free(self.ptr), "topo_amd_free")
+            self.ptr = None
+
+    def __del__(self):  # best effort
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def sync():
+    _lib.check(_lib.lib().topo_amd_sync(), "topo_amd_sync")
+
+
+def timer_start():
+    _lib.check(_lib.lib().topo_amd_timer_start(), "timer_start")
+
+
+def timer_stop():
+    ms = C.c_float()
+    _lib.check(_lib.lib().topo_amd_timer_stop(C.byref(ms)), "timer_stop")
+    return ms.value
+
+
+def synth_dem(rows, nx, row0=0, seed=0, out=None, out_row=0):
+    """Fill (part of) a DeviceArray with the deterministic synthetic terrain."""
+    d = out if out is not None else DeviceArray(rows, nx)
+    _lib.check(_lib.lib().topo_amd_synth_dem_dev(d.row_ptr(out_row), rows, row0, nx, seed),
+               "synth_dem")
+    return d
+
+
+class Block:
+    """A device plane seen as rows [row0, row0+rows) of a global gny x nx DEM."""
+
+    def __init__(self, data, row0=0, gny=None, first_buffer_row=0, rows=None):
+        self.data = data
+        self.first = first_buffer_row
+        self.rows = data.rows - first_buffer_row if rows is None else rows
+        self.row0 = row0
+        self.gny = self.rows if gny is None else gny
+        self.nx = data.nx
+
+    def _head(self):
+        return (self.data.row_ptr(self.first), self.rows, self.row0, self.gny, self.nx)
+
+    def _range(self, out_row0, out_rows):
+        o0 = self.row0 if out_row0 is None else out_row0
+        on = (self.row0 + self.rows - o0) if out_rows is None else out_rows
+        return o0, on
+
+    def tpi_std(self, size, tpi=None, std=None, out_row0=None, out_rows=None):
+        o0, on = self._range(out_row0, out_rows)
+        _lib.check(_lib.lib().topo_amd_tpi_std_dev(*self._head(), int(size), o0, on,
+                                                   tpi.ptr if tpi else None,
+                                                   std.ptr if std else None), "tpi_std_dev")
+
+    def gaussian(self, sigma_y, sigma_x, out, out_row0=None, out_rows=None):
+        o0, on = self._range(out_row0, out_rows)
+        _lib.check(_lib.lib().topo_amd_gaussian_dev(*self._head(), float(sigma_y), float(sigma_x),
+                                                    o0, on, out.ptr), "gaussian_dev")
+
+    def gradient(self, sigma, res_x, res_y, sig_ratio=1.0, dx=None, dy=None, slope=None,
+                 aspect=None, out_row0=None, out_rows=None):
+        o0, on = self._range(out_row0, out_rows)
+        rx = np.ascontiguousarray(res_x, dtype=np.float64)
+        ry = np.ascontiguousarray(res_y, dtype=np.float64)
+        mode = _lib.RES_SCALAR if rx.size == 1 and ry.size == 1 else _lib.RES_1D
+        if mode == _lib.RES_1D:
+            assert rx.size == self.nx and ry.size == self.gny
+        p = [a.ptr if a else None for a in (dx, dy, slope, aspect)]
+        _lib.check(_lib.lib().topo_amd_gradient_dev(*self._head(), float(sigma), float(sig_ratio),
+                                                    mode, _lib.ptr(rx), _lib.ptr(ry), o0, on, *p),
+                   "gradient_dev")
+
+    def sx(self, dj, di, dist, window, height, out, out_row0=None, out_rows=None):
+        o0, on = self._range(out_row0, out_rows)
+        dj = np.ascontiguousarray(dj, dtype=np.int32)
+        di = np.ascontiguousarray(di, dtype=np.int32)
+        dist = np.ascontiguousarray(dist, dtype=np.float64)
+        _lib.check(_lib.lib().topo_amd_sx_dev(*self._head(), dj.ctypes.data_as(_lib._i32p),
+                                              di.ctypes.data_as(_lib._i32p),
+                                              dist.ctypes.data_as(_lib._f64p), dist.size, int(window),
+                                              float(height), o0, on, out.ptr), "sx_dev")
+
+
+def sx_offsets(azimuth, radius, dx, dy, azimuth_arc=10.0, azimuth_steps=15, radius_min=0.0):
+    """(window, dj, di, dist) for the C ABI from Sx parameters and mean grid spacing."""
+    from . import topo  # noqa: PLC0415
+    if azimuth_arc == 0:
+        azimuth_steps = 1
+    az = np.linspace(azimuth - azimuth_arc / 2, azimuth + azimuth_arc / 2, azimuth_steps)
+    wd = topo._sx_distance(radius, dx, dy)
+    wd[wd < radius_min] = np.nan
+    centre = np.floor(np.array(wd.shape) / 2)
+    src = (centre + topo._sx_source_idx_delta(az, radius, dx, dy)).astype(int)
+    lines = topo._sx_bresenhamlines(src, centre).astype(np.int64)
+    window = int(wd.shape[0] / 2)
+    return window, lines[:, 0] - window, lines[:, 1] - window, wd[lines[:, 0], lines[:, 1]]

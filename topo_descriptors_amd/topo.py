@@ -1,0 +1,253 @@
+"""``topo.*`` descriptor functions with the reference's signatures, on MI355X.
+
+Same names, argument meaning, return types and errors as the reference's
+``topo_descriptors/topo.py`` (tpi :145, std :273, dem :62, circular_kernel :191, gradient :598,
+sobel :658, sx :776 and its geometry helpers :861-925).  The per-pixel arithmetic runs in
+hand-written HIP kernels behind the C ABI of ``libtopo_amd.so``; this module only prepares
+parameters, hands over C-contiguous float32 buffers and wraps the results.
+"""
+import logging
+
+import numpy as np
+
+from . import _lib, helpers as hlp
+
+logger = logging.getLogger(__name__)
+
+
+# ---- small utilities ------------------------------------------------------------------------
+def _unwrap(dem):
+    """ndarray view of an ndarray or DataArray-like input, plus a re-wrapper."""
+    if isinstance(dem, np.ndarray):
+        return dem, lambda out: out
+    if hasattr(dem, "values") and hasattr(dem, "copy"):
+        def rewrap(out, src=dem):
+            try:
+                return src.copy(data=out)
+            except TypeError:
+                return out
+        return np.asarray(dem.values), rewrap
+    return np.asarray(dem), lambda out: out
+
+
+def _check_2d(a, who):
+    if a.ndim != 2 or a.shape[0] < 1 or a.shape[1] < 1:
+        raise ValueError(f"{who}: expected a non-empty 2-D array, got shape {a.shape}")
+
+
+def _sigma_arg(sigma):
+    return float(sigma) if sigma else 0.0
+
+
+# ---- disc kernel, TPI, STD ---------------------------------------------------------------------
+def circular_kernel(size):
+    """0/1 float32 disc of diameter ``size``; a full square below 5 (reference topo.py:191)."""
+    size = int(size)
+    mask = np.empty((size, size), dtype=np.float32)
+    if size == 0:
+        return mask
+    lib = _lib.load()  # pure host geometry: no GPU needed
+    _lib.check(lib.topo_amd_disc_mask(size, mask.ctypes.data_as(_lib._f32p)), "topo_amd_disc_mask")
+    return mask
+
+
+def tpi(dem, size, sigma=None):
+    """Topographic position index: elevation minus the mean of the disc neighbourhood of
+    diameter ``size`` pixels, centre excluded; optional Gaussian pre-smoothing ``sigma``
+    (reference topo.py:145-181).  float32 in, float32 out; DataArray in, DataArray out."""
+    values, rewrap = _unwrap(dem)
+    _check_2d(values, "tpi")
+    src = _lib.as_f32(values)
+    out = np.empty_like(src)
+    lib = _lib.lib()
+    _lib.check(lib.topo_amd_tpi_f32(_lib.ptr(src), src.shape[0], src.shape[1], int(size),
+                                    _sigma_arg(sigma), _lib.ptr(out)), "topo_amd_tpi_f32")
+    return rewrap(out)
+
+
+def std(dem, size, sigma=None):
+    """Sample standard deviation inside the disc window, with the reference's int32
+    truncation of the squared term (reference topo.py:273-307).  Returns float64."""
+    values, _ = _unwrap(dem)
+    _check_2d(values, "std")
+    src = _lib.as_f32(values)
+    out = np.empty_like(src)
+    lib = _lib.lib()
+    _lib.check(lib.topo_amd_std_f32(_lib.ptr(src), src.shape[0], src.shape[1], int(size),
+                                    _sigma_arg(sigma), _lib.ptr(out)), "topo_amd_std_f32")
+    return out.astype(np.float64)
+
+
+def tpi_std(dem, size, sigma=None):
+    """TPI and STD of the same window in one pass over the DEM (no reference counterpart:
+    the reference convolves three times for the pair)."""
+    values, _ = _unwrap(dem)
+    _check_2d(values, "tpi_std")
+    src = _lib.as_f32(values)
+    t = np.empty_like(src)
+    s = np.empty_like(src)
+    lib = _lib.lib()
+    _lib.check(lib.topo_amd_tpi_std_f32(_lib.ptr(src), src.shape[0], src.shape[1], int(size),
+                                        _sigma_arg(sigma), _lib.ptr(t), _lib.ptr(s)),
+               "topo_amd_tpi_std_f32")
+    return t, s.astype(np.float64)
+
+
+# ---- Gaussian, Sobel, gradient ------------------------------------------------------------------
+def dem(dem, sigma):
+    """Gaussian-smoothed DEM, reflect boundary, 4-sigma truncation (reference topo.py:62-80).
+    ``sigma`` may be a scalar or an (axis0, axis1) pair."""
+    values, rewrap = _unwrap(dem)
+    _check_2d(values, "dem")
+    sig = np.broadcast_to(np.asarray(sigma, dtype=np.float64), (2,))
+    src = _lib.as_f32(values)
+    out = np.empty_like(src)
+    lib = _lib.lib()
+    _lib.check(lib.topo_amd_gauss_f32(_lib.ptr(src), src.shape[0], src.shape[1], float(sig[0]),
+                                      float(sig[1]), _lib.ptr(out)), "topo_amd_gauss_f32")
+    return rewrap(out)
+
+
+def sobel(dem):
+    """Sobel derivative pair (dx, dy), kernel / 8, reflect boundary (reference topo.py:658-685)."""
+    values, _ = _unwrap(dem)
+    _check_2d(values, "sobel")
+    src = _lib.as_f32(values)
+    dx = np.empty_like(src)
+    dy = np.empty_like(src)
+    lib = _lib.lib()
+    _lib.check(lib.topo_amd_sobel_f32(_lib.ptr(src), src.shape[0], src.shape[1], _lib.ptr(dx),
+                                      _lib.ptr(dy)), "topo_amd_sobel_f32")
+    return dx, dy
+
+
+def _resolution_args(res_meters, shape):
+    """(mode, x array, y array) for the C ABI from the reference's res_meters dict."""
+    rx = np.asarray(res_meters["x"], dtype=np.float64)
+    ry = np.asarray(res_meters["y"], dtype=np.float64)
+    ny, nx = shape
+    if rx.ndim == 0 and ry.ndim == 0:
+        return _lib.RES_SCALAR, np.ascontiguousarray(rx.reshape(1)), np.ascontiguousarray(ry.reshape(1))
+    if rx.ndim <= 1 and ry.ndim <= 1:
+        rx = np.ascontiguousarray(np.broadcast_to(rx, (nx,)))
+        ry = np.ascontiguousarray(np.broadcast_to(ry, (ny,)))
+        return _lib.RES_1D, rx, ry
+    # per-pixel resolutions (WGS84 grids): y may still be a column vector
+    if ry.ndim == 1:
+        ry = ry[:, None]
+    rx = np.ascontiguousarray(np.broadcast_to(rx, shape), dtype=np.float32)
+    ry = np.ascontiguousarray(np.broadcast_to(ry, shape), dtype=np.float32)
+    return _lib.RES_2D, rx, ry
+
+
+def gradient(dem, sigma, res_meters, sig_ratio=1):
+    """[dx, dy, slope, aspect] of the Gaussian-smoothed DEM (reference topo.py:598-644).
+
+    ``sigma <= 1`` uses the Sobel pair; ``sig_ratio != 1`` smooths with ``sigma*sig_ratio``
+    perpendicular to each derivative.  Derivatives are divided by the signed grid
+    resolution ``res_meters`` (second return of :func:`helpers.scale_to_pixel`); slope in
+    degrees; aspect in [0, 360) with north-facing = 0 and east-facing = 90."""
+    values, _ = _unwrap(dem)
+    _check_2d(values, "gradient")
+    src = _lib.as_f32(values)
+    mode, rx, ry = _resolution_args(res_meters, src.shape)
+    outs = [np.empty_like(src) for _ in range(4)]
+    lib = _lib.lib()
+    _lib.check(lib.topo_amd_gradient_f32(_lib.ptr(src), src.shape[0], src.shape[1], float(sigma),
+                                         float(sig_ratio), mode, _lib.ptr(rx), _lib.ptr(ry),
+                                         *[_lib.ptr(o) for o in outs]), "topo_amd_gradient_f32")
+    return outs
+
+
+# ---- Sx ---------------------------------------------------------------------------------------------
+def _sx_distance(radius, dx, dy):
+    """Distance in metres from the centre of the Sx search window to each of its cells
+    (reference topo.py:861-878).  The window has ceil(2*radius_px + 1) cells per side."""
+    radius_px = max(radius / np.abs(dy), radius / np.abs(dx))
+    side = 2 * radius_px + 1
+    mid = np.floor(side / 2)
+    steps = np.arange(side) - mid
+    return np.hypot((steps * dy)[:, None], (steps * dx)[None, :])
+
+
+def _sx_source_idx_delta(azimuths, radius, dx, dy):
+    """(row, col) index offsets of the ray origins at distance ``radius`` in the directions
+    ``azimuths`` (degrees); resolutions are signed (reference topo.py:881-892)."""
+    rad = np.deg2rad(np.asarray(azimuths, dtype=np.float64))
+    out = np.empty((rad.size, 2), dtype=np.int64)
+    out[:, 0] = np.rint(radius / dy * np.cos(rad))
+    out[:, 1] = np.rint(radius / dx * np.sin(rad))
+    return out
+
+
+def _sx_bresenhamlines(start, end):
+    """Pixels on the straight lines from each ``start`` towards ``end``, both excluded
+    (reference topo.py:895-925): unit steps along each ray's dominant axis, half-to-even
+    rounding, cut where the L1 distance to ``end`` stops shrinking."""
+    start = np.asarray(start)
+    end = np.asarray(end)
+    span = end - start                                   # (n_rays, 2)
+    major = np.abs(span).max(axis=1)                     # steps needed per ray
+    n_steps = int(major.max()) if major.size else 0
+    safe = np.where(major == 0, 1, major).astype(np.float64)
+    direction = np.where((major == 0)[:, None], 0.0, span / safe[:, None])
+    t = np.arange(1, n_steps + 1, dtype=np.float64)
+    pts = np.rint(start[:, None, :] + direction[:, None, :] * t[None, :, None]).astype(start.dtype)
+    l1 = np.abs(pts - end).sum(axis=2)                   # (n_rays, n_steps)
+    shrinking = np.ones_like(l1, dtype=bool)
+    shrinking[:, 1:] = l1[:, 1:] <= l1[:, :-1]
+    keep = shrinking & (l1 != 0)
+    return pts[keep]
+
+
+def _sx_rolling(dem, distance, blines, height):
+    """Max elevation angle (degrees) over the ray pixels for every DEM pixel; a frame of
+    ``int(W/2)`` pixels stays 0 (reference topo.py:928-953).  Runs as kernel K6."""
+    dem = np.asarray(dem)
+    _check_2d(dem, "_sx_rolling")
+    window = int(distance.shape[0] / 2)
+    blines = np.asarray(blines, dtype=np.int64).reshape(-1, 2)
+    dist = np.ascontiguousarray(distance[blines[:, 0], blines[:, 1]], dtype=np.float64)
+    dj = np.ascontiguousarray(blines[:, 0] - window, dtype=np.int32)
+    di = np.ascontiguousarray(blines[:, 1] - window, dtype=np.int32)
+    src = _lib.as_f32(dem)
+    out = np.zeros_like(src)
+    ny, nx = src.shape
+    if ny <= 2 * window or nx <= 2 * window:
+        return out.astype(dem.dtype, copy=False)
+    if dist.size == 0 or np.all(np.isnan(dist)):
+        # nanmax over an empty / all-NaN set: NaN inside the frame, like numpy
+        out[window : ny - window, window : nx - window] = np.nan
+        return out.astype(dem.dtype, copy=False)
+    lib = _lib.lib()
+    _lib.check(lib.topo_amd_sx_f32(_lib.ptr(src), ny, nx, dj.ctypes.data_as(_lib._i32p),
+                                   di.ctypes.data_as(_lib._i32p), dist.ctypes.data_as(_lib._f64p),
+                                   int(dist.size), window, float(height), _lib.ptr(out)),
+               "topo_amd_sx_f32")
+    return out.astype(dem.dtype, copy=False)
+
+
+def sx(dem_ds, azimuth, radius, height=10.0, azimuth_arc=10.0, azimuth_steps=15, radius_min=0.0):
+    """Sx (Winstral et al.): maximum slope towards the terrain within ``radius`` metres in a
+    sector of ``azimuth_arc`` degrees around ``azimuth`` (reference topo.py:776-858).
+
+    ``dem_ds`` must be a Dataset (TypeError otherwise, like the reference); the mean signed
+    grid spacing is used; pixels closer than ``radius_min`` are ignored; ``height`` is the
+    instrument height added to the target pixel."""
+    if not hlp._looks_like_dataset(dem_ds):
+        raise TypeError("Argument 'dem_ds' must be a xr.Dataset.")
+    if azimuth_arc == 0:
+        azimuth_steps = 1
+    azimuths = np.linspace(azimuth - azimuth_arc / 2, azimuth + azimuth_arc / 2, azimuth_steps)
+
+    _, res_meters = hlp.scale_to_pixel(radius, dem_ds)
+    dx = res_meters["x"].mean()
+    dy = res_meters["y"].mean()
+
+    window_distance = _sx_distance(radius, dx, dy)
+    window_distance[window_distance < radius_min] = np.nan
+
+    window_center = np.floor(np.array(window_distance.shape) / 2)
+    source = (window_center + _sx_source_idx_delta(azimuths, radius, dx, dy)).astype(int)
+    lines_indices = _sx_bresenhamlines(source, window_center)
+    return _sx_rolling(hlp.get_da(dem_ds).values, window_distance, lines_indices, height)
