@@ -38,7 +38,8 @@ struct DiscArgs {
     int taps;
 };
 
-enum Pass { kPassA = 0, kPassU2 = 1, kPassF = 2 };
+enum Pass { kPassA = 0, kPassU = 1, kPassU2 = 2, kPassF = 3, kPassT2 = 4 };
+enum Flags { kFlagFrac = 1, kFlagBad = 2 };
 
 __device__ __forceinline__ float load_padded(const DiscArgs& p, int gy, int gx) {
     // zero padding outside the global DEM; rows outside the block only feed unused outputs
@@ -47,46 +48,63 @@ __device__ __forceinline__ float load_padded(const DiscArgs& p, int gy, int gx) 
     return p.in[(size_t)by * p.nx + gx];
 }
 
+// What one staging pass writes to LDS for a DEM sample v (c is an integer-valued offset):
+//   A   float  v - c                      U   int32  trunc(v) - c
+//   U2  uint32 (trunc(v) - c)^2           F   float  v - trunc(v)
+//   T2  float  (trunc(v) - c)^2           (float fallback of U2)
 template <int PASS>
-__device__ __forceinline__ float transform(float v, float c) {
-    if (PASS == kPassA) return v - c;
+__device__ __forceinline__ uint32_t transform(float v, float c, int ci) {
+    if (PASS == kPassA) return __float_as_uint(v - c);
     const float t = truncf(v);
-    if (PASS == kPassU2) {
+    if (PASS == kPassF) return __float_as_uint(v - t);
+    if (PASS == kPassT2) {
         const float u = t - c;
-        return u * u;
+        return __float_as_uint(u * u);
     }
-    return v - t;
+    const int u = (int)t - ci;
+    if (PASS == kPassU) return (uint32_t)u;
+    return (uint32_t)u * (uint32_t)u;
 }
 
-// Stage one transformed tile and turn every LDS row into an exclusive-start prefix sum:
-// L[r][0] = 0, L[r][k] = sum of the first k staged values of row r.
-// Returns (block-wide) whether any staged elevation had a fractional part.
-template <int PASS>
-__device__ bool stage_and_scan(const DiscArgs& p, float* L, int stride, int rows_l, int cols_v,
-                               int gy0, int gx0, float c) {
+// Stage one transformed tile and turn every LDS row into a prefix sum in place:
+// L[r][0] = 0, L[r][k] = sum of the first k staged values of row r (T = float or integer).
+// Returns block-wide flags: fractional elevations present / samples the exact integer
+// pipeline cannot take (non-finite, or |trunc(v) - c| > ulim).
+template <int PASS, typename T>
+__device__ int stage_and_scan(const DiscArgs& p, uint32_t* L, int stride, int rows_l, int cols_v,
+                              int gy0, int gx0, float c, int ci, float ulim) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    bool frac = false;
+    int flags = 0;
     for (int r = wave; r < rows_l; r += kThreads / 64) {
         const int gy = gy0 + r;
-        float* row = L + r * stride + 1;
+        uint32_t* row = L + r * stride + 1;
         for (int k = lane; k < cols_v; k += 64) {
             const float v = load_padded(p, gy, gx0 + k);
-            if (PASS == kPassU2) frac |= (v != truncf(v));
-            row[k] = transform<PASS>(v, c);
+            if (PASS == kPassU) {
+                const float t = truncf(v);
+                if (v != t) flags |= kFlagFrac;
+                if (!(fabsf(t - c) <= ulim)) flags |= kFlagBad;  // also catches NaN / inf
+            }
+            row[k] = transform<PASS>(v, c, ci);
         }
     }
-    const bool any_frac = __syncthreads_or(frac);
+    int all = 0;
+    if (PASS == kPassU) {
+        all = __syncthreads_or(flags);
+    } else {
+        __syncthreads();
+    }
     for (int r = threadIdx.x; r < rows_l; r += kThreads) {
-        float* row = L + r * stride;
-        float run = 0.0f;
-        row[0] = 0.0f;
+        T* row = reinterpret_cast<T*>(L + r * stride);
+        T run = (T)0;
+        row[0] = (T)0;
         int k = 1;
         for (; k + 3 <= cols_v; k += 4) {
-            const float v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3];
-            const float s0 = run + v0;
-            const float s1 = s0 + v1;
-            const float s2 = s1 + v2;
+            const T v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3];
+            const T s0 = run + v0;
+            const T s1 = s0 + v1;
+            const T s2 = s1 + v2;
             run = s2 + v3;
             row[k] = s0;
             row[k + 1] = s1;
@@ -99,30 +117,38 @@ __device__ bool stage_and_scan(const DiscArgs& p, float* L, int stride, int rows
         }
     }
     __syncthreads();
-    return any_frac;
+    return all;
 }
 
-template <int NOUT>
-__device__ __forceinline__ void gather(const DiscArgs& p, const float* L, int stride, int col,
-                                       int row_first, float (&acc)[NOUT]) {
+// One prefix difference per disc row; ACC is the accumulator type (float, int32, uint64).
+template <int NOUT, typename T, typename ACC>
+__device__ __forceinline__ void gather(const DiscArgs& p, const uint32_t* L, int stride, int col,
+                                       int row_first, ACC (&acc)[NOUT]) {
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) acc[k] = 0.0f;
+    for (int k = 0; k < NOUT; ++k) acc[k] = (ACC)0;
     for (int d = 0; d < p.n_disc_rows; ++d) {
         const int packed = p.runs[d];  // wave-uniform: scalar load
         const int lo = packed & 0xffff;
         const int hi = packed >> 16;
-        const float* base = L + (row_first + d) * stride + col;
+        const T* base = reinterpret_cast<const T*>(L) + (row_first + d) * stride + col;
 #pragma unroll
         for (int k = 0; k < NOUT; ++k) {
-            const float* rowp = base + (2 * k) * stride;
-            acc[k] += rowp[hi + 1] - rowp[lo];
+            const T* rowp = base + (2 * k) * stride;
+            acc[k] += (ACC)(T)(rowp[hi + 1] - rowp[lo]);
         }
     }
 }
 
+// value of one staged sample recovered from the prefix row: P[k+1] - P[k]
+template <typename T>
+__device__ __forceinline__ T sample(const uint32_t* L, int idx) {
+    const T* q = reinterpret_cast<const T*>(L) + idx;
+    return (T)(q[1] - q[0]);
+}
+
 template <bool WANT_TPI, bool WANT_STD, int TILE_H>
 __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float L[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t L[];
     constexpr int NOUT = TILE_H / 2;  // 256 threads = 128 columns x 2 row phases
 
     const int cols_v = kTileW + p.halo_cols;       // staged values per LDS row
@@ -139,38 +165,85 @@ __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
     cy = min(max(cy, p.in_row0), p.in_row0 + p.in_rows - 1);
     const int cx = min(ox0 + kTileW / 2, p.nx - 1);
     float c = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
-    if (!(fabsf(c) < 1e30f)) c = 0.0f;  // NaN/inf centre: fall back to no offset
+    if (!(fabsf(c) < 1.0e9f)) c = 0.0f;  // NaN/inf/huge centre: no offset
+    const int ci = (int)c;
 
     const int col = threadIdx.x & (kTileW - 1);
     const int phase = threadIdx.x >> 7;
+    // indices (without the per-output row term) of the pixel itself and of the zeroed tap
+    const int self_idx = (phase - p.dj_min) * stride + col - p.di_min;
+    const int ctr_idx = (phase + p.centre_dj - p.dj_min) * stride + col + p.centre_di - p.di_min;
 
-    float sum_a[NOUT], sum_u2[NOUT], sum_f[NOUT];
-    float self_a[NOUT], ctr_a[NOUT];
+    // per-output sums in float64 at the end: s1 = sum (x - c), s2 = sum (trunc(x) - c)^2,
+    // sf = sum frac(x); self / ctr = (x - c) of the pixel and of the zeroed tap
+    double s1[NOUT], s2[NOUT], sf[NOUT], self_a[NOUT], ctr_a[NOUT];
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) s1[k] = s2[k] = sf[k] = self_a[k] = ctr_a[k] = 0.0;
 
-    stage_and_scan<kPassA>(p, L, stride, rows_l, cols_v, gy0, gx0, c);
-    gather<NOUT>(p, L, stride, col, phase, sum_a);
-    if (WANT_TPI) {
-        // a(j,i) itself and the zeroed tap, recovered from the prefix rows
-        const int self_r = -p.dj_min, self_c = col - p.di_min;
-        const int ctr_r = p.centre_dj - p.dj_min, ctr_c = col + p.centre_di - p.di_min;
+    // Exact pipeline first: integer prefix sums cannot round.  ulim keeps one row-window sum
+    // of u^2 below 2^32 so the wrap-around uint32 prefix differences stay exact.  Tiles with
+    // non-finite or out-of-range samples take the float32 pipeline instead (NaN propagates);
+    // TPI alone also takes it for fractional DEMs (one pass, not cancellation-sensitive).
+    const float ulim = fminf(46000.0f, floorf(sqrtf(4294967295.0f / (float)(p.halo_cols + 1))));
+    int flags = stage_and_scan<kPassU, int>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim);
+    bool use_float = (flags & kFlagBad) != 0 || (!WANT_STD && (flags & kFlagFrac) != 0);
+    if (!use_float) {
+        int su[NOUT];
+        gather<NOUT, int, int>(p, L, stride, col, phase, su);
 #pragma unroll
         for (int k = 0; k < NOUT; ++k) {
-            const float* rs = L + (phase + 2 * k + self_r) * stride + self_c;
-            self_a[k] = rs[1] - rs[0];
-            const float* rc = L + (phase + 2 * k + ctr_r) * stride + ctr_c;
-            ctr_a[k] = rc[1] - rc[0];
+            s1[k] = (double)su[k];
+            if (WANT_TPI) {
+                self_a[k] = (double)sample<int>(L, self_idx + 2 * k * stride);
+                ctr_a[k] = (double)sample<int>(L, ctr_idx + 2 * k * stride);
+            }
+        }
+        if (WANT_STD) {
+            __syncthreads();
+            stage_and_scan<kPassU2, uint32_t>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim);
+            unsigned long long q[NOUT];
+            gather<NOUT, uint32_t, unsigned long long>(p, L, stride, col, phase, q);
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) s2[k] = (double)q[k];
         }
     }
-    bool any_frac = false;
-    if (WANT_STD) {
-        __syncthreads();
-        // the fractional-part sum only matters when the tile holds non-integer elevations
-        any_frac = stage_and_scan<kPassU2>(p, L, stride, rows_l, cols_v, gy0, gx0, c);
-        gather<NOUT>(p, L, stride, col, phase, sum_u2);
-        if (any_frac) {
+    __syncthreads();
+    if (use_float) {
+        float fa[NOUT];
+        stage_and_scan<kPassA, float>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, 0.0f);
+        gather<NOUT, float, float>(p, L, stride, col, phase, fa);
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            s1[k] = (double)fa[k];
+            if (WANT_TPI) {
+                self_a[k] = (double)sample<float>(L, self_idx + 2 * k * stride);
+                ctr_a[k] = (double)sample<float>(L, ctr_idx + 2 * k * stride);
+            }
+        }
+        if (WANT_STD) {
             __syncthreads();
-            stage_and_scan<kPassF>(p, L, stride, rows_l, cols_v, gy0, gx0, c);
-            gather<NOUT>(p, L, stride, col, phase, sum_f);
+            stage_and_scan<kPassT2, float>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, 0.0f);
+            gather<NOUT, float, float>(p, L, stride, col, phase, fa);
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) s2[k] = (double)fa[k];
+            __syncthreads();
+        }
+    }
+    if (WANT_STD && (flags & kFlagFrac)) {
+        // fractional parts: small positive floats, their float32 prefix sums are harmless
+        float ff[NOUT];
+        stage_and_scan<kPassF, float>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, 0.0f);
+        gather<NOUT, float, float>(p, L, stride, col, phase, ff);
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            sf[k] = (double)ff[k];
+            if (!use_float) {  // the integer pass left the fractional parts out of s1
+                s1[k] += sf[k];
+                if (WANT_TPI) {
+                    self_a[k] += (double)sample<float>(L, self_idx + 2 * k * stride);
+                    ctr_a[k] += (double)sample<float>(L, ctr_idx + 2 * k * stride);
+                }
+            }
         }
     }
 
@@ -183,15 +256,11 @@ __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
         if (oy >= p.out_row0 + p.out_rows) continue;
         const size_t o = (size_t)(oy - p.out_row0) * p.nx + gx;
         if (WANT_TPI) {
-            // division kept in float64: (n-1) may be 0 for size 1 -> non-finite like the reference
-            const double mean_excl = ((double)sum_a[k] - (double)ctr_a[k]) / (n - 1.0);
-            p.tpi[o] = (float)((double)self_a[k] - mean_excl);
+            // (n-1) may be 0 for size 1 -> non-finite like the reference
+            p.tpi[o] = (float)(self_a[k] - (s1[k] - ctr_a[k]) / (n - 1.0));
         }
         if (WANT_STD) {
-            const double s1 = (double)sum_a[k];
-            double num = (double)sum_u2[k] - s1 * s1 / n;
-            if (any_frac) num -= 2.0 * (double)c * (double)sum_f[k];
-            double var = num / (n - 1.0);
+            double var = (s2[k] - s1[k] * s1[k] / n - 2.0 * (double)c * sf[k]) / (n - 1.0);
             if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
             p.sd[o] = (float)sqrt(var);
         }
