@@ -1,0 +1,367 @@
+// K1/K2 fast path: disc sums by column runs + wavefront shift-accumulate, specialised per size.
+//
+// S(j, i) = sum over column offsets di of C(j, i + di),   C(j, c) = Q(j + hi(di) + 1, c) - Q(j + lo(di), c)
+//
+// where Q is the prefix sum down the columns of the staged tile and [lo(di), hi(di)] the
+// vertical run of the disc at column offset di.  Lanes own NC = 4 adjacent columns, so one
+// ds_read_b128 fetches a prefix row for all of them; the C values of the ~21 distinct runs of
+// a 67-px disc sit in registers, and the sum over di is a chain of adds in which the partial
+// sums hop one lane per step with a DPP wave shift (v_add_*_dpp wave_shl:1) - no LDS traffic
+// and no shuffles for the 67 taps of the chain.  Per output pixel that is ~21 subtractions and
+// ~67 additions instead of 134 LDS reads (row-prefix gather) or 3409 taps (direct).
+//
+// The kernel is instantiated per disc size (every run is a compile-time constant, which is
+// what keeps the C values in statically indexed registers); sizes without an instantiation
+// use the generic LDS kernel in disc.hip.
+#include "common.hpp"
+#include "disc_runs.hpp"
+
+#include <cstdlib>
+
+namespace topo {
+
+namespace {
+
+constexpr int NC = 4;          // columns per lane
+constexpr int ROWW = 64 * NC;  // staged columns per tile row (one wave-row, 1 KiB)
+
+constexpr int cdiv_floor(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+constexpr int cdiv_ceil(int a, int b) { return -cdiv_floor(-a, b); }
+
+template <int SIZE>
+struct Geo {
+    static constexpr DiscTable<SIZE> T = make_disc_table<SIZE>();
+    static constexpr int D_LO = cdiv_ceil(T.off_min - (NC - 1), NC);   // lane offsets spanned
+    static constexpr int D_HI = cdiv_floor(T.off_max + (NC - 1), NC);
+    static constexpr int NVL = 64 - (D_HI - D_LO);   // lanes that end up with a full sum
+    static constexpr int TILE_W = NC * NVL;          // valid output columns per tile
+    static constexpr int X0 = -D_LO * NC;            // staged column of the first valid output
+    static_assert(NVL >= 8, "disc too wide for one wavefront of 4-column lanes");
+};
+
+struct WaveArgs {
+    const float* in;
+    float* tpi;
+    float* sd;
+    int in_rows, in_row0, gny, nx;
+    int out_row0, out_rows;
+    int debug;  // ablation switches, honoured only in -DTOPO_AMD_ABLATE profiling builds
+};
+
+#ifdef TOPO_AMD_ABLATE
+#define ABLATE(p, bit) ((p).debug & (bit))
+#else
+#define ABLATE(p, bit) false
+#endif
+
+template <typename T>
+struct alignas(16) Vec4 {
+    T v[4];
+};
+
+#define DPP_WAVE_SHL1 0x130  // lane i takes lane i + 1; lane 63 takes 0 (bound_ctrl)
+
+__device__ __forceinline__ float hop(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_WAVE_SHL1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int hop(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, DPP_WAVE_SHL1, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t hop(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_SHL1, 0xf, 0xf, true);
+}
+
+// Disc sums of output row jj (tile-relative) for the NC output columns that end up in this
+// lane: lane l receives the sums of staged columns NC * (l - D_LO) + t, valid for l < NVL.
+template <int SIZE, typename T>
+__device__ __forceinline__ void wave_disc_sum(const T* Q, int jj, int lane, T (&acc)[NC]) {
+    using G = Geo<SIZE>;
+    constexpr int NR = G::T.num_runs;
+    T cv[NR][NC];
+    const T* col = Q + lane * NC;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const Vec4<T> top = *reinterpret_cast<const Vec4<T>*>(col + (jj + G::T.run_hi[r] - G::T.off_min + 1) * ROWW);
+        const Vec4<T> bot = *reinterpret_cast<const Vec4<T>*>(col + (jj + G::T.run_lo[r] - G::T.off_min) * ROWW);
+#pragma unroll
+        for (int s = 0; s < NC; ++s) cv[r][s] = top.v[s] - bot.v[s];
+    }
+#pragma unroll
+    for (int D = G::D_HI; D >= G::D_LO; --D) {
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+            // contributions of this lane's NC columns to output sub-column t: a short tree,
+            // independent of the hop chain, so the chain itself is one dependent add per step
+            T part = (T)0;
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < NC; ++s) {
+                const int di = NC * D + s - t;
+                if (di >= G::T.off_min && di <= G::T.off_max) {
+                    const T c = cv[G::T.run_of[di - G::T.off_min]][s];
+                    part = any ? part + c : c;
+                    any = true;
+                }
+            }
+            if (D == G::D_HI) {
+                acc[t] = part;  // nothing to move before the first step
+            } else if (any) {
+                acc[t] = hop(acc[t]) + part;
+            } else {
+                acc[t] = hop(acc[t]);
+            }
+        }
+    }
+}
+
+// One 16-byte row piece of the DEM, zero outside the global DEM (mode="same" padding).
+// nx % 4 == 0 and gx % 4 == 0, so a float4 is entirely inside or entirely outside.  The load is
+// unconditional (clamped address) so that all row loads of a tile can be in flight together.
+__device__ __forceinline__ bool row4_inside(const WaveArgs& p, int gy, int gx) {
+    const int by = gy - p.in_row0;
+    return gy >= 0 && gy < p.gny && gx >= 0 && gx < p.nx && by >= 0 && by < p.in_rows;
+}
+__device__ __forceinline__ Vec4<float> load_row4(const WaveArgs& p, int gy, int gx) {
+    const bool ok = row4_inside(p, gy, gx);
+    const size_t idx = ok ? (size_t)(gy - p.in_row0) * p.nx + gx : 0;
+    return *reinterpret_cast<const Vec4<float>*>(p.in + idx);
+}
+
+// ---- TPI alone: one float32 chain on a = x - c --------------------------------------------------
+// c is integer-valued, so on integer-valued DEMs every partial sum is an integer below 2^24 and
+// the float32 arithmetic is exact; on fractional DEMs it rounds at the 1e-5 m level after the
+// division by n-1.
+//
+// Persistent blocks: each block walks over tiles (vertical neighbours first, XCD-contiguous so
+// that the ghost rows two tiles share meet in one L2), and the DEM rows of the next tile are
+// already in flight to registers while the current tile is being summed.
+template <int SIZE, int TH, int NWAVES, bool PREFETCH>
+__global__ __launch_bounds__(NWAVES * 64) void disc_wave_tpi_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+    using G = Geo<SIZE>;
+    constexpr int NROWS = TH + SIZE - 1;              // staged DEM rows
+    constexpr int SL = (NROWS + NWAVES - 1) / NWAVES;  // rows per wave in the staging phase
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Q = lds;                          // (NROWS + 1) x ROWW column prefix sums
+    float* TOT = lds + (NROWS + 1) * ROWW;   // NWAVES x ROWW segment totals
+    // border tiles only: per output row, prefix over the column offsets di of the number of
+    // in-domain rows of the disc run at di (what the padded convolution really sums over)
+    unsigned short* PL = reinterpret_cast<unsigned short*>(TOT + NWAVES * ROWW);  // TH x (SIZE + 1)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = tiles_x * tiles_y;
+    // blocks are dealt round-robin over the 8 XCDs: give each XCD a contiguous run of tiles
+    const int nb = gridDim.x;
+    const int per_xcd = nb >> 3;
+    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+
+    const int out_lane = lane - G::D_LO;  // lane whose columns this lane's sums belong to
+    // 1/(n-1): inf for size 1 -> non-finite results, like the reference's division by zero
+    const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
+
+    auto tile_origin = [&](int tile, int& ox0, int& oy0) {
+        ox0 = (tile / tiles_y) * G::TILE_W;
+        oy0 = p.out_row0 + (tile % tiles_y) * TH;
+    };
+    auto centre_index = [&](int ox0, int oy0) -> size_t {
+        int cy = min(max(oy0 + TH / 2, 0), p.gny - 1);
+        cy = min(max(cy, p.in_row0), p.in_row0 + p.in_rows - 1);
+        const int cx = min(ox0 + G::TILE_W / 2, p.nx - 1);
+        return (size_t)(cy - p.in_row0) * p.nx + cx;
+    };
+
+    Vec4<float> v[SL];
+    float craw;
+    int tile = vb;
+    if (tile < ntiles) {
+        int ox0, oy0;
+        tile_origin(tile, ox0, oy0);
+        craw = p.in[centre_index(ox0, oy0)];
+#pragma unroll
+        for (int k = 0; k < SL; ++k)
+            v[k] = load_row4(p, oy0 + G::T.off_min + wave * SL + k, ox0 - G::X0 + lane * NC);
+    }
+    for (; tile < ntiles; tile += nb) {
+        int ox0, oy0;
+        tile_origin(tile, ox0, oy0);
+        const int gx = ox0 - G::X0 + lane * NC;
+        const int gy0 = oy0 + G::T.off_min;
+        // integer offset near the local elevation
+        float c = truncf(craw);
+        if (!(fabsf(c) < 1.0e9f)) c = 0.0f;
+        // tiles whose halo leaves the DEM: padded taps are staged as a = 0 and the number of
+        // in-domain taps is counted per pixel instead (exact, no -c bulk in the sums)
+        const bool border = !ABLATE(p, 4) && (gy0 < 0 || gy0 + NROWS > p.gny || ox0 - G::X0 < 0 || ox0 - G::X0 + ROWW > p.nx);
+
+        // ---- phase 1: column prefix sums, each wave scans a segment of rows ------------------
+        if (!ABLATE(p, 2)) {
+            Vec4<float> run{{0.f, 0.f, 0.f, 0.f}};
+            if (wave == 0) *reinterpret_cast<Vec4<float>*>(Q + lane * NC) = run;
+#pragma unroll
+            for (int k = 0; k < SL; ++k) {
+                const int r = wave * SL + k;
+                if (r < NROWS) {
+                    const bool ok = row4_inside(p, gy0 + r, gx);
+#pragma unroll
+                    for (int s = 0; s < NC; ++s) run.v[s] += ok ? v[k].v[s] - c : (border ? 0.0f : -c);
+                    *reinterpret_cast<Vec4<float>*>(Q + (r + 1) * ROWW + lane * NC) = run;
+                }
+            }
+            *reinterpret_cast<Vec4<float>*>(TOT + wave * ROWW + lane * NC) = run;
+        }
+        // the rows of the next tile start their trip now and land during phase 2
+        if (PREFETCH && tile + nb < ntiles && !ABLATE(p, 8)) {
+            int nx0, ny0;
+            tile_origin(tile + nb, nx0, ny0);
+            craw = p.in[centre_index(nx0, ny0)];
+#pragma unroll
+            for (int k = 0; k < SL; ++k)
+                v[k] = load_row4(p, ny0 + G::T.off_min + wave * SL + k, nx0 - G::X0 + lane * NC);
+        }
+        if (!ABLATE(p, 2)) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes done, loads stay in flight
+            __builtin_amdgcn_s_barrier();
+            if (border && threadIdx.x < TH) {
+                const int oy = oy0 + (int)threadIdx.x;
+                unsigned short* row = PL + threadIdx.x * (SIZE + 1);
+                int run = 0;
+                row[0] = 0;
+#pragma unroll 1
+                for (int k = 0; k < SIZE; ++k) {
+                    const int top = max(oy + G::T.lo[k], 0);
+                    const int bot = min(oy + G::T.hi[k], p.gny - 1);
+                    run += max(bot - top + 1, 0);
+                    row[k + 1] = (unsigned short)run;
+                }
+            }
+            if (wave > 0) {
+                Vec4<float> off{{0.f, 0.f, 0.f, 0.f}};
+                for (int w = 0; w < wave; ++w) {
+                    const Vec4<float> t = *reinterpret_cast<const Vec4<float>*>(TOT + w * ROWW + lane * NC);
+#pragma unroll
+                    for (int s = 0; s < NC; ++s) off.v[s] += t.v[s];
+                }
+#pragma unroll
+                for (int k = 0; k < SL; ++k) {
+                    const int r = wave * SL + k;
+                    if (r < NROWS) {
+                        Vec4<float>* q = reinterpret_cast<Vec4<float>*>(Q + (r + 1) * ROWW + lane * NC);
+                        Vec4<float> x = *q;
+#pragma unroll
+                        for (int s = 0; s < NC; ++s) x.v[s] += off.v[s];
+                        *q = x;
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+        }
+
+        // ---- phase 2: each wave takes every NWAVES-th output row --------------------------------
+        const int ocol = ox0 + lane * NC;  // global column of acc[0] (lane < NVL)
+        const bool lane_ok = lane < G::NVL && ocol < p.nx;
+#pragma unroll 1
+        for (int jj = wave; jj < TH; jj += NWAVES) {
+            float acc[NC];
+            if (ABLATE(p, 1)) {
+                acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+            } else {
+                wave_disc_sum<SIZE, float>(Q, jj, lane, acc);
+            }
+            const int oy = oy0 + jj;
+            if (lane_ok && oy < p.out_row0 + p.out_rows) {
+                // the pixel itself and the zeroed tap, recovered from the prefix rows
+                const float* selfp = Q + (jj - G::T.off_min) * ROWW + out_lane * NC;
+                const Vec4<float> s1 = *reinterpret_cast<const Vec4<float>*>(selfp + ROWW);
+                const Vec4<float> s0 = *reinterpret_cast<const Vec4<float>*>(selfp);
+                Vec4<float> res;
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    const float self = s1.v[t] - s0.v[t];
+                    float ctr = self;
+                    if (G::T.centre != 0) {
+                        const float* cp = Q + (jj + G::T.centre - G::T.off_min) * ROWW + out_lane * NC + t + G::T.centre;
+                        ctr = cp[ROWW] - cp[0];
+                    }
+                    if (!border) {
+                        res.v[t] = (float)((double)self - (double)(acc[t] - ctr) * inv_nm1);
+                    } else {
+                        // sum over in-domain taps of x = acc + c m; the zeroed tap contributes
+                        // x_ctr only when it lies inside the DEM
+                        // in-domain taps: column offsets [d_lo, d_hi] keep ox + di inside the DEM
+                        const int d_lo = max(G::T.off_min, -(ocol + t));
+                        const int d_hi = min(G::T.off_max, p.nx - 1 - (ocol + t));
+                        const unsigned short* pl = PL + jj * (SIZE + 1) - G::T.off_min;
+                        const int m = d_hi >= d_lo ? (int)pl[d_hi + 1] - (int)pl[d_lo] : 0;
+                        const int cy2 = oy + G::T.centre, cx2 = ocol + t + G::T.centre;
+                        const bool ctr_in = cy2 >= 0 && cy2 < p.gny && cx2 >= 0 && cx2 < p.nx;
+                        const double x_ctr = ctr_in ? (double)ctr + (double)c : 0.0;
+                        const double total = (double)acc[t] + (double)c * (double)m;
+                        res.v[t] = (float)((double)self + (double)c - (total - x_ctr) * inv_nm1);
+                    }
+                }
+                *reinterpret_cast<Vec4<float>*>(p.tpi + (size_t)(oy - p.out_row0) * p.nx + ocol) = res;
+            }
+        }
+        if (!PREFETCH && tile + nb < ntiles) {
+            int nx0, ny0;
+            tile_origin(tile + nb, nx0, ny0);
+            craw = p.in[centre_index(nx0, ny0)];
+#pragma unroll
+            for (int k = 0; k < SL; ++k)
+                v[k] = load_row4(p, ny0 + G::T.off_min + wave * SL + k, nx0 - G::X0 + lane * NC);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();  // every wave is done reading Q before it is overwritten
+    }
+}
+
+template <int SIZE, int TH, int NWAVES, bool PREFETCH>
+int launch_wave_tpi(const Block& b, float* tpi_out) {
+    using G = Geo<SIZE>;
+    Context& c = ctx();
+    static const int debug = getenv("TOPO_AMD_DEBUG") ? atoi(getenv("TOPO_AMD_DEBUG")) : 0;
+    WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows, debug};
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(float) + (size_t)TH * (SIZE + 1) * sizeof(unsigned short);
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    static_assert(SIZE * SIZE < 65536, "tap counts must fit the 16-bit border table");
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)disc_wave_tpi_kernel<SIZE, TH, NWAVES, PREFETCH>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int n = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &n, (const void*)disc_wave_tpi_kernel<SIZE, TH, NWAVES, PREFETCH>, NWAVES * 64, lds));
+        blocks_per_cu = n < 1 ? 1 : n;
+    }
+    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
+    const int tiles_y = (b.out_rows + TH - 1) / TH;
+    const long ntiles = (long)tiles_x * tiles_y;
+    long grid = (long)c.num_cu * blocks_per_cu;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((disc_wave_tpi_kernel<SIZE, TH, NWAVES, PREFETCH>), dim3((unsigned)grid), dim3(NWAVES * 64),
+                       lds, c.compute, a, tiles_x, tiles_y);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+}  // namespace
+
+// Returns TOPO_AMD_EUNSUP when no specialisation covers the request (caller falls back to the
+// generic kernel): needs nx % 4 == 0 for the 16-byte row accesses.
+int launch_tpi_wave(const Block& b, int size, float* tpi_out) {
+    // 12 waves x 5 rows per tile measured best on MI355X (8 x 8: +9 %, 16 x 4 without the
+    // register prefetch: +70 %)
+    constexpr int WAVES = 12;
+    if (b.nx % 4 != 0 || (reinterpret_cast<uintptr_t>(b.in) & 15) || (reinterpret_cast<uintptr_t>(tpi_out) & 15))
+        return TOPO_AMD_EUNSUP;
+    switch (size) {
+        case 67: return launch_wave_tpi<67, 60, WAVES, true>(b, tpi_out);
+        case 65: return launch_wave_tpi<65, 60, WAVES, true>(b, tpi_out);
+        case 17: return launch_wave_tpi<17, 60, WAVES, true>(b, tpi_out);
+        case 7: return launch_wave_tpi<7, 60, WAVES, true>(b, tpi_out);
+        default: return TOPO_AMD_EUNSUP;
+    }
+}
+
+}  // namespace topo
