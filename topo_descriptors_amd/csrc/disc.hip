@@ -336,8 +336,9 @@ int build_disc(int size, DiscRuns* out) {
 int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out) {
     TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
     Context& c = ctx();
-    if (tpi_out && !std_out) {
-        const int r = launch_tpi_wave(b, disc.size, tpi_out);
+    {
+        const int r = std_out ? launch_std_wave(b, disc.size, tpi_out, std_out)
+                              : launch_tpi_wave(b, disc.size, tpi_out);
         if (r != TOPO_AMD_EUNSUP) return r;
     }
     const int n_rows = disc.dj_max - disc.dj_min + 1;
