@@ -16,6 +16,8 @@
 // Out-of-domain taps read x = 0 (zero padding of mode="same"), n is always the full tap count.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace topo {
 
 namespace {
@@ -156,7 +158,9 @@ __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
     const int rows_l = TILE_H + p.n_disc_rows - 1;
 
     const int ox0 = blockIdx.x * kTileW;
-    const int oy0 = p.out_row0 + blockIdx.y * TILE_H;
+    // row tiles sit on GLOBAL multiples of TILE_H: a pixel is computed by the same instruction
+    // sequence whatever row block it is part of
+    const int oy0 = (p.out_row0 / TILE_H + (int)blockIdx.y) * TILE_H;
     const int gy0 = oy0 + p.dj_min;
     const int gx0 = ox0 + p.di_min;
 
@@ -174,19 +178,19 @@ __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
     const int self_idx = (phase - p.dj_min) * stride + col - p.di_min;
     const int ctr_idx = (phase + p.centre_dj - p.dj_min) * stride + col + p.centre_di - p.di_min;
 
-    // per-output sums in float64 at the end: s1 = sum (x - c), s2 = sum (trunc(x) - c)^2,
-    // sf = sum frac(x); self / ctr = (x - c) of the pixel and of the zeroed tap
-    double s1[NOUT], s2[NOUT], sf[NOUT], self_a[NOUT], ctr_a[NOUT];
+    // per-output sums in float64 at the end: s1 = sum (trunc(x) - c), s2 = sum (trunc(x) - c)^2,
+    // sf = sum frac(x); self_a / ctr_a = trunc(x) - c and self_f / ctr_f = frac(x) of the pixel
+    // and of the zeroed tap
+    double s1[NOUT], s2[NOUT], sf[NOUT], self_a[NOUT], ctr_a[NOUT], self_f[NOUT], ctr_f[NOUT];
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) s1[k] = s2[k] = sf[k] = self_a[k] = ctr_a[k] = 0.0;
+    for (int k = 0; k < NOUT; ++k) s1[k] = s2[k] = sf[k] = self_a[k] = ctr_a[k] = self_f[k] = ctr_f[k] = 0.0;
 
     // Exact pipeline first: integer prefix sums cannot round.  ulim keeps one row-window sum
     // of u^2 below 2^32 so the wrap-around uint32 prefix differences stay exact.  Tiles with
-    // non-finite or out-of-range samples take the float32 pipeline instead (NaN propagates);
-    // TPI alone also takes it for fractional DEMs (one pass, not cancellation-sensitive).
+    // non-finite or out-of-range samples take the float32 pipeline instead (NaN propagates).
     const float ulim = fminf(46000.0f, floorf(sqrtf(4294967295.0f / (float)(p.halo_cols + 1))));
     int flags = stage_and_scan<kPassU, int>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim);
-    bool use_float = (flags & kFlagBad) != 0 || (!WANT_STD && (flags & kFlagFrac) != 0);
+    bool use_float = (flags & kFlagBad) != 0;
     if (!use_float) {
         int su[NOUT];
         gather<NOUT, int, int>(p, L, stride, col, phase, su);
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
             __syncthreads();
         }
     }
-    if (WANT_STD && (flags & kFlagFrac)) {
+    if (flags & kFlagFrac) {
         // fractional parts: small positive floats, their float32 prefix sums are harmless
         float ff[NOUT];
         stage_and_scan<kPassF, float>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, 0.0f);
@@ -237,11 +241,13 @@ __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
 #pragma unroll
         for (int k = 0; k < NOUT; ++k) {
             sf[k] = (double)ff[k];
-            if (!use_float) {  // the integer pass left the fractional parts out of s1
-                s1[k] += sf[k];
-                if (WANT_TPI) {
-                    self_a[k] += (double)sample<float>(L, self_idx + 2 * k * stride);
-                    ctr_a[k] += (double)sample<float>(L, ctr_idx + 2 * k * stride);
+            if (use_float) s1[k] -= sf[k];  // keep s1 = sum of (trunc(x) - c) in both pipelines
+            if (WANT_TPI) {
+                self_f[k] = (double)sample<float>(L, self_idx + 2 * k * stride);
+                ctr_f[k] = (double)sample<float>(L, ctr_idx + 2 * k * stride);
+                if (use_float) {
+                    self_a[k] -= self_f[k];
+                    ctr_a[k] -= ctr_f[k];
                 }
             }
         }
@@ -253,14 +259,21 @@ __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) {
         const int oy = oy0 + phase + 2 * k;
-        if (oy >= p.out_row0 + p.out_rows) continue;
+        if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
         const size_t o = (size_t)(oy - p.out_row0) * p.nx + gx;
+        // With the padded taps staged as trunc = 0 (u = -c), s1 + n c is the exact integer sum of
+        // trunc(x) over the in-domain taps: the results do not depend on the tile's choice of c.
+        const double cd = (double)c;
+        const double sum_x = (s1[k] + cd * n) + sf[k];
         if (WANT_TPI) {
+            const double x_self = (self_a[k] + cd) + self_f[k];
+            const double x_ctr = (ctr_a[k] + cd) + ctr_f[k];
             // (n-1) may be 0 for size 1 -> non-finite like the reference
-            p.tpi[o] = (float)(self_a[k] - (s1[k] - ctr_a[k]) / (n - 1.0));
+            p.tpi[o] = (float)(x_self - (sum_x - x_ctr) / (n - 1.0));
         }
         if (WANT_STD) {
-            double var = (s2[k] - s1[k] * s1[k] / n - 2.0 * (double)c * sf[k]) / (n - 1.0);
+            const double sum_t2 = s2[k] + 2.0 * cd * s1[k] + cd * cd * n;
+            double var = (sum_t2 - sum_x * sum_x / n) / (n - 1.0);
             if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
             p.sd[o] = (float)sqrt(var);
         }
@@ -337,8 +350,10 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
     TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
     Context& c = ctx();
     {
-        const int r = std_out ? launch_std_wave(b, disc.size, tpi_out, std_out)
-                              : launch_tpi_wave(b, disc.size, tpi_out);
+        // TOPO_AMD_TPI_FLOAT=1 selects the float32-chain TPI kernel (profiling comparisons only)
+        static const bool float_tpi = getenv("TOPO_AMD_TPI_FLOAT") != nullptr;
+        const int r = (!std_out && float_tpi) ? launch_tpi_wave(b, disc.size, tpi_out)
+                                              : launch_std_wave(b, disc.size, tpi_out, std_out);
         if (r != TOPO_AMD_EUNSUP) return r;
     }
     const int n_rows = disc.dj_max - disc.dj_min + 1;
@@ -388,7 +403,8 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
     a.centre_di = disc.centre_di;
     a.taps = disc.taps;
 
-    dim3 grid((b.nx + kTileW - 1) / kTileW, (b.out_rows + tile_h - 1) / tile_h);
+    dim3 grid((b.nx + kTileW - 1) / kTileW,
+              (b.out_row0 + b.out_rows - 1) / tile_h - b.out_row0 / tile_h + 1);
     const size_t lds = lds_for(tile_h);
     const bool tpi = tpi_out != nullptr, sd = std_out != nullptr;
     switch (tile_h) {

@@ -169,9 +169,12 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_tpi_kernel(WaveArgs p, 
     // 1/(n-1): inf for size 1 -> non-finite results, like the reference's division by zero
     const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
 
+    // row tiles are aligned to GLOBAL multiples of TH so that a pixel is computed by the same
+    // instruction sequence whatever row block it belongs to
+    const int ty0 = p.out_row0 / TH;
     auto tile_origin = [&](int tile, int& ox0, int& oy0) {
         ox0 = (tile / tiles_y) * G::TILE_W;
-        oy0 = p.out_row0 + (tile % tiles_y) * TH;
+        oy0 = (ty0 + tile % tiles_y) * TH;
     };
     auto centre_index = [&](int ox0, int oy0) -> size_t {
         int cy = min(max(oy0 + TH / 2, 0), p.gny - 1);
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_tpi_kernel(WaveArgs p, 
                 wave_disc_sum<SIZE, float>(Q, jj, lane, acc);
             }
             const int oy = oy0 + jj;
-            if (lane_ok && oy < p.out_row0 + p.out_rows) {
+            if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) {
                 // the pixel itself and the zeroed tap, recovered from the prefix rows
                 const float* selfp = Q + (jj - G::T.off_min) * ROWW + out_lane * NC;
                 const Vec4<float> s1 = *reinterpret_cast<const Vec4<float>*>(selfp + ROWW);
@@ -345,7 +348,7 @@ int launch_wave_tpi(const Block& b, float* tpi_out) {
         blocks_per_cu = n < 1 ? 1 : n;
     }
     const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
-    const int tiles_y = (b.out_rows + TH - 1) / TH;
+    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
     const long ntiles = (long)tiles_x * tiles_y;
     long grid = (long)c.num_cu * blocks_per_cu;
     if (grid > ntiles) grid = ntiles;
@@ -447,7 +450,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     return all;
 }
 
-template <int SIZE, int TH, int NWAVES, bool WANT_TPI>
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
 __global__ __launch_bounds__(NWAVES * 64) void disc_wave_std_kernel(WaveArgs p, int tiles_x, int tiles_y) {
     using G = Geo<SIZE>;
     constexpr int NROWS = TH + SIZE - 1;
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_std_kernel(WaveArgs p, 
 
     for (int tile = vb; tile < ntiles; tile += nb) {
         const int ox0 = (tile / tiles_y) * G::TILE_W;
-        const int oy0 = p.out_row0 + (tile % tiles_y) * TH;
+        const int oy0 = (p.out_row0 / TH + tile % tiles_y) * TH;  // global multiples of TH
         const int gx = ox0 - G::X0 + lane * NC;
         const int gy0 = oy0 + G::T.off_min;
         int cy = min(max(oy0 + TH / 2, 0), p.gny - 1);
@@ -518,6 +521,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_std_kernel(WaveArgs p, 
                 const uint32_t bits[NC] = {(uint32_t)acc[0], (uint32_t)acc[1], (uint32_t)acc[2], (uint32_t)acc[3]};
                 put(0, wave + k * NWAVES, bits);
             }
+            if (WANT_STD) {
             __syncthreads();
             stage_prefix<SIZE, TH, NWAVES, kStU2, uint32_t>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
             if (!wide) {
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_std_kernel(WaveArgs p, 
                     put(2, wave + k * NWAVES, hi);
                 }
             }
+            }
         } else {
             __syncthreads();
             stage_prefix<SIZE, TH, NWAVES, kStA, float>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
@@ -548,6 +553,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_std_kernel(WaveArgs p, 
                                            __float_as_uint(acc[2]), __float_as_uint(acc[3])};
                 put(0, wave + k * NWAVES, bits);
             }
+            if (WANT_STD) {
             __syncthreads();
             stage_prefix<SIZE, TH, NWAVES, kStT2, float>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
 #pragma unroll 1
@@ -557,6 +563,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_std_kernel(WaveArgs p, 
                 const uint32_t bits[NC] = {__float_as_uint(acc[0]), __float_as_uint(acc[1]),
                                            __float_as_uint(acc[2]), __float_as_uint(acc[3])};
                 put(1, wave + k * NWAVES, bits);
+            }
             }
         }
         if (frac) {
@@ -579,12 +586,14 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_std_kernel(WaveArgs p, 
         for (int k = 0; k < RW; ++k) {
             const int jj = wave + k * NWAVES;
             const int oy = oy0 + jj;
-            if (!lane_ok || oy >= p.out_row0 + p.out_rows) continue;
+            if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
             Vec4<float> xs{{0.f, 0.f, 0.f, 0.f}};
             if (WANT_TPI) xs = *reinterpret_cast<const Vec4<float>*>(p.in + (size_t)(oy - p.in_row0) * p.nx + ocol);
-            const Vec4<uint32_t> q0 = get(0, jj), q1 = get(1, jj);
+            const Vec4<uint32_t> q0 = get(0, jj);
+            Vec4<uint32_t> q1{{0u, 0u, 0u, 0u}};
+            if (WANT_STD) q1 = get(1, jj);
             Vec4<uint32_t> q2{{0u, 0u, 0u, 0u}}, q3{{0u, 0u, 0u, 0u}};
-            if (wide && !use_float) q2 = get(2, jj);
+            if (WANT_STD && wide && !use_float) q2 = get(2, jj);
             if (frac) q3 = get(3, jj);
             Vec4<float> out_t, out_s;
 #pragma unroll
@@ -606,11 +615,15 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_std_kernel(WaveArgs p, 
                     su2 = (double)__uint_as_float(q1.v[t]);
                 }
                 const double cd = (double)c;
-                const double s1 = su + sf + cd * m;
-                const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
-                double var = (s2 - s1 * s1 / n) * inv_nm1;
-                if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
-                out_s.v[t] = (float)sqrt(var);
+                // su + c m is an exact integer (= sum of trunc(x)), so the result does not depend on
+                // which c the tile happened to use
+                const double s1 = (su + cd * m) + sf;
+                if (WANT_STD) {
+                    const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
+                    double var = (s2 - s1 * s1 / n) * inv_nm1;
+                    if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
+                    out_s.v[t] = (float)sqrt(var);
+                }
                 if (WANT_TPI) {
                     const int cy2 = oy + G::T.centre, cx2 = ocol + t + G::T.centre;
                     double x_ctr = (double)xs.v[t];
@@ -622,14 +635,14 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_std_kernel(WaveArgs p, 
                 }
             }
             const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
-            *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+            if (WANT_STD) *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
             if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
         }
         __syncthreads();  // Q and PL are rewritten by the next tile
     }
 }
 
-template <int SIZE, int TH, int NWAVES, bool WANT_TPI>
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
 int launch_wave_std(const Block& b, float* tpi_out, float* std_out) {
     using G = Geo<SIZE>;
     Context& c = ctx();
@@ -640,22 +653,22 @@ int launch_wave_std(const Block& b, float* tpi_out, float* std_out) {
     static_assert(SIZE * SIZE < 65536, "tap counts must fit the 16-bit border table");
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)disc_wave_std_kernel<SIZE, TH, NWAVES, WANT_TPI>,
+        TOPO_HIP(hipFuncSetAttribute((const void*)disc_wave_std_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nblk = 0;
         TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nblk, (const void*)disc_wave_std_kernel<SIZE, TH, NWAVES, WANT_TPI>, NWAVES * 64, lds));
+            &nblk, (const void*)disc_wave_std_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
     const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
-    const int tiles_y = (b.out_rows + TH - 1) / TH;
+    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
     const long ntiles = (long)tiles_x * tiles_y;
     long grid = (long)c.num_cu * blocks_per_cu;
     if (grid > ntiles) grid = ntiles;
     void* scratch = nullptr;
     TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
     a.scratch = (uint32_t*)scratch;
-    hipLaunchKernelGGL((disc_wave_std_kernel<SIZE, TH, NWAVES, WANT_TPI>), dim3((unsigned)grid),
+    hipLaunchKernelGGL((disc_wave_std_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>), dim3((unsigned)grid),
                        dim3(NWAVES * 64), lds, c.compute, a, tiles_x, tiles_y);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
@@ -663,8 +676,9 @@ int launch_wave_std(const Block& b, float* tpi_out, float* std_out) {
 
 template <int SIZE>
 int launch_wave_std_any(const Block& b, float* tpi_out, float* std_out) {
-    if (tpi_out) return launch_wave_std<SIZE, 64, 8, true>(b, tpi_out, std_out);
-    return launch_wave_std<SIZE, 64, 8, false>(b, tpi_out, std_out);
+    if (tpi_out && std_out) return launch_wave_std<SIZE, 64, 8, true, true>(b, tpi_out, std_out);
+    if (std_out) return launch_wave_std<SIZE, 64, 8, false, true>(b, tpi_out, std_out);
+    return launch_wave_std<SIZE, 64, 8, true, false>(b, tpi_out, std_out);
 }
 
 }  // namespace

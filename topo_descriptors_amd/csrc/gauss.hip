@@ -31,79 +31,119 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
 struct GaussArgs {
     const float* in;
     float* out;
-    const float* wpad;  // taps padded with TB-1 zeros on both sides
+    const float* taps;  // 2R+1 taps followed by zeros up to a multiple of the tap chunk
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
-    int radius;
+    int radius, nchunks;
+    int group0;  // axis 0: first row group (global numbering) that intersects the output rows
 };
 
+// Register tiling shared by both axes: a thread produces TB consecutive outputs along the
+// filter axis, out[t] = sum_k w[k] in[t + k].  The taps are walked in chunks of KB; a chunk needs
+// the TB + KB - 1 samples in[c KB ... c KB + TB + KB - 2], of which only KB are new, so per chunk
+// the thread fetches KB samples (all in flight together, one chunk ahead of the FMAs) and issues
+// TB x KB FMAs against KB wave-uniform taps (one scalar load per chunk).
+template <int TB, int KB, class Fetch>
+__device__ __forceinline__ void tap_chunks(const float* taps, int nchunks, float c, Fetch fetch,
+                                           float (&acc)[TB]) {
+    float win[TB + KB - 1];
+    float nxt[KB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) acc[t] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TB - 1; ++i) win[i] = fetch(i) - c;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) nxt[i] = fetch(TB - 1 + i);
+    for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+        for (int i = 0; i < KB; ++i) win[TB - 1 + i] = nxt[i] - c;
+        if (ch + 1 < nchunks) {
+#pragma unroll
+            for (int i = 0; i < KB; ++i) nxt[i] = fetch((ch + 1) * KB + TB - 1 + i);
+        }
+        const float* w = taps + ch * KB;  // wave-uniform
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            const float wk = w[kk];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) acc[t] = fmaf(wk, win[t + kk], acc[t]);
+        }
+#pragma unroll
+        for (int i = 0; i < TB - 1; ++i) win[i] = win[i + KB];
+    }
+}
+
 // ---- axis 0 (down the columns): lanes run along x, plain coalesced global loads ------------
-template <int TB>
+// Row groups are aligned to GLOBAL multiples of TB and the accumulation offset c is a sample of
+// the group itself, so an output pixel is computed by exactly the same instruction sequence
+// whatever row block it is part of (shards stay bit-identical to the single-block run).
+template <int TB, int KB>
 __global__ __launch_bounds__(kThreads) void gauss_axis0_kernel(GaussArgs p) {
     const int x = blockIdx.x * kThreads + threadIdx.x;
     if (x >= p.nx) return;
-    const int y0 = p.out_row0 + blockIdx.y * TB;
-    const int R = p.radius;
+    const int y0 = (p.group0 + (int)blockIdx.y) * TB;
+    const int first = y0 - p.radius;                       // global row of sample 0
+    const int last = first + TB - 1 + p.nchunks * KB - 1;  // last sample touched
+    const bool plain = first >= 0 && last < p.gny && first >= p.in_row0 && last < p.in_row0 + p.in_rows;
     const float* col = p.in + x;
-
+    auto fetch = [&](int i) -> float {
+        int gy = first + i;
+        if (!plain) {  // wave-uniform: reflect at the global edges, clamp into the block
+            gy = reflect_index(gy, p.gny);
+            gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
+        }
+        return col[(size_t)(gy - p.in_row0) * p.nx];
+    };
+    // the middle row of the group lies within `radius` rows of every row of the group, hence
+    // inside any block that computes part of it - provided radius >= TB/2 - 1; tiny filters
+    // accumulate without an offset (they have nothing to lose)
+    const float c = p.radius >= TB / 2 - 1 ? fetch(p.radius + TB / 2) : 0.0f;
     float acc[TB];
-#pragma unroll
-    for (int t = 0; t < TB; ++t) acc[t] = 0.0f;
-    const float c = col[(size_t)(reflect_index(min(y0, p.gny - 1), p.gny) - p.in_row0) * p.nx];
-
-    const int n_in = TB + 2 * R;
-    for (int r = 0; r < n_in; ++r) {
-        int gy = reflect_index(y0 - R + r, p.gny);
-        // rows past the block only feed outputs past out_rows (partial last tile)
-        int by = min(max(gy - p.in_row0, 0), p.in_rows - 1);
-        const float v = col[(size_t)by * p.nx] - c;
-        const float* w = p.wpad + r;  // wpad[r - t + TB - 1], t = 0..TB-1
-#pragma unroll
-        for (int t = 0; t < TB; ++t) acc[t] = fmaf(w[TB - 1 - t], v, acc[t]);
-    }
+    tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
         const int oy = y0 + t;
-        if (oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + x] = c + acc[t];
+        if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows)
+            p.out[(size_t)(oy - p.out_row0) * p.nx + x] = c + acc[t];
     }
 }
 
 // ---- axis 1 (along the rows): tile staged in LDS, lanes run along y ------------------------
-// block = 64 rows x (4 * TB) output columns; wave w owns TB consecutive columns of every row.
-template <int TB>
-__global__ __launch_bounds__(kThreads) void gauss_axis1_kernel(GaussArgs p) {
+// block = 64 rows x (NW * TB) output columns; wave w owns TB consecutive columns of every row.
+template <int TB, int KB, int NW>
+__global__ __launch_bounds__(NW * 64) void gauss_axis1_kernel(GaussArgs p) {
     extern __shared__ __attribute__((aligned(16))) float L[];
     constexpr int TR = 64;
-    constexpr int TC = 4 * TB;
+    constexpr int TC = NW * TB;
     const int R = p.radius;
-    const int cols_l = TC + 2 * R;
+    const int cols_l = TC + p.nchunks * KB - 1;  // samples a row of the tile can be asked for
     const int stride = cols_l | 1;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ox0 = blockIdx.x * TC;
     const int oy0 = blockIdx.y * TR;  // relative to out_row0; rows here need no halo
 
-    // stage: wave per row, lanes along x (coalesced), reflect at the left/right DEM edges
-    for (int r = wave; r < TR; r += kThreads / 64) {
+    // stage: wave per row, lanes along x (coalesced); tiles that reach past the left/right DEM
+    // edge reflect there, all others copy straight
+    const bool inner = ox0 - R >= 0 && ox0 - R + cols_l <= p.nx;
+    for (int r = wave; r < TR; r += NW) {
         const int row = min(oy0 + r, p.out_rows - 1);
         const float* src = p.in + (size_t)(row + p.out_row0 - p.in_row0) * p.nx;
         float* dst = L + r * stride;
-        for (int k = lane; k < cols_l; k += 64) dst[k] = src[reflect_index(ox0 - R + k, p.nx)];
+        if (inner) {
+            const float* s0 = src + (ox0 - R);
+            for (int k = lane; k < cols_l; k += 64) dst[k] = s0[k];
+        } else {
+            for (int k = lane; k < cols_l; k += 64) dst[k] = src[reflect_index(ox0 - R + k, p.nx)];
+        }
     }
     __syncthreads();
 
-    float acc[TB];
-#pragma unroll
-    for (int t = 0; t < TB; ++t) acc[t] = 0.0f;
     const float* rowp = L + lane * stride + wave * TB;
+    auto fetch = [&](int i) -> float { return rowp[i]; };
     const float c = rowp[R];
-    const int n_in = TB + 2 * R;
-    for (int r = 0; r < n_in; ++r) {
-        const float v = rowp[r] - c;
-        const float* w = p.wpad + r;
-#pragma unroll
-        for (int t = 0; t < TB; ++t) acc[t] = fmaf(w[TB - 1 - t], v, acc[t]);
-    }
+    float acc[TB];
+    tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
     __syncthreads();
     // transpose back through LDS so the stores are row-coalesced
     constexpr int ostride = TC + 1;
@@ -111,7 +151,7 @@ __global__ __launch_bounds__(kThreads) void gauss_axis1_kernel(GaussArgs p) {
 #pragma unroll
     for (int t = 0; t < TB; ++t) O[lane * ostride + wave * TB + t] = c + acc[t];
     __syncthreads();
-    for (int idx = threadIdx.x; idx < TR * TC; idx += kThreads) {
+    for (int idx = threadIdx.x; idx < TR * TC; idx += NW * 64) {
         const int r = idx / TC, k = idx % TC;
         const int oy = oy0 + r, ox = ox0 + k;
         if (oy < p.out_rows && ox < p.nx) p.out[(size_t)oy * p.nx + ox] = O[r * ostride + k];
@@ -211,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void sobel_kernel(GradArgs p) {
 }
 
 // ---- host side -----------------------------------------------------------------------------
-int upload_weights(int slot, double sigma, int tb, const float** d_w, int* radius) {
+int upload_weights(int slot, double sigma, int kb, GaussArgs* a) {
     const int R = gaussian_radius(sigma);
     std::vector<double> w(2 * R + 1);
     double sum = 0.0;
@@ -219,22 +259,25 @@ int upload_weights(int slot, double sigma, int tb, const float** d_w, int* radiu
         w[k + R] = std::exp(-0.5 / (sigma * sigma) * (double)k * (double)k);
         sum += w[k + R];
     }
-    std::vector<float> padded(2 * R + 1 + 2 * (tb - 1), 0.0f);
-    for (int k = 0; k <= 2 * R; ++k) padded[k + tb - 1] = (float)(w[k] / sum);
+    const int nchunks = (2 * R + 1 + kb - 1) / kb;
+    std::vector<float> padded((size_t)nchunks * kb, 0.0f);
+    for (int k = 0; k <= 2 * R; ++k) padded[k] = (float)(w[k] / sum);
     void* d = nullptr;
     TOPO_TRY(upload_table(slot, padded.data(), padded.size() * sizeof(float), &d));
-    *d_w = (const float*)d;
-    *radius = R;
+    a->taps = (const float*)d;
+    a->radius = R;
+    a->nchunks = nchunks;
     return TOPO_AMD_OK;
 }
 
-int pick_tb(int radius) { return radius >= 32 ? 16 : 4; }
+// wide tiling for long filters, narrow for short ones (fewer padded taps)
+bool wide_tiling(int radius) { return radius >= 24; }
 
 int run_axis0(const Block& b, double sigma, float* out, int table_slot) {
     Context& c = ctx();
-    const int tb = pick_tb(gaussian_radius(sigma));
+    const bool wide = wide_tiling(gaussian_radius(sigma));
     GaussArgs a;
-    TOPO_TRY(upload_weights(table_slot, sigma, tb, &a.wpad, &a.radius));
+    TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
     a.in = b.in;
     a.out = out;
     a.in_rows = b.in_rows;
@@ -243,29 +286,21 @@ int run_axis0(const Block& b, double sigma, float* out, int table_slot) {
     a.nx = b.nx;
     a.out_row0 = b.out_row0;
     a.out_rows = b.out_rows;
-    dim3 grid((b.nx + kThreads - 1) / kThreads, (b.out_rows + tb - 1) / tb);
-    if (tb == 16) hipLaunchKernelGGL(gauss_axis0_kernel<16>, grid, dim3(kThreads), 0, c.compute, a);
-    else hipLaunchKernelGGL(gauss_axis0_kernel<4>, grid, dim3(kThreads), 0, c.compute, a);
+    const int tb = wide ? 16 : 8;
+    a.group0 = b.out_row0 / tb;
+    const int groups = (b.out_row0 + b.out_rows - 1) / tb - a.group0 + 1;
+    dim3 grid((b.nx + kThreads - 1) / kThreads, groups);
+    if (wide) hipLaunchKernelGGL((gauss_axis0_kernel<16, 16>), grid, dim3(kThreads), 0, c.compute, a);
+    else hipLaunchKernelGGL((gauss_axis0_kernel<8, 8>), grid, dim3(kThreads), 0, c.compute, a);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
 
-// `in` holds exactly the rows [out_row0, out_row0 + out_rows) starting at in_row0 == out_row0
-int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int table_slot) {
+template <int TB, int KB, int NW>
+int launch_axis1(const GaussArgs& a, int rows, int nx, double sigma) {
     Context& c = ctx();
-    int tb = pick_tb(gaussian_radius(sigma));
-    GaussArgs a;
-    TOPO_TRY(upload_weights(table_slot, sigma, tb, &a.wpad, &a.radius));
-    a.in = in;
-    a.out = out;
-    a.in_rows = rows;
-    a.in_row0 = 0;
-    a.gny = rows;
-    a.nx = nx;
-    a.out_row0 = 0;
-    a.out_rows = rows;
-    const int tc = 4 * tb;
-    const int cols_l = tc + 2 * a.radius;
+    constexpr int tc = NW * TB;
+    const int cols_l = tc + a.nchunks * KB - 1;
     const size_t lds_in = (size_t)64 * (cols_l | 1) * sizeof(float);
     const size_t lds_out = (size_t)64 * (tc + 1) * sizeof(float);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
@@ -274,18 +309,30 @@ int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int t
                   "large-sigma path is not built yet", sigma, a.radius, lds);
         return TOPO_AMD_EUNSUP;
     }
+    TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_kernel<TB, KB, NW>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((nx + tc - 1) / tc, (rows + 63) / 64);
-    if (tb == 16) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_kernel<16>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(gauss_axis1_kernel<16>, grid, dim3(kThreads), lds, c.compute, a);
-    } else {
-        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_kernel<4>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(gauss_axis1_kernel<4>, grid, dim3(kThreads), lds, c.compute, a);
-    }
+    hipLaunchKernelGGL((gauss_axis1_kernel<TB, KB, NW>), grid, dim3(NW * 64), lds, c.compute, a);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
+}
+
+// `in` holds exactly the rows [out_row0, out_row0 + out_rows) starting at in_row0 == out_row0
+int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int table_slot) {
+    const bool wide = wide_tiling(gaussian_radius(sigma));
+    GaussArgs a;
+    TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
+    a.in = in;
+    a.out = out;
+    a.in_rows = rows;
+    a.in_row0 = 0;
+    a.gny = rows;
+    a.nx = nx;
+    a.out_row0 = 0;
+    a.out_rows = rows;
+    a.group0 = 0;
+    if (wide) return launch_axis1<16, 16, 8>(a, rows, nx, sigma);
+    return launch_axis1<8, 8, 8>(a, rows, nx, sigma);
 }
 
 // Full 2-D smooth of rows [row0, row0+rows) into `out`; ws_slot names the scratch plane.
