@@ -227,3 +227,42 @@ def test_config4_sx_16384():
     assert np.all(frame == 0)
     out.free()
     dev.free()
+
+
+WAVE_SIZES = [5, 7, 9, 11, 13, 17, 21, 33, 41, 51, 65, 67, 81, 101]
+
+
+@pytest.mark.parametrize("size", WAVE_SIZES + [3, 4, 8, 15, 19, 31, 99])
+def test_every_disc_size_against_exact(size):
+    """All wave-shift instantiations plus a few sizes that take the generic kernel."""
+    from topo_descriptors_amd import topo
+    for integer in (True, False):
+        dem = orc.synthetic_dem(230, 264, seed=size + 100 * integer, integer=integer)
+        t, s = topo.tpi_std(dem, size)
+        assert np.max(np.abs(t - orc.tpi_exact(dem, size))) <= 2.5e-4, (size, integer)
+        e = orc.std_exact(dem, size)
+        assert np.max(np.abs(s - e)) <= 1e-4 * np.max(e), (size, integer)
+        assert np.array_equal(topo.tpi(dem, size), t)
+        assert np.array_equal(topo.std(dem, size), s)
+
+
+def test_nodata_and_nan_tiles_do_not_wrap():
+    """-9999 nodata next to terrain exceeds the exact integer range of a tile: the float chains
+    take over (no silent wrap-around); NaN poisons only windows that contain it."""
+    from topo_descriptors_amd import topo
+    dem = orc.synthetic_dem(200, 256, seed=77)
+    dem[:, :40] = -9999.0
+    for size in (7, 67):
+        t, s = topo.tpi_std(dem, size)
+        assert np.max(np.abs(t - orc.tpi_exact(dem, size))) <= 0.05
+        e = orc.std_exact(dem, size)
+        assert np.max(np.abs(s - e)) <= 2e-3 * np.max(e)
+    dem = orc.synthetic_dem(200, 256, seed=78)
+    dem[100, 128] = np.nan
+    t = topo.tpi(dem, 7)
+    assert np.isnan(t[100, 128]) and np.isnan(t[98, 127])
+    clean = orc.tpi_exact(np.nan_to_num(dem, nan=2000.0), 7)
+    far = np.ones_like(dem, bool)
+    far[:, :] = True
+    far[100 - 64:100 + 64, :] = False  # rows of the tiles the NaN can reach
+    assert np.max(np.abs(t[far] - clean[far])) <= 2.5e-4

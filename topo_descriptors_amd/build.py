@@ -8,7 +8,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtopo_amd.so")
-SOURCES = ["disc.hip", "disc_wave.hip", "gauss.hip", "sx.hip", "capi.hip"]
+SOURCES = ["disc_wave_g0.hip", "disc_wave_g1.hip", "disc_wave_g2.hip", "disc_wave_g3.hip", "disc.hip",
+           "disc_wave.hip", "gauss.hip", "sx.hip", "capi.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -29,7 +30,7 @@ def _newer(target, deps):
 
 def build_library(force=False, verbose=True):
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "disc_runs.hpp"),
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "disc_runs.hpp"), os.path.join(CSRC, "disc_wave_impl.hpp"),
                os.path.join(os.path.dirname(HERE), "include", "topo_amd.h")]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if not force and _newer(LIB, srcs + headers):
@@ -46,7 +47,7 @@ def build_library(force=False, verbose=True):
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    with ThreadPoolExecutor(max_workers=6) as pool:
         objs = list(pool.map(compile_one, srcs))
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs,
            "-L/opt/rocm/lib", "-lrccl"]

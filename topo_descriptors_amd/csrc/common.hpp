@@ -86,8 +86,7 @@ int build_disc(int size, DiscRuns* out);
 // ---- kernel launchers (defined in the .hip files) -------------------------------------------
 int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out);
 // size-specialised wave-shift kernels; TOPO_AMD_EUNSUP = not covered, use the generic kernel
-int launch_tpi_wave(const Block& b, int size, float* tpi_out);
-int launch_std_wave(const Block& b, int size, float* tpi_out, float* std_out);
+int launch_disc_wave(const Block& b, int size, float* tpi_out, float* std_out);
 int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out);
 int launch_sobel(const Block& b, float* dx_out, float* dy_out);
 int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode,

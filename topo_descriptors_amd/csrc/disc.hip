@@ -16,8 +16,6 @@
 // Out-of-domain taps read x = 0 (zero padding of mode="same"), n is always the full tap count.
 #include "common.hpp"
 
-#include <cstdlib>
-
 namespace topo {
 
 namespace {
@@ -93,7 +91,9 @@ __device__ int stage_and_scan(const DiscArgs& p, uint32_t* L, int stride, int ro
     }
     int all = 0;
     if (PASS == kPassU) {
-        all = __syncthreads_or(flags);
+        // __syncthreads_or is a LOGICAL or: reduce every flag bit on its own
+        all |= __syncthreads_or(flags & kFlagFrac) ? kFlagFrac : 0;
+        all |= __syncthreads_or(flags & kFlagBad) ? kFlagBad : 0;
     } else {
         __syncthreads();
     }
@@ -350,10 +350,7 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
     TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
     Context& c = ctx();
     {
-        // TOPO_AMD_TPI_FLOAT=1 selects the float32-chain TPI kernel (profiling comparisons only)
-        static const bool float_tpi = getenv("TOPO_AMD_TPI_FLOAT") != nullptr;
-        const int r = (!std_out && float_tpi) ? launch_tpi_wave(b, disc.size, tpi_out)
-                                              : launch_std_wave(b, disc.size, tpi_out, std_out);
+        const int r = launch_disc_wave(b, disc.size, tpi_out, std_out);
         if (r != TOPO_AMD_EUNSUP) return r;
     }
     const int n_rows = disc.dj_max - disc.dj_min + 1;

@@ -1,0 +1,502 @@
+// K1/K2 fast path: disc sums by column runs + wavefront shift-accumulate, specialised per size.
+//
+// S(j, i) = sum over column offsets di of C(j, i + di),   C(j, c) = Q(j + hi(di) + 1, c) - Q(j + lo(di), c)
+//
+// where Q is the prefix sum down the columns of the staged tile and [lo(di), hi(di)] the
+// vertical run of the disc at column offset di.  Lanes own NC = 4 adjacent columns, so one
+// ds_read_b128 fetches a prefix row for all of them; the C values of the ~21 distinct runs of
+// a 67-px disc sit in registers, and the sum over di is a chain of adds in which the partial
+// sums hop one lane per step with a DPP wave shift (v_add_*_dpp wave_shl:1) - no LDS traffic
+// and no shuffles for the 67 taps of the chain.  Per output pixel that is ~21 subtractions and
+// ~67 additions instead of 134 LDS reads (row-prefix gather) or 3409 taps (direct).
+//
+// The kernel is instantiated per disc size (every run is a compile-time constant, which is
+// what keeps the C values in statically indexed registers); sizes without an instantiation
+// use the generic LDS kernel in disc.hip.  Persistent blocks walk the tile list (vertical
+// neighbours first, cut into XCD-contiguous runs so that the ghost rows two tiles share meet in
+// one L2).
+#pragma once
+#include "common.hpp"
+#include "disc_runs.hpp"
+
+namespace topo {
+
+namespace {
+
+constexpr int NC = 4;          // columns per lane
+constexpr int ROWW = 64 * NC;  // staged columns per tile row (one wave-row, 1 KiB)
+
+constexpr int cdiv_floor(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+constexpr int cdiv_ceil(int a, int b) { return -cdiv_floor(-a, b); }
+
+template <int SIZE>
+struct Geo {
+    static constexpr DiscTable<SIZE> T = make_disc_table<SIZE>();
+    static constexpr int D_LO = cdiv_ceil(T.off_min - (NC - 1), NC);   // lane offsets spanned
+    static constexpr int D_HI = cdiv_floor(T.off_max + (NC - 1), NC);
+    static constexpr int NVL = 64 - (D_HI - D_LO);   // lanes that end up with a full sum
+    static constexpr int TILE_W = NC * NVL;          // valid output columns per tile
+    static constexpr int X0 = -D_LO * NC;            // staged column of the first valid output
+    static_assert(NVL >= 8, "disc too wide for one wavefront of 4-column lanes");
+};
+
+struct WaveArgs {
+    const float* in;
+    float* tpi;
+    float* sd;
+    int in_rows, in_row0, gny, nx;
+    int out_row0, out_rows;
+    uint32_t* scratch;  // per-block planes for the per-row sums between the passes
+};
+
+template <typename T>
+struct alignas(16) Vec4 {
+    T v[4];
+};
+
+#define DPP_WAVE_SHL1 0x130  // lane i takes lane i + 1; lane 63 takes 0 (bound_ctrl)
+
+__device__ __forceinline__ float hop(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_WAVE_SHL1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int hop(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, DPP_WAVE_SHL1, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t hop(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_SHL1, 0xf, 0xf, true);
+}
+
+// Disc sums of output row jj (tile-relative) for the NC output columns that end up in this
+// lane: lane l receives the sums of staged columns NC * (l - D_LO) + t, valid for l < NVL.
+// T is the type of the prefix sums (float, int32, uint32 with wrap-around).  HALF selects what
+// of each uint32 column sum enters the chain: 0 all of it, 1 its low 16 bits, 2 its high 16 bits
+// (two 16-bit chains give an exact 48-bit total where one uint32 chain could overflow).
+template <int SIZE, typename T, int HALF = 0>
+__device__ __forceinline__ void wave_disc_sum(const T* Q, int jj, int lane, T (&acc)[NC]) {
+    using ACC = T;
+    using G = Geo<SIZE>;
+    constexpr int NR = G::T.num_runs;
+    T cv[NR][NC];
+    const T* col = Q + lane * NC;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const Vec4<T> top = *reinterpret_cast<const Vec4<T>*>(col + (jj + G::T.run_hi[r] - G::T.off_min + 1) * ROWW);
+        const Vec4<T> bot = *reinterpret_cast<const Vec4<T>*>(col + (jj + G::T.run_lo[r] - G::T.off_min) * ROWW);
+#pragma unroll
+        for (int s = 0; s < NC; ++s) {
+            T d = top.v[s] - bot.v[s];
+            if (HALF == 1) d = (T)((uint32_t)d & 0xffffu);
+            if (HALF == 2) d = (T)((uint32_t)d >> 16);
+            cv[r][s] = d;
+        }
+    }
+#pragma unroll
+    for (int D = G::D_HI; D >= G::D_LO; --D) {
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+            // contributions of this lane's NC columns to output sub-column t: a short tree,
+            // independent of the hop chain, so the chain itself is one dependent add per step
+            ACC part = (ACC)0;
+            bool any = false;
+#pragma unroll
+            for (int s = 0; s < NC; ++s) {
+                const int di = NC * D + s - t;
+                if (di >= G::T.off_min && di <= G::T.off_max) {
+                    const ACC c = (ACC)cv[G::T.run_of[di - G::T.off_min]][s];
+                    part = any ? part + c : c;
+                    any = true;
+                }
+            }
+            if (D == G::D_HI) {
+                acc[t] = part;  // nothing to move before the first step
+            } else if (any) {
+                acc[t] = hop(acc[t]) + part;
+            } else {
+                acc[t] = hop(acc[t]);
+            }
+        }
+    }
+}
+
+// One 16-byte row piece of the DEM, zero outside the global DEM (mode="same" padding).
+// nx % 4 == 0 and gx % 4 == 0, so a float4 is entirely inside or entirely outside.  The load is
+// unconditional (clamped address) so that all row loads of a tile can be in flight together.
+__device__ __forceinline__ bool row4_inside(const WaveArgs& p, int gy, int gx) {
+    const int by = gy - p.in_row0;
+    return gy >= 0 && gy < p.gny && gx >= 0 && gx < p.nx && by >= 0 && by < p.in_rows;
+}
+__device__ __forceinline__ Vec4<float> load_row4(const WaveArgs& p, int gy, int gx) {
+    const bool ok = row4_inside(p, gy, gx);
+    const size_t idx = ok ? (size_t)(gy - p.in_row0) * p.nx + gx : 0;
+    return *reinterpret_cast<const Vec4<float>*>(p.in + idx);
+}
+
+// ---- TPI, STD, and TPI + STD fused: exact integer chains -----------------------------------------
+// With u = trunc(x) - c, f = x - trunc(x) and the sums taken over the in-domain taps (m of them):
+//   s1 = sum x          = Su + Sf + c m
+//   s2 = sum trunc(x)^2 = Su2 + 2 c Su + c^2 m            (the int32 quirk of topo.py:300)
+//   STD = sqrt(max(0, (s2 - s1^2/n) / (n-1))),   TPI = x - (s1 - x_ctr) / (n-1)
+// Su and Su2 are integer sums (int32 / uint32 prefix sums cannot round; the uint32 chain switches
+// to two 16-bit half chains when a tile's |u| would let 3409 u^2 pass 2^32), Sf is a small float
+// sum that exists only on fractional DEMs.  Tiles holding non-finite or absurd samples (|u| so
+// large that one 67-row column sum of u^2 passes 2^32, e.g. -9999 nodata next to real terrain)
+// run float chains on a = x - c and (trunc(x) - c)^2 instead, so NaN propagates and nothing wraps.
+enum Stage { kStU = 0, kStU2 = 1, kStF = 2, kStA = 3, kStT2 = 4 };
+enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4 };
+
+template <int WHAT>
+__device__ __forceinline__ uint32_t stage_value(float x, float c, int ci) {
+    if (WHAT == kStA) return __float_as_uint(x - c);
+    const float t = truncf(x);
+    if (WHAT == kStF) return __float_as_uint(x - t);
+    if (WHAT == kStT2) {
+        const float u = t - c;
+        return __float_as_uint(u * u);
+    }
+    const int u = (int)t - ci;
+    if (WHAT == kStU) return (uint32_t)u;
+    return (uint32_t)u * (uint32_t)u;
+}
+
+// All waves: load the tile's rows, transform, and leave the column prefix sums of it in Q.
+// Padded (out-of-domain) samples are staged as 0; the caller accounts for them through m.
+template <int SIZE, int TH, int NWAVES, int WHAT, typename T>
+__device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, int gy0, int gx, float c,
+                                            int ci, float lim32, float limcv) {
+    constexpr int NROWS = TH + SIZE - 1;
+    constexpr int SL = (NROWS + NWAVES - 1) / NWAVES;
+    T* Q = reinterpret_cast<T*>(lds);
+    T* TOT = Q + (NROWS + 1) * ROWW;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    Vec4<float> v[SL];
+#pragma unroll
+    for (int k = 0; k < SL; ++k) v[k] = load_row4(p, gy0 + wave * SL + k, gx);
+    int flags = 0;
+    uint32_t umax = 0;  // largest |trunc(x) - c| seen, as float bits (NaN / inf sort above all)
+    bool frac = false;
+    Vec4<T> run{{(T)0, (T)0, (T)0, (T)0}};
+    if (wave == 0) *reinterpret_cast<Vec4<T>*>(Q + lane * NC) = run;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+        const int r = wave * SL + k;
+        if (r < NROWS) {
+            const bool ok = row4_inside(p, gy0 + r, gx);
+#pragma unroll
+            for (int s = 0; s < NC; ++s) {
+                const float x = v[k].v[s];
+                uint32_t bits;
+                if (WHAT == kStU) {
+                    // one pass classifies the tile and yields u: d = trunc(x) - c is exact in float
+                    const float t = truncf(x);
+                    const float d = t - c;
+                    frac |= ok && (x != t);
+                    umax = max(umax, ok ? (__float_as_uint(d) & 0x7fffffffu) : 0u);
+                    bits = ok ? (uint32_t)(int)d : 0u;
+                } else {
+                    bits = ok ? stage_value<WHAT>(x, c, ci) : 0u;
+                }
+                T val;
+                __builtin_memcpy(&val, &bits, sizeof(T));
+                run.v[s] += val;
+            }
+            *reinterpret_cast<Vec4<T>*>(Q + (r + 1) * ROWW + lane * NC) = run;
+        }
+    }
+    if (WHAT == kStU) {
+        if (frac) flags |= kTileFrac;
+        if (umax > __float_as_uint(lim32)) flags |= kTileWide;
+        if (umax > __float_as_uint(limcv)) flags |= kTileFloat;  // also NaN / inf
+    }
+    *reinterpret_cast<Vec4<T>*>(TOT + wave * ROWW + lane * NC) = run;
+    // __syncthreads_or is a LOGICAL or: reduce every flag bit on its own
+    int all = 0;
+    if (WHAT == kStU) {
+        all |= __syncthreads_or(flags & kTileFrac) ? kTileFrac : 0;
+        all |= __syncthreads_or(flags & kTileWide) ? kTileWide : 0;
+        all |= __syncthreads_or(flags & kTileFloat) ? kTileFloat : 0;
+    } else {
+        __syncthreads();
+    }
+    if (wave > 0) {
+        Vec4<T> off{{(T)0, (T)0, (T)0, (T)0}};
+        for (int w = 0; w < wave; ++w) {
+            const Vec4<T> t = *reinterpret_cast<const Vec4<T>*>(TOT + w * ROWW + lane * NC);
+#pragma unroll
+            for (int s = 0; s < NC; ++s) off.v[s] += t.v[s];
+        }
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int r = wave * SL + k;
+            if (r < NROWS) {
+                Vec4<T>* q = reinterpret_cast<Vec4<T>*>(Q + (r + 1) * ROWW + lane * NC);
+                Vec4<T> x = *q;
+#pragma unroll
+                for (int s = 0; s < NC; ++s) x.v[s] += off.v[s];
+                *q = x;
+            }
+        }
+    }
+    __syncthreads();
+    return all;
+}
+
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
+__global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+    using G = Geo<SIZE>;
+    constexpr int NROWS = TH + SIZE - 1;
+    constexpr int RW = TH / NWAVES;  // output rows per wave
+    static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    unsigned short* PL = reinterpret_cast<unsigned short*>(lds_u + (NROWS + 1 + NWAVES) * ROWW);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = tiles_x * tiles_y;
+    const int nb = gridDim.x;
+    const int per_xcd = nb >> 3;
+    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const double n = (double)G::T.taps;
+    const double inv_nm1 = 1.0 / (n - 1.0);
+    const float lim32 = floorf(sqrtf(4294967295.0f / (float)G::T.taps));
+    const float limcv = fminf(46000.0f, floorf(sqrtf(4294967295.0f / (float)SIZE)));
+
+    for (int tile = vb; tile < ntiles; tile += nb) {
+        const int ox0 = (tile / tiles_y) * G::TILE_W;
+        const int oy0 = (p.out_row0 / TH + tile % tiles_y) * TH;  // global multiples of TH
+        const int gx = ox0 - G::X0 + lane * NC;
+        const int gy0 = oy0 + G::T.off_min;
+        int cy = min(max(oy0 + TH / 2, 0), p.gny - 1);
+        cy = min(max(cy, p.in_row0), p.in_row0 + p.in_rows - 1);
+        const int cx = min(ox0 + G::TILE_W / 2, p.nx - 1);
+        float c = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
+        if (!(fabsf(c) < 1.0e9f)) c = 0.0f;
+        const int ci = (int)c;
+        const bool border = gy0 < 0 || gy0 + NROWS > p.gny || ox0 - G::X0 < 0 || ox0 - G::X0 + ROWW > p.nx;
+
+        // per-row sums live in this block's scratch planes between the passes (registers cannot
+        // hold RW x NC x 4 values next to the chain): plane 0 Su (int32) or Sa (float bits),
+        // 1/2 Su2 low/high word or St2 (float bits in 1), 3 Sf.  Written and read by the same lane.
+        uint32_t* plane = p.scratch + (size_t)blockIdx.x * (4 * TH * ROWW) + lane * NC;
+        auto put = [&](int which, int jj, const uint32_t (&val)[NC]) {
+            Vec4<uint32_t> x{{val[0], val[1], val[2], val[3]}};
+            *reinterpret_cast<Vec4<uint32_t>*>(plane + (which * TH + jj) * ROWW) = x;
+        };
+        auto get = [&](int which, int jj) {
+            return *reinterpret_cast<const Vec4<uint32_t>*>(plane + (which * TH + jj) * ROWW);
+        };
+
+        const int flags = stage_prefix<SIZE, TH, NWAVES, kStU, int>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+        const bool use_float = (flags & kTileFloat) != 0;
+        const bool wide = (flags & kTileWide) != 0;
+        const bool frac = (flags & kTileFrac) != 0;
+        // TPI alone on an integer-valued tile needs one pass: its rows are finalised straight from
+        // the chain, without the round trip through the scratch planes
+        const bool direct = !WANT_STD && !use_float && !frac;
+        const int ocol = ox0 + lane * NC;
+        const bool lane_ok = lane < G::NVL && ocol < p.nx;
+        auto finalise_row = [&](int jj, const Vec4<uint32_t>& q0, const Vec4<uint32_t>& q1,
+                                const Vec4<uint32_t>& q2, const Vec4<uint32_t>& q3) {
+            const int oy = oy0 + jj;
+            if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) return;
+            Vec4<float> xs{{0.f, 0.f, 0.f, 0.f}};
+            if (WANT_TPI) xs = *reinterpret_cast<const Vec4<float>*>(p.in + (size_t)(oy - p.in_row0) * p.nx + ocol);
+            Vec4<float> out_t, out_s;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                double m = n;
+                if (border) {
+                    const int d_lo = max(G::T.off_min, -(ocol + t));
+                    const int d_hi = min(G::T.off_max, p.nx - 1 - (ocol + t));
+                    const unsigned short* pl = PL + jj * (SIZE + 1) - G::T.off_min;
+                    m = d_hi >= d_lo ? (double)((int)pl[d_hi + 1] - (int)pl[d_lo]) : 0.0;
+                }
+                const double sf = (double)__uint_as_float(q3.v[t]);
+                double su, su2;  // sums of u and u^2 over the in-domain taps
+                if (!use_float) {
+                    su = (double)(int)q0.v[t];
+                    su2 = (double)q2.v[t] * 65536.0 + (double)q1.v[t];  // q2 = 0 unless the tile is wide
+                } else {
+                    su = (double)__uint_as_float(q0.v[t]) - sf;  // Sa = Su + Sf
+                    su2 = (double)__uint_as_float(q1.v[t]);
+                }
+                const double cd = (double)c;
+                // su + c m is an exact integer (= sum of trunc(x)), so the result does not depend on
+                // which c the tile happened to use
+                const double s1 = (su + cd * m) + sf;
+                if (WANT_STD) {
+                    const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
+                    double var = (s2 - s1 * s1 / n) * inv_nm1;
+                    if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
+                    out_s.v[t] = (float)sqrt(var);
+                }
+                if (WANT_TPI) {
+                    const int cy2 = oy + G::T.centre, cx2 = ocol + t + G::T.centre;
+                    double x_ctr = (double)xs.v[t];
+                    if (G::T.centre != 0) {
+                        const bool in = cy2 >= 0 && cy2 < p.gny && cx2 >= 0 && cx2 < p.nx;
+                        x_ctr = in ? (double)p.in[(size_t)(cy2 - p.in_row0) * p.nx + cx2] : 0.0;
+                    }
+                    out_t.v[t] = (float)((double)xs.v[t] - (s1 - x_ctr) * inv_nm1);
+                }
+            }
+            const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+            if (WANT_STD) *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+            if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+        };
+        if (border && threadIdx.x < TH) {
+            // in-domain rows of each column run, prefix-summed over the column offsets: what the
+            // zero-padded convolution really sums over near the DEM border
+            const int oy = oy0 + (int)threadIdx.x;
+            unsigned short* row = PL + threadIdx.x * (SIZE + 1);
+            int run = 0;
+            row[0] = 0;
+#pragma unroll 1
+            for (int k = 0; k < SIZE; ++k) {
+                const int top = max(oy + G::T.lo[k], 0);
+                const int bot = min(oy + G::T.hi[k], p.gny - 1);
+                run += max(bot - top + 1, 0);
+                row[k + 1] = (unsigned short)run;
+            }
+        }
+        if (direct && border) __syncthreads();  // the border table is read right away
+        if (!use_float) {
+#pragma unroll 1
+            for (int k = 0; k < RW; ++k) {
+                int acc[NC];
+                wave_disc_sum<SIZE, int>(reinterpret_cast<const int*>(lds_u), wave + k * NWAVES, lane, acc);
+                const uint32_t bits[NC] = {(uint32_t)acc[0], (uint32_t)acc[1], (uint32_t)acc[2], (uint32_t)acc[3]};
+                if (direct) {
+                    const Vec4<uint32_t> q0{{bits[0], bits[1], bits[2], bits[3]}}, z{{0u, 0u, 0u, 0u}};
+                    finalise_row(wave + k * NWAVES, q0, z, z, z);
+                } else {
+                    put(0, wave + k * NWAVES, bits);
+                }
+            }
+            if (WANT_STD) {
+            __syncthreads();
+            stage_prefix<SIZE, TH, NWAVES, kStU2, uint32_t>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+            if (!wide) {
+#pragma unroll 1
+                for (int k = 0; k < RW; ++k) {
+                    uint32_t acc[NC];
+                    wave_disc_sum<SIZE, uint32_t>(lds_u, wave + k * NWAVES, lane, acc);
+                    put(1, wave + k * NWAVES, acc);
+                }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < RW; ++k) {
+                    uint32_t lo[NC], hi[NC];  // sums of the low / high 16 bits of the column sums
+                    wave_disc_sum<SIZE, uint32_t, 1>(lds_u, wave + k * NWAVES, lane, lo);
+                    wave_disc_sum<SIZE, uint32_t, 2>(lds_u, wave + k * NWAVES, lane, hi);
+                    put(1, wave + k * NWAVES, lo);
+                    put(2, wave + k * NWAVES, hi);
+                }
+            }
+            }
+        } else {
+            __syncthreads();
+            stage_prefix<SIZE, TH, NWAVES, kStA, float>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+#pragma unroll 1
+            for (int k = 0; k < RW; ++k) {
+                float acc[NC];
+                wave_disc_sum<SIZE, float>(reinterpret_cast<const float*>(lds_u), wave + k * NWAVES, lane, acc);
+                const uint32_t bits[NC] = {__float_as_uint(acc[0]), __float_as_uint(acc[1]),
+                                           __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+                put(0, wave + k * NWAVES, bits);
+            }
+            if (WANT_STD) {
+            __syncthreads();
+            stage_prefix<SIZE, TH, NWAVES, kStT2, float>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+#pragma unroll 1
+            for (int k = 0; k < RW; ++k) {
+                float acc[NC];
+                wave_disc_sum<SIZE, float>(reinterpret_cast<const float*>(lds_u), wave + k * NWAVES, lane, acc);
+                const uint32_t bits[NC] = {__float_as_uint(acc[0]), __float_as_uint(acc[1]),
+                                           __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+                put(1, wave + k * NWAVES, bits);
+            }
+            }
+        }
+        if (frac) {
+            __syncthreads();
+            stage_prefix<SIZE, TH, NWAVES, kStF, float>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+#pragma unroll 1
+            for (int k = 0; k < RW; ++k) {
+                float acc[NC];
+                wave_disc_sum<SIZE, float>(reinterpret_cast<const float*>(lds_u), wave + k * NWAVES, lane, acc);
+                const uint32_t bits[NC] = {__float_as_uint(acc[0]), __float_as_uint(acc[1]),
+                                           __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+                put(3, wave + k * NWAVES, bits);
+            }
+        }
+
+        // ---- finalise the leftover rows from the scratch planes ------------------------------------
+        if (!direct) {
+#pragma unroll 1
+            for (int k = 0; k < RW; ++k) {
+                const int jj = wave + k * NWAVES;
+                const Vec4<uint32_t> q0 = get(0, jj);
+                Vec4<uint32_t> q1{{0u, 0u, 0u, 0u}}, q2{{0u, 0u, 0u, 0u}}, q3{{0u, 0u, 0u, 0u}};
+                if (WANT_STD) q1 = get(1, jj);
+                if (WANT_STD && wide && !use_float) q2 = get(2, jj);
+                if (frac) q3 = get(3, jj);
+                finalise_row(jj, q0, q1, q2, q3);
+            }
+        }
+        __syncthreads();  // Q and PL are rewritten by the next tile
+    }
+}
+
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
+int launch_wave(const Block& b, float* tpi_out, float* std_out) {
+    using G = Geo<SIZE>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows, nullptr};
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(float) +
+                           (size_t)TH * (SIZE + 1) * sizeof(unsigned short);
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    static_assert(SIZE * SIZE < 65536, "tap counts must fit the 16-bit border table");
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nblk, (const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, NWAVES * 64, lds));
+        blocks_per_cu = nblk < 1 ? 1 : nblk;
+    }
+    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
+    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
+    const long ntiles = (long)tiles_x * tiles_y;
+    long grid = (long)c.num_cu * blocks_per_cu;
+    if (grid > ntiles) grid = ntiles;
+    void* scratch = nullptr;
+    TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
+    a.scratch = (uint32_t*)scratch;
+    hipLaunchKernelGGL((disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>), dim3((unsigned)grid),
+                       dim3(NWAVES * 64), lds, c.compute, a, tiles_x, tiles_y);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+// Tile heights: as tall as LDS allows (prefix rows + segment totals + border table <= 160 KiB),
+// capped at the heights that measured best for 67 px.
+constexpr int tile_rows(int size, int nwaves, int cap) {
+    int th = cap;
+    while (th > nwaves && (size_t)(th + size + nwaves) * ROWW * 4 + (size_t)th * (size + 1) * 2 > 160 * 1024)
+        th -= nwaves;
+    return th;
+}
+
+template <int SIZE>
+int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
+    constexpr int TH8 = tile_rows(SIZE, 8, 64), TH12 = tile_rows(SIZE, 12, 60);
+    if (tpi_out && std_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out);
+    if (std_out) return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out);
+    return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out);
+}
+
+}  // namespace
+
+}  // namespace topo
