@@ -172,6 +172,49 @@ struct GradArgs {
     float *dx, *dy, *slope, *aspect;
 };
 
+// ---- slope / aspect arithmetic -----------------------------------------------------------------
+// The libm routines (atanf, atan2f, IEEE division with scaling) cost ~300 instructions per pixel
+// together and made the epilogue VALU-bound at 3 TB/s.  These replacements keep float32-level
+// accuracy (atan: Abramowitz & Stegun 4.4.49, |err| <= 2e-8 on [0,1]; division: reciprocal plus
+// one FMA correction, correctly rounded except in rare half-way cases) and the IEEE special cases
+// the descriptors rely on: signed zeros (flat terrain: dy = -0 -> atan2(+0,-0) = pi -> aspect 0),
+// NaN propagation, slope 90 for infinite gradients.
+__device__ __forceinline__ float div_f32(float a, float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    return fmaf(fmaf(-q, b, a), r, q);
+}
+
+__device__ __forceinline__ float atan_unit(float t) {  // t in [0, 1]
+    const float z = t * t;
+    float p = 0.0028662257f;
+    p = fmaf(p, z, -0.0161657367f);
+    p = fmaf(p, z, 0.0429096138f);
+    p = fmaf(p, z, -0.0752896400f);
+    p = fmaf(p, z, 0.1065626393f);
+    p = fmaf(p, z, -0.1420889944f);
+    p = fmaf(p, z, 0.1999355085f);
+    p = fmaf(p, z, -0.3333314528f);
+    return fmaf(p * z, t, t);
+}
+
+__device__ __forceinline__ float atan_pos(float s) {  // s >= 0 (or NaN)
+    const bool big = s > 1.0f;
+    const float r = atan_unit(big ? __builtin_amdgcn_rcpf(s) : s);
+    return big ? 1.5707963267948966f - r : r;
+}
+
+__device__ __forceinline__ float atan2_f32(float y, float x) {
+    const float a = fabsf(y), b = fabsf(x);
+    const float mx = fmaxf(a, b), mn = fminf(a, b);
+    const float t = mx == 0.0f ? 0.0f : mn * __builtin_amdgcn_rcpf(mx);
+    float r = atan_unit(t);
+    if (a > b) r = 1.5707963267948966f - r;
+    if (__float_as_uint(x) >> 31) r = 3.14159265358979323846f - r;  // sign BIT: x = -0 counts
+    r = copysignf(r, y);
+    return (x != x || y != y) ? NAN : r;
+}
+
 __device__ __forceinline__ void finish_gradient(const GradArgs& p, int oy, int ox, float dx,
                                                 float dy) {
     const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
@@ -186,18 +229,18 @@ __device__ __forceinline__ void finish_gradient(const GradArgs& p, int oy, int o
         rx = p.res_x[o];
         ry = p.res_y[o];
     }
-    dx = dx / rx;  // signed resolutions: -0.0 must survive (aspect of flat terrain)
-    dy = dy / ry;
+    dx = div_f32(dx, rx);  // signed resolutions: -0.0 must survive (aspect of flat terrain)
+    dy = div_f32(dy, ry);
     if (p.dx) p.dx[o] = dx;
     if (p.dy) p.dy[o] = dy;
     const float rad2deg = 57.29577951308232f;
     if (p.slope) {
         const float d2 = dx * dx;
         const float e2 = dy * dy;
-        p.slope[o] = atanf(sqrtf(d2 + e2)) * rad2deg;
+        p.slope[o] = atan_pos(__builtin_amdgcn_sqrtf(d2 + e2)) * rad2deg;
     }
     if (p.aspect) {
-        float a = 180.0f + atan2f(dx, dy) * rad2deg;
+        float a = 180.0f + atan2_f32(dx, dy) * rad2deg;
         if (a >= 360.0f) a -= 360.0f;  // float32 "% 360" of a value in [0, 360]
         p.aspect[o] = a;
     }
@@ -247,6 +290,69 @@ __global__ __launch_bounds__(kThreads) void sobel_kernel(GradArgs p) {
         const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
         if (p.dx) p.dx[o] = dx;
         if (p.dy) p.dy[o] = dy;
+    }
+}
+
+// ---- axis 1 fused with the gradient epilogue -------------------------------------------------
+// Same tiling as gauss_axis1_kernel, but the 64 x (NW*TB) smoothed tile stays in LDS and the
+// block emits dx, dy, slope, aspect for the 62 x (NW*TB - 2) pixels inside it: the smoothed
+// plane never goes to HBM (28 instead of 36 B/pixel for the whole gradient).  Tiles sit on
+// global multiples of 62 rows / (NW*TB - 2) columns, so results do not depend on the row block.
+template <int TB, int KB, int NW>
+__global__ __launch_bounds__(NW * 64) void gauss_axis1_grad_kernel(GaussArgs p, GradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    constexpr int TR = 64;
+    constexpr int TC = NW * TB;
+    constexpr int OUT_R = TR - 2, OUT_C = TC - 2;
+    const int R = p.radius;
+    const int cols_l = TC + p.nchunks * KB - 1;
+    const int stride = cols_l | 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ox0 = blockIdx.x * OUT_C;                                  // first output column
+    const int oy0 = (g.out_row0 / OUT_R + (int)blockIdx.y) * OUT_R;       // first output row (global)
+    const int sx0 = ox0 - 1, sy0 = oy0 - 1;                               // smoothed tile origin
+
+    const bool inner = sx0 - R >= 0 && sx0 - R + cols_l <= p.nx;
+    for (int r = wave; r < TR; r += NW) {
+        const int gy = min(max(sy0 + r, p.in_row0), p.in_row0 + p.in_rows - 1);  // unused rows clamp
+        const float* src = p.in + (size_t)(gy - p.in_row0) * p.nx;
+        float* dst = L + r * stride;
+        if (inner) {
+            const float* s0 = src + (sx0 - R);
+            for (int k = lane; k < cols_l; k += 64) dst[k] = s0[k];
+        } else {
+            for (int k = lane; k < cols_l; k += 64) dst[k] = src[reflect_index(sx0 - R + k, p.nx)];
+        }
+    }
+    __syncthreads();
+
+    const float* rowp = L + lane * stride + wave * TB;
+    auto fetch = [&](int i) -> float { return rowp[i]; };
+    const float c = rowp[R];
+    float acc[TB];
+    tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
+    __syncthreads();
+    constexpr int ostride = TC + 1;
+    float* O = L;  // smoothed tile, rounded to float32 like the reference's intermediate
+#pragma unroll
+    for (int t = 0; t < TB; ++t) O[lane * ostride + wave * TB + t] = c + acc[t];
+    __syncthreads();
+
+    for (int idx = threadIdx.x; idx < OUT_R * OUT_C; idx += NW * 64) {
+        const int r = idx / OUT_C, k = idx % OUT_C;
+        const int oy = oy0 + r, ox = ox0 + k;
+        if (oy < g.out_row0 || oy >= g.out_row0 + g.out_rows || ox >= g.nx) continue;
+        const float* q = O + (r + 1) * ostride + (k + 1);  // smoothed value of this pixel
+        // numpy.gradient: central difference / 2 inside, first-order one-sided at the edges
+        float dx, dy;
+        if (ox == 0) dx = q[1] - q[0];
+        else if (ox == g.nx - 1) dx = q[0] - q[-1];
+        else dx = (q[1] - q[-1]) * 0.5f;
+        if (oy == 0) dy = q[ostride] - q[0];
+        else if (oy == g.gny - 1) dy = q[0] - q[-ostride];
+        else dy = (q[ostride] - q[-ostride]) * 0.5f;
+        finish_gradient(g, oy, ox, dx, dy);
     }
 }
 
@@ -333,6 +439,49 @@ int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int t
     a.group0 = 0;
     if (wide) return launch_axis1<16, 16, 8>(a, rows, nx, sigma);
     return launch_axis1<8, 8, 8>(a, rows, nx, sigma);
+}
+
+template <int TB, int KB, int NW>
+int launch_axis1_grad(const GaussArgs& a, const GradArgs& g, double sigma) {
+    Context& c = ctx();
+    constexpr int tc = NW * TB;
+    const int cols_l = tc + a.nchunks * KB - 1;
+    const size_t lds_in = (size_t)64 * (cols_l | 1) * sizeof(float);
+    const size_t lds_out = (size_t)64 * (tc + 1) * sizeof(float);
+    const size_t lds = lds_in > lds_out ? lds_in : lds_out;
+    if (lds > 160 * 1024) {
+        set_error("gradient: sigma %.3f (radius %d) needs %zu B of LDS per tile; the "
+                  "large-sigma path is not built yet", sigma, a.radius, lds);
+        return TOPO_AMD_EUNSUP;
+    }
+    TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_grad_kernel<TB, KB, NW>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    constexpr int out_r = 62, out_c = tc - 2;
+    const int tiles_y = (g.out_row0 + g.out_rows - 1) / out_r - g.out_row0 / out_r + 1;
+    dim3 grid((g.nx + out_c - 1) / out_c, tiles_y);
+    hipLaunchKernelGGL((gauss_axis1_grad_kernel<TB, KB, NW>), grid, dim3(NW * 64), lds, c.compute, a, g);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+// axis-1 smoothing of the plane `in` (rows [s_row0, s_row0 + s_rows) of the DEM, already
+// smoothed along axis 0) fused with the gradient epilogue described by g.
+int run_axis1_grad(const float* in, int s_row0, int s_rows, int gny, int nx, double sigma,
+                   const GradArgs& g, int table_slot) {
+    const bool wide = wide_tiling(gaussian_radius(sigma));
+    GaussArgs a;
+    TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
+    a.in = in;
+    a.out = nullptr;
+    a.in_rows = s_rows;
+    a.in_row0 = s_row0;
+    a.gny = gny;
+    a.nx = nx;
+    a.out_row0 = 0;
+    a.out_rows = 0;
+    a.group0 = 0;
+    if (wide) return launch_axis1_grad<16, 16, 8>(a, g, sigma);
+    return launch_axis1_grad<16, 8, 8>(a, g, sigma);
 }
 
 // Full 2-D smooth of rows [row0, row0+rows) into `out`; ws_slot names the scratch plane.
@@ -445,9 +594,12 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     const size_t bytes = (size_t)s_rows * b.nx * sizeof(float);
     void *plane_a = nullptr, *plane_b = nullptr;
     TOPO_TRY(workspace(1, bytes, &plane_a));
-    if (sig_ratio == 1.0) {  // topo.py:630-631
-        TOPO_TRY(smooth_rows(b, sigma, sigma, s0, s_rows, (float*)plane_a, 0, 1));
-        plane_b = plane_a;
+    if (sig_ratio == 1.0) {  // topo.py:630-631: one smooth; axis 1 and the epilogue run fused
+        Block rows = b;
+        rows.out_row0 = s0;
+        rows.out_rows = s_rows;
+        TOPO_TRY(run_axis0(rows, sigma, (float*)plane_a, 1));
+        return run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);
     } else {  // topo.py:633-635
         const double perp = sigma * sig_ratio;
         TOPO_TRY(workspace(2, bytes, &plane_b));
