@@ -241,3 +241,17 @@ def test_ragged_shapes_and_tiny_inputs():
             assert np.max(np.abs(s - e)) <= REL * max(np.max(e), 1.0), (ny, nx, size)
         sm = topo.dem(dem, 2.25)
         assert np.max(np.abs(sm - orc.gaussian_exact(dem, 2.25))) <= 1e-3, (ny, nx)
+
+
+def test_long_filters_beyond_the_lds_tile():
+    """sigma = 60 (radius 240): axis 1 runs as the wave-shift kernel, which has no LDS tile."""
+    dem = orc.synthetic_dem(700, 1100, seed=31)
+    got = topo.dem(dem, 60.0)
+    assert np.max(np.abs(got - orc.gaussian_exact(dem, 60.0))) <= 1e-3
+    x = 2600000.0 + 30.0 * np.arange(1100)
+    y = 1200000.0 - 30.0 * np.arange(700)
+    res = orc.grid_resolution(x, y)
+    g = topo.gradient(dem, 60.0, res)
+    e = orc.gradient_exact(dem, 60.0, res)
+    for k in range(3):
+        assert np.max(np.abs(g[k] - e[k])) <= 1e-4 * np.max(np.abs(e[k])) + 2e-5

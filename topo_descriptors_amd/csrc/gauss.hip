@@ -387,6 +387,7 @@ struct WaveGradArgs {
     int radius, d_lo, nsteps, nvl;
     int out_c;          // output columns per strip = GC * (nvl - 2)
     int rows_per_wave;
+    float* smooth_out;  // non-NULL: store the smoothed rows themselves instead of the gradient
     GradArgs g;
 };
 
@@ -481,7 +482,12 @@ __global__ __launch_bounds__(kThreads) void gauss_axis1_wave_grad_kernel(WaveGra
             // neighbours across the lane boundary
             const float left = hop_up(mid[GC - 1]);
             const float right = hop_down(mid[0]);
-            if (lane_out) {
+            if (lane_out && p.smooth_out) {
+                const size_t o = (size_t)(y - g.out_row0) * g.nx + col0;
+#pragma unroll
+                for (int t = 0; t < GC; ++t)
+                    if (col0 + t < g.nx) p.smooth_out[o + t] = mid[t];
+            } else if (lane_out) {
                 const size_t o = (size_t)(y - g.out_row0) * g.nx + col0;
 #pragma unroll
                 for (int q = 0; q < GC / 4; ++q) {
@@ -596,6 +602,9 @@ int launch_axis1(const GaussArgs& a, int rows, int nx, double sigma) {
     return TOPO_AMD_OK;
 }
 
+int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, const GradArgs& g,
+                        float* smooth_out);
+
 // `in` holds exactly the rows [out_row0, out_row0 + out_rows) starting at in_row0 == out_row0
 int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int table_slot) {
     const bool wide = wide_tiling(gaussian_radius(sigma));
@@ -610,7 +619,19 @@ int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int t
     a.out_row0 = 0;
     a.out_rows = rows;
     a.group0 = 0;
-    if (wide) return launch_axis1<16, 16, 8>(a, rows, nx, sigma);
+    if (wide) {
+        const int cols_l = 8 * 16 + a.nchunks * 16 - 1;
+        if ((size_t)64 * (cols_l | 1) * sizeof(float) > 160 * 1024) {
+            // long filter: the wave-shift kernel has no LDS tile
+            GradArgs g{};
+            g.gny = rows;
+            g.nx = nx;
+            g.out_row0 = 0;
+            g.out_rows = rows;
+            return run_axis1_wave_grad(in, 0, rows, sigma, g, out);
+        }
+        return launch_axis1<16, 16, 8>(a, rows, nx, sigma);
+    }
     return launch_axis1<8, 8, 8>(a, rows, nx, sigma);
 }
 
@@ -658,7 +679,8 @@ int run_axis1_grad(const float* in, int s_row0, int s_rows, int gny, int nx, dou
 }
 
 // Wave-shift axis 1 + epilogue.  TOPO_AMD_EUNSUP when the filter spans too many lanes.
-int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, const GradArgs& g) {
+int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, const GradArgs& g,
+                        float* smooth_out) {
     Context& c = ctx();
     const int R = gaussian_radius(sigma);
     auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
@@ -718,6 +740,7 @@ int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, c
     a.nvl = nvl;
     a.out_c = GC * (nvl - 2);
     a.rows_per_wave = 32;
+    a.smooth_out = smooth_out;
     a.g = g;
     const int tiles = (g.out_row0 + g.out_rows - 1) / a.rows_per_wave - g.out_row0 / a.rows_per_wave + 1;
     dim3 grid((g.nx + a.out_c - 1) / a.out_c, (tiles + kThreads / 64 - 1) / (kThreads / 64));
@@ -845,7 +868,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         // filters: wave-shift axis 1 (26.7 vs 27.8 ms at sigma 30.25, and no LDS limit on sigma)
         if (!wide_tiling(gaussian_radius(sigma)))
             return run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);
-        const int r = run_axis1_wave_grad((const float*)plane_a, s0, s_rows, sigma, g);
+        const int r = run_axis1_wave_grad((const float*)plane_a, s0, s_rows, sigma, g, nullptr);
         if (r != TOPO_AMD_EUNSUP) return r;
         return run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);
     } else {  // topo.py:633-635
