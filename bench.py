@@ -82,6 +82,20 @@ class Rendezvous:
             self.dist.destroy_process_group()
 
 
+def measured_traffic(ny, nx, size, world):
+    """HBM bytes per launch of the TPI kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this
+    exact workload).  None when the workload differs from the profiled one."""
+    path = os.path.join(REPO, "profiles", "r01_tpi67_traffic.json")
+    if not (os.path.exists(path) and (ny, nx, size, world) == (32768, 32768, 67, 1)):
+        return None
+    try:
+        with open(path) as fh:
+            return json.load(fh).get("traffic_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def time_kernel(fn, reps, dev):
     """Average HIP-event duration (ms) of `fn` over `reps` back-to-back launches."""
     fn()
@@ -239,8 +253,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
-                "kernel": "disc TPI kernel, per-rank launch",
+                "traffic": measured_traffic(ny, nx, size, world),
+                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
+                "algorithmic_bytes_per_launch": px_launch * BYTES_PER_PIXEL["tpi"],
+                "kernel": "disc_wave_kernel<67, 60, 12, true, false> (exact TPI), per-rank launch",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL["tpi"],
             },
