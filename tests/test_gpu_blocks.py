@@ -266,3 +266,28 @@ def test_nodata_and_nan_tiles_do_not_wrap():
     far[:, :] = True
     far[100 - 64:100 + 64, :] = False  # rows of the tiles the NaN can reach
     assert np.max(np.abs(t[far] - clean[far])) <= 2.5e-4
+
+
+def test_rccl_communicator_single_rank():
+    """RCCL is linked, the unique id round-trips through ctypes the way bench.py passes it, and a
+    one-rank communicator drives the sharded entry points (no neighbours: the send/recv group is
+    empty, the interior/seam split and the stream hand-over still run)."""
+    lib = _lib.lib()
+    uid = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+    _lib.check(lib.topo_amd_comm_unique_id(uid), "comm_unique_id")
+    payload = bytes(uid.raw)           # what a broadcast would deliver to the other ranks
+    assert len(payload) == _lib.UNIQUE_ID_BYTES and any(payload)
+    _lib.check(lib.topo_amd_comm_init(0, 1, payload), "comm_init")
+    try:
+        assert lib.topo_amd_comm_size() == 1 and lib.topo_amd_comm_rank() == 0
+        gny, nx, size = 256, 256, 67
+        dem = orc.synthetic_dem(gny, nx, seed=41)
+        up, down = halo(_lib.DESC_TPI, size)
+        sd = shard.ShardedDEM(shard.RowShardPlan(gny, nx, 1, 0, up, down), dem)
+        t = d.DeviceArray(gny, nx)
+        for _ in range(3):             # repeated steps reuse the events / streams
+            sd.tpi_std(size, tpi=t)
+        d.sync()
+        assert np.max(np.abs(t.to_host() - orc.tpi_exact(dem, size))) <= 2.5e-4
+    finally:
+        _lib.check(lib.topo_amd_comm_destroy(), "comm_destroy")
