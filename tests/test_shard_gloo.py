@@ -149,3 +149,37 @@ def test_plan_geometry():
     assert sx.sends() == [(3, 250 - 17, 17)] and sx.recvs() == [(1, 0, 17)]
     with pytest.raises(ValueError):
         RowShardPlan(100, 8, 8, 0, 33, 33).validate()   # 12-row shards cannot feed 33 ghost rows
+
+
+def _rendezvous_worker(rank, world, port, fail):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                          WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        import bench
+        rdv = bench.Rendezvous(world)
+        assert rdv.rank == rank
+        payload = rdv.bcast_bytes(bytes(range(128)) if rank == 0 else None)
+        assert payload == bytes(range(128))       # the ncclUniqueId travels like this
+        rdv.barrier()
+        assert rdv.max(float(rank)) == float(world - 1)
+        rdv.close()
+    except Exception as exc:  # noqa: BLE001
+        fail.put(f"rank {rank}: {type(exc).__name__}: {exc}")
+        raise
+
+
+def test_bench_rendezvous_over_gloo():
+    """The control plane bench.py uses for N > 1 (id broadcast, barrier, max over ranks)."""
+    ctx = mp.get_context("spawn")
+    fail = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_rendezvous_worker, args=(r, 2, port, fail)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    errors = []
+    while not fail.empty():
+        errors.append(fail.get())
+    assert not errors, errors
+    assert all(p.exitcode == 0 for p in procs)
