@@ -1,0 +1,199 @@
+"""Batch wrappers: all scales of one descriptor with the DEM uploaded to the GPU once.
+
+Counterparts of the reference's ``compute_dem / compute_tpi / compute_std / compute_gradient /
+compute_sx`` (reference topo.py:16-59, 88-141, 216-269, 534-594, 715-772): same arguments, same
+output names (``_tpi_name`` topo.py:184, ``_std_name`` :310, ``_gradient_names`` :647, ``_sx_name``
+:956, ``_dem_name`` :83), NaN re-insertion through ``ind_nans`` (topo.py:139), one output per
+scale.  The reference writes netCDF through xarray; here the writer is pluggable: with xarray
+installed the same ``topo_<NAME>.nc`` files are produced, otherwise ``topo_<NAME>.npy``.  Every
+wrapper also returns ``{name: array}``.
+"""
+import logging
+import os
+
+import numpy as np
+
+from . import CFG, _lib, device as d, helpers as hlp, topo
+
+logger = logging.getLogger(__name__)
+
+
+# ---- output names (identical strings to the reference) ---------------------------------------
+def _dem_name(scale):
+    return f"DEM_{scale}M"
+
+
+def _tpi_name(scale, smth_factor):
+    add = f"_SMTHFACT{smth_factor:.3g}" if smth_factor else ""
+    return f"TPI_{scale}M{add}"
+
+
+def _std_name(scale, smth_factor):
+    add = f"_SMTHFACT{smth_factor:.3g}" if smth_factor else ""
+    return f"STD_{scale}M{add}"
+
+
+def _gradient_names(scale, sig_ratio):
+    tail = f"_{scale}M_SIGRATIO{sig_ratio:.3g}"
+    return ["WE_DERIVATIVE" + tail, "SN_DERIVATIVE" + tail, "SLOPE" + tail, "ASPECT" + tail]
+
+
+def _sx_name(radius, azimuth):
+    return f"SX_RADIUS{int(radius)}_AZIMUTH{int(azimuth)}"
+
+
+# ---- writer ------------------------------------------------------------------------------------
+def write_output(array, dem_ds, name, crop=None, outdir=".", units=None):
+    """``hlp.to_netcdf`` of the reference (helpers.py:34-65) when xarray is there, .npy otherwise."""
+    name = str.upper(name)
+    if outdir is None:
+        return None
+    os.makedirs(outdir, exist_ok=True)
+    if hlp._xr is not None and isinstance(dem_ds, hlp._xr.Dataset):  # pragma: no cover
+        ds = hlp._xr.Dataset({name: (hlp.get_da(dem_ds).dims, array)}, coords=dem_ds.coords,
+                             attrs=dem_ds.attrs).sel(crop)
+        if units is not None:
+            ds[name].attrs.update(units=units)
+        path = os.path.join(outdir, f"topo_{name}.nc")
+        ds.to_netcdf(path)
+    else:
+        if crop is not None:
+            raise NotImplementedError("crop needs xarray coordinates")
+        path = os.path.join(outdir, f"topo_{name}.npy")
+        np.save(path, array)
+    logger.info("saved: %s", path)
+    return path
+
+
+def _as_list(x, n=None):
+    if not hasattr(x, "__iter__"):
+        x = [x] if n is None else [x] * n
+    return list(x)
+
+
+class _ResidentDem:
+    """The DEM on the GPU for the duration of one wrapper call."""
+
+    def __init__(self, dem_val):
+        self.host = _lib.as_f32(dem_val)
+        self.dev = d.DeviceArray.from_host(self.host)
+        self.block = d.Block(self.dev)
+        self.shape = self.host.shape
+
+    def plane(self):
+        return d.DeviceArray(*self.shape)
+
+    def close(self):
+        self.dev.free()
+
+
+def _finish(array, ind_nans, dem_ds, name, crop, outdir, units, results):
+    if ind_nans is not None and len(ind_nans):
+        array[ind_nans] = np.nan
+    write_output(array, dem_ds, name, crop, outdir, units)
+    results[name] = array
+
+
+def compute_dem(dem_ds, scales, ind_nans=(), crop=None, outdir="."):
+    """Gaussian-smoothed DEM per scale, sigma = scale_px / CFG.scale_std (reference topo.py:16-59)."""
+    hlp.check_dem(dem_ds)
+    scales = _as_list(scales)
+    scales_pxl, _ = hlp.scale_to_pixel(scales, dem_ds)
+    res = _ResidentDem(hlp.get_da(dem_ds).values)
+    out, results = res.plane(), {}
+    try:
+        for scale, px in zip(scales, scales_pxl):
+            sigma = px / CFG.scale_std
+            res.block.gaussian(sigma, sigma, out)
+            _finish(out.to_host(), ind_nans, dem_ds, _dem_name(scale), crop, outdir, "m", results)
+    finally:
+        out.free()
+        res.close()
+    return results
+
+
+def _tpi_std(dem_ds, scales, smth_factors, ind_nans, crop, outdir, want):
+    hlp.check_dem(dem_ds)
+    scales = _as_list(scales)
+    smth_factors = _as_list(smth_factors, len(scales))
+    scales_pxl, _ = hlp.scale_to_pixel(scales, dem_ds)
+    sigmas = hlp.get_sigmas(smth_factors, scales_pxl)
+    res = _ResidentDem(hlp.get_da(dem_ds).values)
+    out, smooth, results = res.plane(), None, {}
+    try:
+        for scale, px, fact, sigma in zip(scales, scales_pxl, smth_factors, sigmas):
+            logger.info("Computing scale %s meters with smoothing factor %s ...", scale, fact)
+            block = res.block
+            if sigma:  # pre-smoothing (reference topo.py:172-173, :297-298)
+                smooth = smooth or res.plane()
+                res.block.gaussian(sigma, sigma, smooth)
+                block = d.Block(smooth)
+            if want == "tpi":
+                block.tpi_std(int(px), tpi=out)
+                array, name = out.to_host(), _tpi_name(scale, fact)
+            else:
+                block.tpi_std(int(px), std=out)
+                array, name = out.to_host().astype(np.float64), _std_name(scale, fact)
+            _finish(array, ind_nans, dem_ds, name, crop, outdir, "m", results)
+    finally:
+        out.free()
+        if smooth is not None:
+            smooth.free()
+        res.close()
+    return results
+
+
+def compute_tpi(dem_ds, scales, smth_factors=None, ind_nans=(), crop=None, outdir="."):
+    """TPI for every scale (reference topo.py:88-141)."""
+    logger.info("***Starting TPI computation for scales %s meters***", scales)
+    return _tpi_std(dem_ds, scales, smth_factors, ind_nans, crop, outdir, "tpi")
+
+
+def compute_std(dem_ds, scales, smth_factors=None, ind_nans=(), crop=None, outdir="."):
+    """Windowed standard deviation for every scale (reference topo.py:216-269)."""
+    logger.info("***Starting STD computation for scales %s meters***", scales)
+    return _tpi_std(dem_ds, scales, smth_factors, ind_nans, crop, outdir, "std")
+
+
+def compute_gradient(dem_ds, scales, sig_ratios=1, ind_nans=(), crop=None, outdir="."):
+    """dx, dy, slope, aspect for every scale (reference topo.py:534-594)."""
+    hlp.check_dem(dem_ds)
+    logger.info("***Starting gradients computation for scales %s meters***", scales)
+    scales = _as_list(scales)
+    sig_ratios = _as_list(sig_ratios, len(scales))
+    scales_pxl, res_meters = hlp.scale_to_pixel(scales, dem_ds)
+    sigmas = scales_pxl / CFG.scale_std
+    dem_val = hlp.get_da(dem_ds).values
+    results = {}
+    two_d = np.ndim(res_meters["x"]) > 1 or np.ndim(res_meters["y"]) > 1
+    res = None if two_d else _ResidentDem(dem_val)
+    outs = None if two_d else [res.plane() for _ in range(4)]
+    try:
+        for scale, sigma, ratio in zip(scales, sigmas, sig_ratios):
+            names = _gradient_names(scale, ratio)
+            if two_d:  # per-pixel resolutions (WGS84 grids): host-buffer entry point
+                arrays = topo.gradient(dem_val, sigma, res_meters, sig_ratio=ratio)
+            else:
+                res.block.gradient(sigma, res_meters["x"], res_meters["y"], sig_ratio=ratio,
+                                   dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3])
+                arrays = [o.to_host() for o in outs]
+            for array, name, units in zip(arrays, names, ["1", "1", "degree", "degree"]):
+                _finish(array, ind_nans, dem_ds, name, crop, outdir, units, results)
+    finally:
+        if res is not None:
+            for o in outs:
+                o.free()
+            res.close()
+    return results
+
+
+def compute_sx(dem_ds, azimuth, radius, height=10.0, azimuth_arc=10.0, azimuth_steps=15,
+               radius_min=0.0, crop=None, outdir="."):
+    """Sx for one azimuth (reference topo.py:715-772)."""
+    hlp.check_dem(dem_ds)
+    logger.info("***Starting Sx computation for azimuth %s meters and radius %s***", azimuth, radius)
+    array = topo.sx(dem_ds, azimuth, radius, height=height, azimuth_arc=azimuth_arc,
+                    azimuth_steps=azimuth_steps, radius_min=radius_min)
+    results = {}
+    _finish(array, None, dem_ds, _sx_name(radius, azimuth), crop, outdir, "degree", results)
+    return results
