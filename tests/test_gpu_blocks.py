@@ -291,3 +291,28 @@ def test_rccl_communicator_single_rank():
         assert np.max(np.abs(t.to_host() - orc.tpi_exact(dem, size))) <= 2.5e-4
     finally:
         _lib.check(lib.topo_amd_comm_destroy(), "comm_destroy")
+
+
+@pytest.mark.parametrize("size", [121, 151, 256, 401])
+def test_very_large_discs(size):
+    """Discs beyond an LDS tile take the float64 global-prefix kernel (exact, any size); the
+    disc may even be larger than the DEM."""
+    from topo_descriptors_amd import topo
+    for integer in (True, False):
+        dem = orc.synthetic_dem(150, 200, seed=size, integer=integer)
+        t, s = topo.tpi_std(dem, size)
+        assert np.max(np.abs(t - orc.tpi_exact(dem, size))) <= 2.5e-4, (size, integer)
+        e = orc.std_exact(dem, size)
+        assert np.max(np.abs(s - e)) <= 1e-4 * np.max(e), (size, integer)
+    # row blocks stay bit-identical on this path too
+    dem = orc.synthetic_dem(300, 128, seed=size, integer=False)
+    up, down = halo(_lib.DESC_TPI, size)
+
+    def call(blk, row0, rows):
+        a, b = d.DeviceArray(rows, 128), d.DeviceArray(rows, 128)
+        blk.tpi_std(size, tpi=a, std=b, out_row0=row0, out_rows=rows)
+        return [a, b]
+
+    whole = run_blocks(dem, 1, up, down, call)
+    parts = run_blocks(dem, 2, up, down, call)
+    assert np.array_equal(parts[0], whole[0]) and np.array_equal(parts[1], whole[1])

@@ -52,8 +52,8 @@ struct Context {
     hipEvent_t input_ready = nullptr;  // compute -> comm dependency
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // grow-only device workspaces (never freed between calls: no hipMalloc in the hot path)
-    void* ws[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t ws_bytes[4] = {0, 0, 0, 0};
+    void* ws[8] = {};
+    size_t ws_bytes[8] = {};
     // small parameter tables (disc runs, gaussian taps, sx offsets, resolutions)
     void* tab[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t tab_bytes[6] = {0, 0, 0, 0, 0, 0};
@@ -87,6 +87,8 @@ int build_disc(int size, DiscRuns* out);
 int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out);
 // size-specialised wave-shift kernels; TOPO_AMD_EUNSUP = not covered, use the generic kernel
 int launch_disc_wave(const Block& b, int size, float* tpi_out, float* std_out);
+// any size: float64 column prefix sums in HBM (slow, exact)
+int launch_disc_big(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out);
 int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out);
 int launch_sobel(const Block& b, float* dx_out, float* dy_out);
 int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode,

@@ -361,11 +361,7 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
     auto lds_for = [&](int th) { return (size_t)(th + n_rows - 1) * stride * sizeof(float); };
     const size_t lds_cap = 160 * 1024;
     while (tile_h > 8 && lds_for(tile_h) > lds_cap) tile_h /= 2;
-    if (lds_for(tile_h) > lds_cap) {
-        set_error("tpi/std: disc size %d needs %zu B of LDS per tile (limit %zu); "
-                  "the large-radius path is not built yet", disc.size, lds_for(tile_h), lds_cap);
-        return TOPO_AMD_EUNSUP;
-    }
+    if (lds_for(tile_h) > lds_cap) return launch_disc_big(b, disc, tpi_out, std_out);
     // prefer two resident blocks per CU when the tile allows it
     if (tile_h == 32 && lds_for(32) > lds_cap / 2 && lds_for(16) <= lds_cap / 2) {
         // keep 32: fewer halo re-reads beats occupancy for this LDS-bound kernel
