@@ -255,3 +255,30 @@ def test_long_filters_beyond_the_lds_tile():
     e = orc.gradient_exact(dem, 60.0, res)
     for k in range(3):
         assert np.max(np.abs(g[k] - e[k])) <= 1e-4 * np.max(np.abs(e[k])) + 2e-5
+
+
+def test_filters_wider_than_a_wavefront_can_chain():
+    """sigma = 120 (radius 480): axis 1 goes through transpose + axis-0 kernel + transpose."""
+    dem = orc.synthetic_dem(260, 300, seed=33)
+    got = topo.dem(dem, 120.0)
+    assert np.max(np.abs(got - orc.gaussian_exact(dem, 120.0))) <= 1e-3
+    x = 2600000.0 + 30.0 * np.arange(300)
+    y = 1200000.0 - 30.0 * np.arange(260)
+    res = orc.grid_resolution(x, y)
+    g = topo.gradient(dem, 120.0, res)
+    e = orc.gradient_exact(dem, 120.0, res)
+    # the float32 rounding of the smoothed field (a few 1e-4 m, the reference has the same) is
+    # 2e-5 in dx, dy on a 30 m grid and 57.3 times that in the slope in degrees
+    for k, floor in ((0, 2e-5), (1, 2e-5), (2, 57.3 * 2e-5)):
+        assert np.max(np.abs(g[k] - e[k])) <= 1e-4 * np.max(np.abs(e[k])) + floor
+
+
+def test_sx_window_beyond_the_lds_tile():
+    """radius 6000 m on a 30 m grid: window 201 pixels, scanned straight from global memory."""
+    dem = orc.synthetic_dem(460, 470, seed=35)
+    x = 2600000.0 + 30.0 * np.arange(470)
+    y = 1200000.0 - 30.0 * np.arange(460)
+    got = topo.sx(FakeDataset(dem, x, y), 45.0, 6000.0)
+    want = orc.sx(dem, x, y, 45.0, 6000.0)
+    assert np.array_equal(got == 0, want == 0)
+    assert np.max(np.abs(got - want)) <= REL * np.max(np.abs(want))

@@ -535,6 +535,24 @@ __global__ __launch_bounds__(kThreads) void gauss_axis1_wave_grad_kernel(WaveGra
     }
 }
 
+// ---- plane transpose (used to run very long axis-1 filters as axis-0 filters) -----------------
+__global__ __launch_bounds__(kThreads) void transpose_kernel(const float* in, float* out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int y = y0 + ty + k, x = x0 + tx;
+        if (y < rows && x < cols) tile[ty + k][tx] = in[(size_t)y * cols + x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int y = x0 + ty + k, x = y0 + tx;  // coordinates in the transposed plane
+        if (y < cols && x < rows) out[(size_t)y * rows + x] = tile[tx][ty + k];
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------
 int upload_weights(int slot, double sigma, int kb, GaussArgs* a) {
     const int R = gaussian_radius(sigma);
@@ -628,7 +646,22 @@ int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int t
             g.nx = nx;
             g.out_row0 = 0;
             g.out_rows = rows;
-            return run_axis1_wave_grad(in, 0, rows, sigma, g, out);
+            const int r = run_axis1_wave_grad(in, 0, rows, sigma, g, out);
+            if (r != TOPO_AMD_EUNSUP) return r;
+            // filter wider than a wavefront can chain: transpose, filter down the columns, transpose back
+            Context& c = ctx();
+            const size_t bytes = (size_t)rows * nx * sizeof(float);
+            void *t1 = nullptr, *t2 = nullptr;
+            TOPO_TRY(workspace(6, bytes, &t1));
+            TOPO_TRY(workspace(7, bytes, &t2));
+            dim3 g1((nx + 31) / 32, (rows + 31) / 32), g2((rows + 31) / 32, (nx + 31) / 32);
+            hipLaunchKernelGGL(transpose_kernel, g1, dim3(kThreads), 0, c.compute, in, (float*)t1, rows, nx);
+            TOPO_HIP(hipGetLastError());
+            Block tb{(const float*)t1, nx, 0, nx, rows, 0, nx};
+            TOPO_TRY(run_axis0(tb, sigma, (float*)t2, table_slot));
+            hipLaunchKernelGGL(transpose_kernel, g2, dim3(kThreads), 0, c.compute, (const float*)t2, out, nx, rows);
+            TOPO_HIP(hipGetLastError());
+            return TOPO_AMD_OK;
         }
         return launch_axis1<16, 16, 8>(a, rows, nx, sigma);
     }
@@ -870,7 +903,11 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             return run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);
         const int r = run_axis1_wave_grad((const float*)plane_a, s0, s_rows, sigma, g, nullptr);
         if (r != TOPO_AMD_EUNSUP) return r;
-        return run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);
+        // filter wider than a wavefront can chain: finish the smooth unfused (axis 1 goes through
+        // the transpose path) and difference it with the stand-alone epilogue
+        TOPO_TRY(workspace(2, bytes, &plane_b));
+        TOPO_TRY(run_axis1((const float*)plane_a, s_rows, b.nx, sigma, (float*)plane_b, 2));
+        plane_a = plane_b;
     } else {  // topo.py:633-635
         const double perp = sigma * sig_ratio;
         TOPO_TRY(workspace(2, bytes, &plane_b));

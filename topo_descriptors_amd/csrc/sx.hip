@@ -90,6 +90,39 @@ __global__ __launch_bounds__(kThreads) void sx_kernel(SxArgs p) {
     }
 }
 
+// Search windows too large for an LDS tile: the same scan straight from global memory (the ray
+// pixels of neighbouring lanes are neighbours, so every read is a coalesced row segment that L2
+// serves after the first touch).
+struct SxGlobalArgs {
+    const float* in;
+    float* out;
+    const int* dj;
+    const int* di;
+    const float* inv_dist;
+    int n_off;
+    int in_row0, gny, nx, out_row0, out_rows, window;
+    float height;
+};
+
+__global__ __launch_bounds__(kThreads) void sx_global_kernel(SxGlobalArgs p) {
+    const int ox = blockIdx.x * kThreads + threadIdx.x;
+    const int oy = p.out_row0 + blockIdx.y;
+    if (ox >= p.nx) return;
+    const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
+    const bool inside = oy >= p.window && oy < p.gny - p.window && ox >= p.window && ox < p.nx - p.window;
+    if (!inside) {
+        p.out[o] = 0.0f;
+        return;
+    }
+    const float centre = p.in[(size_t)(oy - p.in_row0) * p.nx + ox] + p.height;
+    float best = -INFINITY;
+    for (int n = 0; n < p.n_off; ++n) {
+        const float v = p.in[(size_t)(oy + p.dj[n] - p.in_row0) * p.nx + ox + p.di[n]];
+        best = fmaxf(best, (v - centre) * p.inv_dist[n]);
+    }
+    p.out[o] = best == -INFINITY ? NAN : atanf(best) * 57.29577951308232f;
+}
+
 __global__ __launch_bounds__(kThreads) void fill_kernel(float* out, size_t n, float value) {
     size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
     const size_t step = (size_t)gridDim.x * kThreads;
@@ -175,9 +208,23 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     a.stride = a.cols_l | 1;
     const size_t lds = (size_t)a.rows_l * a.stride * sizeof(float);
     if (lds > 160 * 1024) {
-        set_error("sx: window %d needs %zu B of LDS per tile; large-radius path not built yet",
-                  window, lds);
-        return TOPO_AMD_EUNSUP;
+        std::vector<int> vdj(pts.size()), vdi(pts.size());
+        std::vector<float> vinv(pts.size());
+        for (size_t n = 0; n < pts.size(); ++n) {
+            vdj[n] = pts[n].first.first;
+            vdi[n] = pts[n].first.second;
+            vinv[n] = (float)(1.0 / pts[n].second);
+        }
+        void *d_dj = nullptr, *d_di = nullptr, *d_inv = nullptr;
+        TOPO_TRY(upload_table(0, vdj.data(), vdj.size() * sizeof(int), &d_dj));
+        TOPO_TRY(upload_table(1, vdi.data(), vdi.size() * sizeof(int), &d_di));
+        TOPO_TRY(upload_table(2, vinv.data(), vinv.size() * sizeof(float), &d_inv));
+        SxGlobalArgs ga{b.in, out, (const int*)d_dj, (const int*)d_di, (const float*)d_inv, (int)pts.size(),
+                        b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows, window, (float)height};
+        dim3 ggrid((b.nx + kThreads - 1) / kThreads, b.out_rows);
+        hipLaunchKernelGGL(sx_global_kernel, ggrid, dim3(kThreads), 0, c.compute, ga);
+        TOPO_HIP(hipGetLastError());
+        return TOPO_AMD_OK;
     }
     std::vector<int> off(pts.size());
     std::vector<float> inv(pts.size());
