@@ -662,7 +662,13 @@ Shard make_shard(float* block, int rows_local, int row0, int gny, int nx, int ab
 template <class Fn>
 int run_overlapped(float* block, const Shard& s, int above, int below, Fn fn) {
     TOPO_TRY(topo_amd_halo_exchange_start(block, s.rows_local, s.whole.nx, above, below));
-    if (s.interior1 > s.interior0) TOPO_TRY(fn(s.interior0, s.interior1 - s.interior0));
+    // the interior launch is persistent (it would otherwise hold every CU until it ends): leave
+    // a few CUs to the send/recv kernels so that the exchange really runs next to it
+    ctx().reserve_cus = g_comm.size > 1 ? 16 : 0;
+    int rc = TOPO_AMD_OK;
+    if (s.interior1 > s.interior0) rc = fn(s.interior0, s.interior1 - s.interior0);
+    ctx().reserve_cus = 0;
+    if (rc != TOPO_AMD_OK) return rc;
     TOPO_TRY(topo_amd_halo_wait());
     if (s.interior0 > s.row0) TOPO_TRY(fn(s.row0, s.interior0 - s.row0));
     const int end = s.row0 + s.rows_local;

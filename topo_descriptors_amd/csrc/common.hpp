@@ -45,6 +45,7 @@ struct Context {
     bool ready = false;
     int device = -1;
     int num_cu = 256;
+    int reserve_cus = 0;  // CUs persistent kernels leave free while a ghost-row exchange is in flight
     size_t lds_per_block = 65536;
     hipStream_t compute = nullptr;   // every kernel goes here
     hipStream_t comm = nullptr;      // RCCL ghost-row traffic

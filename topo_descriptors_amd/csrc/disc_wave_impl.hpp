@@ -161,8 +161,8 @@ __device__ __forceinline__ uint32_t stage_value(float x, float c, int ci) {
 // All waves: load the tile's rows, transform, and leave the column prefix sums of it in Q.
 // Padded (out-of-domain) samples are staged as 0; the caller accounts for them through m.
 template <int SIZE, int TH, int NWAVES, int WHAT, typename T>
-__device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, int gy0, int gx, float c,
-                                            int ci, float lim32, float limcv) {
+__device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, int* flag_word, int gy0,
+                                            int gx, float c, int ci, float lim32, float limcv) {
     constexpr int NROWS = TH + SIZE - 1;
     constexpr int SL = (NROWS + NWAVES - 1) / NWAVES;
     T* Q = reinterpret_cast<T*>(lds);
@@ -209,15 +209,17 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
         if (umax > __float_as_uint(limcv)) flags |= kTileFloat;  // also NaN / inf
     }
     *reinterpret_cast<Vec4<T>*>(TOT + wave * ROWW + lane * NC) = run;
-    // __syncthreads_or is a LOGICAL or: reduce every flag bit on its own
-    int all = 0;
+    // tile flags: one ballot per bit inside the wave, one LDS atomic per wave, and the barrier the
+    // fix-up pass needs anyway (the flag word is cleared again at the end of the tile)
     if (WHAT == kStU) {
-        all |= __syncthreads_or(flags & kTileFrac) ? kTileFrac : 0;
-        all |= __syncthreads_or(flags & kTileWide) ? kTileWide : 0;
-        all |= __syncthreads_or(flags & kTileFloat) ? kTileFloat : 0;
-    } else {
-        __syncthreads();
+        int wf = 0;
+        if (__builtin_amdgcn_ballot_w64(flags & kTileFrac)) wf |= kTileFrac;
+        if (__builtin_amdgcn_ballot_w64(flags & kTileWide)) wf |= kTileWide;
+        if (__builtin_amdgcn_ballot_w64(flags & kTileFloat)) wf |= kTileFloat;
+        if (lane == 0 && wf) atomicOr(flag_word, wf);
     }
+    __syncthreads();
+    const int all = WHAT == kStU ? *flag_word : 0;
     if (wave > 0) {
         Vec4<T> off{{(T)0, (T)0, (T)0, (T)0}};
         for (int w = 0; w < wave; ++w) {
@@ -249,6 +251,9 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
     static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
     unsigned short* PL = reinterpret_cast<unsigned short*>(lds_u + (NROWS + 1 + NWAVES) * ROWW);
+    int* flag_word = reinterpret_cast<int*>(PL + ((TH * (SIZE + 1) + 7) & ~7));
+    if (threadIdx.x == 0) *flag_word = 0;
+    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
             return *reinterpret_cast<const Vec4<uint32_t>*>(plane + (which * TH + jj) * ROWW);
         };
 
-        const int flags = stage_prefix<SIZE, TH, NWAVES, kStU, int>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+        const int flags = stage_prefix<SIZE, TH, NWAVES, kStU, int>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
         const bool use_float = (flags & kTileFloat) != 0;
         const bool wide = (flags & kTileWide) != 0;
         const bool frac = (flags & kTileFrac) != 0;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
             }
             if (WANT_STD) {
             __syncthreads();
-            stage_prefix<SIZE, TH, NWAVES, kStU2, uint32_t>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+            stage_prefix<SIZE, TH, NWAVES, kStU2, uint32_t>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
             if (!wide) {
 #pragma unroll 1
                 for (int k = 0; k < RW; ++k) {
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
             }
         } else {
             __syncthreads();
-            stage_prefix<SIZE, TH, NWAVES, kStA, float>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+            stage_prefix<SIZE, TH, NWAVES, kStA, float>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
 #pragma unroll 1
             for (int k = 0; k < RW; ++k) {
                 float acc[NC];
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
             }
             if (WANT_STD) {
             __syncthreads();
-            stage_prefix<SIZE, TH, NWAVES, kStT2, float>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+            stage_prefix<SIZE, TH, NWAVES, kStT2, float>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
 #pragma unroll 1
             for (int k = 0; k < RW; ++k) {
                 float acc[NC];
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
         }
         if (frac) {
             __syncthreads();
-            stage_prefix<SIZE, TH, NWAVES, kStF, float>(p, lds_u, gy0, gx, c, ci, lim32, limcv);
+            stage_prefix<SIZE, TH, NWAVES, kStF, float>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
 #pragma unroll 1
             for (int k = 0; k < RW; ++k) {
                 float acc[NC];
@@ -444,7 +449,8 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
                 finalise_row(jj, q0, q1, q2, q3);
             }
         }
-        __syncthreads();  // Q and PL are rewritten by the next tile
+        if (threadIdx.x == 0) *flag_word = 0;
+        __syncthreads();  // Q, PL and the flag word are rewritten by the next tile
     }
 }
 
@@ -454,7 +460,7 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out) {
     Context& c = ctx();
     WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows, nullptr};
     constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(float) +
-                           (size_t)TH * (SIZE + 1) * sizeof(unsigned short);
+                           (size_t)((TH * (SIZE + 1) + 7) & ~7) * sizeof(unsigned short) + 16;
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     static_assert(SIZE * SIZE < 65536, "tap counts must fit the 16-bit border table");
     static int blocks_per_cu = 0;
@@ -469,7 +475,11 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out) {
     const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
     const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
     const long ntiles = (long)tiles_x * tiles_y;
-    long grid = (long)c.num_cu * blocks_per_cu;
+    // persistent blocks fill the chip, minus the CUs kept free for the RCCL send/recv kernels of
+    // a ghost-row exchange that runs next to this launch
+    long grid = (long)(c.num_cu - c.reserve_cus) * blocks_per_cu;
+    if (grid < 8) grid = 8;
+    grid -= grid % 8;  // whole XCD rounds: the tile list is cut into XCD-contiguous runs
     if (grid > ntiles) grid = ntiles;
     void* scratch = nullptr;
     TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
@@ -484,7 +494,7 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out) {
 // capped at the heights that measured best for 67 px.
 constexpr int tile_rows(int size, int nwaves, int cap) {
     int th = cap;
-    while (th > nwaves && (size_t)(th + size + nwaves) * ROWW * 4 + (size_t)th * (size + 1) * 2 > 160 * 1024)
+    while (th > nwaves && (size_t)(th + size + nwaves) * ROWW * 4 + (size_t)(th * (size + 1) + 8) * 2 + 16 > 160 * 1024)
         th -= nwaves;
     return th;
 }
