@@ -8,8 +8,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtopo_amd.so")
-SOURCES = ["disc_wave_g0.hip", "disc_wave_g1.hip", "disc_wave_g2.hip", "disc_wave_g3.hip", "disc.hip",
-           "disc_wave.hip", "disc_big.hip", "gauss.hip", "sx.hip", "capi.hip"]
+SOURCES = [f"disc_wave_g{g}.hip" for g in range(10)] + ["disc.hip", "disc_wave.hip", "disc_big.hip", "gauss.hip",
+                                                           "sx.hip", "capi.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -47,7 +47,7 @@ def build_library(force=False, verbose=True):
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=6) as pool:
+    with ThreadPoolExecutor(max_workers=8) as pool:
         objs = list(pool.map(compile_one, srcs))
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs,
            "-L/opt/rocm/lib", "-lrccl"]
