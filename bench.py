@@ -123,6 +123,28 @@ def cpu_baseline(size, sample_rows, sample_cols, dem_sample):
     }
 
 
+def cpu_twin_baseline(size, dem_sample):
+    """The oracle's C/OpenMP twin (exact float64 evaluation, row-prefix algorithm) on every host
+    core: TPI at `size` and Sx (azimuth 0, radius 500 m) on a bounded window of the same DEM."""
+    from oracle import c_twin, topo_oracle as orc
+
+    rows, cols = dem_sample.shape
+    t0 = time.perf_counter()
+    c_twin.tpi_std(dem_sample, size, want_tpi=True, want_std=False)
+    dt_tpi = time.perf_counter() - t0
+    window, offs, dist = orc.sx_geometry(0.0, 500.0, 30.0, -30.0)
+    t0 = time.perf_counter()
+    c_twin.sx(dem_sample, offs[:, 0], offs[:, 1], dist, window, 10.0)
+    dt_sx = time.perf_counter() - t0
+    return {
+        "kind": "port", "cores": c_twin.threads(), "unit": "Mpixels/s",
+        "value": round(rows * cols / dt_tpi / 1e6, 2),
+        "sx_az0_r500_value": round(rows * cols / dt_sx / 1e6, 2),
+        "sample": f"oracle/topo_oracle.c (OpenMP, float64) on a {rows}x{cols} window of the same DEM: "
+                  f"TPI size {size} in {dt_tpi:.1f} s, Sx az 0 r 500 m in {dt_sx:.1f} s",
+    }
+
+
 def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     """Per-descriptor throughput on the resident DEM (N = 1 only): not the headline."""
     from topo_descriptors_amd import device as d
@@ -266,6 +288,7 @@ def main():
             cols_s = min(nx, 8192)
             sample = block.to_host(halo_up, rows_s)[:, :cols_s].copy()
             result["cpu_baseline"] = cpu_baseline(size, rows_s, cols_s, sample)
+            result["cpu_baseline_all_cores"] = cpu_twin_baseline(size, sample[:4096, :4096])
             # spot parity at full size: TPI of the same window vs the oracle, interior only
             got = out.to_host(0, rows_s)[:, :cols_s]
             from oracle import topo_oracle as orc
