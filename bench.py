@@ -174,6 +174,14 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
         window, dj, di, dist = d.sx_offsets(0.0, radius, 30.0, -30.0)
         fn = lambda: blk.sx(dj, di, dist, window, 10.0, o1)  # noqa: E731
         entry(f"sx_az0_r{int(radius)}", time_kernel(fn, 3, d), 8)
+    # the same TPI on fractional elevations: every tile runs the integer pass plus the float
+    # chain on the fractional parts and goes through the per-row scratch planes (two passes)
+    frac = d.synth_dem(ny, nx, seed=0, integer=False)
+    fblk = block_cls(frac)
+    for size in (7, 67):
+        entry(f"tpi_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, tpi=o1), 3, d), 8)
+        entry(f"std_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, std=o2), 3, d), 8)
+    frac.free()
     for a in (o1, o2, o3, o4):
         a.free()
     return out
@@ -263,8 +271,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"topo.tpi size={size}px (2000 m @ 30 m) on a {ny}x{nx} f32 DEM, "
-                            f"row-sharded over {world} GPU(s)",
+                "workload": f"topo.tpi size={size}px (2000 m @ 30 m) on a {ny}x{nx} f32 DEM with "
+                            f"integer-valued elevations (whole metres: every tile takes the one-pass "
+                            f"TPI path; see descriptors.tpi_s{size}_fractional_dem for the two-pass "
+                            f"rate on fractional elevations), row-sharded over {world} GPU(s)",
                 "descriptor": "tpi", "disc_px": size, "dem": [ny, nx],
                 "rows_per_gpu": rows_local, "halo_rows": [halo_up, halo_dn],
                 "parallelism": f"rows{world}",

@@ -75,9 +75,11 @@ int topo_amd_sync(void);
 int topo_amd_timer_start(void);
 int topo_amd_timer_stop(float* elapsed_ms); /* records, synchronises, returns ms        */
 
-/* Deterministic synthetic terrain (integer-valued metres, float32) written on the device:
- * value depends only on (global row, column, seed), so shards agree on overlaps.        */
-int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed);
+/* Deterministic synthetic terrain (float32 metres) written on the device: the value depends
+ * only on (global row, column, seed), so shards agree on overlaps.  integer_valued != 0 rounds
+ * to whole metres (SRTM/DHM25-like; TPI then takes the one-pass path), 0 keeps the fractional
+ * part (swissALTI3D-like; every tile takes the two-pass path).                          */
+int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed, int integer_valued);
 
 /* ---- geometry helpers (host) -------------------------------------------------------- */
 /* Tap count of the reference's circular_kernel(size) (topo.py:191-213).               */

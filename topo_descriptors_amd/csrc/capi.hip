@@ -319,10 +319,10 @@ int topo_amd_timer_stop(float* elapsed_ms) {
     return TOPO_AMD_OK;
 }
 
-int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed) {
+int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed, int integer_valued) {
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(out && rows >= 1 && nx >= 1, "synth_dem: bad arguments");
-    return launch_synth(out, rows, row0, nx, seed);
+    return launch_synth(out, rows, row0, nx, seed, integer_valued != 0);
 }
 
 // ---- geometry helpers ---------------------------------------------------------------------

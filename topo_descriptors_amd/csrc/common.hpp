@@ -97,7 +97,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
                     float* aspect);
 int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double* dist,
               int n_off, int window, double height, float* out);
-int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed);
+int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed, bool integer_valued);
 
 int gaussian_radius(double sigma);
 

@@ -141,7 +141,7 @@ __device__ __forceinline__ float hash01(uint32_t a, uint32_t b, uint32_t seed) {
 }
 
 __global__ __launch_bounds__(kThreads) void synth_kernel(float* out, int rows, int row0, int nx,
-                                                         uint32_t seed) {
+                                                         uint32_t seed, bool integer_valued) {
     const int x = blockIdx.x * kThreads + threadIdx.x;
     const int r = blockIdx.y;
     if (x >= nx || r >= rows) return;
@@ -153,15 +153,16 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(float* out, int rows, i
     float u = hash01(row0 + r, x, seed) + hash01(row0 + r, x, seed + 1) +
               hash01(row0 + r, x, seed + 2) + hash01(row0 + r, x, seed + 3) - 2.0f;
     z += u * 8.660254f;
-    out[(size_t)r * nx + x] = rintf(z);
+    out[(size_t)r * nx + x] = integer_valued ? rintf(z) : z;
 }
 
 }  // namespace
 
-int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed) {
+int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed, bool integer_valued) {
     Context& c = ctx();
     dim3 grid((nx + kThreads - 1) / kThreads, rows);
-    hipLaunchKernelGGL(synth_kernel, grid, dim3(kThreads), 0, c.compute, out, rows, row0, nx, seed);
+    hipLaunchKernelGGL(synth_kernel, grid, dim3(kThreads), 0, c.compute, out, rows, row0, nx, seed,
+                       integer_valued);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }

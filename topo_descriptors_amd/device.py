@@ -69,10 +69,12 @@ def timer_stop():
     return ms.value
 
 
-def synth_dem(rows, nx, row0=0, seed=0, out=None, out_row=0):
-    """Fill (part of) a DeviceArray with the deterministic synthetic terrain."""
+def synth_dem(rows, nx, row0=0, seed=0, out=None, out_row=0, integer=True):
+    """Fill (part of) a DeviceArray with the deterministic synthetic terrain.
+
+    integer=True rounds to whole metres, integer=False keeps fractional elevations."""
     d = out if out is not None else DeviceArray(rows, nx)
-    _lib.check(_lib.lib().topo_amd_synth_dem_dev(d.row_ptr(out_row), rows, row0, nx, seed),
+    _lib.check(_lib.lib().topo_amd_synth_dem_dev(d.row_ptr(out_row), rows, row0, nx, seed, int(bool(integer))),
                "synth_dem")
     return d
 
