@@ -230,7 +230,7 @@ int topo_amd_shutdown(void) {
         (void)ncclCommDestroy(g_comm.comm);
         g_comm = Comm();
     }
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 10; ++i)
         if (c.ws[i]) (void)hipFree(c.ws[i]);
     for (int i = 0; i < 6; ++i) {
         if (c.tab[i]) (void)hipFree(c.tab[i]);

@@ -47,6 +47,7 @@ struct WaveArgs {
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
     uint32_t* scratch;  // per-block planes for the per-row sums between the passes
+    uint8_t* defer;     // per tile: 1 = left for the general kernel (FAST build), null = no split
 };
 
 template <typename T>
@@ -243,8 +244,13 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     return all;
 }
 
-template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
+// FAST (TPI alone): the build without the float / fractional fall-backs, which is what lets it
+// fit 168 VGPRs without scratch.  A tile that needs them is marked in p.defer and left to the
+// general build, launched right after over the marked tiles only.  Both builds evaluate the same
+// exact function on any tile, so which of them takes a tile never shows in the output.
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD, bool FAST>
 __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+    static_assert(!FAST || (WANT_TPI && !WANT_STD), "the fast build is the one-pass TPI");
     using G = Geo<SIZE>;
     constexpr int NROWS = TH + SIZE - 1;
     constexpr int RW = TH / NWAVES;  // output rows per wave
@@ -266,7 +272,22 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
     const float lim32 = floorf(sqrtf(4294967295.0f / (float)G::T.taps));
     const float limcv = fminf(46000.0f, floorf(sqrtf(4294967295.0f / (float)SIZE)));
 
-    for (int tile = vb; tile < ntiles; tile += nb) {
+    int deferred_in_a_row = 0;  // FAST: after kGiveUp of them the block stops staging tiles
+    constexpr int kGiveUp = 4;
+    // the block's tiles are vb, vb + nb, ...; 64 of them are tested per ballot, so the general
+    // build reads the defer map with one load per 64 tiles
+    for (int base = vb; base < ntiles; base += 64 * nb) {
+    const int mine = base + lane * nb;
+    bool take = mine < ntiles;
+    if (!FAST && p.defer != nullptr) take = take && p.defer[take ? mine : 0] != 0;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(take);
+    while (todo) {
+        const int tile = base + __builtin_ctzll(todo) * nb;
+        todo &= todo - 1;
+        if (FAST && deferred_in_a_row >= kGiveUp) {
+            if (threadIdx.x == 0) p.defer[tile] = 1;
+            continue;
+        }
         const int ox0 = (tile / tiles_y) * G::TILE_W;
         const int oy0 = (p.out_row0 / TH + tile % tiles_y) * TH;  // global multiples of TH
         const int gx = ox0 - G::X0 + lane * NC;
@@ -292,9 +313,22 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
         };
 
         const int flags = stage_prefix<SIZE, TH, NWAVES, kStU, int>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
-        const bool use_float = (flags & kTileFloat) != 0;
+        if (FAST) {
+            const bool leave = (flags & (kTileFloat | kTileFrac)) != 0;
+            if (threadIdx.x == 0) {
+                p.defer[tile] = leave ? 1 : 0;
+                if (leave) *flag_word = 0;
+            }
+            if (leave) {
+                ++deferred_in_a_row;
+                __syncthreads();  // as at the end of a tile: Q and the flag word are rewritten next
+                continue;
+            }
+            deferred_in_a_row = 0;
+        }
+        const bool use_float = !FAST && (flags & kTileFloat) != 0;
         const bool wide = (flags & kTileWide) != 0;
-        const bool frac = (flags & kTileFrac) != 0;
+        const bool frac = !FAST && (flags & kTileFrac) != 0;
         // TPI alone on an integer-valued tile needs one pass: its rows are finalised straight from
         // the chain, without the round trip through the scratch planes
         const bool direct = !WANT_STD && !use_float && !frac;
@@ -452,24 +486,26 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
         if (threadIdx.x == 0) *flag_word = 0;
         __syncthreads();  // Q, PL and the flag word are rewritten by the next tile
     }
+    }
 }
 
-template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
-int launch_wave(const Block& b, float* tpi_out, float* std_out) {
+// only_deferred: process the tiles a preceding FAST launch of the same geometry marked.
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD, bool FAST = false>
+int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferred = false) {
     using G = Geo<SIZE>;
     Context& c = ctx();
-    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows, nullptr};
+    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows, nullptr, nullptr};
     constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(float) +
                            (size_t)((TH * (SIZE + 1) + 7) & ~7) * sizeof(unsigned short) + 16;
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     static_assert(SIZE * SIZE < 65536, "tap counts must fit the 16-bit border table");
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>,
+        TOPO_HIP(hipFuncSetAttribute((const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD, FAST>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nblk = 0;
         TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nblk, (const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, NWAVES * 64, lds));
+            &nblk, (const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD, FAST>, NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
     const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
@@ -481,10 +517,17 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out) {
     if (grid < 8) grid = 8;
     grid -= grid % 8;  // whole XCD rounds: the tile list is cut into XCD-contiguous runs
     if (grid > ntiles) grid = ntiles;
-    void* scratch = nullptr;
-    TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
-    a.scratch = (uint32_t*)scratch;
-    hipLaunchKernelGGL((disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>), dim3((unsigned)grid),
+    if (!FAST) {
+        void* scratch = nullptr;
+        TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
+        a.scratch = (uint32_t*)scratch;
+    }
+    if (FAST || only_deferred) {
+        void* defer = nullptr;  // same size in both launches of a pair, so the same allocation
+        TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
+        a.defer = (uint8_t*)defer;
+    }
+    hipLaunchKernelGGL((disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD, FAST>), dim3((unsigned)grid),
                        dim3(NWAVES * 64), lds, c.compute, a, tiles_x, tiles_y);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
@@ -504,7 +547,10 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
     constexpr int TH8 = tile_rows(SIZE, 8, 64), TH12 = tile_rows(SIZE, 12, 60);
     if (tpi_out && std_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out);
     if (std_out) return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out);
-    return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out);
+    // TPI alone: the scratch-free fast build first, then the general build over the tiles it left
+    // (none on a DEM of whole metres; all of them on one with fractional elevations)
+    TOPO_TRY((launch_wave<SIZE, TH12, 12, true, false, true>(b, tpi_out, std_out)));
+    return launch_wave<SIZE, TH12, 12, true, false, false>(b, tpi_out, std_out, true);
 }
 
 }  // namespace
