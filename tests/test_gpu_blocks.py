@@ -319,3 +319,48 @@ def test_very_large_discs(size):
     whole = run_blocks(dem, 1, up, down, call)
     parts = run_blocks(dem, 2, up, down, call)
     assert np.array_equal(parts[0], whole[0]) and np.array_equal(parts[1], whole[1])
+
+
+@pytest.mark.parametrize("layout", ["fractional_first", "fractional_band"])
+def test_tpi_fast_and_deferred_tiles_on_a_mixed_dem(layout):
+    """TPI alone runs as a fast build plus a deferred pass over the tiles that need the fractional /
+    float paths (csrc/disc_wave_impl.hpp).  4096 x 4096 gives ~1500 tiles at 67 px, 5-6 per
+    persistent block, so blocks defer, give up after four deferrals in a row (fractional_first: the
+    integer tiles behind them go to the general build unstaged) or go back to the fast path after a
+    deferred stretch (fractional_band).  Which build takes a tile must not show: exact-oracle
+    agreement on windows across the region edges, and bit-identity with the same DEM computed in
+    three row blocks (another tile list, so another tile -> build assignment)."""
+    n, size, r = 4096, 67, 33
+    dev = d.synth_dem(n, n, seed=11)
+    dem = dev.to_host()
+    dev.free()
+    c0, c1 = (0, 2800) if layout == "fractional_first" else (1000, 2500)
+    dem[:, c0:c1] += np.float32(0.37)
+    assert np.any(dem[:, c0:c1] != np.trunc(dem[:, c0:c1])) and np.all(dem[:, c1:] == np.trunc(dem[:, c1:]))
+    up, down = halo(_lib.DESC_TPI, size)
+
+    def call(blk, row0, rows):
+        t = d.DeviceArray(rows, n)
+        blk.tpi_std(size, tpi=t, out_row0=row0, out_rows=rows)
+        return [t]
+
+    whole = run_blocks(dem, 1, up, down, call)[0]
+    parts = run_blocks(dem, 3, up, down, call)[0]
+    assert np.array_equal(whole, parts), layout
+
+    w = 192
+    corners = [(0, max(c0 - w // 2, 0)), (1500, c1 - w // 2), (n - w, c1 - w // 2), (2000, c1 + 600),
+               (700, (c0 + c1) // 2), (n - w, n - w)]
+    for (j, i) in corners:
+        i = min(max(i, 0), n - w)
+        j0, j1, i0, i1 = max(0, j - r), min(n, j + w + r), max(0, i - r), min(n, i + w + r)
+        a, b = j - j0, i - i0
+        want = orc.tpi_exact(dem[j0:j1, i0:i1], size)[a:a + w, b:b + w]
+        got = whole[j:j + w, i:i + w]
+        keep = np.ones((w, w), bool)  # pixels whose disc crosses a cut that is not a DEM edge
+        if j0 > 0 and a < r: keep[: r - a] = False
+        if j1 < n and j1 - (j + w) < r: keep[w - (r - (j1 - (j + w))):] = False
+        if i0 > 0 and b < r: keep[:, : r - b] = False
+        if i1 < n and i1 - (i + w) < r: keep[:, w - (r - (i1 - (i + w))):] = False
+        assert keep.any()
+        assert np.max(np.abs(got - want)[keep]) <= 2.5e-4, (layout, j, i)
