@@ -47,7 +47,7 @@ struct WaveArgs {
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
     uint32_t* scratch;  // per-block planes for the per-row sums between the passes
-    uint8_t* defer;     // per tile: 1 = left for the general kernel (FAST build), null = no split
+    uint8_t* defer;     // per tile: 1 = left by the marching build for the general kernel; null = no split
 };
 
 template <typename T>
@@ -161,7 +161,13 @@ __device__ __forceinline__ uint32_t stage_value(float x, float c, int ci) {
 
 // All waves: load the tile's rows, transform, and leave the column prefix sums of it in Q.
 // Padded (out-of-domain) samples are staged as 0; the caller accounts for them through m.
-template <int SIZE, int TH, int NWAVES, int WHAT, typename T>
+// ABS_CLASS (the builds that compute TPI alone): a tile leaves the integer path when a sample is
+// non-finite or |trunc(x)| > kAbsLim, whatever c is - int32 sums of 3409 such u cannot wrap, u^2 is
+// not needed, and a criterion that does not look at c can be evaluated by the marching build on
+// the rows it adds to a carried window.
+constexpr float kAbsLim = 262144.0f;
+
+template <int SIZE, int TH, int NWAVES, int WHAT, typename T, bool ABS_CLASS = false>
 __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, int* flag_word, int gy0,
                                             int gx, float c, int ci, float lim32, float limcv) {
     constexpr int NROWS = TH + SIZE - 1;
@@ -192,7 +198,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
                     const float t = truncf(x);
                     const float d = t - c;
                     frac |= ok && (x != t);
-                    umax = max(umax, ok ? (__float_as_uint(d) & 0x7fffffffu) : 0u);
+                    umax = max(umax, ok ? (__float_as_uint(ABS_CLASS ? t : d) & 0x7fffffffu) : 0u);
                     bits = ok ? (uint32_t)(int)d : 0u;
                 } else {
                     bits = ok ? stage_value<WHAT>(x, c, ci) : 0u;
@@ -206,8 +212,8 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     }
     if (WHAT == kStU) {
         if (frac) flags |= kTileFrac;
-        if (umax > __float_as_uint(lim32)) flags |= kTileWide;
-        if (umax > __float_as_uint(limcv)) flags |= kTileFloat;  // also NaN / inf
+        if (!ABS_CLASS && umax > __float_as_uint(lim32)) flags |= kTileWide;
+        if (umax > __float_as_uint(ABS_CLASS ? kAbsLim : limcv)) flags |= kTileFloat;  // also NaN / inf
     }
     *reinterpret_cast<Vec4<T>*>(TOT + wave * ROWW + lane * NC) = run;
     // tile flags: one ballot per bit inside the wave, one LDS atomic per wave, and the barrier the
@@ -244,14 +250,12 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     return all;
 }
 
-// FAST (TPI alone): the build without the float / fractional fall-backs, which is what lets it
-// fit 168 VGPRs without scratch.  A tile that needs them is marked in p.defer and left to the
-// general build, launched right after over the marked tiles only.  Both builds evaluate the same
-// exact function on any tile, so which of them takes a tile never shows in the output.
-template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD, bool FAST>
+// With p.defer set (TPI alone) the kernel processes only the tiles the marching build
+// (tpi_march_kernel, below) marked for it.
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
 __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int tiles_x, int tiles_y) {
-    static_assert(!FAST || (WANT_TPI && !WANT_STD), "the fast build is the one-pass TPI");
     using G = Geo<SIZE>;
+    constexpr bool ABS_CLASS = !WANT_STD;
     constexpr int NROWS = TH + SIZE - 1;
     constexpr int RW = TH / NWAVES;  // output rows per wave
     static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
@@ -272,22 +276,16 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
     const float lim32 = floorf(sqrtf(4294967295.0f / (float)G::T.taps));
     const float limcv = fminf(46000.0f, floorf(sqrtf(4294967295.0f / (float)SIZE)));
 
-    int deferred_in_a_row = 0;  // FAST: after kGiveUp of them the block stops staging tiles
-    constexpr int kGiveUp = 4;
-    // the block's tiles are vb, vb + nb, ...; 64 of them are tested per ballot, so the general
-    // build reads the defer map with one load per 64 tiles
+    // the block's tiles are vb, vb + nb, ...; 64 of them are tested per ballot, so the defer map
+    // costs one load per 64 tiles
     for (int base = vb; base < ntiles; base += 64 * nb) {
     const int mine = base + lane * nb;
     bool take = mine < ntiles;
-    if (!FAST && p.defer != nullptr) take = take && p.defer[take ? mine : 0] != 0;
+    if (p.defer != nullptr) take = take && p.defer[take ? mine : 0] != 0;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(take);
     while (todo) {
         const int tile = base + __builtin_ctzll(todo) * nb;
         todo &= todo - 1;
-        if (FAST && deferred_in_a_row >= kGiveUp) {
-            if (threadIdx.x == 0) p.defer[tile] = 1;
-            continue;
-        }
         const int ox0 = (tile / tiles_y) * G::TILE_W;
         const int oy0 = (p.out_row0 / TH + tile % tiles_y) * TH;  // global multiples of TH
         const int gx = ox0 - G::X0 + lane * NC;
@@ -296,7 +294,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
         cy = min(max(cy, p.in_row0), p.in_row0 + p.in_rows - 1);
         const int cx = min(ox0 + G::TILE_W / 2, p.nx - 1);
         float c = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
-        if (!(fabsf(c) < 1.0e9f)) c = 0.0f;
+        if (!(fabsf(c) <= (ABS_CLASS ? kAbsLim : 1.0e9f))) c = 0.0f;
         const int ci = (int)c;
         const bool border = gy0 < 0 || gy0 + NROWS > p.gny || ox0 - G::X0 < 0 || ox0 - G::X0 + ROWW > p.nx;
 
@@ -312,23 +310,10 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
             return *reinterpret_cast<const Vec4<uint32_t>*>(plane + (which * TH + jj) * ROWW);
         };
 
-        const int flags = stage_prefix<SIZE, TH, NWAVES, kStU, int>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
-        if (FAST) {
-            const bool leave = (flags & (kTileFloat | kTileFrac)) != 0;
-            if (threadIdx.x == 0) {
-                p.defer[tile] = leave ? 1 : 0;
-                if (leave) *flag_word = 0;
-            }
-            if (leave) {
-                ++deferred_in_a_row;
-                __syncthreads();  // as at the end of a tile: Q and the flag word are rewritten next
-                continue;
-            }
-            deferred_in_a_row = 0;
-        }
-        const bool use_float = !FAST && (flags & kTileFloat) != 0;
+        const int flags = stage_prefix<SIZE, TH, NWAVES, kStU, int, ABS_CLASS>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
+        const bool use_float = (flags & kTileFloat) != 0;
         const bool wide = (flags & kTileWide) != 0;
-        const bool frac = !FAST && (flags & kTileFrac) != 0;
+        const bool frac = (flags & kTileFrac) != 0;
         // TPI alone on an integer-valued tile needs one pass: its rows are finalised straight from
         // the chain, without the round trip through the scratch planes
         const bool direct = !WANT_STD && !use_float && !frac;
@@ -489,8 +474,218 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
     }
 }
 
-// only_deferred: process the tiles a preceding FAST launch of the same geometry marked.
-template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD, bool FAST = false>
+// ---- TPI alone on tiles of whole metres: the marching build --------------------------------------
+// The general kernel stages TH + SIZE - 1 rows to produce TH of them; for 67 px that is 126 rows for
+// 60, and the 66 extra rows are the ones the tile above staged a moment ago.  This build gives each
+// persistent block a contiguous run of tiles going down a column strip and keeps them: the last
+// SIZE prefix rows of a tile are moved to the top of the LDS image (LDS -> LDS, 67 KiB), the prefix
+// sums of the TH new rows continue from the last carried row, and only those rows are loaded and
+// classified.  It can do so because everything on this path is an integer:
+//   * u = trunc(x) with no offset (c = 0): int32 sums of 3409 samples of |x| <= kAbsLim cannot wrap,
+//     and a running int32 prefix may wrap freely - only differences over <= SIZE rows are used;
+//   * padded taps are staged as 0 and so drop out of sum(x): no tap counting near the DEM border;
+//   * on such a tile x = trunc(x), so the pixel's own value is the difference of two prefix rows
+//     and is not re-read from the DEM.
+// The finalisation evaluates the same float64 expression as the general kernel's integer path on
+// the same exact integer sum(x), so both give the same bits.  A tile with a fractional, non-finite
+// or absurd sample is marked in p.defer and left to the general kernel (launched right after with
+// only_deferred); the carried window is dropped and the next tile staged in full.  After kGiveUp
+// such tiles in a row the block marks the rest of its run without staging it.
+template <int SIZE, int TH, int NWAVES>
+__device__ __forceinline__ int stage_march(const WaveArgs& p, int* Q, int* flag_word, int gy0, int gx) {
+    constexpr int NROWS = TH + SIZE - 1;
+    constexpr int KEEP = NROWS + 1 - TH;  // prefix rows carried over: those of window rows TH-1 .. NROWS-1
+    constexpr int RW = TH / NWAVES;       // new rows per wave
+    constexpr int NT = NWAVES * 64;
+    constexpr int MOVE4 = KEEP * 64;      // 16-byte pieces to move
+    constexpr int MOVES = (MOVE4 + NT - 1) / NT;
+    int* TOT = Q + (NROWS + 1) * ROWW;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r0 = KEEP - 1 + wave * RW;  // first new window row of this wave
+    Vec4<float> v[RW];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) v[k] = load_row4(p, gy0 + r0 + k, gx);
+    // old prefix rows TH .. NROWS become rows 0 .. KEEP-1: read, barrier (also: every wave is done
+    // reading the previous tile's image), write
+    typedef int int4v __attribute__((ext_vector_type(4)));  // a native vector: plain 16-byte loads / stores
+    int4v m[MOVES];
+    const int4v* src = reinterpret_cast<const int4v*>(Q + TH * ROWW);
+#pragma unroll
+    for (int s = 0; s < MOVES; ++s) {
+        // unconditional (clamped) so that m[] stays in registers; the write below is guarded
+        const int idx = (int)threadIdx.x + s * NT;
+        m[s] = src[idx < MOVE4 ? idx : MOVE4 - 1];
+    }
+    __syncthreads();
+    int4v* dst = reinterpret_cast<int4v*>(Q);
+#pragma unroll
+    for (int s = 0; s < MOVES; ++s) {
+        const int idx = (int)threadIdx.x + s * NT;
+        if (idx < MOVE4) dst[idx] = m[s];
+    }
+    uint32_t amax = 0;
+    bool frac = false;
+    Vec4<int> run{{0, 0, 0, 0}};
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        const bool ok = row4_inside(p, gy0 + r0 + k, gx);
+#pragma unroll
+        for (int s = 0; s < NC; ++s) {
+            const float x = v[k].v[s];
+            const float t = truncf(x);
+            frac |= ok && (x != t);
+            amax = max(amax, ok ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
+            run.v[s] += ok ? (int)t : 0;
+        }
+        *reinterpret_cast<Vec4<int>*>(Q + (r0 + k + 1) * ROWW + lane * NC) = run;
+    }
+    *reinterpret_cast<Vec4<int>*>(TOT + wave * ROWW + lane * NC) = run;
+    int wf = 0;
+    if (__builtin_amdgcn_ballot_w64(frac)) wf |= kTileFrac;
+    if (__builtin_amdgcn_ballot_w64(amax > __float_as_uint(kAbsLim))) wf |= kTileFloat;
+    if (lane == 0 && wf) atomicOr(flag_word, wf);
+    __syncthreads();
+    const int all = *flag_word;
+    // every wave adds the carried prefix (row KEEP-1) and the totals of the waves above it
+    Vec4<int> off = *reinterpret_cast<const Vec4<int>*>(Q + (KEEP - 1) * ROWW + lane * NC);
+    for (int w = 0; w < wave; ++w) {
+        const Vec4<int> t = *reinterpret_cast<const Vec4<int>*>(TOT + w * ROWW + lane * NC);
+#pragma unroll
+        for (int s = 0; s < NC; ++s) off.v[s] += t.v[s];
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        Vec4<int>* q = reinterpret_cast<Vec4<int>*>(Q + (r0 + k + 1) * ROWW + lane * NC);
+        Vec4<int> x = *q;
+#pragma unroll
+        for (int s = 0; s < NC; ++s) x.v[s] += off.v[s];
+        *q = x;
+    }
+    __syncthreads();
+    return all;
+}
+
+template <int SIZE, int TH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+    using G = Geo<SIZE>;
+    static_assert(G::T.centre == 0, "odd disc sizes only: the zeroed tap is the pixel itself");
+    static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
+    constexpr int NROWS = TH + SIZE - 1;
+    constexpr int RW = TH / NWAVES;
+    constexpr int kGiveUp = 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    int* Q = reinterpret_cast<int*>(lds_u);
+    int* flag_word = Q + (NROWS + 1 + NWAVES) * ROWW;
+    if (threadIdx.x == 0) *flag_word = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = tiles_x * tiles_y;
+    const int nb = gridDim.x;
+    const int per_xcd = nb >> 3;
+    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    // a contiguous run of the strip-major tile list per block; neighbouring runs sit in one XCD
+    const int per = (ntiles + nb - 1) / nb;
+    const int first = vb * per;
+    const int last = min(first + per, ntiles);
+    const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
+
+    bool carry = false;  // the LDS image holds the window of the tile right above, all integer
+    int deferred_in_a_row = 0;
+#pragma unroll 1
+    for (int tile = first; tile < last; ++tile) {
+        if (deferred_in_a_row >= kGiveUp) {
+            if (threadIdx.x == 0) p.defer[tile] = 1;
+            continue;
+        }
+        const int ty = tile % tiles_y;
+        const int ox0 = (tile / tiles_y) * G::TILE_W;
+        const int oy0 = (p.out_row0 / TH + ty) * TH;  // global multiples of TH
+        const int gx = ox0 - G::X0 + lane * NC;
+        const int gy0 = oy0 + G::T.off_min;
+        if (ty == 0) carry = false;  // top of a strip
+        int flags;
+        if (carry) {
+            flags = stage_march<SIZE, TH, NWAVES>(p, Q, flag_word, gy0, gx);
+        } else {
+            __syncthreads();  // the image and the flag word of the previous tile are done with
+            flags = stage_prefix<SIZE, TH, NWAVES, kStU, int, true>(p, lds_u, flag_word, gy0, gx, 0.0f, 0, 0.0f, 0.0f);
+        }
+        const bool leave = (flags & (kTileFloat | kTileFrac)) != 0;
+        if (threadIdx.x == 0) {
+            p.defer[tile] = leave ? 1 : 0;
+            *flag_word = 0;  // every thread has read it; the next atomicOr is behind a barrier
+        }
+        if (leave) {
+            ++deferred_in_a_row;
+            carry = false;
+            continue;
+        }
+        deferred_in_a_row = 0;
+        carry = true;
+
+        const int ocol = ox0 + lane * NC;
+        const bool lane_ok = lane < G::NVL && ocol < p.nx;
+#pragma unroll 1
+        for (int k = 0; k < RW; ++k) {
+            const int jj = wave + k * NWAVES;
+            int acc[NC];
+            wave_disc_sum<SIZE, int>(Q, jj, lane, acc);
+            const int oy = oy0 + jj;
+            if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
+            // the pixel's own (integer) value: prefix through its row minus prefix above it
+            const int* own = Q + (jj - G::T.off_min) * ROWW + lane * NC + G::X0;
+            const Vec4<int> hi = *reinterpret_cast<const Vec4<int>*>(own + ROWW);
+            const Vec4<int> lo = *reinterpret_cast<const Vec4<int>*>(own);
+            Vec4<float> out_t;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const float x = (float)(hi.v[t] - lo.v[t]);
+                const double s1 = (double)acc[t];  // sum of x over the in-domain taps, exact
+                const double x_ctr = (double)x;
+                out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+            }
+            *reinterpret_cast<Vec4<float>*>(p.tpi + (size_t)(oy - p.out_row0) * p.nx + ocol) = out_t;
+        }
+    }
+}
+
+template <int SIZE, int TH, int NWAVES>
+int launch_march(const Block& b, float* tpi_out) {
+    using G = Geo<SIZE>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows, nullptr, nullptr};
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16;
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_march_kernel<SIZE, TH, NWAVES>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)tpi_march_kernel<SIZE, TH, NWAVES>,
+                                                              NWAVES * 64, lds));
+        blocks_per_cu = nblk < 1 ? 1 : nblk;
+    }
+    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
+    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
+    const long ntiles = (long)tiles_x * tiles_y;
+    long grid = (long)(c.num_cu - c.reserve_cus) * blocks_per_cu;
+    if (grid < 8) grid = 8;
+    grid -= grid % 8;  // whole XCD rounds
+    if (grid > ntiles) grid = ntiles;
+    void* defer = nullptr;  // same size as in the general launch that follows, so the same allocation
+    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
+    a.defer = (uint8_t*)defer;
+    hipLaunchKernelGGL((tpi_march_kernel<SIZE, TH, NWAVES>), dim3((unsigned)grid), dim3(NWAVES * 64), lds, c.compute, a,
+                       tiles_x, tiles_y);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+// only_deferred: process the tiles a preceding launch_march of the same geometry marked.
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
 int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferred = false) {
     using G = Geo<SIZE>;
     Context& c = ctx();
@@ -501,11 +696,11 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferr
     static_assert(SIZE * SIZE < 65536, "tap counts must fit the 16-bit border table");
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD, FAST>,
+        TOPO_HIP(hipFuncSetAttribute((const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nblk = 0;
         TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nblk, (const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD, FAST>, NWAVES * 64, lds));
+            &nblk, (const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
     const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
@@ -517,17 +712,15 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferr
     if (grid < 8) grid = 8;
     grid -= grid % 8;  // whole XCD rounds: the tile list is cut into XCD-contiguous runs
     if (grid > ntiles) grid = ntiles;
-    if (!FAST) {
-        void* scratch = nullptr;
-        TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
-        a.scratch = (uint32_t*)scratch;
-    }
-    if (FAST || only_deferred) {
-        void* defer = nullptr;  // same size in both launches of a pair, so the same allocation
+    void* scratch = nullptr;
+    TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
+    a.scratch = (uint32_t*)scratch;
+    if (only_deferred) {
+        void* defer = nullptr;  // same size as in launch_march, so the same allocation
         TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
         a.defer = (uint8_t*)defer;
     }
-    hipLaunchKernelGGL((disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD, FAST>), dim3((unsigned)grid),
+    hipLaunchKernelGGL((disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>), dim3((unsigned)grid),
                        dim3(NWAVES * 64), lds, c.compute, a, tiles_x, tiles_y);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
@@ -547,10 +740,10 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
     constexpr int TH8 = tile_rows(SIZE, 8, 64), TH12 = tile_rows(SIZE, 12, 60);
     if (tpi_out && std_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out);
     if (std_out) return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out);
-    // TPI alone: the scratch-free fast build first, then the general build over the tiles it left
-    // (none on a DEM of whole metres; all of them on one with fractional elevations)
-    TOPO_TRY((launch_wave<SIZE, TH12, 12, true, false, true>(b, tpi_out, std_out)));
-    return launch_wave<SIZE, TH12, 12, true, false, false>(b, tpi_out, std_out, true);
+    // TPI alone: the marching build first, then the general build over the tiles it left (none on
+    // a DEM of whole metres; all of them on one with fractional elevations)
+    TOPO_TRY((launch_march<SIZE, TH12, 12>(b, tpi_out)));
+    return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true);
 }
 
 }  // namespace
