@@ -62,6 +62,9 @@ int topo_amd_device_count(void);
 int topo_amd_init(int device);            /* idempotent for the same device           */
 int topo_amd_shutdown(void);
 int topo_amd_device_name(char* buf, int buflen);
+/* Compute units the persistent kernels size their grids for: the device's CU count, or the
+ * smaller TOPO_AMD_CU_LIMIT from the environment at init.  Results never depend on it.   */
+int topo_amd_cu_count(void);
 
 int topo_amd_malloc(void** dptr, size_t bytes);
 int topo_amd_free(void* dptr);

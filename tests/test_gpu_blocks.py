@@ -364,3 +364,43 @@ def test_tpi_fast_and_deferred_tiles_on_a_mixed_dem(layout):
         if i1 < n and i1 - (i + w) < r: keep[:, w - (r - (i1 - (i + w))):] = False
         assert keep.any()
         assert np.max(np.abs(got - want)[keep]) <= 2.5e-4, (layout, j, i)
+
+
+_WRAP_CHILD = r"""
+import numpy as np
+from oracle import topo_oracle as orc
+from topo_descriptors_amd import topo, _lib
+assert _lib.lib().topo_amd_cu_count() == 8, "TOPO_AMD_CU_LIMIT did not take effect: the runs would be too short to wrap"
+ny, nx, size, r = 16384, 768, 67, 33
+rng = np.random.default_rng(5)
+dem = (250000.0 + rng.integers(-60, 61, size=(ny, nx))).astype(np.float32)
+dem[:, 400:] -= 500000.0          # a strip of large negative values: the prefix wraps downwards there
+got = topo.tpi(dem, size)
+worst = 0.0
+for j in (0, 4000, 8500, 8700, 10200, 12000, ny - 160):
+    for i in (0, 300, nx - 160):
+        j0, j1, i0, i1 = max(0, j - r), min(ny, j + 160 + r), max(0, i - r), min(nx, i + 160 + r)
+        want = orc.tpi_exact(dem[j0:j1, i0:i1], size)[j - j0:j - j0 + 160, i - i0:i - i0 + 160]
+        # 2.5e-4 m where TPI is noise-sized; one float32 ulp where it is ~5e5 m (across the sign change)
+        tol = np.maximum(2.5e-4, np.spacing(np.abs(want).astype(np.float32)).astype(np.float64))
+        worst = max(worst, float(np.max(np.abs(got[j:j + 160, i:i + 160] - want) / tol)))
+print("WORST", worst)
+"""
+
+
+def test_marching_prefix_wraps_harmlessly():
+    """The marching TPI kernel keeps a running uint32 prefix down a column strip and relies on
+    wrap-around being harmless.  With the grid limited to 8 blocks (TOPO_AMD_CU_LIMIT, read at
+    init, hence a child process) a 16384-row DEM of +-250000 m gives runs of ~170 tiles: the
+    prefix passes 2^31 after ~8600 rows (and -2^31 in the negative strip).  Exact-oracle agreement
+    on windows before, at and after the wrap."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, TOPO_AMD_CU_LIMIT="8")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _WRAP_CHILD], cwd=root, env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float(out.stdout.strip().splitlines()[-1].split()[1])  # max |gpu - exact| / tolerance
+    assert worst <= 1.0, worst

@@ -3,6 +3,7 @@
 #include <rccl/rccl.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -211,6 +212,12 @@ int topo_amd_init(int device) {
     hipDeviceProp_t prop;
     TOPO_HIP(hipGetDeviceProperties(&prop, device));
     c.num_cu = prop.multiProcessorCount;
+    // TOPO_AMD_CU_LIMIT=<n>: persistent kernels size their grids for at most n compute units (to
+    // leave room for other work on the GPU; the results do not depend on it)
+    if (const char* lim = std::getenv("TOPO_AMD_CU_LIMIT")) {
+        const int n = std::atoi(lim);
+        if (n >= 8 && n < c.num_cu) c.num_cu = n;
+    }
     TOPO_HIP(hipStreamCreateWithFlags(&c.compute, hipStreamNonBlocking));
     TOPO_HIP(hipStreamCreateWithFlags(&c.comm, hipStreamNonBlocking));
     TOPO_HIP(hipEventCreateWithFlags(&c.halo_done, hipEventDisableTiming));
@@ -254,6 +261,11 @@ int topo_amd_device_name(char* buf, int buflen) {
     TOPO_HIP(hipGetDeviceProperties(&prop, ctx().device));
     snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return TOPO_AMD_OK;
+}
+
+int topo_amd_cu_count(void) {
+    if (require_ready() != TOPO_AMD_OK) return TOPO_AMD_ENODEV;
+    return ctx().num_cu;
 }
 
 int topo_amd_malloc(void** dptr, size_t bytes) {

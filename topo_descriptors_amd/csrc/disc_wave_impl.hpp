@@ -492,14 +492,14 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
 // only_deferred); the carried window is dropped and the next tile staged in full.  After kGiveUp
 // such tiles in a row the block marks the rest of its run without staging it.
 template <int SIZE, int TH, int NWAVES>
-__device__ __forceinline__ int stage_march(const WaveArgs& p, int* Q, int* flag_word, int gy0, int gx) {
+__device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* flag_word, int gy0, int gx) {
     constexpr int NROWS = TH + SIZE - 1;
     constexpr int KEEP = NROWS + 1 - TH;  // prefix rows carried over: those of window rows TH-1 .. NROWS-1
     constexpr int RW = TH / NWAVES;       // new rows per wave
     constexpr int NT = NWAVES * 64;
     constexpr int MOVE4 = KEEP * 64;      // 16-byte pieces to move
     constexpr int MOVES = (MOVE4 + NT - 1) / NT;
-    int* TOT = Q + (NROWS + 1) * ROWW;
+    uint32_t* TOT = Q + (NROWS + 1) * ROWW;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r0 = KEEP - 1 + wave * RW;  // first new window row of this wave
@@ -508,7 +508,7 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, int* Q, int* flag_
     for (int k = 0; k < RW; ++k) v[k] = load_row4(p, gy0 + r0 + k, gx);
     // old prefix rows TH .. NROWS become rows 0 .. KEEP-1: read, barrier (also: every wave is done
     // reading the previous tile's image), write
-    typedef int int4v __attribute__((ext_vector_type(4)));  // a native vector: plain 16-byte loads / stores
+    typedef uint32_t int4v __attribute__((ext_vector_type(4)));  // a native vector: plain 16-byte loads / stores
     int4v m[MOVES];
     const int4v* src = reinterpret_cast<const int4v*>(Q + TH * ROWW);
 #pragma unroll
@@ -526,7 +526,7 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, int* Q, int* flag_
     }
     uint32_t amax = 0;
     bool frac = false;
-    Vec4<int> run{{0, 0, 0, 0}};
+    Vec4<uint32_t> run{{0u, 0u, 0u, 0u}};  // unsigned: the running prefix is allowed to wrap
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
         const bool ok = row4_inside(p, gy0 + r0 + k, gx);
@@ -536,11 +536,11 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, int* Q, int* flag_
             const float t = truncf(x);
             frac |= ok && (x != t);
             amax = max(amax, ok ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
-            run.v[s] += ok ? (int)t : 0;
+            run.v[s] += ok ? (uint32_t)(int)t : 0u;
         }
-        *reinterpret_cast<Vec4<int>*>(Q + (r0 + k + 1) * ROWW + lane * NC) = run;
+        *reinterpret_cast<Vec4<uint32_t>*>(Q + (r0 + k + 1) * ROWW + lane * NC) = run;
     }
-    *reinterpret_cast<Vec4<int>*>(TOT + wave * ROWW + lane * NC) = run;
+    *reinterpret_cast<Vec4<uint32_t>*>(TOT + wave * ROWW + lane * NC) = run;
     int wf = 0;
     if (__builtin_amdgcn_ballot_w64(frac)) wf |= kTileFrac;
     if (__builtin_amdgcn_ballot_w64(amax > __float_as_uint(kAbsLim))) wf |= kTileFloat;
@@ -548,16 +548,16 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, int* Q, int* flag_
     __syncthreads();
     const int all = *flag_word;
     // every wave adds the carried prefix (row KEEP-1) and the totals of the waves above it
-    Vec4<int> off = *reinterpret_cast<const Vec4<int>*>(Q + (KEEP - 1) * ROWW + lane * NC);
+    Vec4<uint32_t> off = *reinterpret_cast<const Vec4<uint32_t>*>(Q + (KEEP - 1) * ROWW + lane * NC);
     for (int w = 0; w < wave; ++w) {
-        const Vec4<int> t = *reinterpret_cast<const Vec4<int>*>(TOT + w * ROWW + lane * NC);
+        const Vec4<uint32_t> t = *reinterpret_cast<const Vec4<uint32_t>*>(TOT + w * ROWW + lane * NC);
 #pragma unroll
         for (int s = 0; s < NC; ++s) off.v[s] += t.v[s];
     }
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
-        Vec4<int>* q = reinterpret_cast<Vec4<int>*>(Q + (r0 + k + 1) * ROWW + lane * NC);
-        Vec4<int> x = *q;
+        Vec4<uint32_t>* q = reinterpret_cast<Vec4<uint32_t>*>(Q + (r0 + k + 1) * ROWW + lane * NC);
+        Vec4<uint32_t> x = *q;
 #pragma unroll
         for (int s = 0; s < NC; ++s) x.v[s] += off.v[s];
         *q = x;
@@ -575,8 +575,8 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
     constexpr int RW = TH / NWAVES;
     constexpr int kGiveUp = 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
-    int* Q = reinterpret_cast<int*>(lds_u);
-    int* flag_word = Q + (NROWS + 1 + NWAVES) * ROWW;
+    uint32_t* Q = lds_u;  // uint32 prefix sums of trunc(x): wrap-around is defined and harmless
+    int* flag_word = reinterpret_cast<int*>(Q + (NROWS + 1 + NWAVES) * ROWW);
     if (threadIdx.x == 0) *flag_word = 0;
     __syncthreads();
 
@@ -631,19 +631,19 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
 #pragma unroll 1
         for (int k = 0; k < RW; ++k) {
             const int jj = wave + k * NWAVES;
-            int acc[NC];
-            wave_disc_sum<SIZE, int>(Q, jj, lane, acc);
+            uint32_t acc[NC];  // sum of trunc(x) over the disc modulo 2^32; the true value fits int32
+            wave_disc_sum<SIZE, uint32_t>(Q, jj, lane, acc);
             const int oy = oy0 + jj;
             if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
             // the pixel's own (integer) value: prefix through its row minus prefix above it
-            const int* own = Q + (jj - G::T.off_min) * ROWW + lane * NC + G::X0;
-            const Vec4<int> hi = *reinterpret_cast<const Vec4<int>*>(own + ROWW);
-            const Vec4<int> lo = *reinterpret_cast<const Vec4<int>*>(own);
+            const uint32_t* own = Q + (jj - G::T.off_min) * ROWW + lane * NC + G::X0;
+            const Vec4<uint32_t> hi = *reinterpret_cast<const Vec4<uint32_t>*>(own + ROWW);
+            const Vec4<uint32_t> lo = *reinterpret_cast<const Vec4<uint32_t>*>(own);
             Vec4<float> out_t;
 #pragma unroll
             for (int t = 0; t < NC; ++t) {
-                const float x = (float)(hi.v[t] - lo.v[t]);
-                const double s1 = (double)acc[t];  // sum of x over the in-domain taps, exact
+                const float x = (float)(int)(hi.v[t] - lo.v[t]);
+                const double s1 = (double)(int)acc[t];  // sum of x over the in-domain taps, exact
                 const double x_ctr = (double)x;
                 out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
             }
