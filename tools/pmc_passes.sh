@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect rocprofv3 PMC counters for one command, one counter group per pass (TCC FETCH/WRITE
 # cannot share a pass; never combined with tracing other than --kernel-trace).
-# usage: tools/pmc_passes.sh <outdir-under-gpurun_out> <python args...>
+# usage: tools/pmc_passes.sh <outdir-under-gpurun_out> <args of the script...>
+#        PMC_SCRIPT=tools/std_trace.py tools/pmc_passes.sh <outdir> <args>   (default script: bench.py)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1; shift
 mkdir -p $OUT
@@ -11,7 +12,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pass$i -- python3 $R/bench.py "$@" > $OUT/pass$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pass$i -- python3 $R/${PMC_SCRIPT:-bench.py} "$@" > $OUT/pass$i.log 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

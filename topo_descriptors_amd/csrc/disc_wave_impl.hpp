@@ -16,6 +16,9 @@
 // neighbours first, cut into XCD-contiguous runs so that the ghost rows two tiles share meet in
 // one L2).
 #pragma once
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.hpp"
 #include "disc_runs.hpp"
 
@@ -47,7 +50,10 @@ struct WaveArgs {
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
     uint32_t* scratch;  // per-block planes for the per-row sums between the passes
-    uint8_t* defer;     // per tile: 1 = left by the marching build for the general kernel; null = no split
+    uint8_t* defer;     // per tile: 1 = left by the marching kernels for the general kernel; null = no split
+    int32_t* sums;      // marching kernels: exact sum of trunc(x) over the disc per pixel, laid out like the outputs
+    int map_th;         // general kernel: tile height of the geometry p.defer was built for (0 = its own)
+    int map_tiles_y;    //                 and its number of tile rows
 };
 
 template <typename T>
@@ -72,13 +78,41 @@ __device__ __forceinline__ uint32_t hop(uint32_t x) {
 // T is the type of the prefix sums (float, int32, uint32 with wrap-around).  HALF selects what
 // of each uint32 column sum enters the chain: 0 all of it, 1 its low 16 bits, 2 its high 16 bits
 // (two 16-bit chains give an exact 48-bit total where one uint32 chain could overflow).
-template <int SIZE, typename T, int HALF = 0>
+// PIPE pins the order "read the prefix rows of run r+1, then subtract those of run r": left to
+// itself the scheduler does that in the kernels with registers to spare, and in the ones at the
+// 168-VGPR limit it waits for every pair of reads before issuing the next (21 exposed LDS
+// latencies per row).
+template <int SIZE, typename T, int HALF = 0, bool PIPE = false>
 __device__ __forceinline__ void wave_disc_sum(const T* Q, int jj, int lane, T (&acc)[NC]) {
     using ACC = T;
     using G = Geo<SIZE>;
     constexpr int NR = G::T.num_runs;
     T cv[NR][NC];
     const T* col = Q + lane * NC;
+    if (PIPE) {
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        t4 top = *reinterpret_cast<const t4*>(col + (jj + G::T.run_hi[0] - G::T.off_min + 1) * ROWW);
+        t4 bot = *reinterpret_cast<const t4*>(col + (jj + G::T.run_lo[0] - G::T.off_min) * ROWW);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            t4 ntop = top, nbot = bot;
+            if (r + 1 < NR) {
+                ntop = *reinterpret_cast<const t4*>(col + (jj + G::T.run_hi[r + 1] - G::T.off_min + 1) * ROWW);
+                nbot = *reinterpret_cast<const t4*>(col + (jj + G::T.run_lo[r + 1] - G::T.off_min) * ROWW);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NC; ++s) {
+                T d = top[s] - bot[s];
+                if (HALF == 1) d = (T)((uint32_t)d & 0xffffu);
+                if (HALF == 2) d = (T)((uint32_t)d >> 16);
+                cv[r][s] = d;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            top = ntop;
+            bot = nbot;
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const Vec4<T> top = *reinterpret_cast<const Vec4<T>*>(col + (jj + G::T.run_hi[r] - G::T.off_min + 1) * ROWW);
@@ -90,6 +124,7 @@ __device__ __forceinline__ void wave_disc_sum(const T* Q, int jj, int lane, T (&
             if (HALF == 2) d = (T)((uint32_t)d >> 16);
             cv[r][s] = d;
         }
+    }
     }
 #pragma unroll
     for (int D = G::D_HI; D >= G::D_LO; --D) {
@@ -143,6 +178,27 @@ __device__ __forceinline__ Vec4<float> load_row4(const WaveArgs& p, int gy, int 
 // large that one 67-row column sum of u^2 passes 2^32, e.g. -9999 nodata next to real terrain)
 // run float chains on a = x - c and (trunc(x) - c)^2 instead, so NaN propagates and nothing wraps.
 enum Stage { kStU = 0, kStU2 = 1, kStF = 2, kStA = 3, kStT2 = 4 };
+
+// sqrt(max(0, (s2 - s1^2/n) / (n-1))) from the float64 sums.  The variance stays in float64 (the
+// difference cancels a few hundred-fold), but 1/n and 1/(n-1) are multiplied in and the root is
+// taken in float32: an IEEE float64 division and square root per pixel cost more than the 67-step
+// chain (159 f64 instructions per wave-row against 24 for TPI).  Every wave-shift kernel uses
+// this one function, so they agree bit for bit.
+__device__ __forceinline__ float std_from_sums(double s1, double s2, double inv_n, double inv_nm1) {
+    double var = (s2 - s1 * s1 * inv_n) * inv_nm1;
+    if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
+    return sqrtf((float)var);
+}
+// The same for a pixel whose n taps are all inside the DEM, on a tile of the integer path:
+// n s2 - s1^2 = n Su2 - Su^2 whatever offset c the sums were taken with, and n Su2, Su^2 and their
+// difference are integers below 2^53 (|u| <= 8006 on that path), hence exact in float64.  One
+// rounding (the multiply by 1/(n(n-1))) instead of a cancelling difference, 6 f64 instructions
+// instead of ~15, and identical bits from kernels that used different offsets.
+__device__ __forceinline__ float std_from_int_sums(double su, double su2, double n, double inv_nn1) {
+    double var = (n * su2 - su * su) * inv_nn1;
+    if (var < 0.0) var = 0.0;
+    return sqrtf((float)var);
+}
 enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4 };
 
 template <int WHAT>
@@ -272,7 +328,9 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
     const int per_xcd = nb >> 3;
     const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     const double n = (double)G::T.taps;
+    const double inv_n = 1.0 / n;
     const double inv_nm1 = 1.0 / (n - 1.0);
+    const double inv_nn1 = 1.0 / (n * (n - 1.0));
     const float lim32 = floorf(sqrtf(4294967295.0f / (float)G::T.taps));
     const float limcv = fminf(46000.0f, floorf(sqrtf(4294967295.0f / (float)SIZE)));
 
@@ -281,7 +339,25 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
     for (int base = vb; base < ntiles; base += 64 * nb) {
     const int mine = base + lane * nb;
     bool take = mine < ntiles;
-    if (p.defer != nullptr) take = take && p.defer[take ? mine : 0] != 0;
+    if (p.defer != nullptr) {
+        bool marked = false;
+        if (take) {
+            if (p.map_th == 0) {
+                marked = p.defer[mine] != 0;
+            } else {
+                // the map belongs to the marching kernels' geometry (same strips, rows of map_th): this
+                // tile is taken when a map tile that shares output rows with it is marked.  Rows of
+                // unmarked map tiles get recomputed with identical bits.
+                const int tx = mine / tiles_y, ty = mine % tiles_y;
+                const int r0 = max((p.out_row0 / TH + ty) * TH, p.out_row0);
+                const int r1 = min((p.out_row0 / TH + ty) * TH + TH, p.out_row0 + p.out_rows) - 1;
+                const int base = p.out_row0 / p.map_th;
+                for (int my = r0 / p.map_th; my <= r1 / p.map_th; ++my)
+                    marked = marked || p.defer[tx * p.map_tiles_y + (my - base)] != 0;
+            }
+        }
+        take = marked;
+    }
     unsigned long long todo = __builtin_amdgcn_ballot_w64(take);
     while (todo) {
         const int tile = base + __builtin_ctzll(todo) * nb;
@@ -349,10 +425,12 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
                 // which c the tile happened to use
                 const double s1 = (su + cd * m) + sf;
                 if (WANT_STD) {
-                    const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
-                    double var = (s2 - s1 * s1 / n) * inv_nm1;
-                    if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
-                    out_s.v[t] = (float)sqrt(var);
+                    if (!use_float && !frac && m == n) {
+                        out_s.v[t] = std_from_int_sums(su, su2, n, inv_nn1);
+                    } else {
+                        const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
+                        out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
+                    }
                 }
                 if (WANT_TPI) {
                     const int cy2 = oy + G::T.centre, cx2 = ocol + t + G::T.centre;
@@ -566,9 +644,12 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
     return all;
 }
 
-template <int SIZE, int TH, int NWAVES>
+// OUT_TPI: write TPI.  OUT_SUM: write the exact disc sums of trunc(x) to p.sums, for the STD kernel
+// that follows (std_march_kernel).
+template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM>
 __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int tiles_x, int tiles_y) {
     using G = Geo<SIZE>;
+    static_assert(OUT_TPI || OUT_SUM, "nothing to write");
     static_assert(G::T.centre == 0, "odd disc sizes only: the zeroed tap is the pixel itself");
     static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
     constexpr int NROWS = TH + SIZE - 1;
@@ -635,61 +716,378 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
             wave_disc_sum<SIZE, uint32_t>(Q, jj, lane, acc);
             const int oy = oy0 + jj;
             if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
-            // the pixel's own (integer) value: prefix through its row minus prefix above it
-            const uint32_t* own = Q + (jj - G::T.off_min) * ROWW + lane * NC + G::X0;
-            const Vec4<uint32_t> hi = *reinterpret_cast<const Vec4<uint32_t>*>(own + ROWW);
-            const Vec4<uint32_t> lo = *reinterpret_cast<const Vec4<uint32_t>*>(own);
-            Vec4<float> out_t;
-#pragma unroll
-            for (int t = 0; t < NC; ++t) {
-                const float x = (float)(int)(hi.v[t] - lo.v[t]);
-                const double s1 = (double)(int)acc[t];  // sum of x over the in-domain taps, exact
-                const double x_ctr = (double)x;
-                out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+            const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+            if (OUT_SUM) {
+                const Vec4<int> sv{{(int)acc[0], (int)acc[1], (int)acc[2], (int)acc[3]}};
+                *reinterpret_cast<Vec4<int>*>(p.sums + o) = sv;
             }
-            *reinterpret_cast<Vec4<float>*>(p.tpi + (size_t)(oy - p.out_row0) * p.nx + ocol) = out_t;
+            if (OUT_TPI) {
+                // the pixel's own (integer) value: prefix through its row minus prefix above it
+                const uint32_t* own = Q + (jj - G::T.off_min) * ROWW + lane * NC + G::X0;
+                const Vec4<uint32_t> hi = *reinterpret_cast<const Vec4<uint32_t>*>(own + ROWW);
+                const Vec4<uint32_t> lo = *reinterpret_cast<const Vec4<uint32_t>*>(own);
+                Vec4<float> out_t;
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    const float x = (float)(int)(hi.v[t] - lo.v[t]);
+                    const double s1 = (double)(int)acc[t];  // sum of x over the in-domain taps, exact
+                    const double x_ctr = (double)x;
+                    out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+                }
+                *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+            }
+        }
+    }
+}
+
+// Grid of the marching launches: persistent blocks, whole XCD rounds, never more blocks than tiles.
+inline long march_grid(Context& c, int blocks_per_cu, long ntiles) {
+    long grid = (long)(c.num_cu - c.reserve_cus) * blocks_per_cu;
+    if (grid < 8) grid = 8;
+    grid -= grid % 8;
+    return grid > ntiles ? ntiles : grid;
+}
+
+template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM>
+int launch_march(const Block& b, float* tpi_out) {
+    using G = Geo<SIZE>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0};
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16;
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nblk, (const void*)tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM>, NWAVES * 64, lds));
+        blocks_per_cu = nblk < 1 ? 1 : nblk;
+    }
+    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
+    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
+    const long ntiles = (long)tiles_x * tiles_y;
+    const long grid = march_grid(c, blocks_per_cu, ntiles);
+    void* defer = nullptr;  // same size in every launch of a group, so the same allocation
+    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
+    a.defer = (uint8_t*)defer;
+    if (OUT_SUM) {
+        void* sums = nullptr;
+        TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
+        a.sums = (int32_t*)sums;
+    }
+    hipLaunchKernelGGL((tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM>), dim3((unsigned)grid), dim3(NWAVES * 64),
+                       lds, c.compute, a, tiles_x, tiles_y);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+// ---- STD on tiles of whole metres: the second marching kernel ------------------------------------
+// STD needs s1 = sum trunc(x) and s2 = sum trunc(x)^2 over the disc.  tpi_march_kernel<.., OUT_SUM>
+// leaves s1 in p.sums (exact, no offset).  This kernel marches the prefix sums of u^2,
+// u = trunc(x) - c, down the same runs of the same tile list and finalises:
+//   s2 = Su2 + 2 c (s1 - c m) + c^2 m        (m in-domain taps; every term an exact integer < 2^53)
+// so the float64 variance is the one the general kernel computes, bit for bit, whatever c either
+// of them used.  c is constant along a carried run (a changed c would change every carried u^2);
+// the 32-bit sums need |u| <= lim32 over the whole window (3409 u^2 < 2^32).  When the rows a tile
+// adds break that, the window is restaged in full around the tile's own centre value; a tile that
+// is wide even then is marked for the general kernel, which runs two 16-bit half chains on it.
+// Tiles the first kernel marked are skipped.
+template <int SIZE, int TH, int NWAVES, bool FULL>
+__device__ __forceinline__ int stage_u2(const WaveArgs& p, uint32_t* Q, int* flag_word, int gy0, int gx, float c,
+                                        int ci, float lim32) {
+    constexpr int NROWS = TH + SIZE - 1;
+    constexpr int KEEP = NROWS + 1 - TH;
+    constexpr int NT = NWAVES * 64;
+    constexpr int SL = FULL ? (NROWS + NWAVES - 1) / NWAVES : TH / NWAVES;  // rows staged per wave
+    constexpr int FIRST = FULL ? 0 : KEEP - 1;                              // first window row staged
+    constexpr int MOVE4 = KEEP * 64;
+    constexpr int MOVES = (MOVE4 + NT - 1) / NT;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    uint32_t* TOT = Q + (NROWS + 1) * ROWW;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r0 = FIRST + wave * SL;
+    Vec4<float> v[SL];
+#pragma unroll
+    for (int k = 0; k < SL; ++k) v[k] = load_row4(p, gy0 + r0 + k, gx);
+    if (!FULL) {
+        u4 m[MOVES];
+        const u4* src = reinterpret_cast<const u4*>(Q + TH * ROWW);
+#pragma unroll
+        for (int s = 0; s < MOVES; ++s) {
+            const int idx = (int)threadIdx.x + s * NT;
+            m[s] = src[idx < MOVE4 ? idx : MOVE4 - 1];
+        }
+        __syncthreads();  // every wave is done reading the previous tile's image
+        u4* dst = reinterpret_cast<u4*>(Q);
+#pragma unroll
+        for (int s = 0; s < MOVES; ++s) {
+            const int idx = (int)threadIdx.x + s * NT;
+            if (idx < MOVE4) dst[idx] = m[s];
+        }
+    } else if (wave == 0) {
+        *reinterpret_cast<Vec4<uint32_t>*>(Q + lane * NC) = Vec4<uint32_t>{{0u, 0u, 0u, 0u}};
+    }
+    uint32_t amax = 0, umax = 0;
+    bool frac = false;
+    Vec4<uint32_t> run{{0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+        const int r = r0 + k;
+        if (FULL && r >= NROWS) break;
+        const bool ok = row4_inside(p, gy0 + r, gx);
+#pragma unroll
+        for (int s = 0; s < NC; ++s) {
+            const float x = v[k].v[s];
+            const float t = truncf(x);
+            const float d = t - c;  // exact: |t|, |c| <= kAbsLim on the tiles that stay here
+            frac |= ok && (x != t);
+            amax = max(amax, ok ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
+            umax = max(umax, ok ? (__float_as_uint(d) & 0x7fffffffu) : 0u);
+            const uint32_t u = (uint32_t)((int)t - ci);
+            run.v[s] += ok ? u * u : 0u;
+        }
+        *reinterpret_cast<Vec4<uint32_t>*>(Q + (r + 1) * ROWW + lane * NC) = run;
+    }
+    *reinterpret_cast<Vec4<uint32_t>*>(TOT + wave * ROWW + lane * NC) = run;
+    int wf = 0;
+    if (__builtin_amdgcn_ballot_w64(frac)) wf |= kTileFrac;
+    if (__builtin_amdgcn_ballot_w64(amax > __float_as_uint(kAbsLim))) wf |= kTileFloat;
+    if (__builtin_amdgcn_ballot_w64(umax > __float_as_uint(lim32))) wf |= kTileWide;
+    if (lane == 0 && wf) atomicOr(flag_word, wf);
+    __syncthreads();
+    const int all = *flag_word;
+    Vec4<uint32_t> off{{0u, 0u, 0u, 0u}};
+    if (!FULL) off = *reinterpret_cast<const Vec4<uint32_t>*>(Q + (KEEP - 1) * ROWW + lane * NC);
+    for (int w = 0; w < wave; ++w) {
+        const Vec4<uint32_t> t = *reinterpret_cast<const Vec4<uint32_t>*>(TOT + w * ROWW + lane * NC);
+#pragma unroll
+        for (int s = 0; s < NC; ++s) off.v[s] += t.v[s];
+    }
+    if (!FULL || wave > 0) {
+#pragma unroll
+        for (int k = 0; k < SL; ++k) {
+            const int r = r0 + k;
+            if (FULL && r >= NROWS) break;
+            Vec4<uint32_t>* q = reinterpret_cast<Vec4<uint32_t>*>(Q + (r + 1) * ROWW + lane * NC);
+            Vec4<uint32_t> x = *q;
+#pragma unroll
+            for (int s = 0; s < NC; ++s) x.v[s] += off.v[s];
+            *q = x;
+        }
+    }
+    __syncthreads();
+    return all;
+}
+
+template <int SIZE, int TH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void std_march_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+    using G = Geo<SIZE>;
+    static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
+    constexpr int NROWS = TH + SIZE - 1;
+    constexpr int RW = TH / NWAVES;
+    constexpr int kGiveUp = 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    uint32_t* Q = lds_u;
+    uint32_t* TOT = Q + (NROWS + 1) * ROWW;  // segment totals while staging; one sums row per wave afterwards
+    unsigned short* PL = reinterpret_cast<unsigned short*>(lds_u + (NROWS + 1 + NWAVES) * ROWW);
+    int* flag_word = reinterpret_cast<int*>(PL + ((TH * (SIZE + 1) + 7) & ~7));
+    if (threadIdx.x == 0) *flag_word = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = tiles_x * tiles_y;
+    const int nb = gridDim.x;
+    const int per_xcd = nb >> 3;
+    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int per = (ntiles + nb - 1) / nb;  // the same runs as tpi_march_kernel
+    const int first = vb * per;
+    const int last = min(first + per, ntiles);
+    const double n = (double)G::T.taps;
+    const double inv_n = 1.0 / n;
+    const double inv_nm1 = 1.0 / (n - 1.0);
+    const double inv_nn1 = 1.0 / (n * (n - 1.0));
+    const float lim32 = floorf(sqrtf(4294967295.0f / (float)G::T.taps));
+
+    bool carry = false;
+    float c = 0.0f;
+    int ci = 0;
+    int deferred_in_a_row = 0;
+#pragma unroll 1
+    for (int tile = first; tile < last; ++tile) {
+        if (p.defer[tile] != 0) {  // left by the first kernel (fractional / non-finite / absurd samples)
+            carry = false;
+            continue;
+        }
+        if (deferred_in_a_row >= kGiveUp) {
+            if (threadIdx.x == 0) p.defer[tile] = 1;
+            continue;
+        }
+        const int ty = tile % tiles_y;
+        const int ox0 = (tile / tiles_y) * G::TILE_W;
+        const int oy0 = (p.out_row0 / TH + ty) * TH;
+        const int gx = ox0 - G::X0 + lane * NC;
+        const int gy0 = oy0 + G::T.off_min;
+        const bool border = gy0 < 0 || gy0 + NROWS > p.gny || ox0 - G::X0 < 0 || ox0 - G::X0 + ROWW > p.nx;
+        if (ty == 0) carry = false;
+        int flags = kTileWide;
+        if (carry) {
+            flags = stage_u2<SIZE, TH, NWAVES, false>(p, Q, flag_word, gy0, gx, c, ci, lim32);
+            if (threadIdx.x == 0) *flag_word = 0;  // read by every thread; the next atomicOr is behind a barrier
+        }
+        if (flags & kTileWide) {
+            // (re)start: the whole window, around this tile's own centre value
+            int cy = min(max(oy0 + TH / 2, 0), p.gny - 1);
+            cy = min(max(cy, p.in_row0), p.in_row0 + p.in_rows - 1);
+            const int cx = min(ox0 + G::TILE_W / 2, p.nx - 1);
+            c = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
+            if (!(fabsf(c) <= kAbsLim)) c = 0.0f;
+            // the same for every lane: keep it in a scalar register, the chain needs the vector ones
+            c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c)));
+            ci = (int)c;
+            __syncthreads();  // the image and the flag word are free
+            flags = stage_u2<SIZE, TH, NWAVES, true>(p, Q, flag_word, gy0, gx, c, ci, lim32);
+            if (threadIdx.x == 0) *flag_word = 0;
+        }
+        if (flags != 0) {  // wide even around its own centre (or a class the first kernel would have caught)
+            if (threadIdx.x == 0) p.defer[tile] = 1;
+            ++deferred_in_a_row;
+            carry = false;
+            continue;
+        }
+        deferred_in_a_row = 0;
+        carry = true;
+
+        if (border) {
+            if (threadIdx.x < TH) {
+                // in-domain rows of each column run, prefix-summed over the column offsets
+                const int oy = oy0 + (int)threadIdx.x;
+                unsigned short* row = PL + threadIdx.x * (SIZE + 1);
+                int run = 0;
+                row[0] = 0;
+#pragma unroll 1
+                for (int k = 0; k < SIZE; ++k) {
+                    const int top = max(oy + G::T.lo[k], 0);
+                    const int bot = min(oy + G::T.hi[k], p.gny - 1);
+                    run += max(bot - top + 1, 0);
+                    row[k + 1] = (unsigned short)run;
+                }
+            }
+            __syncthreads();
+        }
+        const double cd = (double)c;
+        // one copy of the row loop per kind of tile: away from the DEM border every pixel has all n
+        // taps, so m is a constant and only the short formula is compiled in
+        auto rows = [&](auto border_tag) {
+            constexpr bool BORDER = decltype(border_tag)::value;
+#pragma unroll 1
+            for (int k = 0; k < RW; ++k) {
+                const int jj = wave + k * NWAVES;
+                const int oy = oy0 + jj;
+                // The row's sums of x come from a plane that left L2 long ago.  Fetch them straight
+                // into this wave's (now idle) slot of the segment totals with an LDS-DMA load: it
+                // is in flight during the chain and costs no vector register, which this kernel
+                // does not have to spare (a register prefetch spills; an ordinary load after the
+                // chain exposes the whole memory latency once per row).
+                {
+                    const int pcol = ox0 + lane * NC;
+                    const bool pl_ok = lane < G::NVL && pcol < p.nx && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows;
+                    const size_t po = pl_ok ? (size_t)(oy - p.out_row0) * p.nx + pcol : 0;
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(p.sums + po),
+                        (__attribute__((address_space(3))) void*)(TOT + wave * ROWW + lane * NC), 16, 0, 0);
+                }
+                uint32_t acc[NC];
+                wave_disc_sum<SIZE, uint32_t, 0, true>(Q, jj, lane, acc);
+                // Everything below is derived from the lane's column again, behind an opaque barrier:
+                // otherwise the per-lane invariants of the finalisation (column limits, output index)
+                // are hoisted above the chain, and at 168 VGPRs the chain then loses the registers it
+                // needs to keep its next pair of LDS reads in flight.
+                int lcol = lane * NC;
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(lcol) : : "memory");  // the DMA has landed
+                const Vec4<int> sv = *reinterpret_cast<const Vec4<int>*>(TOT + wave * ROWW + lcol);
+                const int ocol = ox0 + lcol;
+                const bool lane_ok = lcol < G::NVL * NC && ocol < p.nx;
+                if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
+                const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+                Vec4<float> out_s;
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    const double su2 = (double)acc[t];
+                    double m = n;
+                    if (BORDER) {
+                        const int d_lo = max(G::T.off_min, -(ocol + t));
+                        const int d_hi = min(G::T.off_max, p.nx - 1 - (ocol + t));
+                        const unsigned short* pl = PL + jj * (SIZE + 1) - G::T.off_min;
+                        m = d_hi >= d_lo ? (double)((int)pl[d_hi + 1] - (int)pl[d_lo]) : 0.0;
+                    }
+                    if (!BORDER || m == n) {
+                        // sum of u, what the general kernel's first chain yields: |ci n| < 2^30, |su| < 2^25
+                        const double su = (double)(sv.v[t] - ci * G::T.taps);
+                        out_s.v[t] = std_from_int_sums(su, su2, n, inv_nn1);
+                    } else {
+                        const double s1 = (double)sv.v[t];
+                        const double su = s1 - cd * m;
+                        const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
+                        out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
+                    }
+                }
+                *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+            }
+        };
+        if (border) {
+            rows(std::true_type{});
+        } else {
+            rows(std::false_type{});
         }
     }
 }
 
 template <int SIZE, int TH, int NWAVES>
-int launch_march(const Block& b, float* tpi_out) {
+int launch_std_march(const Block& b, float* std_out) {
     using G = Geo<SIZE>;
     Context& c = ctx();
-    WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows, nullptr, nullptr};
-    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16;
+    WaveArgs a{b.in, nullptr, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0};
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) +
+                           (size_t)((TH * (SIZE + 1) + 7) & ~7) * sizeof(unsigned short) + 16;
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_march_kernel<SIZE, TH, NWAVES>,
+        TOPO_HIP(hipFuncSetAttribute((const void*)std_march_kernel<SIZE, TH, NWAVES>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nblk = 0;
-        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)tpi_march_kernel<SIZE, TH, NWAVES>,
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_march_kernel<SIZE, TH, NWAVES>,
                                                               NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
     const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
     const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
     const long ntiles = (long)tiles_x * tiles_y;
-    long grid = (long)(c.num_cu - c.reserve_cus) * blocks_per_cu;
-    if (grid < 8) grid = 8;
-    grid -= grid % 8;  // whole XCD rounds
-    if (grid > ntiles) grid = ntiles;
-    void* defer = nullptr;  // same size as in the general launch that follows, so the same allocation
+    const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
+    void* defer = nullptr;
     TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
     a.defer = (uint8_t*)defer;
-    hipLaunchKernelGGL((tpi_march_kernel<SIZE, TH, NWAVES>), dim3((unsigned)grid), dim3(NWAVES * 64), lds, c.compute, a,
+    void* sums = nullptr;
+    TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
+    a.sums = (int32_t*)sums;
+    hipLaunchKernelGGL((std_march_kernel<SIZE, TH, NWAVES>), dim3((unsigned)grid), dim3(NWAVES * 64), lds, c.compute, a,
                        tiles_x, tiles_y);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
 
 // only_deferred: process the tiles a preceding launch_march of the same geometry marked.
+// map_th: tile height of the marching launch when it differs from TH.
 template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
-int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferred = false) {
+int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferred = false, int map_th = 0) {
     using G = Geo<SIZE>;
     Context& c = ctx();
-    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows, nullptr, nullptr};
+    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0};
     constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(float) +
                            (size_t)((TH * (SIZE + 1) + 7) & ~7) * sizeof(unsigned short) + 16;
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
@@ -716,8 +1114,14 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferr
     TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
     a.scratch = (uint32_t*)scratch;
     if (only_deferred) {
-        void* defer = nullptr;  // same size as in launch_march, so the same allocation
-        TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
+        long map_tiles = ntiles;
+        if (map_th != 0 && map_th != TH) {
+            a.map_th = map_th;
+            a.map_tiles_y = (b.out_row0 + b.out_rows - 1) / map_th - b.out_row0 / map_th + 1;
+            map_tiles = (long)tiles_x * a.map_tiles_y;
+        }
+        void* defer = nullptr;  // same size as in the marching launches, so the same allocation
+        TOPO_TRY(workspace(8, (size_t)map_tiles, &defer));
         a.defer = (uint8_t*)defer;
     }
     hipLaunchKernelGGL((disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>), dim3((unsigned)grid),
@@ -735,14 +1139,51 @@ constexpr int tile_rows(int size, int nwaves, int cap) {
     return th;
 }
 
+// Which discs take the marching kernels.  Measured on a 32768^2 DEM of whole metres
+// (tools/std_crossover.py, profiles/r01_std_crossover.txt): for STD / TPI+STD the marching pair wins
+// from 31 px (2 %) to 67 px (11 %) and loses below (three planes of traffic in one general kernel
+// against five) and wherever LDS no longer holds the full 60-row tile (101 px: 36-row tiles, 46 ms
+// against 31 ms).  TOPO_AMD_STD_MARCH_MIN / TOPO_AMD_TPI_MARCH_MIN move the lower bounds (tuning
+// knobs; the results do not depend on them).
+inline int env_int(const char* name, int fallback) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : fallback;
+}
+inline int std_march_min_size() {
+    static const int v = env_int("TOPO_AMD_STD_MARCH_MIN", 31);
+    return v;
+}
+inline int tpi_march_min_size() {
+    static const int v = env_int("TOPO_AMD_TPI_MARCH_MIN", 1);
+    return v;
+}
+
 template <int SIZE>
 int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
     constexpr int TH8 = tile_rows(SIZE, 8, 64), TH12 = tile_rows(SIZE, 12, 60);
-    if (tpi_out && std_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out);
-    if (std_out) return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out);
-    // TPI alone: the marching build first, then the general build over the tiles it left (none on
-    // a DEM of whole metres; all of them on one with fractional elevations)
-    TOPO_TRY((launch_march<SIZE, TH12, 12>(b, tpi_out)));
+    // The marching kernels take the tiles of whole metres, the general kernel the tiles they left
+    // (none on a DEM of whole metres; all of them on one with fractional elevations).
+    constexpr bool kFullTile = TH12 == 60;  // LDS holds the tile height the marching kernels were tuned for
+    if (std_out && (SIZE < std_march_min_size() || !kFullTile)) {
+        // small discs: one general kernel (two passes per tile, the second one out of L2) moves three
+        // planes where the marching pair moves five, and the chains are too short to matter
+        if (tpi_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out);
+        return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out);
+    }
+    if (std_out) {
+        // sum x (and TPI) marching, then sum u^2 -> STD marching over the same runs, then the
+        // 8-wave general kernel (tiles of TH8 rows) over whatever overlaps a marked tile
+        if (tpi_out) {
+            TOPO_TRY((launch_march<SIZE, TH12, 12, true, true>(b, tpi_out)));
+        } else {
+            TOPO_TRY((launch_march<SIZE, TH12, 12, false, true>(b, nullptr)));
+        }
+        TOPO_TRY((launch_std_march<SIZE, TH12, 12>(b, std_out)));
+        if (tpi_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out, true, TH12);
+        return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out, true, TH12);
+    }
+    if (SIZE < tpi_march_min_size()) return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out);
+    TOPO_TRY((launch_march<SIZE, TH12, 12, true, false>(b, tpi_out)));
     return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true);
 }
 
