@@ -307,61 +307,96 @@ __global__ __launch_bounds__(kThreads) void sobel_kernel(GradArgs p) {
 // block emits dx, dy, slope, aspect for the 62 x (NW*TB - 2) pixels inside it: the smoothed
 // plane never goes to HBM (28 instead of 36 B/pixel for the whole gradient).  Tiles sit on
 // global multiples of 62 rows / (NW*TB - 2) columns, so results do not depend on the row block.
+//
+// Blocks are persistent and walk the tile list in row-major order.  A stamped build of the
+// one-tile-per-block version showed a wave spending 42 % of its time fetching its tile and 14 % in
+// the convolution, so the next tile's samples are loaded into registers as soon as the current
+// tile is in LDS and stay in flight through the convolution and the epilogue.  The barriers are raw
+// s_barrier + lgkmcnt(0): __syncthreads() would also wait for those loads.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int TB, int KB, int NW>
-__global__ __launch_bounds__(NW * 64) void gauss_axis1_grad_kernel(GaussArgs p, GradArgs g) {
+__global__ __launch_bounds__(NW * 64) void gauss_axis1_grad_kernel(GaussArgs p, GradArgs g, int tiles_x, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float L[];
     constexpr int TR = 64;
     constexpr int TC = NW * TB;
     constexpr int OUT_R = TR - 2, OUT_C = TC - 2;
+    constexpr int RPW = TR / NW;  // tile rows fetched per wave
+    constexpr int PF = 3;         // samples per lane and row: cols_l <= 192 (asserted by the launcher)
     const int R = p.radius;
     const int cols_l = TC + p.nchunks * KB - 1;
     const int stride = cols_l | 1;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int ox0 = blockIdx.x * OUT_C;                                  // first output column
-    const int oy0 = (g.out_row0 / OUT_R + (int)blockIdx.y) * OUT_R;       // first output row (global)
-    const int sx0 = ox0 - 1, sy0 = oy0 - 1;                               // smoothed tile origin
 
-    const bool inner = sx0 - R >= 0 && sx0 - R + cols_l <= p.nx;
-    for (int r = wave; r < TR; r += NW) {
-        const int gy = min(max(sy0 + r, p.in_row0), p.in_row0 + p.in_rows - 1);  // unused rows clamp
-        const float* src = p.in + (size_t)(gy - p.in_row0) * p.nx;
-        float* dst = L + r * stride;
-        if (inner) {
-            const float* s0 = src + (sx0 - R);
-            for (int k = lane; k < cols_l; k += 64) dst[k] = s0[k];
-        } else {
-            for (int k = lane; k < cols_l; k += 64) dst[k] = src[reflect_index(sx0 - R + k, p.nx)];
-        }
-    }
-    __syncthreads();
-
-    const float* rowp = L + lane * stride + wave * TB;
-    auto fetch = [&](int i) -> float { return rowp[i]; };
-    const float c = rowp[R];
-    float acc[TB];
-    tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
-    __syncthreads();
-    constexpr int ostride = TC + 1;
-    float* O = L;  // smoothed tile, rounded to float32 like the reference's intermediate
+    float pf[RPW][PF];
+    auto issue = [&](int tile) {
+        const int sx0 = (tile % tiles_x) * OUT_C - 1;                                   // smoothed tile origin
+        const int sy0 = (g.out_row0 / OUT_R + tile / tiles_x) * OUT_R - 1;
+        const bool inner = sx0 - R >= 0 && sx0 - R + cols_l <= p.nx;
 #pragma unroll
-    for (int t = 0; t < TB; ++t) O[lane * ostride + wave * TB + t] = c + acc[t];
-    __syncthreads();
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave + rr * NW;
+            const int gy = min(max(sy0 + r, p.in_row0), p.in_row0 + p.in_rows - 1);  // unused rows clamp
+            const float* src = p.in + (size_t)(gy - p.in_row0) * p.nx;
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int k = min(lane + 64 * q, cols_l - 1);
+                pf[rr][q] = inner ? src[sx0 - R + k] : src[reflect_index(sx0 - R + k, p.nx)];
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            float* dst = L + (wave + rr * NW) * stride;
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int k = lane + 64 * q;
+                if (k < cols_l) dst[k] = pf[rr][q];
+            }
+        }
+    };
 
-    for (int idx = threadIdx.x; idx < OUT_R * OUT_C; idx += NW * 64) {
-        const int r = idx / OUT_C, k = idx % OUT_C;
-        const int oy = oy0 + r, ox = ox0 + k;
-        if (oy < g.out_row0 || oy >= g.out_row0 + g.out_rows || ox >= g.nx) continue;
-        const float* q = O + (r + 1) * ostride + (k + 1);  // smoothed value of this pixel
-        // numpy.gradient: central difference / 2 inside, first-order one-sided at the edges
-        float dx, dy;
-        if (ox == 0) dx = q[1] - q[0];
-        else if (ox == g.nx - 1) dx = q[0] - q[-1];
-        else dx = (q[1] - q[-1]) * 0.5f;
-        if (oy == 0) dy = q[ostride] - q[0];
-        else if (oy == g.gny - 1) dy = q[0] - q[-ostride];
-        else dy = (q[ostride] - q[-ostride]) * 0.5f;
-        finish_gradient(g, oy, ox, dx, dy);
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int ox0 = (tile % tiles_x) * OUT_C;                                   // first output column
+        const int oy0 = (g.out_row0 / OUT_R + tile / tiles_x) * OUT_R;               // first output row (global)
+        lds_barrier();  // the previous tile's epilogue is done with the LDS image
+        commit();
+        lds_barrier();
+        if (tile + (int)gridDim.x < ntiles) issue(tile + (int)gridDim.x);
+
+        const float* rowp = L + lane * stride + wave * TB;
+        auto fetch = [&](int i) -> float { return rowp[i]; };
+        const float c = rowp[R];
+        float acc[TB];
+        tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
+        lds_barrier();
+        constexpr int ostride = TC + 1;
+        float* O = L;  // smoothed tile, rounded to float32 like the reference's intermediate
+#pragma unroll
+        for (int t = 0; t < TB; ++t) O[lane * ostride + wave * TB + t] = c + acc[t];
+        lds_barrier();
+
+        for (int idx = threadIdx.x; idx < OUT_R * OUT_C; idx += NW * 64) {
+            const int r = idx / OUT_C, k = idx % OUT_C;
+            const int oy = oy0 + r, ox = ox0 + k;
+            if (oy < g.out_row0 || oy >= g.out_row0 + g.out_rows || ox >= g.nx) continue;
+            const float* q = O + (r + 1) * ostride + (k + 1);  // smoothed value of this pixel
+            // numpy.gradient: central difference / 2 inside, first-order one-sided at the edges
+            float dx, dy;
+            if (ox == 0) dx = q[1] - q[0];
+            else if (ox == g.nx - 1) dx = q[0] - q[-1];
+            else dx = (q[1] - q[-1]) * 0.5f;
+            if (oy == 0) dy = q[ostride] - q[0];
+            else if (oy == g.gny - 1) dy = q[0] - q[-ostride];
+            else dy = (q[ostride] - q[-ostride]) * 0.5f;
+            finish_gradient(g, oy, ox, dx, dy);
+        }
     }
 }
 
@@ -676,17 +711,26 @@ int launch_axis1_grad(const GaussArgs& a, const GradArgs& g, double sigma) {
     const size_t lds_in = (size_t)64 * (cols_l | 1) * sizeof(float);
     const size_t lds_out = (size_t)64 * (tc + 1) * sizeof(float);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
-    if (lds > 160 * 1024) {
-        set_error("gradient: sigma %.3f (radius %d) needs %zu B of LDS per tile; the "
-                  "large-sigma path is not built yet", sigma, a.radius, lds);
+    if (lds > 160 * 1024 || cols_l > 192) {
+        set_error("gradient: sigma %.3f (radius %d) needs %zu B of LDS and %d columns per tile; "
+                  "outside what the LDS-tiled axis-1 kernel is built for", sigma, a.radius, lds, cols_l);
         return TOPO_AMD_EUNSUP;
     }
     TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_grad_kernel<TB, KB, NW>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gauss_axis1_grad_kernel<TB, KB, NW>,
+                                                          NW * 64, lds));
+    if (per_cu < 1) per_cu = 1;
     constexpr int out_r = 62, out_c = tc - 2;
     const int tiles_y = (g.out_row0 + g.out_rows - 1) / out_r - g.out_row0 / out_r + 1;
-    dim3 grid((g.nx + out_c - 1) / out_c, tiles_y);
-    hipLaunchKernelGGL((gauss_axis1_grad_kernel<TB, KB, NW>), grid, dim3(NW * 64), lds, c.compute, a, g);
+    const int tiles_x = (g.nx + out_c - 1) / out_c;
+    const long ntiles = (long)tiles_x * tiles_y;
+    long grid = (long)(c.num_cu - c.reserve_cus) * per_cu;  // persistent: every block walks the tile list
+    if (grid > ntiles) grid = ntiles;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((gauss_axis1_grad_kernel<TB, KB, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, c.compute, a, g,
+                       tiles_x, (int)ntiles);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
