@@ -467,8 +467,14 @@ __device__ __forceinline__ void wave_row_smooth(const WaveGradArgs& p, int lane,
 #pragma unroll
     for (int t = 0; t < GC; ++t) acc[t] = 0.0f;
     for (int step = 0; step < p.nsteps; ++step) {
-        const float* w = p.wtab + step * 32;   // wave-uniform
-        const float* wc = p.wsum + step * GC;
+        // Wave-uniform tap tables, read through the constant address space: the kernel stores to
+        // global memory between uses, so as plain global pointers the compiler does not treat these
+        // loads as invariant and fetched all 47 taps of a step through the vector path into VGPRs
+        // (3.9e8 vector loads per 32768^2 launch, in a kernel at 246 VGPRs).  Nothing writes the
+        // tables while the kernel runs.
+        typedef const __attribute__((address_space(4))) float* cptr;
+        cptr w = (cptr)p.wtab + step * 32;
+        cptr wc = (cptr)p.wsum + step * GC;
 #pragma unroll
         for (int t = 0; t < GC; ++t) {
             float a = step == 0 ? 0.0f : hop_down(acc[t]);
