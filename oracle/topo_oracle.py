@@ -290,6 +290,109 @@ def wrapped_angle_diff(a, b):
 # ----------------------------------------------------------------------------------------
 # Sx
 # ----------------------------------------------------------------------------------------
+# Valley / ridge index (topo.py:389-531)
+# ----------------------------------------------------------------------------------------
+def valley_kernels(size, flat_list):
+    """Normalised V / U profiles, one plane per flat fraction (topo.py:456-492).
+
+    A plane is |row - middle| repeated along the columns (a valley running along x); a flat
+    fraction f levels the band of half-width ``int(floor(floor(size*f/2) + 0.5))`` around the
+    centre row to the value on its edge.  The reference re-normalises *all* planes (mean 0,
+    std 1 over each plane) inside the loop over the fractions, after levelling each one
+    (topo.py:484-490), so later planes are levelled on already normalised values; the same
+    order of operations is kept here because it decides the float32 bits."""
+    size = int(size)
+    middle = size // 2
+    profile = np.abs(np.arange(-middle, middle + 1)).astype(np.float32)  # odd sizes only, like the reference
+    plane = np.repeat(profile[:, None], size, axis=1)
+    kernels = np.repeat(plane[None, :, :], len(flat_list), axis=0).copy()
+    for ind, flat in enumerate(flat_list):
+        half = int(np.floor(np.floor(size * flat / 2) + 0.5))
+        kernels[ind, middle - half:middle + half + 1, :] = kernels[ind, middle - half, 0]
+        kernels = (kernels - np.mean(kernels, axis=(1, 2), keepdims=True)) / np.std(
+            kernels, axis=(1, 2), keepdims=True)
+    return kernels
+
+
+def ridge_kernels(size, flat_list):
+    """topo.py:495-512."""
+    return valley_kernels(size, flat_list) * -1
+
+
+def rotate_kernels(kernels, angle):
+    """topo.py:515-525: quadratic-spline rotation in the (row, column) plane with the output
+    enlarged to hold the rotated square, cells outside it marked with -9999, statistics taken
+    over the marked-in cells only, marked-out cells set to 0, float32."""
+    import numpy.ma as ma
+
+    rot = ndimage.rotate(kernels, angle, axes=(1, 2), reshape=True, order=2, mode="constant", cval=-9999)
+    rot = ma.masked_array(rot, mask=rot == -9999)
+    rot = (rot - np.mean(rot, axis=(1, 2), keepdims=True)) / np.std(rot, axis=(1, 2), keepdims=True)
+    return ma.MaskedArray.filled(rot, 0).astype(np.float32)
+
+
+def valley_ridge_plane_sums(kernels_rot):
+    """What the reference's 3-D ``signal.convolve(dem3, kernels_rot, mode="same")`` applies to
+    the DEM in each output plane (topo.py:436): the DEM is broadcast to ``L`` identical planes,
+    so along the plane axis the "same" convolution adds up the kernel planes that overlap,
+    out[i] = dem (*) sum of K[b] for 0 <= i - b + (L-1)//2 < L.  For the default three planes
+    that is K0+K1, K0+K1+K2, K1+K2.  Returned in float64."""
+    n = kernels_rot.shape[0]
+    c = (n - 1) // 2
+    k64 = kernels_rot.astype(np.float64)
+    return [sum(k64[b] for b in range(n) if 0 <= i - b + c < n) for i in range(n)]
+
+
+def _valley_ridge_base(mode, size, flat_list):
+    if mode not in ("valley", "ridge"):
+        raise ValueError(f"Unknown mode {mode!r}")
+    return ridge_kernels(size, flat_list) if mode == "ridge" else valley_kernels(size, flat_list)
+
+
+def normalise_dem(dem, sigma=None):
+    """topo.py:424-427: optional Gaussian pre-smooth, then (dem - mean) / std of the whole array,
+    in the array's own precision."""
+    field = ndimage.gaussian_filter(dem, sigma) if sigma else dem
+    return (field - field.mean()) / field.std()
+
+
+def valley_ridge_scipy(dem, size, mode, flat_list=(0, 0.15, 0.3), sigma=None):
+    """The reference's call sequence (topo.py:420-447) with the same third-party calls."""
+    base = _valley_ridge_base(mode, size, list(flat_list))
+    field = normalise_dem(dem, sigma)
+    ny, nx = field.shape
+    stack = np.broadcast_to(field, (len(flat_list), ny, nx))
+    norm = np.zeros((ny, nx), dtype=np.float32) - np.inf
+    direction = np.empty((ny, nx), dtype=np.float32)
+    for angle in np.arange(0, 180, dtype=np.float32):
+        conv = np.max(signal.convolve(stack, rotate_kernels(base, angle), mode="same"), axis=0)
+        better = conv > norm
+        norm[better] = conv[better]
+        direction[better] = angle
+    return [np.ndarray.clip(norm, min=0), direction]
+
+
+def valley_ridge_exact(dem, size, mode, flat_list=(0, 0.15, 0.3), sigma=None, angles=None,
+                       return_maps=False):
+    """Float64 evaluation of the same index from the same float32 kernels and the same float32
+    normalised DEM: per angle the maximum over the plane sums of a float64 2-D convolution.
+    ``return_maps`` also returns the per-angle maxima (n_angles x ny x nx), which is what a
+    direction has to be judged against (the arg-max over 180 near-equal candidates is not
+    stable under rounding)."""
+    base = _valley_ridge_base(mode, size, list(flat_list))
+    field = np.asarray(normalise_dem(dem, sigma), dtype=np.float64)
+    angles = np.arange(0, 180, dtype=np.float32) if angles is None else np.asarray(angles, dtype=np.float32)
+    maps = np.empty((len(angles),) + field.shape, dtype=np.float64)
+    for a, angle in enumerate(angles):
+        sums = valley_ridge_plane_sums(rotate_kernels(base, angle))
+        maps[a] = np.max([signal.fftconvolve(field, k, mode="same") for k in sums], axis=0)
+    best = np.argmax(maps, axis=0)  # first maximum, like the reference's strict ">" update
+    norm = np.clip(np.take_along_axis(maps, best[None], axis=0)[0], 0, None)
+    direction = angles[best].astype(np.float64)
+    return ([norm, direction], maps) if return_maps else [norm, direction]
+
+
+# ----------------------------------------------------------------------------------------
 def sx_distance(radius, dx, dy):
     """Metric distance of every cell of the search window to its centre (topo.py:861-878)."""
     rad_px = max(radius / abs(dy), radius / abs(dx))

@@ -276,6 +276,38 @@ def main():
                                          full["radius_min"]], dtype=np.float64)
     save("sx", **out)
 
+    # ---- valley / ridge index ------------------------------------------------------
+    # Small DEMs: the reference evaluates 180 FFT convolutions per call.  The kernels the
+    # reference builds (before and after rotation) are stored too, so that the oracle's and the
+    # product's own constructions can be checked bit for bit without the reference at hand.
+    vr_int = orc.synthetic_dem(72, 88, seed=4, integer=True)
+    vr_frac = orc.synthetic_dem(64, 80, seed=5, integer=False)
+    out = {"dem_int": vr_int, "dem_frac": vr_frac}
+    cases = [
+        ("int_valley_s7", vr_int, 7, "valley", [0, 0.15, 0.3], None),
+        ("int_ridge_s7", vr_int, 7, "ridge", [0, 0.15, 0.3], None),
+        ("int_valley_s5", vr_int, 5, "valley", [0, 0.15, 0.3], None),
+        ("int_valley_s17", vr_int, 17, "valley", [0, 0.15, 0.3], None),
+        ("int_valley_s9_flat0", vr_int, 9, "valley", [0], None),
+        ("int_ridge_s9_flat2", vr_int, 9, "ridge", [0.2, 0.4], None),
+        ("frac_valley_s7", vr_frac, 7, "valley", [0, 0.15, 0.3], None),
+        ("frac_valley_s9_sig", vr_frac, 9, "valley", [0, 0.15, 0.3], 1.125),
+    ]
+    for tag, dem, size, mode, flats, sigma in cases:
+        norm, direction = ref_topo.valley_ridge(dem, size, mode, flats, sigma)
+        exact = orc.valley_ridge_exact(dem, size, mode, flats, sigma)
+        out[f"{tag}_norm"] = norm
+        out[f"{tag}_norm_exact"] = exact[0]
+        out[f"{tag}_dir"] = direction
+        out[f"{tag}_params"] = np.array([size, 0 if mode == "valley" else 1, -1.0 if sigma is None else sigma]
+                                        + list(flats), dtype=np.float64)
+    for size, flats in ((5, [0, 0.15, 0.3]), (7, [0, 0.15, 0.3]), (9, [0.2, 0.4]), (17, [0, 0.15, 0.3])):
+        base = ref_topo._valley_kernels(size, flats)
+        out[f"kernels_s{size}_n{len(flats)}"] = base
+        for angle in (0, 1, 33, 45, 90, 137, 179):
+            out[f"kernels_s{size}_n{len(flats)}_rot{angle}"] = ref_topo._rotate_kernels(base, np.float32(angle))
+    save("valley_ridge", **out)
+
 
 if __name__ == "__main__":
     main()

@@ -248,3 +248,66 @@ def test_sx_golden(golden, tag):
     # this oracle in float64: 1e-6 degrees apart at most
     assert np.max(np.abs(got.astype(np.float64) - ref)) <= 2e-5
     assert np.array_equal(got == 0, ref == 0)
+
+
+# ---- valley / ridge index -------------------------------------------------------
+VR_TAGS = ["int_valley_s7", "int_ridge_s7", "int_valley_s5", "int_valley_s17", "int_valley_s9_flat0",
+           "int_ridge_s9_flat2", "frac_valley_s7", "frac_valley_s9_sig"]
+
+
+def _vr_case(g, tag):
+    p = g[f"{tag}_params"]
+    size, mode, sigma, flats = int(p[0]), ("valley", "ridge")[int(p[1])], (None if p[2] < 0 else float(p[2])), list(p[3:])
+    dem = g["dem_int"] if tag.startswith("int") else g["dem_frac"]
+    return dem, size, mode, flats, sigma
+
+
+def test_valley_kernels_golden(golden):
+    """The kernels the reference builds, before and after rotation, bit for bit."""
+    g = golden("valley_ridge")
+    for size, flats in ((5, [0, 0.15, 0.3]), (7, [0, 0.15, 0.3]), (9, [0.2, 0.4]), (17, [0, 0.15, 0.3])):
+        base = orc.valley_kernels(size, flats)
+        want = g[f"kernels_s{size}_n{len(flats)}"]
+        assert base.dtype == want.dtype and np.array_equal(base, want), (size, flats)
+        assert np.array_equal(orc.ridge_kernels(size, flats), -want)
+        for angle in (0, 1, 33, 45, 90, 137, 179):
+            rot = orc.rotate_kernels(base, np.float32(angle))
+            w = g[f"kernels_s{size}_n{len(flats)}_rot{angle}"]
+            assert rot.shape == w.shape and rot.dtype == w.dtype, (size, angle)
+            assert np.max(np.abs(rot - w)) <= 1e-6, (size, angle)  # spline arithmetic of another scipy build
+
+
+def test_valley_ridge_plane_sums_are_what_the_3d_convolution_does():
+    """The reference convolves a 3-plane broadcast of the DEM with the 3-plane kernel stack in 3-D
+    (topo.py:436); per output plane that is a 2-D convolution with a sum of kernel planes."""
+    from scipy import signal
+    rng = np.random.default_rng(0)
+    dem = rng.normal(size=(30, 36))
+    for n in (1, 2, 3, 4):
+        k = rng.normal(size=(n, 6, 7)).astype(np.float32)
+        full = signal.convolve(np.broadcast_to(dem, (n, 30, 36)), k.astype(np.float64), mode="same", method="direct")
+        for i, ksum in enumerate(orc.valley_ridge_plane_sums(k)):
+            assert np.max(np.abs(full[i] - signal.convolve(dem, ksum, mode="same", method="direct"))) <= 1e-10, (n, i)
+
+
+@pytest.mark.parametrize("tag", VR_TAGS)
+def test_valley_ridge_golden(golden, tag):
+    g = golden("valley_ridge")
+    dem, size, mode, flats, sigma = _vr_case(g, tag)
+    norm_ref, dir_ref = g[f"{tag}_norm"], g[f"{tag}_dir"]
+    got = orc.valley_ridge_scipy(dem, size, mode, flats, sigma)
+    assert got[0].dtype == np.float32 and got[1].dtype == np.float32
+    assert rel_range(got[0], norm_ref) <= 1e-5
+    assert np.mean(got[1] == dir_ref) >= 0.999
+    # the float64 evaluation sits within the recorded floor, and every direction the reference
+    # chose is a maximiser of the exact per-angle maps up to that floor
+    (norm_ex, _), maps = orc.valley_ridge_exact(dem, size, mode, flats, sigma, return_maps=True)
+    floor = float(g[f"{tag}_norm_floor"])
+    assert np.max(np.abs(norm_ex - norm_ref)) <= floor * 1.001 + 1e-12
+    at_ref_dir = np.take_along_axis(maps, dir_ref.astype(int)[None], axis=0)[0]
+    assert np.max(np.max(maps, axis=0) - at_ref_dir) <= 4 * floor + 1e-6
+
+
+def test_valley_ridge_unknown_mode():
+    with pytest.raises(ValueError):
+        orc.valley_ridge_scipy(np.zeros((8, 8), np.float32), 5, "canyon")
