@@ -49,6 +49,7 @@ extern "C" {
 #define TOPO_AMD_DESC_GRADIENT 3
 #define TOPO_AMD_DESC_SOBEL 4
 #define TOPO_AMD_DESC_SX 5
+#define TOPO_AMD_DESC_VALLEY_RIDGE 6 /* p0 = side of the largest rotated kernel */
 
 /* resolution layout for the gradient normalisation (reference topo.py:688-712) */
 #define TOPO_AMD_RES_SCALAR 0 /* res_x[0], res_y[0]                                   */
@@ -131,6 +132,25 @@ int topo_amd_sx_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
                     const int32_t* dj, const int32_t* di, const double* dist, int n_off,
                     int window, double height, int out_row0, int out_rows, float* out);
 
+/* Valley / ridge index (replaces the angle loop of topo.valley_ridge, topo.py:431-447).
+ * The host builds the kernels exactly as the reference does (V / U profiles topo.py:456-492,
+ * quadratic-spline rotation and re-normalisation :515-525) and hands over, for each of
+ * n_angles angles, n_planes (1..4) 2-D kernels of side ksize[a]: the sums of neighbouring
+ * kernel planes that the reference's 3-D "same" convolution of the broadcast DEM applies
+ * (DESIGN.md), flipped in both axes so that the device evaluates a correlation.  taps: HOST
+ * float32, angle after angle, ksize[a]^2 taps in row-major order, 4 floats per tap (one per
+ * plane, unused ones 0).  angles: HOST float32, the value stored in dir_out for each angle.
+ * mean / stdev: the DEM is normalised as (x - mean) / stdev in float32 while it is read
+ * (topo.py:427); topo_amd_mean_std_dev computes them for a device-resident DEM.
+ * norm_out = max over angles and planes, clipped at 0; dir_out = first angle reaching it.   */
+int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
+                              const float* taps, const int32_t* ksize, const float* angles,
+                              int n_angles, int n_planes, double mean, double stdev,
+                              int out_row0, int out_rows, float* norm_out, float* dir_out);
+/* Mean and population standard deviation (numpy's default ddof = 0) of count device floats,
+ * accumulated in float64.                                                                */
+int topo_amd_mean_std_dev(const float* in, size_t count, double* mean, double* stdev);
+
 /* ---- descriptors, host-buffer form (single block, whole DEM) -------------------------- */
 int topo_amd_tpi_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
 int topo_amd_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
@@ -145,6 +165,10 @@ int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double
                           float* dy_out, float* slope_out, float* aspect_out);
 int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const int32_t* di,
                     const double* dist, int n_off, int window, double height, float* out);
+int topo_amd_valley_ridge_f32(const float* dem, int ny, int nx, const float* taps,
+                              const int32_t* ksize, const float* angles, int n_angles,
+                              int n_planes, double mean, double stdev, float* norm_out,
+                              float* dir_out);
 
 /* ---- row sharding over the GPUs of one node (RCCL over xGMI) -------------------------- */
 /* The reference's only precedent is dask map_overlap(depth, boundary="none") for TPI

@@ -1,0 +1,96 @@
+"""Valley / ridge index on the GPU against the golden vectors captured from the
+real reference and against the float64 oracle.
+
+The norm is compared directly.  The direction is an arg-max over 180 candidates that are often
+equal to within rounding (neighbouring angles respond almost identically), so it is judged through
+the oracle's per-angle maps: the response AT the direction the GPU chose must be the maximum up to
+the tolerance of the norm itself."""
+import numpy as np
+import pytest
+
+from oracle import topo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+from topo_descriptors_amd import _lib, device as d, shard, topo  # noqa: E402
+
+VR_TAGS = ["int_valley_s7", "int_ridge_s7", "int_valley_s5", "int_valley_s17", "int_valley_s9_flat0",
+           "int_ridge_s9_flat2", "frac_valley_s7", "frac_valley_s9_sig"]
+
+
+def _case(g, tag):
+    p = g[f"{tag}_params"]
+    size, mode, sigma, flats = int(p[0]), ("valley", "ridge")[int(p[1])], (None if p[2] < 0 else float(p[2])), list(p[3:])
+    dem = g["dem_int"] if tag.startswith("int") else g["dem_frac"]
+    return dem, size, mode, flats, sigma
+
+
+@pytest.mark.parametrize("tag", VR_TAGS)
+def test_valley_ridge_against_the_reference(golden, tag):
+    g = golden("valley_ridge")
+    dem, size, mode, flats, sigma = _case(g, tag)
+    norm_ref, dir_ref = g[f"{tag}_norm"], g[f"{tag}_dir"]
+    norm, direction = topo.valley_ridge(dem, size, mode, flats, sigma)
+    assert norm.dtype == np.float32 and direction.dtype == np.float32 and norm.shape == dem.shape
+    scale = float(np.max(np.abs(norm_ref)))
+    floor = float(g[f"{tag}_norm_floor"])
+    # tolerance contract of SURVEY.md section 8: range-normalised 1e-4, with the reference's own
+    # float32-FFT floor next to it
+    assert np.max(np.abs(norm - norm_ref)) <= floor + 1e-4 * scale, tag
+    (norm_ex, _), maps = orc.valley_ridge_exact(dem, size, mode, flats, sigma, return_maps=True)
+    assert np.max(np.abs(norm - norm_ex)) <= 1e-4 * scale, tag
+    assert np.all((direction >= 0) & (direction <= 179) & (direction == np.round(direction)))
+    at_gpu_dir = np.take_along_axis(maps, direction.astype(int)[None], axis=0)[0]
+    assert np.max(np.max(maps, axis=0) - at_gpu_dir) <= 1e-4 * scale, tag
+    # and in practice nearly every direction is the reference's
+    assert np.mean(direction == dir_ref) >= 0.99, (tag, float(np.mean(direction == dir_ref)))
+
+
+def test_valley_ridge_rejects_unknown_mode_like_the_reference():
+    with pytest.raises(ValueError):
+        topo.valley_ridge(np.zeros((16, 16), np.float32), 5, "canyon")
+
+
+def test_valley_ridge_row_blocks_are_bit_identical():
+    """Row blocks with ghost rows (the reach of the largest rotated kernel) against the single
+    block; the standardisation uses the mean / std of the whole DEM in both."""
+    dem = orc.synthetic_dem(150, 200, seed=9)
+    size, flats = 9, [0, 0.15, 0.3]
+    kernels = topo._valley_kernels(size, flats)
+    taps, ksize, angles = topo._valley_ridge_tables(kernels, np.arange(0, 180, 7, dtype=np.float32))
+    up, down = shard.halo_rows(_lib.DESC_VALLEY_RIDGE, int(ksize.max()))
+    assert up == ksize.max() // 2 and down == ksize.max() - 1 - ksize.max() // 2
+    mean, stdev = float(dem.mean()), float(dem.std())
+    gny, nx = dem.shape
+
+    def run(nblocks):
+        norms, dirs = [], []
+        for row0, rows in shard.split_rows(gny, nblocks):
+            lo, hi = max(0, row0 - up), min(gny, row0 + rows + down)
+            dev = d.DeviceArray.from_host(dem[lo:hi])
+            blk = d.Block(dev, row0=lo, gny=gny)
+            n, a = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+            blk.valley_ridge(taps, ksize, angles, len(flats), mean, stdev, n, a, out_row0=row0, out_rows=rows)
+            d.sync()
+            norms.append(n.to_host())
+            dirs.append(a.to_host())
+            for x in (n, a, dev):
+                x.free()
+        return np.concatenate(norms), np.concatenate(dirs)
+
+    whole = run(1)
+    for nb in (2, 3):
+        parts = run(nb)
+        assert np.array_equal(parts[0], whole[0]) and np.array_equal(parts[1], whole[1]), nb
+    # a subset of angles is what the oracle gets too
+    (norm_ex, _), maps = orc.valley_ridge_exact(dem, size, "valley", flats, angles=angles, return_maps=True)
+    assert np.max(np.abs(whole[0] - norm_ex)) <= 1e-4 * np.max(norm_ex)
+
+
+def test_device_mean_std_matches_numpy():
+    dem = orc.synthetic_dem(700, 900, seed=12)
+    dev = d.DeviceArray.from_host(dem)
+    mean, stdev = d.mean_std(dev)
+    dev.free()
+    assert abs(mean - float(np.mean(dem, dtype=np.float64))) <= 1e-9 * abs(mean)
+    assert abs(stdev - float(np.std(dem, dtype=np.float64))) <= 1e-9 * stdev

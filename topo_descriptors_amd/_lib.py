@@ -46,6 +46,11 @@ SIGNATURES = {
                                         _vp, _vp]),
     "topo_amd_sx_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p,
                                   C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _vp]),
+    "topo_amd_valley_ridge_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _i32p, _vp, C.c_int,
+                                            C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp]),
+    "topo_amd_mean_std_dev": (C.c_int, [_vp, C.c_size_t, _f64p, _f64p]),
+    "topo_amd_valley_ridge_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _i32p, _vp, C.c_int, C.c_int,
+                                            C.c_double, C.c_double, _vp, _vp]),
     "topo_amd_tpi_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp]),
     "topo_amd_std_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp]),
     "topo_amd_tpi_std_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp]),
@@ -71,7 +76,7 @@ SIGNATURES = {
 
 UNIQUE_ID_BYTES = 128
 RES_SCALAR, RES_1D, RES_2D = 0, 1, 2
-DESC_TPI, DESC_STD, DESC_GAUSS, DESC_GRADIENT, DESC_SOBEL, DESC_SX = range(6)
+DESC_TPI, DESC_STD, DESC_GAUSS, DESC_GRADIENT, DESC_SOBEL, DESC_SX, DESC_VALLEY_RIDGE = range(7)
 
 
 class TopoAmdError(RuntimeError):

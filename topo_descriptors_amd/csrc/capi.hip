@@ -384,6 +384,12 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
             *above = p0 > 0 ? (int)p0 : 0;
             *below = p1 > 0 ? (int)p1 : 0;
             return TOPO_AMD_OK;
+        case TOPO_AMD_DESC_VALLEY_RIDGE: {
+            const int32_t kmax = (int32_t)p0;
+            TOPO_REQUIRE(kmax >= 1, "halo_rows: kernel side %d", kmax);
+            (void)valley_ridge_reach(&kmax, 1, above, below);
+            return TOPO_AMD_OK;
+        }
         default:
             set_error("halo_rows: unknown descriptor %d", descriptor);
             return TOPO_AMD_EINVAL;
@@ -444,6 +450,24 @@ int topo_amd_sx_dev(const float* in, int in_rows, int in_row0, int gny, int nx, 
     // rows of the zero frame need no neighbours, interior rows never reach outside the DEM
     TOPO_TRY(check_block(b, up, down, "sx"));
     return launch_sx(b, dj, di, dist, n_off, window, height, out);
+}
+
+int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny, int nx, const float* taps,
+                              const int32_t* ksize, const float* angles, int n_angles, int n_planes, double mean,
+                              double stdev, int out_row0, int out_rows, float* norm_out, float* dir_out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(taps && ksize && angles && norm_out && dir_out && n_angles >= 1, "valley_ridge: NULL argument");
+    int up = 0, down = 0;
+    (void)valley_ridge_reach(ksize, n_angles, &up, &down);
+    Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    TOPO_TRY(check_block(b, up, down, "valley_ridge"));
+    return launch_valley_ridge(b, taps, ksize, angles, n_angles, n_planes, mean, stdev, norm_out, dir_out);
+}
+
+int topo_amd_mean_std_dev(const float* in, size_t count, double* mean, double* stdev) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(in && mean && stdev && count >= 1, "mean_std: bad arguments");
+    return launch_mean_std(in, count, mean, stdev);
 }
 
 // ---- host-buffer entry points ----------------------------------------------------------------
@@ -554,6 +578,26 @@ int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const i
     TOPO_TRY(topo_amd_sx_dev((const float*)d_in, ny, 0, ny, nx, dj, di, dist, n_off, window, height,
                              0, ny, (float*)d_out));
     TOPO_TRY(download(out, d_out, bytes));
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_valley_ridge_f32(const float* dem, int ny, int nx, const float* taps, const int32_t* ksize,
+                              const float* angles, int n_angles, int n_planes, double mean, double stdev,
+                              float* norm_out, float* dir_out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dem && ny >= 1 && nx >= 1 && norm_out && dir_out, "valley_ridge: bad arguments");
+    const size_t bytes = (size_t)ny * nx * sizeof(float);
+    HostRun run;
+    void *d_in = nullptr, *d_norm = nullptr, *d_dir = nullptr;
+    TOPO_TRY(run.alloc(&d_in, bytes));
+    TOPO_TRY(run.alloc(&d_norm, bytes));
+    TOPO_TRY(run.alloc(&d_dir, bytes));
+    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
+    TOPO_TRY(topo_amd_valley_ridge_dev((const float*)d_in, ny, 0, ny, nx, taps, ksize, angles, n_angles, n_planes,
+                                       mean, stdev, 0, ny, (float*)d_norm, (float*)d_dir));
+    TOPO_TRY(download(norm_out, d_norm, bytes));
+    TOPO_TRY(download(dir_out, d_dir, bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     return TOPO_AMD_OK;
 }

@@ -98,6 +98,11 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
 int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double* dist,
               int n_off, int window, double height, float* out);
 int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed, bool integer_valued);
+// valley / ridge index (valley.hip): taps = per angle ksize^2 x 4 floats (plane sums, flipped)
+int valley_ridge_reach(const int32_t* ksize, int n_angles, int* above, int* below);
+int launch_mean_std(const float* in, size_t count, double* mean, double* stdev);
+int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles,
+                        int n_planes, double mean, double stdev, float* norm_out, float* dir_out);
 
 int gaussian_radius(double sigma);
 

@@ -133,6 +133,28 @@ class Block:
                                               float(height), o0, on, out.ptr), "sx_dev")
 
 
+    def valley_ridge(self, taps, ksize, angles, n_planes, mean, stdev, norm, direction, out_row0=None,
+                     out_rows=None):
+        """taps / ksize / angles as returned by ``topo._valley_ridge_tables``; mean / stdev of the
+        WHOLE DEM (``mean_std`` for a device-resident one)."""
+        o0, on = self._range(out_row0, out_rows)
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        ksize = np.ascontiguousarray(ksize, dtype=np.int32)
+        angles = np.ascontiguousarray(angles, dtype=np.float32)
+        _lib.check(_lib.lib().topo_amd_valley_ridge_dev(
+            *self._head(), taps.ctypes.data_as(_lib._vp), ksize.ctypes.data_as(_lib._i32p),
+            angles.ctypes.data_as(_lib._vp), ksize.size, int(n_planes), float(mean), float(stdev), o0, on,
+            norm.ptr, direction.ptr), "valley_ridge_dev")
+
+
+def mean_std(array):
+    """(mean, population std) of a DeviceArray, accumulated in float64 on the GPU."""
+    m, s = C.c_double(), C.c_double()
+    _lib.check(_lib.lib().topo_amd_mean_std_dev(array.ptr, array.rows * array.nx, C.byref(m), C.byref(s)),
+               "mean_std_dev")
+    return m.value, s.value
+
+
 def sx_offsets(azimuth, radius, dx, dy, azimuth_arc=10.0, azimuth_steps=15, radius_min=0.0):
     """(window, dj, di, dist) for the C ABI from Sx parameters and mean grid spacing."""
     from . import topo  # noqa: PLC0415

@@ -251,3 +251,92 @@ def sx(dem_ds, azimuth, radius, height=10.0, azimuth_arc=10.0, azimuth_steps=15,
     source = (window_center + _sx_source_idx_delta(azimuths, radius, dx, dy)).astype(int)
     lines_indices = _sx_bresenhamlines(source, window_center)
     return _sx_rolling(hlp.get_da(dem_ds).values, window_distance, lines_indices, height)
+
+
+# ---- valley / ridge index ---------------------------------------------------------------------
+def _valley_kernels(size, flat_list):
+    """One normalised V / U profile per flat fraction (reference topo.py:456-492): distance to the
+    centre row, repeated along the columns; a fraction ``f`` flattens the band of half-width
+    ``int(floor(floor(size * f / 2) + 0.5))`` to the value on its edge.  Like the reference, every
+    plane is brought to mean 0 / std 1 again after each fraction is applied, so later planes are
+    flattened on normalised values (this order decides the float32 result).  Odd sizes only."""
+    size = int(size)
+    middle = size // 2
+    rows = np.abs(np.arange(-middle, middle + 1)).astype(np.float32)
+    kernels = np.tile(rows[None, :, None], (len(flat_list), 1, size))
+    for ind, flat in enumerate(flat_list):
+        half = int(np.floor(np.floor(size * flat / 2) + 0.5))
+        kernels[ind, middle - half:middle + half + 1, :] = kernels[ind, middle - half, 0]
+        kernels = (kernels - kernels.mean(axis=(1, 2), keepdims=True)) / kernels.std(axis=(1, 2), keepdims=True)
+    return kernels
+
+
+def _ridge_kernels(size, flat_list):
+    """reference topo.py:495-512"""
+    return _valley_kernels(size, flat_list) * -1
+
+
+def _rotate_kernels(kernel, angle):
+    """The kernel stack turned by ``angle`` degrees in its (row, column) plane with scipy's
+    quadratic-spline ``ndimage.rotate`` on an enlarged canvas; canvas cells outside the turned
+    square (left at the fill value -9999) are excluded from the re-normalisation and end up 0
+    (reference topo.py:515-525).  Host-side parameter preparation, like the Sx ray geometry."""
+    from numpy import ma
+    from scipy import ndimage
+
+    turned = ndimage.rotate(kernel, angle, axes=(1, 2), reshape=True, order=2, mode="constant", cval=-9999)
+    turned = ma.masked_array(turned, mask=turned == -9999)
+    turned = (turned - turned.mean(axis=(1, 2), keepdims=True)) / turned.std(axis=(1, 2), keepdims=True)
+    return ma.MaskedArray.filled(turned, 0).astype(np.float32)
+
+
+def _valley_ridge_tables(kernels, angles):
+    """Per angle, what the reference's 3-D ``signal.convolve(dem3, kernels_rot, mode="same")``
+    (topo.py:436) applies to the DEM in each output plane, laid out for the C ABI.
+
+    The DEM is broadcast to one identical plane per kernel plane, so along that axis the "same"
+    convolution just adds the kernel planes that overlap: output plane ``i`` of ``L`` sees the sum of
+    ``K[b]`` with ``0 <= i - b + (L - 1) // 2 < L`` (three planes: K0+K1, K0+K1+K2, K1+K2).  The
+    sums are flipped in both axes (a convolution becomes a correlation) and interleaved as four
+    floats per tap.  Returns (taps float32, ksize int32, angles float32)."""
+    n = kernels.shape[0]
+    if not 1 <= n <= 4:
+        raise ValueError(f"valley_ridge: {n} flat fractions; 1 to 4 are supported")
+    centre = (n - 1) // 2
+    taps, ksize = [], []
+    for angle in angles:
+        turned = _rotate_kernels(kernels, angle).astype(np.float64)
+        side = turned.shape[1]
+        block = np.zeros((side, side, 4), dtype=np.float32)
+        for i in range(n):
+            total = sum(turned[b] for b in range(n) if 0 <= i - b + centre < n)
+            block[:, :, i] = total[::-1, ::-1]
+        taps.append(block.reshape(-1))
+        ksize.append(side)
+    return (np.ascontiguousarray(np.concatenate(taps), dtype=np.float32), np.asarray(ksize, dtype=np.int32),
+            np.ascontiguousarray(angles, dtype=np.float32))
+
+
+def valley_ridge(dem, size, mode, flat_list=[0, 0.15, 0.3], sigma=None):  # noqa: B006 (the reference's default)
+    """Valley or ridge index: for 180 directions, the response of the standardised DEM to V- and
+    U-shaped kernels of side ``size`` turned to that direction; returns ``[norm, direction]``, the
+    largest response clipped at 0 and the direction (degrees, 0 = W-E, 90 = S-N) it came from
+    (reference topo.py:389-447).  The 180 x ``len(flat_list)`` convolutions run in one pass over
+    the DEM on the GPU."""
+    if mode not in ("valley", "ridge"):
+        raise ValueError(f"Unknown mode {mode!r}")
+    values, _ = _unwrap(dem)
+    _check_2d(values, "valley_ridge")
+    field = globals()["dem"](values, sigma) if sigma else values
+    src = _lib.as_f32(field)
+    # the reference standardises with numpy's own float32 mean / std of the whole array (topo.py:427)
+    mean, stdev = float(field.mean()), float(field.std())
+    kernels = _ridge_kernels(size, flat_list) if mode == "ridge" else _valley_kernels(size, flat_list)
+    taps, ksize, angles = _valley_ridge_tables(kernels, np.arange(0, 180, dtype=np.float32))
+    norm = np.empty(src.shape, dtype=np.float32)
+    direction = np.empty(src.shape, dtype=np.float32)
+    _lib.check(_lib.lib().topo_amd_valley_ridge_f32(
+        src.ctypes.data_as(_lib._vp), src.shape[0], src.shape[1], taps.ctypes.data_as(_lib._vp),
+        ksize.ctypes.data_as(_lib._i32p), angles.ctypes.data_as(_lib._vp), ksize.size, kernels.shape[0], mean, stdev,
+        norm.ctypes.data_as(_lib._vp), direction.ctypes.data_as(_lib._vp)), "topo_amd_valley_ridge_f32")
+    return [norm, direction]
