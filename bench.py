@@ -174,6 +174,16 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
         window, dj, di, dist = d.sx_offsets(0.0, radius, 30.0, -30.0)
         fn = lambda: blk.sx(dj, di, dist, window, 10.0, o1)  # noqa: E731
         entry(f"sx_az0_r{int(radius)}", time_kernel(fn, 3, d), 8)
+    # valley index at 200 m (7 px): 180 angles x 3 plane sums of rotated kernels in one pass
+    # (first version, direct float32 evaluation)
+    from topo_descriptors_amd import topo
+    mean, stdev = d.mean_std(dem)
+    taps, ksize, angles = topo._valley_ridge_tables(topo._valley_kernels(7, [0, 0.15, 0.3]),
+                                                    np.arange(0, 180, dtype=np.float32))
+    ms = time_kernel(lambda: blk.valley_ridge(taps, ksize, angles, 3, mean, stdev, o1, o2), 1, d)
+    entry("valley_ridge_s7", ms, 12)
+    out["valley_ridge_s7"]["GFMA_per_s"] = round(px * int((ksize.astype(np.int64) ** 2).sum()) * 3 / ms / 1e6, 0)
+
     # the same TPI on fractional elevations: every tile runs the integer pass plus the float
     # chain on the fractional parts and goes through the per-row scratch planes (two passes)
     frac = d.synth_dem(ny, nx, seed=0, integer=False)

@@ -201,6 +201,14 @@ int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int
 int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx,
                       const int32_t* dj, const int32_t* di, const double* dist, int n_off,
                       int window, double height, float* out);
+/* Sharded valley / ridge index: `block` as above with halo_above / halo_below =
+ * topo_amd_halo_rows(VALLEY_RIDGE, largest kernel side).  The mean and standard deviation of
+ * the whole DEM come from float64 moments of the owned rows and one ncclAllReduce (the only
+ * true collective on the path; exact, hence the same for every sharding, on a DEM of whole
+ * metres).                                                                                  */
+int topo_amd_shard_valley_ridge(float* block, int rows_local, int row0, int gny, int nx,
+                                const float* taps, const int32_t* ksize, const float* angles,
+                                int n_angles, int n_planes, float* norm_out, float* dir_out);
 
 #ifdef __cplusplus
 }

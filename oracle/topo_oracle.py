@@ -349,11 +349,14 @@ def _valley_ridge_base(mode, size, flat_list):
     return ridge_kernels(size, flat_list) if mode == "ridge" else valley_kernels(size, flat_list)
 
 
-def normalise_dem(dem, sigma=None):
+def normalise_dem(dem, sigma=None, stats=None):
     """topo.py:424-427: optional Gaussian pre-smooth, then (dem - mean) / std of the whole array,
-    in the array's own precision."""
+    in the array's own precision.  ``stats=(mean, std)`` supplies the statistics from outside (a row
+    block of a sharded DEM is standardised with those of the whole DEM)."""
     field = ndimage.gaussian_filter(dem, sigma) if sigma else dem
-    return (field - field.mean()) / field.std()
+    if stats is None:
+        return (field - field.mean()) / field.std()
+    return (field - field.dtype.type(stats[0])) / field.dtype.type(stats[1])
 
 
 def valley_ridge_scipy(dem, size, mode, flat_list=(0, 0.15, 0.3), sigma=None):
@@ -373,19 +376,23 @@ def valley_ridge_scipy(dem, size, mode, flat_list=(0, 0.15, 0.3), sigma=None):
 
 
 def valley_ridge_exact(dem, size, mode, flat_list=(0, 0.15, 0.3), sigma=None, angles=None,
-                       return_maps=False):
+                       return_maps=False, stats=None, method="fft"):
     """Float64 evaluation of the same index from the same float32 kernels and the same float32
     normalised DEM: per angle the maximum over the plane sums of a float64 2-D convolution.
     ``return_maps`` also returns the per-angle maxima (n_angles x ny x nx), which is what a
     direction has to be judged against (the arg-max over 180 near-equal candidates is not
-    stable under rounding)."""
+    stable under rounding).  ``method="direct"`` sums the taps pixel by pixel instead of going
+    through an FFT, so a pixel's value does not depend on the size of the array around it."""
     base = _valley_ridge_base(mode, size, list(flat_list))
-    field = np.asarray(normalise_dem(dem, sigma), dtype=np.float64)
+    field = np.asarray(normalise_dem(dem, sigma, stats), dtype=np.float64)
     angles = np.arange(0, 180, dtype=np.float32) if angles is None else np.asarray(angles, dtype=np.float32)
     maps = np.empty((len(angles),) + field.shape, dtype=np.float64)
     for a, angle in enumerate(angles):
         sums = valley_ridge_plane_sums(rotate_kernels(base, angle))
-        maps[a] = np.max([signal.fftconvolve(field, k, mode="same") for k in sums], axis=0)
+        if method == "direct":
+            maps[a] = np.max([signal.convolve(field, k, mode="same", method="direct") for k in sums], axis=0)
+        else:
+            maps[a] = np.max([signal.fftconvolve(field, k, mode="same") for k in sums], axis=0)
     best = np.argmax(maps, axis=0)  # first maximum, like the reference's strict ">" update
     norm = np.clip(np.take_along_axis(maps, best[None], axis=0)[0], 0, None)
     direction = angles[best].astype(np.float64)

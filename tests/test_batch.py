@@ -15,6 +15,8 @@ def test_output_names_match_the_reference_strings():
                                              "SLOPE_500M_SIGRATIO1", "ASPECT_500M_SIGRATIO1"]
     assert batch._gradient_names(500, 0.25)[2] == "SLOPE_500M_SIGRATIO0.25"
     assert batch._sx_name(500.0, 225.7) == "SX_RADIUS500_AZIMUTH225"
+    assert batch._valley_ridge_names(2000, "valley", None) == ["valley_NORM_2000M", "valley_DIR_2000M"]
+    assert batch._valley_ridge_names(500, "ridge", 0.5) == ["ridge_NORM_500M_SMTHFACT0.5", "ridge_DIR_500M_SMTHFACT0.5"]
 
 
 class FakeVar:
@@ -76,3 +78,15 @@ def test_wrappers_equal_the_single_calls(tmp_path):
 
     out = batch.compute_sx(ds, 0, 300.0, outdir=None)
     assert np.array_equal(out["SX_RADIUS300_AZIMUTH0"], topo.sx(ds, 0, 300.0))
+
+    out = batch.compute_valley_ridge(ds, 200, "valley", smth_factors=None, ind_nans=ind_nans, outdir=None)
+    assert set(out) == {"valley_NORM_200M", "valley_DIR_200M"}
+    want = topo.valley_ridge(filled, 7, "valley")
+    got = out["valley_NORM_200M"]
+    assert np.isnan(got[5, 7]) and np.isnan(out["valley_DIR_200M"][5, 7])
+    # the wrapper standardises with the float64 mean / std formed on the GPU, topo.valley_ridge with
+    # numpy's float32 ones like the reference: the same to the last float32 bit or nearly so
+    assert np.max(np.abs(got[mask] - want[0][mask])) <= 1e-5 * np.max(want[0])
+    assert np.mean(out["valley_DIR_200M"][mask] == want[1][mask]) >= 0.999
+    with pytest.raises(ValueError):
+        batch.compute_valley_ridge(ds, 200, "canyon", outdir=None)

@@ -94,3 +94,37 @@ def test_device_mean_std_matches_numpy():
     dev.free()
     assert abs(mean - float(np.mean(dem, dtype=np.float64))) <= 1e-9 * abs(mean)
     assert abs(stdev - float(np.std(dem, dtype=np.float64))) <= 1e-9 * stdev
+
+
+def test_single_rank_shard_valley_ridge():
+    """topo_amd_shard_valley_ridge with one rank: moments and standardisation on the device, the
+    exchange a no-op, interior / seam split still run.  Against the float64 oracle, and equal to
+    the device-block call given the same mean / std."""
+    dem = orc.synthetic_dem(140, 192, seed=21)
+    gny, nx = dem.shape
+    size, flats = 7, [0, 0.15, 0.3]
+    angles_in = np.arange(0, 180, 5, dtype=np.float32)
+    taps, ksize, angles = topo._valley_ridge_tables(topo._valley_kernels(size, flats), angles_in)
+    up, down = shard.halo_rows(_lib.DESC_VALLEY_RIDGE, int(ksize.max()))
+    plan = shard.RowShardPlan(gny, nx, 1, 0, up, down)
+    sd = shard.ShardedDEM(plan, dem)
+    n, a = d.DeviceArray(gny, nx), d.DeviceArray(gny, nx)
+    sd.valley_ridge(taps, ksize, angles, len(flats), n, a)
+    d.sync()
+    norm, direction = n.to_host(), a.to_host()
+    (norm_ex, _), maps = orc.valley_ridge_exact(dem, size, "valley", flats, angles=angles_in, return_maps=True)
+    scale = float(np.max(norm_ex))
+    assert np.max(np.abs(norm - norm_ex)) <= 1e-4 * scale
+    idx = np.searchsorted(angles_in, direction)
+    assert np.all(angles_in[idx] == direction)
+    assert np.max(np.max(maps, axis=0) - np.take_along_axis(maps, idx[None], axis=0)[0]) <= 1e-4 * scale
+    # whole metres: the float64 moments are exact, so they are numpy's float64 mean / std
+    dev = d.DeviceArray.from_host(dem)
+    mean, stdev = d.mean_std(dev)
+    assert mean == float(np.mean(dem, dtype=np.float64))
+    n2, a2 = d.DeviceArray(gny, nx), d.DeviceArray(gny, nx)
+    d.Block(dev).valley_ridge(taps, ksize, angles, len(flats), mean, stdev, n2, a2)
+    d.sync()
+    assert np.array_equal(n2.to_host(), norm) and np.array_equal(a2.to_host(), direction)
+    for x in (n, a, n2, a2, dev):
+        x.free()

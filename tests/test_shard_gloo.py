@@ -70,13 +70,19 @@ def evaluate(name, window, x, y_window, params):
                              y_window[-1] - 30.0 * np.arange(1, bot + 1)])
         out = orc.sx(padded, x, yy, 0.0, params["radius"]).astype(np.float64)
         return out[top: top + window.shape[0]]
+    if name == "valley":
+        # standardised with the statistics of the WHOLE DEM, which the ranks obtained by an all-reduce
+        return orc.valley_ridge_exact(window, params["size"], "valley", angles=params["angles"],
+                                      stats=params["stats"], method="direct")[0]
     raise KeyError(name)
 
 
 CASES = [("tpi", {"size": 17}, _lib.DESC_TPI), ("tpi", {"size": 6}, _lib.DESC_TPI),
          ("std", {"size": 7}, _lib.DESC_STD), ("gauss", {"sigma": 2.25}, _lib.DESC_GAUSS),
          ("slope", {"sigma": 2.25}, _lib.DESC_GRADIENT), ("slope", {"sigma": 0.75}, _lib.DESC_GRADIENT),
-         ("sx", {"radius": 150.0}, _lib.DESC_SX)]
+         ("sx", {"radius": 150.0}, _lib.DESC_SX),
+         ("valley", {"size": 7, "angles": np.array([0, 30, 45, 100, 160], dtype=np.float32)},
+          _lib.DESC_VALLEY_RIDGE)]
 
 
 def worker(rank, world, port, gny, nx, fail):
@@ -91,6 +97,11 @@ def worker(rank, world, port, gny, nx, fail):
             if desc == _lib.DESC_SX:
                 window, offs, _ = orc.sx_geometry(0.0, params["radius"], 30.0, -30.0)
                 up, down = halo_rows(desc, max(0, -offs[:, 0].min()), max(0, offs[:, 0].max()))
+            elif desc == _lib.DESC_VALLEY_RIDGE:
+                kmax = max(orc.rotate_kernels(orc.valley_kernels(params["size"], [0, 0.15, 0.3]), a).shape[1]
+                           for a in params["angles"])
+                up, down = halo_rows(desc, kmax)
+                assert (up, down) == (kmax // 2, kmax - 1 - kmax // 2)
             else:
                 p0 = params.get("size", params.get("sigma"))
                 up, down = halo_rows(desc, p0)
@@ -103,6 +114,18 @@ def worker(rank, world, port, gny, nx, fail):
             window = block[first: first + rows]
             assert not np.isnan(window).any()
             assert np.array_equal(window, dem[g0: g0 + rows])        # ghosts are the neighbours' rows
+            if desc == _lib.DESC_VALLEY_RIDGE:
+                # the protocol of topo_amd_shard_valley_ridge: float64 moments about 0 of the owned
+                # rows, one all-reduce, mean and population std of the whole DEM on every rank
+                own = dem[plan.row0: plan.row0 + plan.rows_local].astype(np.float64)
+                mom = torch.tensor([own.size, own.sum(), (own * own).sum()], dtype=torch.float64)
+                dist.all_reduce(mom)
+                cnt, s1, s2 = (float(v) for v in mom)
+                mean = s1 / cnt
+                stats = (mean, float(np.sqrt(max(s2 / cnt - mean * mean, 0.0))))
+                full = dem.astype(np.float64)
+                assert cnt == dem.size and s1 == full.sum() and s2 == (full * full).sum()  # exact on whole metres
+                params = dict(params, stats=stats)
             params = dict(params, at_top=(g0 == 0), at_bottom=(g0 + rows == gny))
             out = evaluate(name, window, x, y[g0: g0 + rows], params)
             mine = out[plan.row0 - g0: plan.row0 - g0 + plan.rows_local]

@@ -60,6 +60,8 @@ SIGNATURES = {
                                         _vp, _vp, _vp, _vp, _vp, _vp]),
     "topo_amd_sx_f32": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int,
                                   C.c_double, _vp]),
+    "topo_amd_shard_valley_ridge": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _i32p, _vp, C.c_int,
+                                              C.c_int, _vp, _vp]),
     "topo_amd_comm_unique_id": (C.c_int, [C.c_char_p]),
     "topo_amd_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
     "topo_amd_comm_rank": (C.c_int, []),

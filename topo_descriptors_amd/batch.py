@@ -38,6 +38,12 @@ def _gradient_names(scale, sig_ratio):
     return ["WE_DERIVATIVE" + tail, "SN_DERIVATIVE" + tail, "SLOPE" + tail, "ASPECT" + tail]
 
 
+def _valley_ridge_names(scale, mode, smth_factor):
+    """reference topo.py:450-458"""
+    add = f"_SMTHFACT{smth_factor:.3g}" if smth_factor else ""
+    return [f"{mode}_NORM_{scale}M{add}", f"{mode}_DIR_{scale}M{add}"]
+
+
 def _sx_name(radius, azimuth):
     return f"SX_RADIUS{int(radius)}_AZIMUTH{int(azimuth)}"
 
@@ -196,4 +202,43 @@ def compute_sx(dem_ds, azimuth, radius, height=10.0, azimuth_arc=10.0, azimuth_s
                     azimuth_steps=azimuth_steps, radius_min=radius_min)
     results = {}
     _finish(array, None, dem_ds, _sx_name(radius, azimuth), crop, outdir, "degree", results)
+    return results
+
+
+def compute_valley_ridge(dem_ds, scales, mode, flat_list=[0, 0.15, 0.3], smth_factors=None, ind_nans=(),  # noqa: B006
+                         crop=None, outdir="."):
+    """Valley or ridge index (norm and direction) for every scale (reference topo.py:317-386).
+
+    The DEM goes to the GPU once; per scale the optional pre-smoothing, the mean and standard
+    deviation of the (smoothed) DEM and the 180-angle pass all run on the device-resident plane."""
+    hlp.check_dem(dem_ds)
+    if mode not in ("valley", "ridge"):
+        raise ValueError(f"Unknown mode {mode!r}")
+    logger.info("***Starting %s index computation for scales %s meters***", mode, scales)
+    scales = _as_list(scales)
+    smth_factors = _as_list(smth_factors, len(scales))
+    scales_pxl, _ = hlp.scale_to_pixel(scales, dem_ds)
+    sigmas = hlp.get_sigmas(smth_factors, scales_pxl)
+    res = _ResidentDem(hlp.get_da(dem_ds).values)
+    norm, direction, smooth, results = res.plane(), res.plane(), None, {}
+    angles = np.arange(0, 180, dtype=np.float32)
+    try:
+        for scale, px, fact, sigma in zip(scales, scales_pxl, smth_factors, sigmas):
+            logger.info("Computing scale %s meters with smoothing factor %s ...", scale, fact)
+            block, plane = res.block, res.dev
+            if sigma:  # pre-smoothing (reference topo.py:424-425)
+                smooth = smooth or res.plane()
+                res.block.gaussian(sigma, sigma, smooth)
+                block, plane = d.Block(smooth), smooth
+            mean, stdev = d.mean_std(plane)
+            kernels = topo._ridge_kernels(int(px), flat_list) if mode == "ridge" else topo._valley_kernels(int(px), flat_list)
+            taps, ksize, ang = topo._valley_ridge_tables(kernels, angles)
+            block.valley_ridge(taps, ksize, ang, kernels.shape[0], mean, stdev, norm, direction)
+            for array, name in zip((norm.to_host(), direction.to_host()), _valley_ridge_names(scale, mode, fact)):
+                _finish(array, ind_nans, dem_ds, name, crop, outdir, "1", results)
+    finally:
+        for a in (norm, direction, smooth):
+            if a is not None:
+                a.free()
+        res.close()
     return results

@@ -797,4 +797,41 @@ int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx, c
     });
 }
 
+int topo_amd_shard_valley_ridge(float* block, int rows_local, int row0, int gny, int nx, const float* taps,
+                                const int32_t* ksize, const float* angles, int n_angles, int n_planes,
+                                float* norm_out, float* dir_out) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(block && taps && ksize && angles && norm_out && dir_out && n_angles >= 1,
+                 "shard_valley_ridge: NULL argument");
+    int above = 0, below = 0;
+    (void)valley_ridge_reach(ksize, n_angles, &above, &below);
+    // the standardisation needs the mean and standard deviation of the WHOLE DEM (topo.py:427):
+    // float64 moments about 0 of the owned rows, then the one all-reduce of the whole path.
+    // On a DEM of whole metres the three numbers are exact integers (< 2^53), so every sharding
+    // gets the same mean and std.
+    double mom[3] = {(double)rows_local * (double)nx, 0.0, 0.0};
+    TOPO_TRY(launch_moments(block + (size_t)above * nx, (size_t)rows_local * nx, 0.0, false, &mom[1], &mom[2]));
+    if (g_comm.size > 1) {
+        void* d_mom = nullptr;
+        TOPO_TRY(workspace(0, 3 * sizeof(double), &d_mom));
+        TOPO_HIP(hipMemcpyAsync(d_mom, mom, sizeof(mom), hipMemcpyHostToDevice, ctx().compute));
+        TOPO_NCCL(ncclAllReduce(d_mom, d_mom, 3, ncclDouble, ncclSum, g_comm.comm, ctx().compute));
+        TOPO_HIP(hipMemcpyAsync(mom, d_mom, sizeof(mom), hipMemcpyDeviceToHost, ctx().compute));
+        TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    }
+    const double mean = mom[1] / mom[0];
+    double var = mom[2] / mom[0] - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double stdev = std::sqrt(var);
+    Shard s = make_shard(block, rows_local, row0, gny, nx, above, below);
+    return run_overlapped(block, s, above, below, [&](int o0, int on) {
+        Block b = s.whole;
+        b.out_row0 = o0;
+        b.out_rows = on;
+        TOPO_TRY(check_block(b, above, below, "shard_valley_ridge"));
+        return launch_valley_ridge(b, taps, ksize, angles, n_angles, n_planes, mean, stdev,
+                                   shift(norm_out, o0 - row0, nx), shift(dir_out, o0 - row0, nx));
+    });
+}
+
 }  // extern "C"

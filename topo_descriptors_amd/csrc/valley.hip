@@ -143,9 +143,10 @@ int launch_np(const VrArgs& a, dim3 grid, size_t lds) {
 // per block; the host adds the partials.  Deviations from a pivot keep the variance of ~2000 m
 // elevations with ~500 m spread free of cancellation.
 namespace {
-__global__ __launch_bounds__(kThreads) void moments_kernel(const float* in, size_t count, double* partial) {
+__global__ __launch_bounds__(kThreads) void moments_kernel(const float* in, size_t count, double pivot_value,
+                                                           int pivot_is_first_sample, double* partial) {
     __shared__ double s1[kThreads], s2[kThreads];
-    const double pivot = (double)in[0];
+    const double pivot = pivot_is_first_sample ? (double)in[0] : pivot_value;
     double a = 0.0, b = 0.0;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads) {
         const double d = (double)in[i] - pivot;
@@ -169,23 +170,35 @@ __global__ __launch_bounds__(kThreads) void moments_kernel(const float* in, size
 }
 }  // namespace
 
-int launch_mean_std(const float* in, size_t count, double* mean, double* stdev) {
+// sum and sum of squares of (x - pivot) over count samples, float64, returned to the host
+int launch_moments(const float* in, size_t count, double pivot, bool pivot_is_first_sample, double* sum,
+                   double* sumsq) {
     Context& c = ctx();
     const int blocks = 1024;
     void* d_part = nullptr;
     TOPO_TRY(workspace(0, (size_t)blocks * 2 * sizeof(double), &d_part));
-    hipLaunchKernelGGL(moments_kernel, dim3(blocks), dim3(kThreads), 0, c.compute, in, count, (double*)d_part);
+    hipLaunchKernelGGL(moments_kernel, dim3(blocks), dim3(kThreads), 0, c.compute, in, count, pivot,
+                       pivot_is_first_sample ? 1 : 0, (double*)d_part);
     TOPO_HIP(hipGetLastError());
     std::vector<double> h((size_t)blocks * 2);
-    float pivot = 0.0f;
     TOPO_HIP(hipMemcpyAsync(h.data(), d_part, h.size() * sizeof(double), hipMemcpyDeviceToHost, c.compute));
-    TOPO_HIP(hipMemcpyAsync(&pivot, in, sizeof(float), hipMemcpyDeviceToHost, c.compute));
     TOPO_HIP(hipStreamSynchronize(c.compute));
     double a = 0.0, b = 0.0;
     for (int i = 0; i < blocks; ++i) {
         a += h[2 * i];
         b += h[2 * i + 1];
     }
+    *sum = a;
+    *sumsq = b;
+    return TOPO_AMD_OK;
+}
+
+int launch_mean_std(const float* in, size_t count, double* mean, double* stdev) {
+    Context& c = ctx();
+    float pivot = 0.0f;
+    TOPO_HIP(hipMemcpyAsync(&pivot, in, sizeof(float), hipMemcpyDeviceToHost, c.compute));
+    double a = 0.0, b = 0.0;
+    TOPO_TRY(launch_moments(in, count, 0.0, true, &a, &b));
     const double n = (double)count;
     const double m = a / n;
     double var = b / n - m * m;

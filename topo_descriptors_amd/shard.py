@@ -159,6 +159,19 @@ class ShardedDEM:
                                                       float(sigma), float(sig_ratio), mode,
                                                       _lib.ptr(rx), _lib.ptr(ry), *outs), "shard_gradient")
 
+    def valley_ridge(self, taps, ksize, angles, n_planes, norm, direction):
+        """Collective.  The plan's halo must be ``halo_rows(DESC_VALLEY_RIDGE, ksize.max())``; the mean
+        and standard deviation of the whole DEM are formed inside (one all-reduce)."""
+        from . import _lib
+        p = self.plan
+        taps = np.ascontiguousarray(taps, dtype=np.float32)
+        ksize = np.ascontiguousarray(ksize, dtype=np.int32)
+        angles = np.ascontiguousarray(angles, dtype=np.float32)
+        _lib.check(_lib.lib().topo_amd_shard_valley_ridge(
+            self.block.ptr, p.rows_local, p.row0, p.gny, p.nx, taps.ctypes.data_as(_lib._vp),
+            ksize.ctypes.data_as(_lib._i32p), angles.ctypes.data_as(_lib._vp), ksize.size, int(n_planes),
+            norm.ptr, direction.ptr), "shard_valley_ridge")
+
     def sx(self, dj, di, dist, window, height, out):
         from . import _lib
         p = self.plan
