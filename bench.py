@@ -182,7 +182,8 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
                                                     np.arange(0, 180, dtype=np.float32))
     ms = time_kernel(lambda: blk.valley_ridge(taps, ksize, angles, 3, mean, stdev, o1, o2), 1, d)
     entry("valley_ridge_s7", ms, 12)
-    out["valley_ridge_s7"]["GFMA_per_s"] = round(px * int((ksize.astype(np.int64) ** 2).sum()) * 3 / ms / 1e6, 0)
+    nonzero = int(np.any(taps.reshape(-1, 4)[:, :3] != 0, axis=1).sum())  # the taps the kernel evaluates
+    out["valley_ridge_s7"]["GFMA_per_s_executed"] = round(px * nonzero * 3 / ms / 1e6, 0)
 
     # the same TPI on fractional elevations: every tile runs the integer pass plus the float
     # chain on the fractional parts and goes through the per-row scratch planes (two passes)
