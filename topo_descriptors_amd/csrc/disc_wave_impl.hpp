@@ -173,8 +173,8 @@ __device__ __forceinline__ Vec4<float> load_row4(const WaveArgs& p, int gy, int 
 //   s2 = sum trunc(x)^2 = Su2 + 2 c Su + c^2 m            (the int32 quirk of topo.py:300)
 //   STD = sqrt(max(0, (s2 - s1^2/n) / (n-1))),   TPI = x - (s1 - x_ctr) / (n-1)
 // Su and Su2 are integer sums (int32 / uint32 prefix sums cannot round; the uint32 chain switches
-// to two 16-bit half chains when a tile's |u| would let 3409 u^2 pass 2^32), Sf is a small float
-// sum that exists only on fractional DEMs.  Tiles holding non-finite or absurd samples (|u| so
+// to two 16-bit half chains when a tile's |u| would let 3409 u^2 pass 2^32), Sf is the sum of the
+// fractional parts in integer units of 2^-16 m (exact as well) and exists only on fractional DEMs.  Tiles holding non-finite or absurd samples (|u| so
 // large that one 67-row column sum of u^2 passes 2^32, e.g. -9999 nodata next to real terrain)
 // run float chains on a = x - c and (trunc(x) - c)^2 instead, so NaN propagates and nothing wraps.
 enum Stage { kStU = 0, kStU2 = 1, kStF = 2, kStA = 3, kStT2 = 4 };
@@ -205,7 +205,11 @@ template <int WHAT>
 __device__ __forceinline__ uint32_t stage_value(float x, float c, int ci) {
     if (WHAT == kStA) return __float_as_uint(x - c);
     const float t = truncf(x);
-    if (WHAT == kStF) return __float_as_uint(x - t);
+    // the fractional part in units of 2^-16 m, as an integer: |x - t| < 1, so 3409 of them stay far
+    // inside int32, the sums are exact (hence the same for every row block and every kernel that
+    // forms them, and a running prefix may be carried from tile to tile), and the quantisation,
+    // at most 7.6e-6 m per sample, is two orders below the reference's own float32-FFT floor
+    if (WHAT == kStF) return (uint32_t)(int)rintf((x - t) * 65536.0f);
     if (WHAT == kStT2) {
         const float u = t - c;
         return __float_as_uint(u * u);
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
                     const unsigned short* pl = PL + jj * (SIZE + 1) - G::T.off_min;
                     m = d_hi >= d_lo ? (double)((int)pl[d_hi + 1] - (int)pl[d_lo]) : 0.0;
                 }
-                const double sf = (double)__uint_as_float(q3.v[t]);
+                const double sf = (double)(int)q3.v[t] * (1.0 / 65536.0);  // exact in float64
                 double su, su2;  // sums of u and u^2 over the in-domain taps
                 if (!use_float) {
                     su = (double)(int)q0.v[t];
@@ -522,14 +526,12 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
         }
         if (frac) {
             __syncthreads();
-            stage_prefix<SIZE, TH, NWAVES, kStF, float>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
+            stage_prefix<SIZE, TH, NWAVES, kStF, uint32_t>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
 #pragma unroll 1
             for (int k = 0; k < RW; ++k) {
-                float acc[NC];
-                wave_disc_sum<SIZE, float>(reinterpret_cast<const float*>(lds_u), wave + k * NWAVES, lane, acc);
-                const uint32_t bits[NC] = {__float_as_uint(acc[0]), __float_as_uint(acc[1]),
-                                           __float_as_uint(acc[2]), __float_as_uint(acc[3])};
-                put(3, wave + k * NWAVES, bits);
+                uint32_t acc[NC];  // sum of the fractional parts in units of 2^-16 m, modulo 2^32 (fits int32)
+                wave_disc_sum<SIZE, uint32_t>(lds_u, wave + k * NWAVES, lane, acc);
+                put(3, wave + k * NWAVES, acc);
             }
         }
 
