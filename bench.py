@@ -299,9 +299,10 @@ def main():
                 "traffic": measured_traffic(ny, nx, size, world),
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
                 "algorithmic_bytes_per_launch": px_launch * BYTES_PER_PIXEL["tpi"],
-                "kernel": "tpi_march_kernel<67, 60, 12, true, false> (exact one-pass TPI on whole-metre tiles, marching down "
+                "kernel": "tpi_march_kernel<67, 60, 12, true, true, true> (exact one-pass TPI on whole-metre tiles, marching down "
                           "column strips), per-rank launch; kernel_ms also covers the general kernel launched after "
-                          "it over the tiles it deferred (none on this DEM, ~10 us)",
+                          "it over the tiles it deferred and the fraction pass for tiles with fractional elevations "
+                          "(neither finds a tile on this DEM, ~10 us together)",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL["tpi"],
             },

@@ -321,7 +321,7 @@ def test_very_large_discs(size):
     assert np.array_equal(parts[0], whole[0]) and np.array_equal(parts[1], whole[1])
 
 
-@pytest.mark.parametrize("layout", ["fractional_first", "fractional_band"])
+@pytest.mark.parametrize("layout", ["fractional_first", "fractional_band", "fractional_rows"])
 def test_tpi_fast_and_deferred_tiles_on_a_mixed_dem(layout):
     """TPI alone runs as a fast build plus a deferred pass over the tiles that need the fractional /
     float paths (csrc/disc_wave_impl.hpp).  4096 x 4096 gives ~1500 tiles at 67 px, 5-6 per
@@ -329,14 +329,21 @@ def test_tpi_fast_and_deferred_tiles_on_a_mixed_dem(layout):
     integer tiles behind them go to the general build unstaged) or go back to the fast path after a
     deferred stretch (fractional_band).  Which build takes a tile must not show: exact-oracle
     agreement on windows across the region edges, and bit-identity with the same DEM computed in
-    three row blocks (another tile list, so another tile -> build assignment)."""
+    three row blocks (another tile list, so another tile -> build assignment).
+    fractional_rows: a fractional band of rows; just below it, and at the bottom of the DEM in the
+    other layouts, a marched tile adds only whole-metre (or out-of-DEM) rows to a window whose
+    carried rows are fractional - the classification has to remember them."""
     n, size, r = 4096, 67, 33
     dev = d.synth_dem(n, n, seed=11)
     dem = dev.to_host()
     dev.free()
     c0, c1 = (0, 2800) if layout == "fractional_first" else (1000, 2500)
-    dem[:, c0:c1] += np.float32(0.37)
-    assert np.any(dem[:, c0:c1] != np.trunc(dem[:, c0:c1])) and np.all(dem[:, c1:] == np.trunc(dem[:, c1:]))
+    if layout == "fractional_rows":
+        dem[c0:c1, :] += np.float32(0.37)
+        assert np.any(dem[c0:c1] != np.trunc(dem[c0:c1])) and np.all(dem[c1:] == np.trunc(dem[c1:]))
+    else:
+        dem[:, c0:c1] += np.float32(0.37)
+        assert np.any(dem[:, c0:c1] != np.trunc(dem[:, c0:c1])) and np.all(dem[:, c1:] == np.trunc(dem[:, c1:]))
     up, down = halo(_lib.DESC_TPI, size)
 
     def call(blk, row0, rows):
@@ -351,6 +358,8 @@ def test_tpi_fast_and_deferred_tiles_on_a_mixed_dem(layout):
     w = 192
     corners = [(0, max(c0 - w // 2, 0)), (1500, c1 - w // 2), (n - w, c1 - w // 2), (2000, c1 + 600),
                (700, (c0 + c1) // 2), (n - w, n - w)]
+    if layout == "fractional_rows":  # the band's upper and lower edges, and the DEM's bottom edge
+        corners = [(c0 - w // 2, 300), (c1 - w // 2, 1900), (c1 - 20, 3500), (c1 + 30, 100), (n - w, 2000), (n - w, 0)]
     for (j, i) in corners:
         i = min(max(i, 0), n - w)
         j0, j1, i0, i1 = max(0, j - r), min(n, j + w + r), max(0, i - r), min(n, i + w + r)

@@ -44,7 +44,9 @@ int main(int argc, char** argv) {
         if (variant == 8) return topo::launch_wave<67, 64, 8, true, false>(b, (float*)out, nullptr);
         if (variant == 12) return topo::launch_wave<67, 60, 12, true, false>(b, (float*)out, nullptr);
         // variant 0: what the product launches - marching build, then the general build over the deferred tiles
-        int rc = topo::launch_march<67, 60, 12, true, false>(b, (float*)out);
+        int rc = topo::launch_march<67, 60, 12, true, true, true>(b, (float*)out);
+        if (rc != TOPO_AMD_OK) return rc;
+        rc = topo::launch_fraction_march<67, 60, 12>(b, (float*)out);
         if (rc != TOPO_AMD_OK) return rc;
         return topo::launch_wave<67, 60, 12, true, false>(b, (float*)out, nullptr, true);
     };

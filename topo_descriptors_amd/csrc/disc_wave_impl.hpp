@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
         bool marked = false;
         if (take) {
             if (p.map_th == 0) {
-                marked = p.defer[mine] != 0;
+                marked = p.defer[mine] == 1;  // kTileGeneral (2 = waiting for tpi_fraction_march_kernel)
             } else {
                 // the map belongs to the marching kernels' geometry (same strips, rows of map_th): this
                 // tile is taken when a map tile that shares output rows with it is marked.  Rows of
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
                 const int r1 = min((p.out_row0 / TH + ty) * TH + TH, p.out_row0 + p.out_rows) - 1;
                 const int base = p.out_row0 / p.map_th;
                 for (int my = r0 / p.map_th; my <= r1 / p.map_th; ++my)
-                    marked = marked || p.defer[tx * p.map_tiles_y + (my - base)] != 0;
+                    marked = marked || p.defer[tx * p.map_tiles_y + (my - base)] == 1;
             }
         }
         take = marked;
@@ -571,7 +571,9 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
 // or absurd sample is marked in p.defer and left to the general kernel (launched right after with
 // only_deferred); the carried window is dropped and the next tile staged in full.  After kGiveUp
 // such tiles in a row the block marks the rest of its run without staging it.
-template <int SIZE, int TH, int NWAVES>
+// FRACTION: stage the fractional parts (integers in units of 2^-16 m, stage_value<kStF>) instead of
+// trunc(x), without classifying: the window was classified when its trunc(x) sums were formed.
+template <int SIZE, int TH, int NWAVES, bool FRACTION = false>
 __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* flag_word, int gy0, int gx) {
     constexpr int NROWS = TH + SIZE - 1;
     constexpr int KEEP = NROWS + 1 - TH;  // prefix rows carried over: those of window rows TH-1 .. NROWS-1
@@ -613,20 +615,26 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
 #pragma unroll
         for (int s = 0; s < NC; ++s) {
             const float x = v[k].v[s];
-            const float t = truncf(x);
-            frac |= ok && (x != t);
-            amax = max(amax, ok ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
-            run.v[s] += ok ? (uint32_t)(int)t : 0u;
+            if (FRACTION) {
+                run.v[s] += ok ? stage_value<kStF>(x, 0.0f, 0) : 0u;
+            } else {
+                const float t = truncf(x);
+                frac |= ok && (x != t);
+                amax = max(amax, ok ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
+                run.v[s] += ok ? (uint32_t)(int)t : 0u;
+            }
         }
         *reinterpret_cast<Vec4<uint32_t>*>(Q + (r0 + k + 1) * ROWW + lane * NC) = run;
     }
     *reinterpret_cast<Vec4<uint32_t>*>(TOT + wave * ROWW + lane * NC) = run;
-    int wf = 0;
-    if (__builtin_amdgcn_ballot_w64(frac)) wf |= kTileFrac;
-    if (__builtin_amdgcn_ballot_w64(amax > __float_as_uint(kAbsLim))) wf |= kTileFloat;
-    if (lane == 0 && wf) atomicOr(flag_word, wf);
+    if (!FRACTION) {
+        int wf = 0;
+        if (__builtin_amdgcn_ballot_w64(frac)) wf |= kTileFrac;
+        if (__builtin_amdgcn_ballot_w64(amax > __float_as_uint(kAbsLim))) wf |= kTileFloat;
+        if (lane == 0 && wf) atomicOr(flag_word, wf);
+    }
     __syncthreads();
-    const int all = *flag_word;
+    const int all = FRACTION ? 0 : *flag_word;
     // every wave adds the carried prefix (row KEEP-1) and the totals of the waves above it
     Vec4<uint32_t> off = *reinterpret_cast<const Vec4<uint32_t>*>(Q + (KEEP - 1) * ROWW + lane * NC);
     for (int w = 0; w < wave; ++w) {
@@ -647,8 +655,13 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
 }
 
 // OUT_TPI: write TPI.  OUT_SUM: write the exact disc sums of trunc(x) to p.sums, for the STD kernel
-// that follows (std_march_kernel).
-template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM>
+// that follows (std_march_kernel).  ALLOW_FRAC (TPI alone): a tile with fractional samples is not
+// left to the general kernel; its sums of trunc(x), which are exact whatever the fractional parts
+// are, go to p.sums instead of TPI, and the tile is marked kNeedsFraction for
+// tpi_fraction_march_kernel, which adds the sum of the fractional parts and finalises.
+enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2 };
+
+template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
 __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int tiles_x, int tiles_y) {
     using G = Geo<SIZE>;
     static_assert(OUT_TPI || OUT_SUM, "nothing to write");
@@ -675,7 +688,16 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
     const int last = min(first + per, ntiles);
     const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
 
-    bool carry = false;  // the LDS image holds the window of the tile right above, all integer
+    bool carry = false;  // the LDS image holds the window of the tile right above
+    // ALLOW_FRAC keeps the carry across tiles with fractional samples, and a marched staging pass
+    // classifies only the TH rows it adds.  The SIZE - 1 carried rows are the new rows of the last
+    // kHist tiles, so "fractional" is kept as a history of those tiles' flags: bit 0 the current
+    // tile's new rows, bit k those of the k-th tile above.  (Marking a window fractional that no
+    // longer holds a fractional sample only costs time: its fractional sum is exactly 0 and the
+    // result has the same bits.)  Without this, e.g. the last tile of a strip, whose new rows lie
+    // below the DEM, would drop the fractional parts of the rows it carries.
+    constexpr int kHist = (SIZE - 1 + TH - 1) / TH;
+    unsigned frac_hist = 0;
     int deferred_in_a_row = 0;
 #pragma unroll 1
     for (int tile = first; tile < last; ++tile) {
@@ -696,9 +718,15 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
             __syncthreads();  // the image and the flag word of the previous tile are done with
             flags = stage_prefix<SIZE, TH, NWAVES, kStU, int, true>(p, lds_u, flag_word, gy0, gx, 0.0f, 0, 0.0f, 0.0f);
         }
-        const bool leave = (flags & (kTileFloat | kTileFrac)) != 0;
+        const bool leave = (flags & (ALLOW_FRAC ? kTileFloat : (kTileFloat | kTileFrac))) != 0;
+        if (ALLOW_FRAC) {
+            const unsigned now = (flags & kTileFrac) ? 1u : 0u;
+            // a full staging pass classified the whole window: it stands for every row carried on
+            frac_hist = carry ? (((frac_hist << 1) | now) & ((2u << kHist) - 1u)) : (now ? (2u << kHist) - 1u : 0u);
+        }
+        const bool fraction = ALLOW_FRAC && !leave && frac_hist != 0;  // sums only, TPI later
         if (threadIdx.x == 0) {
-            p.defer[tile] = leave ? 1 : 0;
+            p.defer[tile] = leave ? kTileGeneral : (fraction ? kNeedsFraction : kTileDone);
             *flag_word = 0;  // every thread has read it; the next atomicOr is behind a barrier
         }
         if (leave) {
@@ -711,33 +739,43 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
 
         const int ocol = ox0 + lane * NC;
         const bool lane_ok = lane < G::NVL && ocol < p.nx;
+        // one copy of the row loop per kind of tile (the choice is the same for the whole block), so
+        // that the whole-metre copy is exactly the loop of the kernel without ALLOW_FRAC
+        auto rows = [&](auto fraction_tag) {
+            constexpr bool SUMS_ONLY = decltype(fraction_tag)::value;  // fractional tile: sums now, TPI later
 #pragma unroll 1
-        for (int k = 0; k < RW; ++k) {
-            const int jj = wave + k * NWAVES;
-            uint32_t acc[NC];  // sum of trunc(x) over the disc modulo 2^32; the true value fits int32
-            wave_disc_sum<SIZE, uint32_t>(Q, jj, lane, acc);
-            const int oy = oy0 + jj;
-            if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
-            const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
-            if (OUT_SUM) {
-                const Vec4<int> sv{{(int)acc[0], (int)acc[1], (int)acc[2], (int)acc[3]}};
-                *reinterpret_cast<Vec4<int>*>(p.sums + o) = sv;
-            }
-            if (OUT_TPI) {
-                // the pixel's own (integer) value: prefix through its row minus prefix above it
-                const uint32_t* own = Q + (jj - G::T.off_min) * ROWW + lane * NC + G::X0;
-                const Vec4<uint32_t> hi = *reinterpret_cast<const Vec4<uint32_t>*>(own + ROWW);
-                const Vec4<uint32_t> lo = *reinterpret_cast<const Vec4<uint32_t>*>(own);
-                Vec4<float> out_t;
-#pragma unroll
-                for (int t = 0; t < NC; ++t) {
-                    const float x = (float)(int)(hi.v[t] - lo.v[t]);
-                    const double s1 = (double)(int)acc[t];  // sum of x over the in-domain taps, exact
-                    const double x_ctr = (double)x;
-                    out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+            for (int k = 0; k < RW; ++k) {
+                const int jj = wave + k * NWAVES;
+                uint32_t acc[NC];  // sum of trunc(x) over the disc modulo 2^32; the true value fits int32
+                wave_disc_sum<SIZE, uint32_t>(Q, jj, lane, acc);
+                const int oy = oy0 + jj;
+                if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
+                const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+                if (OUT_SUM && (!ALLOW_FRAC || SUMS_ONLY)) {
+                    const Vec4<int> sv{{(int)acc[0], (int)acc[1], (int)acc[2], (int)acc[3]}};
+                    *reinterpret_cast<Vec4<int>*>(p.sums + o) = sv;
                 }
-                *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+                if (OUT_TPI && !SUMS_ONLY) {
+                    // the pixel's own (integer) value: prefix through its row minus prefix above it
+                    const uint32_t* own = Q + (jj - G::T.off_min) * ROWW + lane * NC + G::X0;
+                    const Vec4<uint32_t> hi = *reinterpret_cast<const Vec4<uint32_t>*>(own + ROWW);
+                    const Vec4<uint32_t> lo = *reinterpret_cast<const Vec4<uint32_t>*>(own);
+                    Vec4<float> out_t;
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) {
+                        const float x = (float)(int)(hi.v[t] - lo.v[t]);
+                        const double s1 = (double)(int)acc[t];  // sum of x over the in-domain taps, exact
+                        const double x_ctr = (double)x;
+                        out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+                    }
+                    *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+                }
             }
+        };
+        if (ALLOW_FRAC && fraction) {
+            rows(std::true_type{});
+        } else {
+            rows(std::false_type{});
         }
     }
 }
@@ -750,7 +788,7 @@ inline long march_grid(Context& c, int blocks_per_cu, long ntiles) {
     return grid > ntiles ? ntiles : grid;
 }
 
-template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM>
+template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
 int launch_march(const Block& b, float* tpi_out) {
     using G = Geo<SIZE>;
     Context& c = ctx();
@@ -760,11 +798,11 @@ int launch_march(const Block& b, float* tpi_out) {
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM>,
+        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nblk = 0;
         TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nblk, (const void*)tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM>, NWAVES * 64, lds));
+            &nblk, (const void*)tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>, NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
     const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
@@ -779,8 +817,138 @@ int launch_march(const Block& b, float* tpi_out) {
         TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
         a.sums = (int32_t*)sums;
     }
-    hipLaunchKernelGGL((tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM>), dim3((unsigned)grid), dim3(NWAVES * 64),
+    hipLaunchKernelGGL((tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>), dim3((unsigned)grid), dim3(NWAVES * 64),
                        lds, c.compute, a, tiles_x, tiles_y);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+// ---- TPI on tiles with fractional elevations: the fraction pass ---------------------------------
+// For the tiles tpi_march_kernel<.., ALLOW_FRAC> marked kNeedsFraction, p.sums holds the exact sum of
+// trunc(x) over the disc.  This kernel marches the prefix sums of the fractional parts (integers in
+// units of 2^-16 m) down the same runs and finalises
+//   TPI = x - ((sum trunc(x) + 2^-16 sum g) - x) / (n - 1)
+// in float64, which is the expression and the operands of the general kernel's fractional path
+// (s1 = (su + c m) + sf with su + c m = sum trunc(x) exactly), so both give the same bits.  A
+// window is carried only from a tile this kernel processed itself; otherwise it is staged in full.
+// Each row's sum of trunc(x) arrives by an LDS-DMA load into the wave's idle slot of the segment
+// totals, in flight during the chain; the pixel's own x is an ordinary load issued before the chain.
+template <int SIZE, int TH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+    using G = Geo<SIZE>;
+    static_assert(G::T.centre == 0, "odd disc sizes only: the zeroed tap is the pixel itself");
+    static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
+    constexpr int NROWS = TH + SIZE - 1;
+    constexpr int RW = TH / NWAVES;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    uint32_t* Q = lds_u;
+    uint32_t* TOT = Q + (NROWS + 1) * ROWW;
+    int* flag_word = reinterpret_cast<int*>(Q + (NROWS + 1 + NWAVES) * ROWW);
+    if (threadIdx.x == 0) *flag_word = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = tiles_x * tiles_y;
+    const int nb = gridDim.x;
+    const int per_xcd = nb >> 3;
+    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int per = (ntiles + nb - 1) / nb;  // the same runs as tpi_march_kernel
+    const int first = vb * per;
+    const int last = min(first + per, ntiles);
+    const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
+
+    // Nothing to do on a DEM of whole metres: find that out with one flag per lane (64 tiles per
+    // load) instead of walking the run with a dependent byte load per tile.
+    bool any = false;
+    for (int base = first; base < last; base += 64) {
+        const int mine = base + lane;
+        any = any || __builtin_amdgcn_ballot_w64(mine < last && p.defer[mine < last ? mine : first] == kNeedsFraction) != 0;
+    }
+    if (!any) return;  // the same for every thread of the block
+
+    bool carry = false;
+#pragma unroll 1
+    for (int tile = first; tile < last; ++tile) {
+        if (p.defer[tile] != kNeedsFraction) {
+            carry = false;
+            continue;
+        }
+        const int ty = tile % tiles_y;
+        const int ox0 = (tile / tiles_y) * G::TILE_W;
+        const int oy0 = (p.out_row0 / TH + ty) * TH;
+        const int gx = ox0 - G::X0 + lane * NC;
+        const int gy0 = oy0 + G::T.off_min;
+        if (ty == 0) carry = false;
+        if (carry) {
+            (void)stage_march<SIZE, TH, NWAVES, true>(p, Q, flag_word, gy0, gx);
+        } else {
+            __syncthreads();  // the previous tile's image is done with
+            (void)stage_prefix<SIZE, TH, NWAVES, kStF, uint32_t>(p, lds_u, flag_word, gy0, gx, 0.0f, 0, 0.0f, 0.0f);
+        }
+        if (threadIdx.x == 0) p.defer[tile] = kTileDone;
+        carry = true;
+
+#pragma unroll 1
+        for (int k = 0; k < RW; ++k) {
+            const int jj = wave + k * NWAVES;
+            const int oy = oy0 + jj;
+            const int ocol = ox0 + lane * NC;
+            const bool live = lane < G::NVL && ocol < p.nx && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows;
+            const size_t o = live ? (size_t)(oy - p.out_row0) * p.nx + ocol : 0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.sums + o),
+                                             (__attribute__((address_space(3))) void*)(TOT + wave * ROWW + lane * NC), 16,
+                                             0, 0);
+            const size_t xi = live ? (size_t)(oy - p.in_row0) * p.nx + ocol : 0;
+            const Vec4<float> xs = *reinterpret_cast<const Vec4<float>*>(p.in + xi);
+            uint32_t acc[NC];  // sum of the fractional parts in units of 2^-16 m (fits int32)
+            wave_disc_sum<SIZE, uint32_t>(Q, jj, lane, acc);
+            int lcol = lane * NC;
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(lcol) : : "memory");  // the DMA has landed
+            const Vec4<int> sv = *reinterpret_cast<const Vec4<int>*>(TOT + wave * ROWW + lcol);
+            if (!live) continue;
+            Vec4<float> out_t;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const double sf = (double)(int)acc[t] * (1.0 / 65536.0);
+                const double s1 = (double)sv.v[t] + sf;
+                const double x_ctr = (double)xs.v[t];
+                out_t.v[t] = (float)((double)xs.v[t] - (s1 - x_ctr) * inv_nm1);
+            }
+            *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+        }
+    }
+}
+
+template <int SIZE, int TH, int NWAVES>
+int launch_fraction_march(const Block& b, float* tpi_out) {
+    using G = Geo<SIZE>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0};
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16;
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_fraction_march_kernel<SIZE, TH, NWAVES>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nblk, (const void*)tpi_fraction_march_kernel<SIZE, TH, NWAVES>, NWAVES * 64, lds));
+        blocks_per_cu = nblk < 1 ? 1 : nblk;
+    }
+    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
+    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
+    const long ntiles = (long)tiles_x * tiles_y;
+    const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
+    void* defer = nullptr;
+    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
+    a.defer = (uint8_t*)defer;
+    void* sums = nullptr;
+    TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
+    a.sums = (int32_t*)sums;
+    hipLaunchKernelGGL((tpi_fraction_march_kernel<SIZE, TH, NWAVES>), dim3((unsigned)grid), dim3(NWAVES * 64), lds,
+                       c.compute, a, tiles_x, tiles_y);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
@@ -1159,6 +1327,12 @@ inline int tpi_march_min_size() {
     static const int v = env_int("TOPO_AMD_TPI_MARCH_MIN", 1);
     return v;
 }
+// Disc size from which TPI on tiles with fractional elevations takes the two marching passes
+// (sum of trunc(x), then sum of the fractional parts) instead of the general kernel.
+inline int tpi_fraction_min_size() {
+    static const int v = env_int("TOPO_AMD_TPI_FRACTION_MIN", 17);
+    return v;
+}
 
 template <int SIZE>
 int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
@@ -1185,7 +1359,16 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
         return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out, true, TH12);
     }
     if (SIZE < tpi_march_min_size()) return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out);
-    TOPO_TRY((launch_march<SIZE, TH12, 12, true, false>(b, tpi_out)));
+    // TPI alone: whole-metre tiles are finished by the first marching kernel; tiles with fractional
+    // elevations get their exact sum of trunc(x) there and the sum of the fractional parts in the
+    // second; the general kernel takes what neither could (non-finite or absurd samples)
+    if (SIZE < tpi_fraction_min_size()) {
+        // small discs: the general kernel's two passes over one tile beat two marching kernels
+        TOPO_TRY((launch_march<SIZE, TH12, 12, true, false, false>(b, tpi_out)));
+        return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true);
+    }
+    TOPO_TRY((launch_march<SIZE, TH12, 12, true, true, true>(b, tpi_out)));
+    TOPO_TRY((launch_fraction_march<SIZE, TH12, 12>(b, tpi_out)));
     return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true);
 }
 
