@@ -750,7 +750,7 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
             for (int k = 0; k < RW; ++k) {
                 const int jj = wave + k * NWAVES;
                 uint32_t acc[NC];  // sum of trunc(x) over the disc modulo 2^32; the true value fits int32
-                wave_disc_sum<SIZE, uint32_t>(Q, jj, lane, acc);
+                wave_disc_sum<SIZE, uint32_t, 0, (SIZE >= 41)>(Q, jj, lane, acc);
                 const int oy = oy0 + jj;
                 if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
                 const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveArg
             const size_t xi = live ? (size_t)(oy - p.in_row0) * p.nx + ocol : 0;
             const Vec4<float> xs = *reinterpret_cast<const Vec4<float>*>(p.in + xi);
             uint32_t acc[NC];  // sum of the fractional parts in units of 2^-16 m (fits int32)
-            wave_disc_sum<SIZE, uint32_t>(Q, jj, lane, acc);
+            wave_disc_sum<SIZE, uint32_t, 0, (SIZE >= 41)>(Q, jj, lane, acc);
             int lcol = lane * NC;
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(lcol) : : "memory");  // the DMA has landed
             const Vec4<int> sv = *reinterpret_cast<const Vec4<int>*>(TOT + wave * ROWW + lcol);
