@@ -303,7 +303,9 @@ def valley_kernels(size, flat_list):
     order of operations is kept here because it decides the float32 bits."""
     size = int(size)
     middle = size // 2
-    profile = np.abs(np.arange(-middle, middle + 1)).astype(np.float32)  # odd sizes only, like the reference
+    if 2 * middle + 1 != size:  # the reference's broadcast_to fails the same way (topo.py:477-482)
+        raise ValueError(f"operands could not be broadcast together: ({2 * middle + 1},{size}) -> ({size},{size})")
+    profile = np.abs(np.arange(-middle, middle + 1)).astype(np.float32)
     plane = np.repeat(profile[:, None], size, axis=1)
     kernels = np.repeat(plane[None, :, :], len(flat_list), axis=0).copy()
     for ind, flat in enumerate(flat_list):

@@ -164,3 +164,29 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(root, f)).read()
                 assert "oracle" not in text.lower() or f == "__init__.py" and False, os.path.join(root, f)
+
+
+def test_valley_kernels_match_the_reference_kernels_and_errors(golden):
+    """Host-side kernel construction of topo.valley_ridge (no GPU needed): bit for bit the
+    reference's kernels (golden fixture), the table layout of the C ABI, ValueError for even sizes
+    (the reference's broadcast fails, topo.py:477-482) and for an unknown mode (topo.py:421-422)."""
+    g = golden("valley_ridge")
+    for size, flats in ((5, [0, 0.15, 0.3]), (7, [0, 0.15, 0.3]), (9, [0.2, 0.4]), (17, [0, 0.15, 0.3])):
+        base = topo._valley_kernels(size, flats)
+        want = g[f"kernels_s{size}_n{len(flats)}"]
+        assert base.dtype == want.dtype and np.array_equal(base, want)
+        assert np.array_equal(topo._ridge_kernels(size, flats), -want)
+        for angle in (0, 1, 33, 45, 90, 137, 179):
+            rot = topo._rotate_kernels(base, np.float32(angle))
+            w = g[f"kernels_s{size}_n{len(flats)}_rot{angle}"]
+            assert rot.shape == w.shape and np.max(np.abs(rot - w)) <= 1e-6
+    taps, ksize, angles = topo._valley_ridge_tables(topo._valley_kernels(7, [0, 0.15, 0.3]),
+                                                    np.arange(0, 180, dtype=np.float32))
+    assert taps.dtype == np.float32 and ksize.dtype == np.int32 and len(ksize) == 180 and len(angles) == 180
+    assert taps.size == 4 * int((ksize.astype(np.int64) ** 2).sum())
+    assert np.all(taps.reshape(-1, 4)[:, 3] == 0)  # three planes: the fourth component stays empty
+    for size in (4, 6, 8):
+        with pytest.raises(ValueError):
+            topo._valley_kernels(size, [0, 0.15, 0.3])
+    with pytest.raises(ValueError):
+        topo.valley_ridge(np.zeros((8, 8), np.float32), 5, "canyon")

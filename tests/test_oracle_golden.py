@@ -311,3 +311,10 @@ def test_valley_ridge_golden(golden, tag):
 def test_valley_ridge_unknown_mode():
     with pytest.raises(ValueError):
         orc.valley_ridge_scipy(np.zeros((8, 8), np.float32), 5, "canyon")
+
+
+def test_valley_kernels_even_size_fails_like_the_reference():
+    # reference topo.py:477-482: a (size + 1, size) profile cannot be broadcast to (size, size)
+    for size in (4, 6, 8):
+        with pytest.raises(ValueError):
+            orc.valley_kernels(size, [0, 0.15, 0.3])

@@ -262,6 +262,11 @@ def _valley_kernels(size, flat_list):
     flattened on normalised values (this order decides the float32 result).  Odd sizes only."""
     size = int(size)
     middle = size // 2
+    if 2 * middle + 1 != size:
+        # the reference fails here too: its profile has 2 * (size // 2) + 1 rows and cannot be
+        # broadcast to (size, size) (topo.py:477-482); scale_to_pixel only ever yields odd sizes
+        raise ValueError(f"valley / ridge kernels need an odd size, got {size}: operands could not be broadcast "
+                         f"together with remapped shapes ({2 * middle + 1},{size}) -> ({size},{size})")
     rows = np.abs(np.arange(-middle, middle + 1)).astype(np.float32)
     kernels = np.tile(rows[None, :, None], (len(flat_list), 1, size))
     for ind, flat in enumerate(flat_list):
