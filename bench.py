@@ -174,6 +174,12 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
         window, dj, di, dist = d.sx_offsets(0.0, radius, 30.0, -30.0)
         fn = lambda: blk.sx(dj, di, dist, window, 10.0, o1)  # noqa: E731
         entry(f"sx_az0_r{int(radius)}", time_kernel(fn, 3, d), 8)
+    # 8 azimuths every 5 degrees in one pass: ms and rate are per azimuth plane
+    sectors = [d.sx_offsets(5.0 * k, 500.0, 30.0, -30.0) for k in range(8)]
+    fan = [o1, o2, o3, o4] + [d.DeviceArray(ny, nx) for _ in range(4)]
+    entry("sx_r500_8_azimuths_step5_per_azimuth", time_kernel(lambda: blk.sx_multi(sectors, 10.0, fan), 3, d) / 8, 8)
+    for a in fan[4:]:
+        a.free()
     # valley index at 200 m (7 px): 180 angles x 3 plane sums of rotated kernels in one pass
     # (first version, direct float32 evaluation)
     from topo_descriptors_amd import topo

@@ -132,6 +132,19 @@ int topo_amd_sx_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
                     const int32_t* dj, const int32_t* di, const double* dist, int n_off,
                     int window, double height, int out_row0, int out_rows, float* out);
 
+/* Sx for n_az azimuth sectors in one pass over the DEM (the reference scans one
+ * azimuth per call, topo.py:715-772 / :856, and its users loop).  Sector a owns entries
+ * first[a] .. first[a+1]-1 of dj / di / dist (first: host int32, n_az + 1 entries), has the zero
+ * frame window[a] and writes the device plane outs[a] (outs: host array of device pointers).
+ * Neighbouring sectors overlap: ray pixels shared by several sectors are scanned once.  Every
+ * plane has exactly the bits topo_amd_sx_dev gives for that sector alone.  A sector without a
+ * usable ray pixel is treated as by topo_amd_sx_dev (plane zero-filled, TOPO_AMD_EINVAL), but
+ * only after the other sectors are done.                                                     */
+int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int n_az,
+                          const int32_t* first, const int32_t* dj, const int32_t* di,
+                          const double* dist, const int32_t* window, double height,
+                          int out_row0, int out_rows, float* const* outs);
+
 /* Valley / ridge index (replaces the angle loop of topo.valley_ridge, topo.py:431-447).
  * The host builds the kernels exactly as the reference does (V / U profiles topo.py:456-492,
  * quadratic-spline rotation and re-normalisation :515-525) and hands over, for each of
@@ -165,6 +178,10 @@ int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double
                           float* dy_out, float* slope_out, float* aspect_out);
 int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const int32_t* di,
                     const double* dist, int n_off, int window, double height, float* out);
+/* outs: host array of n_az HOST planes [ny x nx].                                          */
+int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int32_t* first,
+                          const int32_t* dj, const int32_t* di, const double* dist,
+                          const int32_t* window, double height, float* const* outs);
 int topo_amd_valley_ridge_f32(const float* dem, int ny, int nx, const float* taps,
                               const int32_t* ksize, const float* angles, int n_angles,
                               int n_planes, double mean, double stdev, float* norm_out,
@@ -201,6 +218,12 @@ int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int
 int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx,
                       const int32_t* dj, const int32_t* di, const double* dist, int n_off,
                       int window, double height, float* out);
+/* halo_above / halo_below: the largest -dj / dj over the usable ray pixels of all sectors;
+ * one ghost-row exchange serves every sector.                                               */
+int topo_amd_shard_sx_multi(float* block, int rows_local, int row0, int gny, int nx, int n_az,
+                            const int32_t* first, const int32_t* dj, const int32_t* di,
+                            const double* dist, const int32_t* window, double height,
+                            float* const* outs);
 /* Sharded valley / ridge index: `block` as above with halo_above / halo_below =
  * topo_amd_halo_rows(VALLEY_RIDGE, largest kernel side).  The mean and standard deviation of
  * the whole DEM come from float64 moments of the owned rows and one ncclAllReduce (the only

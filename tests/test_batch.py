@@ -78,6 +78,10 @@ def test_wrappers_equal_the_single_calls(tmp_path):
 
     out = batch.compute_sx(ds, 0, 300.0, outdir=None)
     assert np.array_equal(out["SX_RADIUS300_AZIMUTH0"], topo.sx(ds, 0, 300.0))
+    fan = batch.compute_sx(ds, [0, 5, 90], 300.0, outdir=None)
+    assert sorted(fan) == ["SX_RADIUS300_AZIMUTH0", "SX_RADIUS300_AZIMUTH5", "SX_RADIUS300_AZIMUTH90"]
+    for az in (0, 5, 90):
+        assert np.array_equal(fan[f"SX_RADIUS300_AZIMUTH{az}"], topo.sx(ds, az, 300.0))
 
     out = batch.compute_valley_ridge(ds, 200, "valley", smth_factors=None, ind_nans=ind_nans, outdir=None)
     assert set(out) == {"valley_NORM_200M", "valley_DIR_200M"}

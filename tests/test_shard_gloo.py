@@ -18,7 +18,7 @@ import torch.multiprocessing as mp  # noqa: E402
 
 from oracle import topo_oracle as orc  # noqa: E402
 from topo_descriptors_amd import _lib  # noqa: E402
-from topo_descriptors_amd.shard import RowShardPlan, halo_rows, split_rows  # noqa: E402
+from topo_descriptors_amd.shard import RowShardPlan, halo_rows, split_rows, sx_multi_halo  # noqa: E402
 
 
 def free_port():
@@ -62,14 +62,19 @@ def evaluate(name, window, x, y_window, params):
     if name == "sx":
         # the oracle zeroes a frame of `w` rows at BOTH ends of whatever it is given; at an open
         # seam that frame must fall on throw-away rows, so pad `w` rows there and crop again
-        w, _, _ = orc.sx_geometry(0.0, params["radius"], 30.0, -30.0)
-        top = 0 if params["at_top"] else w
-        bot = 0 if params["at_bottom"] else w
-        padded = np.pad(window, ((top, bot), (0, 0)))
-        yy = np.concatenate([y_window[0] + 30.0 * np.arange(top, 0, -1), y_window,
-                             y_window[-1] - 30.0 * np.arange(1, bot + 1)])
-        out = orc.sx(padded, x, yy, 0.0, params["radius"]).astype(np.float64)
-        return out[top: top + window.shape[0]]
+        # several azimuths (topo_amd_shard_sx_multi): one block with the union of the ghost rows
+        # serves every sector; the planes are stacked along x here
+        planes = []
+        for az in params.get("azimuths", [0.0]):
+            w, _, _ = orc.sx_geometry(az, params["radius"], 30.0, -30.0)
+            top = 0 if params["at_top"] else w
+            bot = 0 if params["at_bottom"] else w
+            padded = np.pad(window, ((top, bot), (0, 0)))
+            yy = np.concatenate([y_window[0] + 30.0 * np.arange(top, 0, -1), y_window,
+                                 y_window[-1] - 30.0 * np.arange(1, bot + 1)])
+            out = orc.sx(padded, x, yy, az, params["radius"]).astype(np.float64)
+            planes.append(out[top: top + window.shape[0]])
+        return np.concatenate(planes, axis=1)
     if name == "valley":
         # standardised with the statistics of the WHOLE DEM, which the ranks obtained by an all-reduce
         return orc.valley_ridge_exact(window, params["size"], "valley", angles=params["angles"],
@@ -81,6 +86,7 @@ CASES = [("tpi", {"size": 17}, _lib.DESC_TPI), ("tpi", {"size": 6}, _lib.DESC_TP
          ("std", {"size": 7}, _lib.DESC_STD), ("gauss", {"sigma": 2.25}, _lib.DESC_GAUSS),
          ("slope", {"sigma": 2.25}, _lib.DESC_GRADIENT), ("slope", {"sigma": 0.75}, _lib.DESC_GRADIENT),
          ("sx", {"radius": 150.0}, _lib.DESC_SX),
+         ("sx", {"radius": 150.0, "azimuths": [0.0, 5.0, 180.0, 270.0]}, _lib.DESC_SX),
          ("valley", {"size": 7, "angles": np.array([0, 30, 45, 100, 160], dtype=np.float32)},
           _lib.DESC_VALLEY_RIDGE)]
 
@@ -95,8 +101,15 @@ def worker(rank, world, port, gny, nx, fail):
         y = 1200000.0 - 30.0 * np.arange(gny)
         for name, params, desc in CASES:
             if desc == _lib.DESC_SX:
-                window, offs, _ = orc.sx_geometry(0.0, params["radius"], 30.0, -30.0)
-                up, down = halo_rows(desc, max(0, -offs[:, 0].min()), max(0, offs[:, 0].max()))
+                sectors = []
+                for az in params.get("azimuths", [0.0]):
+                    window, offs, dist_m = orc.sx_geometry(az, params["radius"], 30.0, -30.0)
+                    sectors.append((window, offs[:, 0], offs[:, 1], dist_m))
+                up, down = sx_multi_halo(sectors)   # the union of the sectors' reach
+                assert (up, down) == halo_rows(desc, max(max(0, -s[1].min()) for s in sectors),
+                                               max(max(0, s[1].max()) for s in sectors))
+                if "azimuths" in params:
+                    assert up > 0 and down > 0      # north and south rays in one exchange
             elif desc == _lib.DESC_VALLEY_RIDGE:
                 kmax = max(orc.rotate_kernels(orc.valley_kernels(params["size"], [0, 0.15, 0.3]), a).shape[1]
                            for a in params["angles"])

@@ -46,6 +46,8 @@ SIGNATURES = {
                                         _vp, _vp]),
     "topo_amd_sx_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p,
                                   C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _vp]),
+    "topo_amd_sx_multi_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p,
+                                        _f64p, _i32p, C.c_double, C.c_int, C.c_int, C.POINTER(_vp)]),
     "topo_amd_valley_ridge_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _i32p, _vp, C.c_int,
                                             C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _vp, _vp]),
     "topo_amd_mean_std_dev": (C.c_int, [_vp, C.c_size_t, _f64p, _f64p]),
@@ -60,6 +62,10 @@ SIGNATURES = {
                                         _vp, _vp, _vp, _vp, _vp, _vp]),
     "topo_amd_sx_f32": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int, C.c_int,
                                   C.c_double, _vp]),
+    "topo_amd_sx_multi_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _f64p, _i32p,
+                                        C.c_double, C.POINTER(_vp)]),
+    "topo_amd_shard_sx_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p,
+                                          _i32p, _f64p, _i32p, C.c_double, C.POINTER(_vp)]),
     "topo_amd_shard_valley_ridge": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _i32p, _vp, C.c_int,
                                               C.c_int, _vp, _vp]),
     "topo_amd_comm_unique_id": (C.c_int, [C.c_char_p]),

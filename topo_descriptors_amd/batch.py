@@ -195,13 +195,21 @@ def compute_gradient(dem_ds, scales, sig_ratios=1, ind_nans=(), crop=None, outdi
 
 def compute_sx(dem_ds, azimuth, radius, height=10.0, azimuth_arc=10.0, azimuth_steps=15,
                radius_min=0.0, crop=None, outdir="."):
-    """Sx for one azimuth (reference topo.py:715-772)."""
+    """Sx for one azimuth (reference topo.py:715-772).  ``azimuth`` may also be a sequence: the
+    planes of all azimuths then come from one pass over the DEM (``topo.sx_multi``), each saved
+    under the name the reference gives it."""
     hlp.check_dem(dem_ds)
     logger.info("***Starting Sx computation for azimuth %s meters and radius %s***", azimuth, radius)
-    array = topo.sx(dem_ds, azimuth, radius, height=height, azimuth_arc=azimuth_arc,
-                    azimuth_steps=azimuth_steps, radius_min=radius_min)
     results = {}
-    _finish(array, None, dem_ds, _sx_name(radius, azimuth), crop, outdir, "degree", results)
+    if np.ndim(azimuth) == 0:
+        array = topo.sx(dem_ds, azimuth, radius, height=height, azimuth_arc=azimuth_arc,
+                        azimuth_steps=azimuth_steps, radius_min=radius_min)
+        _finish(array, None, dem_ds, _sx_name(radius, azimuth), crop, outdir, "degree", results)
+        return results
+    arrays = topo.sx_multi(dem_ds, azimuth, radius, height=height, azimuth_arc=azimuth_arc,
+                           azimuth_steps=azimuth_steps, radius_min=radius_min)
+    for az, array in zip(azimuth, arrays):
+        _finish(array, None, dem_ds, _sx_name(radius, az), crop, outdir, "degree", results)
     return results
 
 

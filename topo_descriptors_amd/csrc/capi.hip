@@ -452,6 +452,32 @@ int topo_amd_sx_dev(const float* in, int in_rows, int in_row0, int gny, int nx, 
     return launch_sx(b, dj, di, dist, n_off, window, height, out);
 }
 
+namespace {
+// rows above / below an output row that the ray pixels of all sectors reach
+void sx_multi_reach(int n_az, const int32_t* first, const int32_t* dj, const double* dist, int* up, int* down) {
+    *up = *down = 0;
+    for (int n = first[0]; n < first[n_az]; ++n) {
+        if (std::isnan(dist[n])) continue;
+        *up = std::max(*up, -dj[n]);
+        *down = std::max(*down, dj[n]);
+    }
+}
+}  // namespace
+
+int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int n_az,
+                          const int32_t* first, const int32_t* dj, const int32_t* di, const double* dist,
+                          const int32_t* window, double height, int out_row0, int out_rows,
+                          float* const* outs) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(n_az >= 1 && first && dj && di && dist && window && outs, "sx_multi: NULL argument");
+    for (int k = 0; k < n_az; ++k) TOPO_REQUIRE(outs[k], "sx_multi: NULL output plane %d", k);
+    int up = 0, down = 0;
+    sx_multi_reach(n_az, first, dj, dist, &up, &down);
+    Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    TOPO_TRY(check_block(b, up, down, "sx_multi"));
+    return launch_sx_multi(b, n_az, first, dj, di, dist, window, height, outs);
+}
+
 int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny, int nx, const float* taps,
                               const int32_t* ksize, const float* angles, int n_angles, int n_planes, double mean,
                               double stdev, int out_row0, int out_rows, float* norm_out, float* dir_out) {
@@ -580,6 +606,26 @@ int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const i
     TOPO_TRY(download(out, d_out, bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     return TOPO_AMD_OK;
+}
+
+int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int32_t* first,
+                          const int32_t* dj, const int32_t* di, const double* dist, const int32_t* window,
+                          double height, float* const* outs) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dem && outs && n_az >= 1 && ny >= 1 && nx >= 1, "sx_multi: bad arguments");
+    const size_t bytes = (size_t)ny * nx * sizeof(float);
+    HostRun run;
+    void* d_in = nullptr;
+    std::vector<float*> d_out(n_az, nullptr);
+    TOPO_TRY(run.alloc(&d_in, bytes));
+    for (int k = 0; k < n_az; ++k) TOPO_TRY(run.alloc((void**)&d_out[k], bytes));
+    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
+    const int rc = topo_amd_sx_multi_dev((const float*)d_in, ny, 0, ny, nx, n_az, first, dj, di, dist, window,
+                                         height, 0, ny, d_out.data());
+    if (rc != TOPO_AMD_OK && rc != TOPO_AMD_EINVAL) return rc;
+    for (int k = 0; k < n_az; ++k) TOPO_TRY(download(outs[k], d_out[k], bytes));
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return rc;
 }
 
 int topo_amd_valley_ridge_f32(const float* dem, int ny, int nx, const float* taps, const int32_t* ksize,
@@ -794,6 +840,25 @@ int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx, c
         b.out_rows = on;
         TOPO_TRY(check_block(b, up, down, "shard_sx"));
         return launch_sx(b, dj, di, dist, n_off, window, height, shift(out, o0 - row0, nx));
+    });
+}
+
+int topo_amd_shard_sx_multi(float* block, int rows_local, int row0, int gny, int nx, int n_az,
+                            const int32_t* first, const int32_t* dj, const int32_t* di, const double* dist,
+                            const int32_t* window, double height, float* const* outs) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(n_az >= 1 && first && dj && di && dist && window && outs, "shard_sx_multi: NULL argument");
+    int up = 0, down = 0;
+    sx_multi_reach(n_az, first, dj, dist, &up, &down);
+    Shard s = make_shard(block, rows_local, row0, gny, nx, up, down);
+    std::vector<float*> moved(n_az);
+    return run_overlapped(block, s, up, down, [&](int o0, int on) {
+        Block b = s.whole;
+        b.out_row0 = o0;
+        b.out_rows = on;
+        TOPO_TRY(check_block(b, up, down, "shard_sx_multi"));
+        for (int k = 0; k < n_az; ++k) moved[k] = shift(outs[k], o0 - row0, nx);
+        return launch_sx_multi(b, n_az, first, dj, di, dist, window, height, moved.data());
     });
 }
 

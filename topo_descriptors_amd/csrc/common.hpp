@@ -97,6 +97,9 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
                     float* aspect);
 int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double* dist,
               int n_off, int window, double height, float* out);
+// several azimuth sectors in one pass: sector a owns entries [first[a], first[a+1]) of the tables
+int launch_sx_multi(const Block& b, int n_az, const int32_t* first, const int32_t* dj, const int32_t* di,
+                    const double* dist, const int32_t* window, double height, float* const* outs);
 int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed, bool integer_valued);
 // valley / ridge index (valley.hip): taps = per angle ksize^2 x 4 floats (plane sums, flipped)
 int valley_ridge_reach(const int32_t* ksize, int n_angles, int* above, int* below);

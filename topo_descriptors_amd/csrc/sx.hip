@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 namespace topo {
@@ -87,6 +88,101 @@ __global__ __launch_bounds__(kThreads) void sx_kernel(SxArgs p) {
         float v = 0.0f;
         if (inside) v = best[k] == -INFINITY ? NAN : atanf(best[k]) * rad2deg;
         p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = v;
+    }
+}
+
+// ---- several azimuth sectors in one pass ------------------------------------------
+// The reference computes one azimuth per call (topo.py:715-772, looped by its users); sectors of
+// neighbouring azimuths overlap (arc 10 degrees, usual step 5), so most ray pixels belong to two of
+// them.  The launcher sorts the unique ray pixels of up to kMaxAz sectors into classes of equal
+// membership; the kernel stages the tile once, scans every class once with the loop of sx_kernel
+// and folds the class maximum into the sectors that contain it.  max() does not care about the
+// order, so each plane has the bits of the single-azimuth kernel.
+constexpr int kMaxAz = 8;
+
+struct SxMultiArgs {
+    const float* in;
+    float* out[kMaxAz];
+    int window[kMaxAz];
+    const int* lds_off;     // per unique ray pixel, sorted by class
+    const float* inv_dist;
+    const int* cls_first;   // n_cls + 1 entries
+    const int* cls_mask;    // bit a: sector a contains the class
+    int n_cls, n_az;
+    int in_rows, in_row0, gny, nx;
+    int out_row0, out_rows;
+    int dj_min, di_min, rows_l, cols_l, stride;
+    float height;
+};
+
+template <int NA>
+__global__ __launch_bounds__(kThreads) void sx_multi_kernel(SxMultiArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ox0 = blockIdx.x * kTileW;
+    const int oy0 = p.out_row0 + blockIdx.y * kTileH;
+
+    for (int r = wave; r < p.rows_l; r += kThreads / 64) {
+        const int gy = oy0 + p.dj_min + r;
+        const int by = gy - p.in_row0;
+        const bool row_ok = gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
+        float* dst = L + r * p.stride;
+        for (int k = lane; k < p.cols_l; k += 64) {
+            const int gx = ox0 + p.di_min + k;
+            dst[k] = (row_ok && gx >= 0 && gx < p.nx) ? p.in[(size_t)by * p.nx + gx] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const int ox = ox0 + lane;
+    constexpr int NOUT = kTileH / (kThreads / 64);
+    float best[NA][NOUT], centre[NOUT];
+    const int self = -p.dj_min * p.stride - p.di_min + lane;
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        centre[k] = L[self + (wave + 4 * k) * p.stride] + p.height;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) best[a][k] = -INFINITY;
+    }
+    for (int c = 0; c < p.n_cls; ++c) {
+        float top[NOUT];
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) top[k] = -INFINITY;
+        const int n1 = p.cls_first[c + 1];
+        for (int n = p.cls_first[c]; n < n1; ++n) {
+            const int off = p.lds_off[n] + lane;  // wave-uniform table entries
+            const float inv = p.inv_dist[n];
+#pragma unroll
+            for (int k = 0; k < NOUT; ++k) {
+                const float z = L[off + (wave + 4 * k) * p.stride] - centre[k];
+                top[k] = fmaxf(top[k], z * inv);  // fmaxf drops NaN operands like nanmax
+            }
+        }
+        const int mask = p.cls_mask[c];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            if (mask >> a & 1) {
+#pragma unroll
+                for (int k = 0; k < NOUT; ++k) best[a][k] = fmaxf(best[a][k], top[k]);
+            }
+        }
+    }
+    if (ox >= p.nx) return;
+    const float rad2deg = 57.29577951308232f;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        if (a >= p.n_az) break;
+        const int w = p.window[a];
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            const int oy = oy0 + wave + 4 * k;
+            if (oy >= p.out_row0 + p.out_rows) continue;
+            const bool inside = oy >= w && oy < p.gny - w && ox >= w && ox < p.nx - w;
+            float v = 0.0f;
+            if (inside) v = best[a][k] == -INFINITY ? NAN : atanf(best[a][k]) * rad2deg;
+            p.out[a][(size_t)(oy - p.out_row0) * p.nx + ox] = v;
+        }
     }
 }
 
@@ -255,6 +351,152 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     hipLaunchKernelGGL(sx_kernel, grid, dim3(kThreads), lds, c.compute, a);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
+}
+
+namespace {
+
+struct SectorPoints {
+    std::vector<std::pair<std::pair<int, int>, double>> pts;  // unique usable (dj, di), distance
+    int dj_min = 0, dj_max = 0, di_min = 0, di_max = 0;       // box, the target pixel included
+};
+
+size_t sx_tile_bytes(int dj_min, int dj_max, int di_min, int di_max) {
+    const int rows_l = kTileH + dj_max - dj_min, cols_l = kTileW + di_max - di_min;
+    return (size_t)rows_l * (cols_l | 1) * sizeof(float);
+}
+
+// one launch of sx_multi_kernel for sectors [a0, a1)
+int launch_sx_group(const Block& b, const std::vector<SectorPoints>& sec, int a0, int a1,
+                    const int32_t* window, double height, float* const* outs) {
+    Context& c = ctx();
+    std::vector<std::pair<std::pair<int, int>, std::pair<int, double>>> all;  // (dj, di) -> (mask, dist)
+    SxMultiArgs a;
+    a.dj_min = a.di_min = 0;
+    int dj_max = 0, di_max = 0;
+    for (int k = a0; k < a1; ++k) {
+        for (auto& q : sec[k].pts) all.push_back({q.first, {1 << (k - a0), q.second}});
+        a.dj_min = std::min(a.dj_min, sec[k].dj_min);
+        a.di_min = std::min(a.di_min, sec[k].di_min);
+        dj_max = std::max(dj_max, sec[k].dj_max);
+        di_max = std::max(di_max, sec[k].di_max);
+    }
+    std::sort(all.begin(), all.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    size_t w = 0;  // merge equal offsets: union of the masks (the distance depends on the offset only)
+    for (size_t n = 0; n < all.size(); ++n) {
+        if (w > 0 && all[w - 1].first == all[n].first) {
+            all[w - 1].second.first |= all[n].second.first;
+        } else {
+            all[w++] = all[n];
+        }
+    }
+    all.resize(w);
+    std::stable_sort(all.begin(), all.end(),
+                     [](const auto& x, const auto& y) { return x.second.first < y.second.first; });
+    a.rows_l = kTileH + dj_max - a.dj_min;
+    a.cols_l = kTileW + di_max - a.di_min;
+    a.stride = a.cols_l | 1;
+    const size_t lds = (size_t)a.rows_l * a.stride * sizeof(float);
+    std::vector<int> off(all.size()), first, mask;
+    std::vector<float> inv(all.size());
+    for (size_t n = 0; n < all.size(); ++n) {
+        off[n] = (all[n].first.first - a.dj_min) * a.stride + (all[n].first.second - a.di_min);
+        inv[n] = (float)(1.0 / all[n].second.second);
+        if (n == 0 || all[n].second.first != all[n - 1].second.first) {
+            first.push_back((int)n);
+            mask.push_back(all[n].second.first);
+        }
+    }
+    first.push_back((int)all.size());
+    void *d_off = nullptr, *d_inv = nullptr, *d_first = nullptr, *d_mask = nullptr;
+    TOPO_TRY(upload_table(0, off.data(), off.size() * sizeof(int), &d_off));
+    TOPO_TRY(upload_table(1, inv.data(), inv.size() * sizeof(float), &d_inv));
+    TOPO_TRY(upload_table(2, first.data(), first.size() * sizeof(int), &d_first));
+    TOPO_TRY(upload_table(3, mask.data(), mask.size() * sizeof(int), &d_mask));
+    a.in = b.in;
+    for (int k = 0; k < kMaxAz; ++k) {
+        a.out[k] = k < a1 - a0 ? outs[a0 + k] : nullptr;
+        a.window[k] = k < a1 - a0 ? window[a0 + k] : 0;
+    }
+    a.lds_off = (const int*)d_off;
+    a.inv_dist = (const float*)d_inv;
+    a.cls_first = (const int*)d_first;
+    a.cls_mask = (const int*)d_mask;
+    a.n_cls = (int)mask.size();
+    a.n_az = a1 - a0;
+    a.in_rows = b.in_rows;
+    a.in_row0 = b.in_row0;
+    a.gny = b.gny;
+    a.nx = b.nx;
+    a.out_row0 = b.out_row0;
+    a.out_rows = b.out_rows;
+    a.height = (float)height;
+    dim3 grid((b.nx + kTileW - 1) / kTileW, (b.out_rows + kTileH - 1) / kTileH);
+    auto go = [&](auto kernel) -> int {
+        TOPO_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, c.compute, a);
+        TOPO_HIP(hipGetLastError());
+        return TOPO_AMD_OK;
+    };
+    if (a.n_az <= 2) return go(sx_multi_kernel<2>);
+    if (a.n_az <= 4) return go(sx_multi_kernel<4>);
+    return go(sx_multi_kernel<kMaxAz>);
+}
+
+}  // namespace
+
+int launch_sx_multi(const Block& b, int n_az, const int32_t* first, const int32_t* dj, const int32_t* di,
+                    const double* dist, const int32_t* window, double height, float* const* outs) {
+    // at most this much LDS per block, so that three blocks still share a CU
+    static const size_t kGroupLds = [] {
+        const char* e = std::getenv("TOPO_AMD_SX_GROUP_LDS_KIB");
+        const int kib = e && *e ? std::atoi(e) : 48;
+        return (size_t)std::min(std::max(kib, 1), 160) * 1024;
+    }();
+    std::vector<SectorPoints> sec(n_az);
+    for (int k = 0; k < n_az; ++k) {
+        TOPO_REQUIRE(window[k] >= 0 && first[k + 1] >= first[k], "sx_multi: bad sector %d", k);
+        SectorPoints& s = sec[k];
+        for (int n = first[k]; n < first[k + 1]; ++n) {
+            if (std::isnan(dist[n])) continue;
+            TOPO_REQUIRE(std::abs(dj[n]) <= window[k] && std::abs(di[n]) <= window[k],
+                         "sx_multi: offset (%d, %d) reaches beyond the zero frame of width %d", dj[n], di[n],
+                         window[k]);
+            s.pts.push_back({{dj[n], di[n]}, dist[n]});
+        }
+        std::sort(s.pts.begin(), s.pts.end());
+        s.pts.erase(std::unique(s.pts.begin(), s.pts.end(),
+                                [](const auto& x, const auto& y) { return x.first == y.first; }),
+                    s.pts.end());
+        for (auto& q : s.pts) {
+            s.dj_min = std::min(s.dj_min, q.first.first);
+            s.dj_max = std::max(s.dj_max, q.first.first);
+            s.di_min = std::min(s.di_min, q.first.second);
+            s.di_max = std::max(s.di_max, q.first.second);
+        }
+    }
+    int rc = TOPO_AMD_OK;
+    for (int a0 = 0; a0 < n_az;) {
+        // neighbouring sectors while their common tile stays small; a sector on its own (or one
+        // without a usable ray pixel) takes the single-azimuth path, whatever its size
+        int a1 = a0 + 1;
+        int dj_min = sec[a0].dj_min, dj_max = sec[a0].dj_max, di_min = sec[a0].di_min, di_max = sec[a0].di_max;
+        while (a1 < n_az && a1 - a0 < kMaxAz && !sec[a0].pts.empty() && !sec[a1].pts.empty()) {
+            const int j0 = std::min(dj_min, sec[a1].dj_min), j1 = std::max(dj_max, sec[a1].dj_max);
+            const int i0 = std::min(di_min, sec[a1].di_min), i1 = std::max(di_max, sec[a1].di_max);
+            if (sx_tile_bytes(j0, j1, i0, i1) > kGroupLds) break;
+            dj_min = j0, dj_max = j1, di_min = i0, di_max = i1;
+            ++a1;
+        }
+        if (a1 - a0 == 1) {
+            const int n0 = first[a0];
+            const int r = launch_sx(b, dj + n0, di + n0, dist + n0, first[a0 + 1] - n0, window[a0], height, outs[a0]);
+            if (r != TOPO_AMD_OK) rc = r;  // an empty sector: reported at the end, the others still run
+        } else {
+            TOPO_TRY(launch_sx_group(b, sec, a0, a1, window, height, outs));
+        }
+        a0 = a1;
+    }
+    return rc;
 }
 
 }  // namespace topo

@@ -132,6 +132,16 @@ class Block:
                                               dist.ctypes.data_as(_lib._f64p), dist.size, int(window),
                                               float(height), o0, on, out.ptr), "sx_dev")
 
+    def sx_multi(self, sectors, height, outs, out_row0=None, out_rows=None):
+        """Sx of several azimuth sectors in one pass.  sectors: [(window, dj, di, dist), ...] as
+        returned by ``sx_offsets``; outs: one DeviceArray per sector.  Same bits as ``sx`` per sector."""
+        o0, on = self._range(out_row0, out_rows)
+        first, dj, di, dist, window = pack_sectors(sectors)
+        planes = (C.c_void_p * len(outs))(*[o.ptr for o in outs])
+        _lib.check(_lib.lib().topo_amd_sx_multi_dev(
+            *self._head(), len(sectors), first.ctypes.data_as(_lib._i32p), dj.ctypes.data_as(_lib._i32p),
+            di.ctypes.data_as(_lib._i32p), dist.ctypes.data_as(_lib._f64p), window.ctypes.data_as(_lib._i32p),
+            float(height), o0, on, planes), "sx_multi_dev")
 
     def valley_ridge(self, taps, ksize, angles, n_planes, mean, stdev, norm, direction, out_row0=None,
                      out_rows=None):
@@ -153,6 +163,19 @@ def mean_std(array):
     _lib.check(_lib.lib().topo_amd_mean_std_dev(array.ptr, array.rows * array.nx, C.byref(m), C.byref(s)),
                "mean_std_dev")
     return m.value, s.value
+
+
+def pack_sectors(sectors):
+    """Concatenated tables of the multi-azimuth entry points: (first, dj, di, dist, window)."""
+    if len(sectors) == 0:
+        raise ValueError("sx_multi needs at least one sector")
+    counts = [len(np.atleast_1d(sec[1])) for sec in sectors]
+    first = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    dj = np.ascontiguousarray(np.concatenate([np.atleast_1d(sec[1]) for sec in sectors]), dtype=np.int32)
+    di = np.ascontiguousarray(np.concatenate([np.atleast_1d(sec[2]) for sec in sectors]), dtype=np.int32)
+    dist = np.ascontiguousarray(np.concatenate([np.atleast_1d(sec[3]) for sec in sectors]), dtype=np.float64)
+    window = np.array([int(sec[0]) for sec in sectors], dtype=np.int32)
+    return first, dj, di, dist, window
 
 
 def sx_offsets(azimuth, radius, dx, dy, azimuth_arc=10.0, azimuth_steps=15, radius_min=0.0):

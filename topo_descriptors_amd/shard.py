@@ -183,3 +183,28 @@ class ShardedDEM:
                                                 di.ctypes.data_as(_lib._i32p),
                                                 dist.ctypes.data_as(_lib._f64p), dist.size, int(window),
                                                 float(height), out.ptr), "shard_sx")
+
+    def sx_multi(self, sectors, height, outs):
+        """Sx of several azimuth sectors with ONE ghost-row exchange.  The plan's halo must be the
+        largest (-dj, dj) over the usable ray pixels of all sectors (``sx_multi_halo``)."""
+        import ctypes as C
+
+        from . import _lib
+        from .device import pack_sectors
+        p = self.plan
+        first, dj, di, dist, window = pack_sectors(sectors)
+        planes = (C.c_void_p * len(outs))(*[o.ptr for o in outs])
+        _lib.check(_lib.lib().topo_amd_shard_sx_multi(
+            self.block.ptr, p.rows_local, p.row0, p.gny, p.nx, len(sectors), first.ctypes.data_as(_lib._i32p),
+            dj.ctypes.data_as(_lib._i32p), di.ctypes.data_as(_lib._i32p), dist.ctypes.data_as(_lib._f64p),
+            window.ctypes.data_as(_lib._i32p), float(height), planes), "shard_sx_multi")
+
+
+def sx_multi_halo(sectors):
+    """(above, below) ghost depth that serves every sector of ``sectors``."""
+    up = down = 0
+    for _, dj, _, dist in sectors:
+        dj = np.atleast_1d(dj)[~np.isnan(np.atleast_1d(dist))]
+        if dj.size:
+            up, down = max(up, int(-dj.min())), max(down, int(dj.max()))
+    return max(up, 0), max(down, 0)

@@ -6,6 +6,7 @@ sobel :658, sx :776 and its geometry helpers :861-925).  The per-pixel arithmeti
 hand-written HIP kernels behind the C ABI of ``libtopo_amd.so``; this module only prepares
 parameters, hands over C-contiguous float32 buffers and wraps the results.
 """
+import ctypes as C
 import logging
 
 import numpy as np
@@ -251,6 +252,46 @@ def sx(dem_ds, azimuth, radius, height=10.0, azimuth_arc=10.0, azimuth_steps=15,
     source = (window_center + _sx_source_idx_delta(azimuths, radius, dx, dy)).astype(int)
     lines_indices = _sx_bresenhamlines(source, window_center)
     return _sx_rolling(hlp.get_da(dem_ds).values, window_distance, lines_indices, height)
+
+
+def sx_multi(dem_ds, azimuths, radius, height=10.0, azimuth_arc=10.0, azimuth_steps=15, radius_min=0.0):
+    """``sx`` for a sequence of azimuths in one pass over the DEM: ``[sx(dem_ds, a, radius, ...) for a
+    in azimuths]`` with the same bits.  The reference scans one azimuth per call (topo.py:776-858) and
+    its users loop; here the DEM is uploaded once and ray pixels shared by neighbouring sectors are
+    scanned once.  Give the azimuths in angular order for the sharing to apply."""
+    if not hlp._looks_like_dataset(dem_ds):
+        raise TypeError("Argument 'dem_ds' must be a xr.Dataset.")
+    azimuths = [float(a) for a in np.atleast_1d(azimuths)]
+    if len(azimuths) == 0:
+        return []
+    from . import device  # noqa: PLC0415
+    _, res_meters = hlp.scale_to_pixel(radius, dem_ds)
+    dx = res_meters["x"].mean()
+    dy = res_meters["y"].mean()
+    sectors = [device.sx_offsets(a, radius, dx, dy, azimuth_arc, azimuth_steps, radius_min) for a in azimuths]
+    dem = np.asarray(hlp.get_da(dem_ds).values)
+    _check_2d(dem, "sx_multi")
+    src = _lib.as_f32(dem)
+    ny, nx = src.shape
+    outs = [np.zeros_like(src) for _ in sectors]
+    # sectors the device has something to do for: the DEM is larger than the zero frame and there
+    # is a usable ray pixel (else zeros, or NaN inside the frame, as in _sx_rolling)
+    todo = []
+    for k, (window, _, _, dist) in enumerate(sectors):
+        if ny <= 2 * window or nx <= 2 * window:
+            continue
+        if dist.size == 0 or np.all(np.isnan(dist)):
+            outs[k][window : ny - window, window : nx - window] = np.nan
+            continue
+        todo.append(k)
+    if todo:
+        first, dj, di, dist, window = device.pack_sectors([sectors[k] for k in todo])
+        planes = (C.c_void_p * len(todo))(*[_lib.ptr(outs[k]) for k in todo])
+        _lib.check(_lib.lib().topo_amd_sx_multi_f32(
+            _lib.ptr(src), ny, nx, len(todo), first.ctypes.data_as(_lib._i32p), dj.ctypes.data_as(_lib._i32p),
+            di.ctypes.data_as(_lib._i32p), dist.ctypes.data_as(_lib._f64p), window.ctypes.data_as(_lib._i32p),
+            float(height), planes), "topo_amd_sx_multi_f32")
+    return [o.astype(dem.dtype, copy=False) for o in outs]
 
 
 # ---- valley / ridge index ---------------------------------------------------------------------
