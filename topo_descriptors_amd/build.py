@@ -50,7 +50,7 @@ def build_library(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=8) as pool:
         objs = list(pool.map(compile_one, srcs))
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs,
-           "-L/opt/rocm/lib", "-lrccl"]
+           "-L/opt/rocm/lib", "-lrccl", "-pthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -2,13 +2,19 @@
 // and host-buffer descriptor entry points, and RCCL ghost-row exchange for row shards.
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 
 #include "common.hpp"
+
+#include <sys/mman.h>
+
+#include <thread>
 
 namespace topo {
 
@@ -161,15 +167,51 @@ int gradient_halo(double sigma, double sig_ratio) {
 }
 
 // RAII-less helper for the host-buffer entry points
+// Device buffers of one host-buffer call, and the preparation of its result arrays.  A result array
+// fresh from the allocator has no pages yet; faulting them in one by one under the download is what a
+// host-buffer call spends most of its time on (tools/ubench/page_touch.cpp: 92 ms per GiB against 19 ms
+// for the copy itself).  prefault() asks for huge pages and touches the array from a few threads
+// while the upload and the kernels run; ready() joins them before the first download.
 struct HostRun {
     std::vector<void*> bufs;
+    std::vector<std::thread> touchers;
     ~HostRun() {
+        ready();
         for (void* p : bufs) (void)hipFree(p);
     }
     int alloc(void** p, size_t bytes) {
         TOPO_HIP(hipMalloc(p, bytes));
         bufs.push_back(*p);
         return TOPO_AMD_OK;
+    }
+    void prefault(void* host, size_t bytes) {
+        constexpr uintptr_t kPage = 4096, kHuge = (uintptr_t)2 << 20;
+        static const bool enabled = [] {
+            const char* e = std::getenv("TOPO_AMD_HOST_PREFAULT");  // 0 switches it off (for measurements)
+            return !(e && e[0] == '0');
+        }();
+        if (!enabled || !host || bytes < 4 * kHuge) return;
+        const uintptr_t lo = ((uintptr_t)host + kPage - 1) & ~(kPage - 1);
+        const uintptr_t hi = ((uintptr_t)host + bytes) & ~(kPage - 1);
+        if (hi <= lo) return;
+        (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);  // a hint; refused where THP is off
+        const unsigned hw = std::thread::hardware_concurrency();
+        const uintptr_t n = std::min<uintptr_t>(hw >= 16 ? 8 : (hw >= 4 ? 2 : 1), (hi - lo) / kHuge);
+        const uintptr_t per = (((hi - lo) / n) + kHuge - 1) & ~(kHuge - 1);
+        for (uintptr_t a = lo; a < hi; a += per) {
+            const uintptr_t b = std::min(a + per, hi);
+            touchers.emplace_back([a, b] {
+                // read and write back one byte per page: the array keeps whatever it held
+                for (uintptr_t q = a; q < b; q += kPage) {
+                    volatile char* c = (volatile char*)q;
+                    *c = *c;
+                }
+            });
+        }
+    }
+    void ready() {
+        for (auto& t : touchers) t.join();
+        touchers.clear();
     }
 };
 
@@ -503,17 +545,39 @@ int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigm
     TOPO_REQUIRE(dem && ny >= 1 && nx >= 1, "tpi_std: bad DEM");
     TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
     const size_t bytes = (size_t)ny * nx * sizeof(float);
-    HostRun run;
-    void *d_in = nullptr, *d_tpi = nullptr, *d_std = nullptr;
-    TOPO_TRY(run.alloc(&d_in, bytes));
-    if (tpi_out) TOPO_TRY(run.alloc(&d_tpi, bytes));
-    if (std_out) TOPO_TRY(run.alloc(&d_std, bytes));
-    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
-    Block b{(const float*)d_in, ny, 0, ny, nx, 0, ny};
-    TOPO_TRY(tpi_std_block(b, size, sigma, (float*)d_tpi, (float*)d_std));
-    TOPO_TRY(download(tpi_out, d_tpi, bytes));
-    TOPO_TRY(download(std_out, d_std, bytes));
-    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    // TOPO_AMD_TRACE_HOST=1: where a host-buffer call spends its time (stderr, this entry point only)
+    static const bool trace = std::getenv("TOPO_AMD_TRACE_HOST") != nullptr;
+    double t_prev = 0.0;
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx().compute);
+        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (what) std::fprintf(stderr, "topo_amd_tpi_std_f32 %-22s %8.2f ms\n", what, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
+    lap(nullptr);
+    {
+        HostRun run;
+        void *d_in = nullptr, *d_tpi = nullptr, *d_std = nullptr;
+        TOPO_TRY(run.alloc(&d_in, bytes));
+        if (tpi_out) TOPO_TRY(run.alloc(&d_tpi, bytes));
+        if (std_out) TOPO_TRY(run.alloc(&d_std, bytes));
+        lap("hipMalloc");
+        run.prefault(tpi_out, bytes);
+        run.prefault(std_out, bytes);
+        TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
+        lap("upload");
+        Block b{(const float*)d_in, ny, 0, ny, nx, 0, ny};
+        TOPO_TRY(tpi_std_block(b, size, sigma, (float*)d_tpi, (float*)d_std));
+        lap("kernels");
+        run.ready();
+        lap("wait for result pages");
+        TOPO_TRY(download(tpi_out, d_tpi, bytes));
+        TOPO_TRY(download(std_out, d_std, bytes));
+        TOPO_HIP(hipStreamSynchronize(ctx().compute));
+        lap("download");
+    }
+    lap("hipFree");
     return TOPO_AMD_OK;
 }
 
@@ -535,9 +599,11 @@ int topo_amd_gauss_f32(const float* dem, int ny, int nx, double sigma_y, double 
     void *d_in = nullptr, *d_out = nullptr;
     TOPO_TRY(run.alloc(&d_in, bytes));
     TOPO_TRY(run.alloc(&d_out, bytes));
+    run.prefault(out, bytes);
     TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
     TOPO_TRY(topo_amd_gaussian_dev((const float*)d_in, ny, 0, ny, nx, sigma_y, sigma_x, 0, ny,
                                    (float*)d_out));
+    run.ready();
     TOPO_TRY(download(out, d_out, bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     return TOPO_AMD_OK;
@@ -552,8 +618,11 @@ int topo_amd_sobel_f32(const float* dem, int ny, int nx, float* dx_out, float* d
     TOPO_TRY(run.alloc(&d_in, bytes));
     TOPO_TRY(run.alloc(&d_dx, bytes));
     TOPO_TRY(run.alloc(&d_dy, bytes));
+    run.prefault(dx_out, bytes);
+    run.prefault(dy_out, bytes);
     TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
     TOPO_TRY(topo_amd_sobel_dev((const float*)d_in, ny, 0, ny, nx, 0, ny, (float*)d_dx, (float*)d_dy));
+    run.ready();
     TOPO_TRY(download(dx_out, d_dx, bytes));
     TOPO_TRY(download(dy_out, d_dy, bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
@@ -572,6 +641,7 @@ int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double
     TOPO_TRY(run.alloc(&d_in, bytes));
     for (int k = 0; k < 4; ++k)
         if (host_out[k]) TOPO_TRY(run.alloc(&d_o[k], bytes));
+    for (int k = 0; k < 4; ++k) run.prefault(host_out[k], bytes);
     TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
     const void *rx = res_x, *ry = res_y;
     if (res_mode == TOPO_AMD_RES_2D) {
@@ -586,6 +656,7 @@ int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double
     TOPO_TRY(topo_amd_gradient_dev((const float*)d_in, ny, 0, ny, nx, sigma, sig_ratio, res_mode, rx,
                                    ry, 0, ny, (float*)d_o[0], (float*)d_o[1], (float*)d_o[2],
                                    (float*)d_o[3]));
+    run.ready();
     for (int k = 0; k < 4; ++k) TOPO_TRY(download(host_out[k], d_o[k], bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     return TOPO_AMD_OK;
@@ -600,9 +671,11 @@ int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const i
     void *d_in = nullptr, *d_out = nullptr;
     TOPO_TRY(run.alloc(&d_in, bytes));
     TOPO_TRY(run.alloc(&d_out, bytes));
+    run.prefault(out, bytes);
     TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
     TOPO_TRY(topo_amd_sx_dev((const float*)d_in, ny, 0, ny, nx, dj, di, dist, n_off, window, height,
                              0, ny, (float*)d_out));
+    run.ready();
     TOPO_TRY(download(out, d_out, bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     return TOPO_AMD_OK;
@@ -619,10 +692,12 @@ int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int3
     std::vector<float*> d_out(n_az, nullptr);
     TOPO_TRY(run.alloc(&d_in, bytes));
     for (int k = 0; k < n_az; ++k) TOPO_TRY(run.alloc((void**)&d_out[k], bytes));
+    for (int k = 0; k < n_az; ++k) run.prefault(outs[k], bytes);
     TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
     const int rc = topo_amd_sx_multi_dev((const float*)d_in, ny, 0, ny, nx, n_az, first, dj, di, dist, window,
                                          height, 0, ny, d_out.data());
     if (rc != TOPO_AMD_OK && rc != TOPO_AMD_EINVAL) return rc;
+    run.ready();
     for (int k = 0; k < n_az; ++k) TOPO_TRY(download(outs[k], d_out[k], bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     return rc;
@@ -639,9 +714,12 @@ int topo_amd_valley_ridge_f32(const float* dem, int ny, int nx, const float* tap
     TOPO_TRY(run.alloc(&d_in, bytes));
     TOPO_TRY(run.alloc(&d_norm, bytes));
     TOPO_TRY(run.alloc(&d_dir, bytes));
+    run.prefault(norm_out, bytes);
+    run.prefault(dir_out, bytes);
     TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
     TOPO_TRY(topo_amd_valley_ridge_dev((const float*)d_in, ny, 0, ny, nx, taps, ksize, angles, n_angles, n_planes,
                                        mean, stdev, 0, ny, (float*)d_norm, (float*)d_dir));
+    run.ready();
     TOPO_TRY(download(norm_out, d_norm, bytes));
     TOPO_TRY(download(dir_out, d_dir, bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
