@@ -29,3 +29,17 @@ for rep in range(4):
     dt = time.perf_counter() - t0
     print(f"{n}x{n} recycled result pages, call {rep}: {dt * 1e3:7.1f} ms  {n * n / dt / 1e6:8.0f} Mpixels/s", flush=True)
     del out
+
+# the device-resident path: DeviceArray.to_host() into a fresh numpy array
+from topo_descriptors_amd import device as d  # noqa: E402
+
+dev = d.DeviceArray.from_host(dem)
+blk = d.Block(dev)
+out_dev = d.DeviceArray(n, n)
+keep = []
+for rep in range(3):
+    t0 = time.perf_counter()
+    blk.tpi_std(67, tpi=out_dev)
+    keep.append(out_dev.to_host())
+    dt = time.perf_counter() - t0
+    print(f"{n}x{n} resident DEM, kernel + to_host(), call {rep}: {dt * 1e3:7.1f} ms", flush=True)

@@ -335,6 +335,12 @@ int topo_amd_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 
 int topo_amd_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     TOPO_TRY(require_ready());
+    {
+        // a destination fresh from the allocator has no pages yet: fault them in from several
+        // threads (the kernels launched before this call are usually still running meanwhile)
+        HostRun pages;
+        pages.prefault(dst, bytes);
+    }
     TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().compute));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     return TOPO_AMD_OK;
