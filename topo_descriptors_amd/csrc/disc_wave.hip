@@ -1,5 +1,5 @@
 // K1/K2 fast path dispatch: size-specialised wave-shift kernels (disc_wave_impl.hpp) for every
-// odd disc size from 5 to 101, compiled in ten groups (disc_wave_g*.hip).
+// odd disc size from 3 to 101, compiled in ten groups (disc_wave_g*.hip).
 #include "common.hpp"
 
 namespace topo {
@@ -22,7 +22,8 @@ int launch_disc_wave(const Block& b, int size, float* tpi_out, float* std_out) {
     if (b.nx % 4 != 0 || (reinterpret_cast<uintptr_t>(b.in) & 15) || (reinterpret_cast<uintptr_t>(std_out) & 15) ||
         (reinterpret_cast<uintptr_t>(tpi_out) & 15))
         return TOPO_AMD_EUNSUP;
-    if (size < 5 || size > 101 || (size & 1) == 0) return TOPO_AMD_EUNSUP;
+    if (size < 3 || size > 101 || (size & 1) == 0) return TOPO_AMD_EUNSUP;
+    if (size == 3) return launch_disc_wave_group9(b, size, tpi_out, std_out);
     switch (((size - 5) / 2) % 10) {
         case 0: return launch_disc_wave_group0(b, size, tpi_out, std_out);
         case 1: return launch_disc_wave_group1(b, size, tpi_out, std_out);

@@ -6,6 +6,7 @@ namespace topo {
 
 int launch_disc_wave_group9(const Block& b, int size, float* tpi_out, float* std_out) {
     switch (size) {
+        case 3: return launch_wave_any<3>(b, tpi_out, std_out);
         case 23: return launch_wave_any<23>(b, tpi_out, std_out);
         case 43: return launch_wave_any<43>(b, tpi_out, std_out);
         case 63: return launch_wave_any<63>(b, tpi_out, std_out);
