@@ -413,3 +413,35 @@ def test_marching_prefix_wraps_harmlessly():
     assert out.returncode == 0, out.stderr[-2000:]
     worst = float(out.stdout.strip().splitlines()[-1].split()[1])  # max |gpu - exact| / tolerance
     assert worst <= 1.0, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx", [257, 258, 259])
+@pytest.mark.parametrize("size", [3, 17, 67])
+def test_widths_that_are_not_multiples_of_four(nx, size):
+    """Rows that are not 16-byte aligned go through a re-pitched copy with zero columns on the right:
+    the result equals, bit for bit, the valid columns of the same DEM widened with zeros."""
+    ny = 200
+    rng = np.random.default_rng(nx * 100 + size)
+    dem = np.rint(orc.synthetic_dem(ny, nx, seed=size)).astype(np.float32)
+    if nx == 258:
+        dem += rng.uniform(0, 1, dem.shape).astype(np.float32)  # fractional tiles too
+    dev = d.DeviceArray.from_host(dem)
+    t, s = d.DeviceArray(ny, nx), d.DeviceArray(ny, nx)
+    d.Block(dev).tpi_std(size, tpi=t, std=s)
+    d.sync()
+    got_t, got_s = t.to_host(), s.to_host()
+    nxp = (nx + 3) // 4 * 4
+    wide = np.zeros((ny, nxp), dtype=np.float32)
+    wide[:, :nx] = dem
+    devw = d.DeviceArray.from_host(wide)
+    tw, sw = d.DeviceArray(ny, nxp), d.DeviceArray(ny, nxp)
+    d.Block(devw).tpi_std(size, tpi=tw, std=sw)
+    d.sync()
+    assert np.array_equal(got_t, tw.to_host()[:, :nx])
+    assert np.array_equal(got_s, sw.to_host()[:, :nx])
+    assert np.max(np.abs(got_t - orc.tpi_exact(dem, size))) <= 2.5e-4
+    e = orc.std_exact(dem, size)
+    assert np.max(np.abs(got_s - e)) <= 1e-4 * max(np.max(e), 1.0)
+    for a in (dev, t, s, devw, tw, sw):
+        a.free()

@@ -88,6 +88,7 @@ int build_disc(int size, DiscRuns* out);
 int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out);
 // size-specialised wave-shift kernels; TOPO_AMD_EUNSUP = not covered, use the generic kernel
 int launch_disc_wave(const Block& b, int size, float* tpi_out, float* std_out);
+bool disc_wave_covers(int size);  // a specialisation exists for this disc size
 // any size: float64 column prefix sums in HBM (slow, exact)
 int launch_disc_big(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out);
 int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out);

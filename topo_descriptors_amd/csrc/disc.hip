@@ -346,11 +346,60 @@ int build_disc(int size, DiscRuns* out) {
     return TOPO_AMD_OK;
 }
 
+namespace {
+
+// rows [r0, r0 + rows) of a plane of pitch src_pitch -> a plane of pitch dst_pitch; columns at and
+// beyond `width` of the destination (dst_pitch > width) are set to 0
+__global__ __launch_bounds__(kThreads) void repitch_kernel(const float* src, int src_pitch, float* dst,
+                                                           int dst_pitch, int width, int cols) {
+    const int x = blockIdx.x * kThreads + threadIdx.x;
+    if (x >= cols) return;
+    const size_t r = blockIdx.y;
+    dst[r * dst_pitch + x] = x < width ? src[r * src_pitch + x] : 0.0f;
+}
+
+int repitch(const float* src, int src_pitch, float* dst, int dst_pitch, int width, int cols, int rows) {
+    if (rows <= 0) return TOPO_AMD_OK;
+    dim3 grid((cols + kThreads - 1) / kThreads, rows);
+    hipLaunchKernelGGL(repitch_kernel, grid, dim3(kThreads), 0, ctx().compute, src, src_pitch, dst, dst_pitch,
+                       width, cols);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+// The wave-shift kernels move 16-byte pieces of rows, so they need nx % 4 == 0 and 16-byte aligned
+// planes; three DEM widths in four are not like that.  Such a block is copied into a plane whose
+// pitch is nx rounded up to 4 with zeros in the extra columns, the kernels run on that plane as if
+// it were the DEM, and the nx valid columns of the results are copied back.  Columns of zeros to
+// the right of the DEM are exactly what the zero padding of the convolution stands for (n is the
+// full tap count everywhere, see above), so every valid output is unchanged; the two copies cost
+// about as much as a 7-pixel TPI, a fifth of what the generic kernel costs at 67 pixels.
+int launch_disc_wave_repitched(const Block& b, int size, float* tpi_out, float* std_out) {
+    const int nxp = (b.nx + 3) & ~3;
+    void *in_p = nullptr, *tpi_p = nullptr, *std_p = nullptr;
+    TOPO_TRY(workspace(4, (size_t)b.in_rows * nxp * sizeof(float), &in_p));
+    if (tpi_out) TOPO_TRY(workspace(5, (size_t)b.out_rows * nxp * sizeof(float), &tpi_p));
+    if (std_out) TOPO_TRY(workspace(6, (size_t)b.out_rows * nxp * sizeof(float), &std_p));
+    TOPO_TRY(repitch(b.in, b.nx, (float*)in_p, nxp, b.nx, nxp, b.in_rows));
+    Block bp = b;
+    bp.in = (const float*)in_p;
+    bp.nx = nxp;
+    const int r = launch_disc_wave(bp, size, (float*)tpi_p, (float*)std_p);
+    if (r != TOPO_AMD_OK) return r;
+    if (tpi_out) TOPO_TRY(repitch((const float*)tpi_p, nxp, tpi_out, b.nx, b.nx, b.nx, b.out_rows));
+    if (std_out) TOPO_TRY(repitch((const float*)std_p, nxp, std_out, b.nx, b.nx, b.nx, b.out_rows));
+    return TOPO_AMD_OK;
+}
+
+}  // namespace
+
 int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out) {
     TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
     Context& c = ctx();
     {
-        const int r = launch_disc_wave(b, disc.size, tpi_out, std_out);
+        int r = launch_disc_wave(b, disc.size, tpi_out, std_out);
+        if (r == TOPO_AMD_EUNSUP && disc_wave_covers(disc.size) && b.nx >= 4)
+            r = launch_disc_wave_repitched(b, disc.size, tpi_out, std_out);
         if (r != TOPO_AMD_EUNSUP) return r;
     }
     const int n_rows = disc.dj_max - disc.dj_min + 1;

@@ -18,11 +18,13 @@ int launch_disc_wave_group9(const Block& b, int size, float* tpi_out, float* std
 // TPI alone (std_out == NULL), STD alone (tpi_out == NULL) or both fused.  Returns
 // TOPO_AMD_EUNSUP when no specialisation covers the request (the caller falls back to the
 // generic kernel): needs nx % 4 == 0 and 16-byte aligned planes for the 16-byte row accesses.
+bool disc_wave_covers(int size) { return size >= 3 && size <= 101 && (size & 1) == 1; }
+
 int launch_disc_wave(const Block& b, int size, float* tpi_out, float* std_out) {
     if (b.nx % 4 != 0 || (reinterpret_cast<uintptr_t>(b.in) & 15) || (reinterpret_cast<uintptr_t>(std_out) & 15) ||
         (reinterpret_cast<uintptr_t>(tpi_out) & 15))
         return TOPO_AMD_EUNSUP;
-    if (size < 3 || size > 101 || (size & 1) == 0) return TOPO_AMD_EUNSUP;
+    if (!disc_wave_covers(size)) return TOPO_AMD_EUNSUP;
     if (size == 3) return launch_disc_wave_group9(b, size, tpi_out, std_out);
     switch (((size - 5) / 2) % 10) {
         case 0: return launch_disc_wave_group0(b, size, tpi_out, std_out);
