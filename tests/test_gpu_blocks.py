@@ -65,7 +65,9 @@ def test_tpi_std_blocks_bit_identical(size, nx, integer):
     assert np.max(np.abs(whole[1] - e)) <= 1e-4 * np.max(e)
 
 
-@pytest.mark.parametrize("sigma", [0.75, 3.25, 12.0])
+# radius int(4 sigma + 0.5): 13, 28 and 48 (fused LDS-tiled axis 1, 3 / 3 / 4 samples per lane held for
+# the next tile), 64 and 88 (the same kernel with 16-wide tap chunks, 4 / 5 samples), 104 (wave-shift axis 1)
+@pytest.mark.parametrize("sigma", [0.75, 3.25, 7.0, 12.0, 16.0, 22.0, 26.0])
 def test_gradient_blocks_bit_identical(sigma):
     gny, nx = 420, 320
     dem = orc.synthetic_dem(gny, nx, seed=9)

@@ -12,6 +12,8 @@
 // offset so float32 accumulation keeps its digits on 2000 m terrain.
 #include "common.hpp"
 
+#include <cstdlib>
+
 #include <cmath>
 
 namespace topo {
@@ -317,14 +319,14 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int TB, int KB, int NW>
+template <int TB, int KB, int NW, int PF>
 __global__ __launch_bounds__(NW * 64) void gauss_axis1_grad_kernel(GaussArgs p, GradArgs g, int tiles_x, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float L[];
     constexpr int TR = 64;
     constexpr int TC = NW * TB;
     constexpr int OUT_R = TR - 2, OUT_C = TC - 2;
     constexpr int RPW = TR / NW;  // tile rows fetched per wave
-    constexpr int PF = 3;         // samples per lane and row: cols_l <= 192 (asserted by the launcher)
+    // PF: samples per lane and row held in registers for the next tile, cols_l <= 64 PF (the launcher picks it)
     const int R = p.radius;
     const int cols_l = TC + p.nchunks * KB - 1;
     const int stride = cols_l | 1;
@@ -615,7 +617,13 @@ int upload_weights(int slot, double sigma, int kb, GaussArgs* a) {
 }
 
 // wide tiling for long filters, narrow for short ones (fewer padded taps)
-bool wide_tiling(int radius) { return radius >= 24; }
+bool wide_tiling(int radius) {
+    static const int from = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_WIDE_MIN_RADIUS");
+        return e && *e ? std::atoi(e) : 24;
+    }();
+    return radius >= from;
+}
 
 int run_axis0(const Block& b, double sigma, float* out, int table_slot) {
     Context& c = ctx();
@@ -709,23 +717,34 @@ int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int t
     return launch_axis1<8, 8, 8>(a, rows, nx, sigma);
 }
 
+template <int TB, int KB, int NW, int PF>
+int launch_axis1_grad_pf(const GaussArgs& a, const GradArgs& g, size_t lds);
+
 template <int TB, int KB, int NW>
 int launch_axis1_grad(const GaussArgs& a, const GradArgs& g, double sigma) {
-    Context& c = ctx();
     constexpr int tc = NW * TB;
     const int cols_l = tc + a.nchunks * KB - 1;
     const size_t lds_in = (size_t)64 * (cols_l | 1) * sizeof(float);
     const size_t lds_out = (size_t)64 * (tc + 1) * sizeof(float);
     const size_t lds = lds_in > lds_out ? lds_in : lds_out;
-    if (lds > 160 * 1024 || cols_l > 192) {
+    if (lds > 160 * 1024 || cols_l > 320) {
         set_error("gradient: sigma %.3f (radius %d) needs %zu B of LDS and %d columns per tile; "
                   "outside what the LDS-tiled axis-1 kernel is built for", sigma, a.radius, lds, cols_l);
         return TOPO_AMD_EUNSUP;
     }
-    TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_grad_kernel<TB, KB, NW>,
+    if (cols_l > 256) return launch_axis1_grad_pf<TB, KB, NW, 5>(a, g, lds);
+    if (cols_l > 192) return launch_axis1_grad_pf<TB, KB, NW, 4>(a, g, lds);
+    return launch_axis1_grad_pf<TB, KB, NW, 3>(a, g, lds);
+}
+
+template <int TB, int KB, int NW, int PF>
+int launch_axis1_grad_pf(const GaussArgs& a, const GradArgs& g, size_t lds) {
+    Context& c = ctx();
+    constexpr int tc = NW * TB;
+    TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_grad_kernel<TB, KB, NW, PF>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
-    TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gauss_axis1_grad_kernel<TB, KB, NW>,
+    TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gauss_axis1_grad_kernel<TB, KB, NW, PF>,
                                                           NW * 64, lds));
     if (per_cu < 1) per_cu = 1;
     constexpr int out_r = 62, out_c = tc - 2;
@@ -735,7 +754,7 @@ int launch_axis1_grad(const GaussArgs& a, const GradArgs& g, double sigma) {
     long grid = (long)(c.num_cu - c.reserve_cus) * per_cu;  // persistent: every block walks the tile list
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((gauss_axis1_grad_kernel<TB, KB, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, c.compute, a, g,
+    hipLaunchKernelGGL((gauss_axis1_grad_kernel<TB, KB, NW, PF>), dim3((unsigned)grid), dim3(NW * 64), lds, c.compute, a, g,
                        tiles_x, (int)ntiles);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
@@ -745,7 +764,13 @@ int launch_axis1_grad(const GaussArgs& a, const GradArgs& g, double sigma) {
 // smoothed along axis 0) fused with the gradient epilogue described by g.
 int run_axis1_grad(const float* in, int s_row0, int s_rows, int gny, int nx, double sigma,
                    const GradArgs& g, int table_slot) {
-    const bool wide = wide_tiling(gaussian_radius(sigma));
+    static const int wide_from = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED_WIDE_MIN_RADIUS");
+        // 16-wide tap chunks pay from radius ~60: 4.13 (narrow) / 3.92 ms (wide) at radius 64, 3.33 / 3.65
+        // at radius 56 on 16384^2 (tools/gauss_fused_sweep.sh)
+        return e && *e ? std::atoi(e) : 60;
+    }();
+    const bool wide = gaussian_radius(sigma) >= wide_from;
     GaussArgs a;
     TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
     a.in = in;
@@ -769,8 +794,14 @@ int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, c
     auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
     const int d_lo = -fdiv(R + GC - 1, GC), d_hi = fdiv(R + GC - 1, GC);
     const int nsteps = d_hi - d_lo + 1;
-    const int nvl = 64 - (d_hi - d_lo);
-    if (nvl < 10) return TOPO_AMD_EUNSUP;
+    const int nvl = 64 - (d_hi - d_lo);  // lanes of a wavefront that produce output
+    static const int min_lanes = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_WAVE_MIN_LANES");
+        // below ~42 of 64 output lanes (radius > 176, sigma > ~44) the transpose path is faster:
+        // 11.2 vs 9.0 ms at sigma 50, 68 vs 17 ms at sigma 107 on 16384^2 (tools/gauss_long_crossover.py)
+        return e && *e ? std::atoi(e) : 42;
+    }();
+    if (nvl < min_lanes) return TOPO_AMD_EUNSUP;
     std::vector<double> w(2 * R + 1);
     double sum = 0.0;
     for (int k = -R; k <= R; ++k) {
@@ -947,10 +978,18 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         rows.out_row0 = s0;
         rows.out_rows = s_rows;
         TOPO_TRY(run_axis0(rows, sigma, (float*)plane_a, 1));
-        // short filters: LDS-tiled axis 1 (measured 9.8 vs 13.6 ms at sigma 3.25 on 32768^2); long
-        // filters: wave-shift axis 1 (26.7 vs 27.8 ms at sigma 30.25, and no LDS limit on sigma)
-        if (!wide_tiling(gaussian_radius(sigma)))
-            return run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);
+        // short and medium filters: LDS-tiled axis 1 (9.8 vs 13.6 ms at sigma 3.25 on 32768^2); long
+        // filters: wave-shift axis 1 (26.7 vs 27.8 ms at sigma 30.25) while enough lanes produce output
+        static const int fused_max = [] {
+            const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED_MAX_RADIUS");
+            // the LDS-tiled fused kernel while its tile fits (320 columns: radius 92), the wave-shift one
+            // beyond: 2.67 vs 3.63 ms at radius 32, 3.33 vs 4.07 at 56, 4.60 vs 5.17 at 92 on 16384^2
+            return e && *e ? std::atoi(e) : 92;
+        }();
+        if (gaussian_radius(sigma) <= fused_max) {
+            const int r = run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);
+            if (r != TOPO_AMD_EUNSUP) return r;
+        }
         const int r = run_axis1_wave_grad((const float*)plane_a, s0, s_rows, sigma, g, nullptr);
         if (r != TOPO_AMD_EUNSUP) return r;
         // filter wider than a wavefront can chain: finish the smooth unfused (axis 1 goes through
