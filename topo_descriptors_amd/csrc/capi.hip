@@ -200,13 +200,17 @@ struct HostRun {
         const uintptr_t per = (((hi - lo) / n) + kHuge - 1) & ~(kHuge - 1);
         for (uintptr_t a = lo; a < hi; a += per) {
             const uintptr_t b = std::min(a + per, hi);
-            touchers.emplace_back([a, b] {
-                // read and write back one byte per page: the array keeps whatever it held
-                for (uintptr_t q = a; q < b; q += kPage) {
-                    volatile char* c = (volatile char*)q;
-                    *c = *c;
-                }
-            });
+            try {
+                touchers.emplace_back([a, b] {
+                    // read and write back one byte per page: the array keeps whatever it held
+                    for (uintptr_t q = a; q < b; q += kPage) {
+                        volatile char* c = (volatile char*)q;
+                        *c = *c;
+                    }
+                });
+            } catch (...) {
+                return;  // no thread to be had: the download faults the remaining pages in itself
+            }
         }
     }
     void ready() {
