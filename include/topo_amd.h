@@ -155,7 +155,11 @@ int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, in
  * plane, unused ones 0).  angles: HOST float32, the value stored in dir_out for each angle.
  * mean / stdev: the DEM is normalised as (x - mean) / stdev in float32 while it is read
  * (topo.py:427); topo_amd_mean_std_dev computes them for a device-resident DEM.
- * norm_out = max over angles and planes, clipped at 0; dir_out = first angle reaching it.   */
+ * norm_out = max over angles and planes, clipped at 0; dir_out = first angle reaching it.
+ * Kernels of 64 px and more (TOPO_AMD_VALLEY_FFT_MIN_KERNEL), and any too large for the
+ * direct kernel, are evaluated by FFT like the reference's signal.convolve: same contract
+ * (1e-4 of the range), but a NaN in the block then reaches every output and row blocks
+ * agree to rounding instead of bit for bit.                                                 */
 int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
                               const float* taps, const int32_t* ksize, const float* angles,
                               int n_angles, int n_planes, double mean, double stdev,

@@ -25,8 +25,12 @@ def _case(g, tag):
     return dem, size, mode, flats, sigma
 
 
+# both evaluations of the angle loop: the direct kernel (what these sizes take by default) and the
+# FFT route that large kernels take (TOPO_AMD_VALLEY_FFT_MIN_KERNEL is read at every launch)
+@pytest.mark.parametrize("route", ["direct", "fft"])
 @pytest.mark.parametrize("tag", VR_TAGS)
-def test_valley_ridge_against_the_reference(golden, tag):
+def test_valley_ridge_against_the_reference(golden, tag, route, monkeypatch):
+    monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "1" if route == "fft" else "100000")
     g = golden("valley_ridge")
     dem, size, mode, flats, sigma = _case(g, tag)
     norm_ref, dir_ref = g[f"{tag}_norm"], g[f"{tag}_dir"]
@@ -128,3 +132,56 @@ def test_single_rank_shard_valley_ridge():
     assert np.array_equal(n2.to_host(), norm) and np.array_equal(a2.to_host(), direction)
     for x in (n, a, n2, a2, dev):
         x.free()
+
+
+def _block_run(dem, taps, ksize, angles, n_planes, nblocks):
+    gny, nx = dem.shape
+    up, down = shard.halo_rows(_lib.DESC_VALLEY_RIDGE, int(ksize.max()))
+    mean, stdev = float(dem.mean()), float(dem.std())
+    norms, dirs = [], []
+    for row0, rows in shard.split_rows(gny, nblocks):
+        lo, hi = max(0, row0 - up), min(gny, row0 + rows + down)
+        dev = d.DeviceArray.from_host(dem[lo:hi])
+        n, a = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+        d.Block(dev, row0=lo, gny=gny).valley_ridge(taps, ksize, angles, n_planes, mean, stdev, n, a,
+                                                    out_row0=row0, out_rows=rows)
+        d.sync()
+        norms.append(n.to_host())
+        dirs.append(a.to_host())
+        for x in (dev, n, a):
+            x.free()
+    return np.concatenate(norms), np.concatenate(dirs)
+
+
+def test_kernels_beyond_the_lds_tile_go_through_the_fft():
+    """151 px: rotated kernels up to 214 px, more than the direct kernel can stage.  Against the
+    float64 oracle on a handful of angles; row blocks agree to rounding (the FFT size differs)."""
+    dem = orc.synthetic_dem(260, 300, seed=4)
+    size, flats = 151, [0, 0.15, 0.3]
+    angles = np.array([0, 20, 45, 90, 133], dtype=np.float32)
+    taps, ksize, ang = topo._valley_ridge_tables(topo._valley_kernels(size, flats), angles)
+    assert ksize.max() > 200
+    norm, direction = _block_run(dem, taps, ksize, ang, len(flats), 1)
+    (norm_ex, _), maps = orc.valley_ridge_exact(dem, size, "valley", flats, angles=angles, return_maps=True)
+    scale = float(np.max(np.abs(norm_ex)))
+    assert np.max(np.abs(norm - norm_ex)) <= 1e-4 * scale
+    index = np.searchsorted(angles, direction)
+    assert np.all(angles[index] == direction)
+    at_gpu_dir = np.take_along_axis(maps, index[None], axis=0)[0]
+    assert np.max(np.max(maps, axis=0) - at_gpu_dir) <= 1e-4 * scale
+    norm2, direction2 = _block_run(dem, taps, ksize, ang, len(flats), 2)
+    assert np.max(np.abs(norm2 - norm)) <= 1e-5 * scale
+    assert np.mean(direction2 == direction) >= 0.999
+
+
+def test_fft_route_equals_the_direct_kernel_to_rounding(monkeypatch):
+    dem = orc.synthetic_dem(200, 240, seed=6)
+    flats = [0, 0.15, 0.3]
+    taps, ksize, ang = topo._valley_ridge_tables(topo._ridge_kernels(33, flats), np.arange(0, 180, 9, dtype=np.float32))
+    monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "100000")
+    norm_d, dir_d = _block_run(dem, taps, ksize, ang, 3, 1)
+    monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "1")
+    norm_f, dir_f = _block_run(dem, taps, ksize, ang, 3, 1)
+    scale = float(norm_d.max())
+    assert np.max(np.abs(norm_f - norm_d)) <= 2e-5 * scale
+    assert np.mean(dir_f == dir_d) >= 0.995

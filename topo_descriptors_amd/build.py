@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtopo_amd.so")
 SOURCES = [f"disc_wave_g{g}.hip" for g in range(10)] + ["disc.hip", "disc_wave.hip", "disc_big.hip", "gauss.hip",
-                                                           "sx.hip", "valley.hip", "capi.hip"]
+                                                           "sx.hip", "valley.hip", "valley_fft.hip", "capi.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -50,7 +50,7 @@ def build_library(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=8) as pool:
         objs = list(pool.map(compile_one, srcs))
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs,
-           "-L/opt/rocm/lib", "-lrccl", "-pthread"]
+           "-L/opt/rocm/lib", "-lrccl", "-lhipfft", "-pthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

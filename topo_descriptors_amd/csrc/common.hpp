@@ -103,6 +103,10 @@ int launch_sx_multi(const Block& b, int n_az, const int32_t* first, const int32_
                     const double* dist, const int32_t* window, double height, float* const* outs);
 int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed, bool integer_valued);
 // valley / ridge index (valley.hip): taps = per angle ksize^2 x 4 floats (plane sums, flipped)
+// the same by FFT, for kernels of any size (valley_fft.hip)
+int launch_valley_ridge_fft(const Block& b, const float* taps, const int32_t* ksize, const float* angles,
+                            int n_angles, int n_planes, int kmax, double mean, double stdev, float* norm_out,
+                            float* dir_out);
 int valley_ridge_reach(const int32_t* ksize, int n_angles, int* above, int* below);
 int launch_mean_std(const float* in, size_t count, double* mean, double* stdev);
 int launch_moments(const float* in, size_t count, double pivot, bool pivot_is_first_sample, double* sum, double* sumsq);

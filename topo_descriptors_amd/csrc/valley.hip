@@ -18,11 +18,12 @@
 // the reference masks the cells its spline contaminated), so the launcher hands the kernel a
 // compressed list: weights plus the LDS offset of each non-zero tap.  Skipping exact zeros does not
 // change a sum.
-// First version: direct float32 evaluation on the vector ALU; cost ~ taps x angles x planes per
-// pixel (see DESIGN.md for what that means at 67 px).
+// Direct float32 evaluation on the vector ALU; cost ~ taps x angles x planes per pixel, so kernels of
+// 64 px and more are handed to the FFT route (valley_fft.hip), as are those too large for the LDS tile.
 #include "common.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace topo {
@@ -33,6 +34,8 @@ constexpr int kThreads = 256;
 constexpr int kTileW = 64;
 constexpr int kTileH = 16;
 constexpr int kRows = kTileH / (kThreads / 64);  // output rows per thread
+// side of the largest rotated kernel from which the FFT path takes over (TOPO_AMD_VALLEY_FFT_MIN_KERNEL)
+constexpr int kValleyFftFrom = 64;  // measured: direct 911 ms / FFT 1818 ms at 47 px, 6216 / 1818 at 95 px (8192^2)
 typedef float tap4 __attribute__((ext_vector_type(4)));  // one tap: the weights of up to four planes
 
 struct VrArgs {
@@ -251,10 +254,12 @@ int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize,
     a.mean = (float)mean;
     a.stdev = (float)stdev;
     const size_t lds = (size_t)a.rows_l * a.stride * sizeof(float);
-    if (lds > 160 * 1024) {
-        set_error("valley_ridge: rotated kernels of side %d need %zu B of LDS per tile (limit 160 KiB)", kmax, lds);
-        return TOPO_AMD_EUNSUP;
-    }
+    // large kernels: by FFT (valley_fft.hip), whose cost does not depend on the kernel size
+    const char* e = std::getenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL");
+    const int fft_from = e && *e ? std::atoi(e) : kValleyFftFrom;
+    if (kmax >= fft_from || lds > 160 * 1024)
+        return launch_valley_ridge_fft(b, taps, ksize, angles, n_angles, n_planes, kmax, mean, stdev, norm_out,
+                                       dir_out);
     // compress: the non-zero taps of each angle, with their offset in the LDS tile (smaller kernels
     // sit centred inside the reach staged for the largest one)
     std::vector<int> meta((size_t)2 * n_angles);
