@@ -94,3 +94,59 @@ def test_wrappers_equal_the_single_calls(tmp_path):
     assert np.mean(out["valley_DIR_200M"][mask] == want[1][mask]) >= 0.999
     with pytest.raises(ValueError):
         batch.compute_valley_ridge(ds, 200, "canyon", outdir=None)
+
+
+@pytest.mark.gpu
+def test_the_calls_of_the_reference_example_script_at_its_large_scales():
+    """scripts/compute_topo_descriptors.py of the reference, call by call, on a 100 m grid with scales
+    up to 30 km: disc sizes 1 ... 301 px (larger than the wave-shift kernels cover), Gaussian sigma up
+    to 75, valley / ridge kernels up to ~430 px (the FFT route).  Every output must carry the
+    reference's name and equal the single call it stands for (whose parity with the oracle the
+    other GPU tests hold, test_very_large_discs and test_kernels_beyond_the_lds_tile... included)."""
+    from oracle import topo_oracle as orc
+    from topo_descriptors_amd import helpers as hlp, topo
+
+    ny, nx = 330, 400
+    dem = orc.synthetic_dem(ny, nx, seed=12)
+    x = 2600000.0 + 100.0 * np.arange(nx)
+    y = 1200000.0 - 100.0 * np.arange(ny)
+    ds = FakeDataset(dem, x, y)
+    scales = [100, 500, 2000, 10000, 30000]
+    px, res = hlp.scale_to_pixel(scales, ds)
+    assert list(px) == [1, 5, 21, 101, 301]
+    ind_nans = (np.array([3, 200]), np.array([4, 17]))
+
+    def same(got, want, name):
+        mask = np.ones(got.shape, bool)
+        mask[ind_nans] = False
+        assert np.isnan(got[ind_nans]).all(), name
+        # (a 1-pixel disc has no neighbour: 0 / 0 everywhere, in the reference as well)
+        assert np.array_equal(got[mask], np.asarray(want)[mask], equal_nan=True), name
+
+    out = batch.compute_dem(ds, scales, ind_nans=ind_nans, outdir=None)
+    assert sorted(out) == sorted(f"DEM_{s}M" for s in scales)
+    same(out["DEM_30000M"], topo.dem(dem, 301 / 4), "DEM_30000M")
+    out = batch.compute_tpi(ds, scales, smth_factors=None, ind_nans=ind_nans, outdir=None)
+    for s, p in zip(scales, px):
+        same(out[f"TPI_{s}M"], topo.tpi(dem, int(p)), f"TPI_{s}M")
+    out = batch.compute_tpi(ds, scales, smth_factors=1, ind_nans=ind_nans, outdir=None)
+    same(out["TPI_10000M_SMTHFACT1"], topo.tpi(dem, 101, sigma=101 / 4), "TPI_10000M_SMTHFACT1")
+    out = batch.compute_gradient(ds, scales, sig_ratios=1, ind_nans=ind_nans, outdir=None)
+    want = topo.gradient(dem, 301 / 4, res)
+    for k, name in enumerate(batch._gradient_names(30000, 1)):
+        same(out[name], want[k], name)
+    out = batch.compute_std(ds, scales, ind_nans=ind_nans, outdir=None)
+    for s, p in zip(scales, px):
+        same(out[f"STD_{s}M"], topo.std(dem, int(p)), f"STD_{s}M")
+    for mode, flats in (("valley", [0, 0.2, 0.4]), ("ridge", [0, 0.15, 0.3])):
+        out = batch.compute_valley_ridge(ds, scales[3:], mode, flat_list=flats, smth_factors=0.5,
+                                         ind_nans=ind_nans, outdir=None)
+        assert sorted(out) == sorted(n for s in scales[3:] for n in batch._valley_ridge_names(s, mode, 0.5))
+        for name, array in out.items():
+            assert np.isnan(array[ind_nans]).all() and np.isfinite(np.delete(array.ravel(), ind_nans[0] * nx + ind_nans[1])).all(), name
+        norm = out[batch._valley_ridge_names(10000, mode, 0.5)[0]]
+        want = topo.valley_ridge(dem, 101, mode, flats, sigma=0.5 * 101 / 4)[0]
+        mask = ~np.isnan(norm)
+        assert np.max(np.abs(norm[mask] - want[mask])) <= 2e-5 * np.max(want), mode
+    out = batch.compute_sx(ds, 0, 1000, outdir=None)
+    assert np.array_equal(out["SX_RADIUS1000_AZIMUTH0"], topo.sx(ds, 0, 1000))
