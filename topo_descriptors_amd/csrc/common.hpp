@@ -107,6 +107,7 @@ int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed, bool int
 int launch_valley_ridge_fft(const Block& b, const float* taps, const int32_t* ksize, const float* angles,
                             int n_angles, int n_planes, int kmax, double mean, double stdev, float* norm_out,
                             float* dir_out);
+void valley_fft_release();  // destroys the cached FFT plans (topo_amd_shutdown)
 int valley_ridge_reach(const int32_t* ksize, int n_angles, int* above, int* below);
 int launch_mean_std(const float* in, size_t count, double* mean, double* stdev);
 int launch_moments(const float* in, size_t count, double pivot, bool pivot_is_first_sample, double* sum, double* sumsq);

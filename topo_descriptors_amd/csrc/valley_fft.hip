@@ -142,6 +142,14 @@ dim3 grid1(size_t n) { return dim3((unsigned)((n + kThreads - 1) / kThreads)); }
 
 }  // namespace
 
+void valley_fft_release() {
+    for (auto& kv : plan_cache()) {
+        (void)hipfftDestroy(kv.second.fwd);
+        (void)hipfftDestroy(kv.second.inv);
+    }
+    plan_cache().clear();
+}
+
 int launch_valley_ridge_fft(const Block& b, const float* taps, const int32_t* ksize, const float* angles,
                             int n_angles, int n_planes, int kmax, double mean, double stdev, float* norm_out,
                             float* dir_out) {
