@@ -321,6 +321,18 @@ def test_very_large_discs(size):
     whole = run_blocks(dem, 1, up, down, call)
     parts = run_blocks(dem, 2, up, down, call)
     assert np.array_equal(parts[0], whole[0]) and np.array_equal(parts[1], whole[1])
+    # a NaN in the upper block sends that block (and the whole DEM) to the float64 planes while the
+    # lower block keeps the uint32 ones: the same bits wherever both results are finite (on the
+    # float64 planes a NaN travels down its column's running sum, so the whole-DEM run has more NaN)
+    dem[5, 7] = np.nan
+    dem[9, 100] = -3.0e6
+    whole = run_blocks(dem, 1, up, down, call)
+    parts = run_blocks(dem, 2, up, down, call)
+    for w, q in zip(whole, parts):
+        both = np.isfinite(w) & np.isfinite(q)
+        assert np.array_equal(w[both], q[both])
+        assert both[150:].any() or size > 151  # (the widest discs reach the NaN's column from every pixel)
+        assert not np.isfinite(w[~np.isfinite(q)]).any()  # the split run is NaN only where the whole one is
 
 
 @pytest.mark.parametrize("layout", ["fractional_first", "fractional_band", "fractional_rows"])

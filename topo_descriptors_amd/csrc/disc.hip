@@ -16,6 +16,8 @@
 // Out-of-domain taps read x = 0 (zero padding of mode="same"), n is always the full tap count.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace topo {
 
 namespace {
@@ -402,6 +404,15 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
             r = launch_disc_wave_repitched(b, disc.size, tpi_out, std_out);
         if (r != TOPO_AMD_EUNSUP) return r;
     }
+    // sizes the wave-shift kernels do not cover (even, 1, 2, beyond 101): the prefix-plane path from
+    // this size on, the LDS-gather kernel below it
+    static const int big_from = [] {
+        const char* e = std::getenv("TOPO_AMD_DISC_BIG_MIN_SIZE");
+        // measured at 8192^2 (tools/generic_vs_big.py): size 66 TPI 2.24 ms (gather) / 2.05 ms (planes), STD
+        // 4.23 / 4.44; size 84 4.79 / 2.40 and 9.51 / 5.41
+        return e && *e ? std::atoi(e) : 70;
+    }();
+    if (disc.size >= big_from) return launch_disc_big(b, disc, tpi_out, std_out);
     const int n_rows = disc.dj_max - disc.dj_min + 1;
     const int halo_cols = disc.di_max - disc.di_min;
     const int cols_v = kTileW + halo_cols;
