@@ -422,10 +422,8 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
     const size_t lds_cap = 160 * 1024;
     while (tile_h > 8 && lds_for(tile_h) > lds_cap) tile_h /= 2;
     if (lds_for(tile_h) > lds_cap) return launch_disc_big(b, disc, tpi_out, std_out);
-    // prefer two resident blocks per CU when the tile allows it
-    if (tile_h == 32 && lds_for(32) > lds_cap / 2 && lds_for(16) <= lds_cap / 2) {
-        // keep 32: fewer halo re-reads beats occupancy for this LDS-bound kernel
-    }
+    // (32 rows are kept even where 16 would let two blocks share a CU: fewer halo re-reads beat
+    // occupancy for this LDS-bound kernel)
 
     std::vector<int> packed(n_rows);
     for (int r = 0; r < n_rows; ++r) {
