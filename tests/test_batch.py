@@ -19,6 +19,15 @@ def test_output_names_match_the_reference_strings():
     assert batch._valley_ridge_names(500, "ridge", 0.5) == ["ridge_NORM_500M_SMTHFACT0.5", "ridge_DIR_500M_SMTHFACT0.5"]
 
 
+def test_the_wrappers_are_reachable_from_topo_like_in_the_reference():
+    from topo_descriptors_amd import topo
+    for name in ("compute_dem", "compute_tpi", "compute_std", "compute_gradient", "compute_sx",
+                 "compute_valley_ridge"):
+        assert getattr(topo, name) is getattr(batch, name)
+    with pytest.raises(AttributeError):
+        topo.compute_nothing  # noqa: B018
+
+
 class FakeVar:
     def __init__(self, values, dims):
         self.values, self.dims = values, dims

@@ -16,6 +16,16 @@ from . import _lib, helpers as hlp
 logger = logging.getLogger(__name__)
 
 
+def __getattr__(name):
+    """The reference keeps its batch wrappers in this module (``tp.compute_tpi(...)``, topo.py:24-141 and
+    on); here they live in ``batch`` (which imports this module) and are resolved on first use."""
+    if name.startswith("compute_"):
+        from . import batch  # noqa: PLC0415
+        if hasattr(batch, name):
+            return getattr(batch, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
 # ---- small utilities ------------------------------------------------------------------------
 def _unwrap(dem):
     """ndarray view of an ndarray or DataArray-like input, plus a re-wrapper."""
