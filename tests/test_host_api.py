@@ -190,3 +190,34 @@ def test_valley_kernels_match_the_reference_kernels_and_errors(golden):
             topo._valley_kernels(size, [0, 0.15, 0.3])
     with pytest.raises(ValueError):
         topo.valley_ridge(np.zeros((8, 8), np.float32), 5, "canyon")
+
+
+def test_the_helpers_either_side_of_the_path(caplog):
+    from topo_descriptors_amd import helpers as hlp
+
+    @hlp.timer
+    def work(a, b=2):
+        """doc"""
+        return a * b
+
+    with caplog.at_level("INFO", logger="topo_descriptors_amd.helpers"):
+        assert work(3, b=4) == 12
+    assert work.__name__ == "work" and work.__doc__ == "doc"
+    assert any("Computed in" in r.getMessage() for r in caplog.records)
+
+    nan = np.nan
+    a = np.array([[nan, 1.0, nan, nan, 4.0, nan],
+                  [nan, nan, nan, nan, nan, nan],
+                  [7.0, nan, nan, nan, nan, nan],
+                  [1.0, 2.0, 3.0, 4.0, 5.0, 6.0]], dtype=np.float32)
+    f = hlp.fill_na_array(a)
+    assert f.dtype == np.float32 and np.isnan(a[0, 0])  # a copy
+    assert f[0, 0] == 1.0 and f[0, 5] == 4.0             # edge values beyond the valid samples
+    assert f[0, 2] == 1.0 and f[0, 3] == 4.0             # nearest valid sample along x
+    assert np.isnan(f[1]).all() and np.isnan(f[2, 1:]).all() and f[2, 0] == 7.0  # too few samples: left alone
+    assert np.array_equal(f[3], a[3])
+    if hlp._xr is None:
+        for call in (lambda: hlp.get_dem_netcdf("dem.nc"), lambda: hlp.fill_na(None),
+                     lambda: hlp.to_netcdf(a, None, "x")):
+            with pytest.raises(ImportError, match="xarray"):
+                call()

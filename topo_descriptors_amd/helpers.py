@@ -6,7 +6,10 @@ check_dem :171, get_da :191).  No per-pixel arithmetic happens here.  xarray is 
 anything that quacks like a Dataset (``ds["x"].values``, ``ds.attrs["crs"]``, iterable
 variable names, ``ds[name].dims``) is accepted, because the GPU box may not have xarray.
 """
+import datetime
+import functools
 import logging
+import time
 
 import numpy as np
 
@@ -86,3 +89,65 @@ def get_sigmas(smth_factors, scales_pxl):
     factors = np.array([f if f else np.nan for f in smth_factors], dtype=np.float64)
     sigmas = factors * np.asarray(scales_pxl) / CFG.scale_std
     return [None if np.isnan(s) else s for s in sigmas]
+
+
+# ---- the steps either side of the path: thin, and xarray's where the reference uses it
+def _need_xarray(what):
+    if _xr is None:
+        raise ImportError(f"{what} reads / writes netCDF through xarray, which is not installed here; "
+                          "the descriptor functions themselves accept any Dataset-like object")
+    return _xr
+
+
+def get_dem_netcdf(path_dem):
+    """The DEM of a netCDF file as a float32 Dataset, elevations at or below ``CFG.min_elevation``
+    masked as NaN (reference helpers.py:17-31).  Needs xarray."""
+    xr = _need_xarray("get_dem_netcdf")
+    dem_ds = xr.open_dataset(path_dem).astype(np.float32).squeeze(drop=True)
+    return dem_ds.where(dem_ds > CFG.min_elevation)
+
+
+def to_netcdf(array, dem_ds, name, crop=None, outdir=".", units=None):
+    """``array`` saved as ``topo_<NAME>.nc`` with the coordinates and attributes of ``dem_ds``
+    (reference helpers.py:34-65).  Needs xarray; ``batch.write_output`` is the same writer and falls
+    back to ``.npy`` without it."""
+    _need_xarray("to_netcdf")
+    from . import batch  # noqa: PLC0415  (batch imports this module)
+    return batch.write_output(array, dem_ds, name, crop=crop, outdir=outdir, units=units)
+
+
+def fill_na_array(values, x_coords=None):
+    """NaNs of a 2-D array replaced row by row with the nearest valid sample along x, the edge value
+    beyond the first / last valid sample: what ``interpolate_na(dim="x", method="nearest",
+    fill_value="extrapolate")`` does in the reference's ``fill_na`` (helpers.py:137-154), through the
+    same ``scipy.interpolate.interp1d`` xarray uses.  Rows with fewer than two valid samples are left
+    alone.  Not checked against the reference here (xarray is absent from the image)."""
+    from scipy.interpolate import interp1d  # noqa: PLC0415
+
+    out = np.array(values, copy=True)
+    x = np.arange(out.shape[1], dtype=np.float64) if x_coords is None else np.asarray(x_coords, dtype=np.float64)
+    for row in out:
+        bad = np.isnan(row)
+        if bad.any() and (~bad).sum() >= 2:
+            fill = interp1d(x[~bad], row[~bad], kind="nearest", fill_value="extrapolate", assume_sorted=False)
+            row[bad] = fill(x[bad])
+    return out
+
+
+def fill_na(dem_ds):
+    """``(ind_nans, filled Dataset)``: where the DEM has NaNs, and the DEM with them interpolated
+    along x by the nearest valid value (reference helpers.py:137-154).  Needs xarray."""
+    _need_xarray("fill_na")
+    ind_nans = np.where(np.isnan(get_da(dem_ds)))
+    return ind_nans, dem_ds.interpolate_na(dim="x", method="nearest", fill_value="extrapolate")
+
+
+def timer(func):
+    """Decorator that logs how long ``func`` took (reference helpers.py:157-168)."""
+    @functools.wraps(func)
+    def timed(*args, **kwargs):
+        start = time.monotonic()
+        result = func(*args, **kwargs)
+        logger.info("Computed in %s (HH:mm:ss)", datetime.timedelta(seconds=time.monotonic() - start))
+        return result
+    return timed
