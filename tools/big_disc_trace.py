@@ -1,3 +1,5 @@
+"""Launch topo tpi / std at 151, 401 and 1001 px on an 8192^2 DEM a few times: the workload for
+`rocprofv3 --kernel-trace` when looking at the prefix-plane kernels (disc_big.hip)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 from topo_descriptors_amd import device as d

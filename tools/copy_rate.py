@@ -1,3 +1,5 @@
+"""What a plain device-to-device copy of the bench DEM reaches (the practical ceiling of a 1:1
+read / write stream), next to TPI on the smallest discs.  usage: copy_rate.py"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 from topo_descriptors_amd import _lib, device as d

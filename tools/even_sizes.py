@@ -1,3 +1,5 @@
+"""TPI / STD on disc sizes the wave-shift kernels do not cover (1, even sizes, beyond 101) on a 16384^2
+DEM.  usage: even_sizes.py"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 from topo_descriptors_amd import device as d

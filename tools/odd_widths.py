@@ -1,3 +1,5 @@
+"""Every descriptor on DEM widths that are and are not multiples of 4 (16384 rows): the unaligned
+widths go through the re-pitched copy of disc.hip.  usage: odd_widths.py"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 from topo_descriptors_amd import device as d

@@ -1,3 +1,5 @@
+"""topo_amd_shutdown followed by a new initialisation, with FFT plans cached in between: the second
+run must reproduce the first.  usage: shutdown_reinit_check.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
