@@ -1,7 +1,7 @@
 """Randomised parity sweep of topo.tpi / topo.std / topo.tpi_std against the exact oracle, plus
 row-block bit-identity, over shapes, disc sizes and value classes the structured tests do not
 enumerate (test-side tool: imports the oracle).  Run on the GPU box:
-    python tools/fuzz_parity.py [seconds=60] [seed=0]
+    python tools/fuzz_parity.py [seconds=60] [seed=0] [big]
 Prints one line per failure and a summary; exit code 1 if anything failed."""
 import os
 import sys
@@ -66,10 +66,14 @@ def check(name, got, want, tol, ctx):
         fails.append(f"{name} {ctx}: max err {np.max(err):.3g} tol {tol:.3g}")
 
 
+# third argument "big": the sizes around and beyond the wave-shift range (LDS-gather kernel up to 68,
+# prefix planes from 70 / beyond 101) instead of the common ones
+SIZES = ([66, 68, 70, 84, 100, 101, 103, 121, 151, 200, 255] if len(sys.argv) > 3 and sys.argv[3] == "big"
+         else [1, 2, 3, 4, 5, 6, 7, 9, 11, 15, 17, 19, 25, 31, 33, 41, 67])
 while time.time() < t_end:
     ny = int(rng.choice([1, 2, 3, 7, 33, 59, 60, 61, 120, 127, 200, 333, int(rng.integers(1, 400))]))
     nx = int(rng.choice([1, 3, 4, 5, 64, 189, 190, 191, 192, 250, 256, 380, int(rng.integers(1, 500))]))
-    size = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9, 11, 15, 17, 19, 25, 31, 33, 41, 67]))
+    size = int(rng.choice(SIZES))
     dem, kind = make_dem(ny, nx)
     ctx = f"ny={ny} nx={nx} size={size} dem={kind}"
     cases += 1
