@@ -8,6 +8,7 @@ parameters, hands over C-contiguous float32 buffers and wraps the results.
 """
 import ctypes as C
 import logging
+import os
 
 import numpy as np
 
@@ -359,16 +360,26 @@ def _valley_ridge_tables(kernels, angles):
     if not 1 <= n <= 4:
         raise ValueError(f"valley_ridge: {n} flat fractions; 1 to 4 are supported")
     centre = (n - 1) // 2
-    taps, ksize = [], []
-    for angle in angles:
+
+    def one_angle(angle):
         turned = _rotate_kernels(kernels, angle).astype(np.float64)
         side = turned.shape[1]
         block = np.zeros((side, side, 4), dtype=np.float32)
         for i in range(n):
             total = sum(turned[b] for b in range(n) if 0 <= i - b + centre < n)
             block[:, :, i] = total[::-1, ::-1]
-        taps.append(block.reshape(-1))
-        ksize.append(side)
+        return block.reshape(-1)
+
+    # the angles are independent and scipy / numpy release the GIL in the rotation and the
+    # re-normalisation: for large kernels (seconds per call) they are spread over host threads
+    workers = min(32, os.cpu_count() or 1, len(angles))
+    if kernels.shape[1] >= 65 and workers > 1:
+        from concurrent.futures import ThreadPoolExecutor  # noqa: PLC0415
+        with ThreadPoolExecutor(workers) as pool:
+            taps = list(pool.map(one_angle, angles))
+    else:
+        taps = [one_angle(angle) for angle in angles]
+    ksize = [int(round((t.size // 4) ** 0.5)) for t in taps]
     return (np.ascontiguousarray(np.concatenate(taps), dtype=np.float32), np.asarray(ksize, dtype=np.int32),
             np.ascontiguousarray(angles, dtype=np.float32))
 
