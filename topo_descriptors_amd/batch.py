@@ -230,8 +230,17 @@ def compute_valley_ridge(dem_ds, scales, mode, flat_list=[0, 0.15, 0.3], smth_fa
     res = _ResidentDem(hlp.get_da(dem_ds).values)
     norm, direction, smooth, results = res.plane(), res.plane(), None, {}
     angles = np.arange(0, 180, dtype=np.float32)
+
+    def tables(px):
+        kernels = topo._ridge_kernels(int(px), flat_list) if mode == "ridge" else topo._valley_kernels(int(px), flat_list)
+        return (kernels.shape[0],) + topo._valley_ridge_tables(kernels, angles)
+
+    # the rotated kernels of the next scale are built on the host while the GPU works on this one
+    from concurrent.futures import ThreadPoolExecutor  # noqa: PLC0415
+    pool = ThreadPoolExecutor(1)
     try:
-        for scale, px, fact, sigma in zip(scales, scales_pxl, smth_factors, sigmas):
+        ahead = pool.submit(tables, scales_pxl[0]) if len(scales) else None
+        for k, (scale, px, fact, sigma) in enumerate(zip(scales, scales_pxl, smth_factors, sigmas)):
             logger.info("Computing scale %s meters with smoothing factor %s ...", scale, fact)
             block, plane = res.block, res.dev
             if sigma:  # pre-smoothing (reference topo.py:424-425)
@@ -239,12 +248,13 @@ def compute_valley_ridge(dem_ds, scales, mode, flat_list=[0, 0.15, 0.3], smth_fa
                 res.block.gaussian(sigma, sigma, smooth)
                 block, plane = d.Block(smooth), smooth
             mean, stdev = d.mean_std(plane)
-            kernels = topo._ridge_kernels(int(px), flat_list) if mode == "ridge" else topo._valley_kernels(int(px), flat_list)
-            taps, ksize, ang = topo._valley_ridge_tables(kernels, angles)
-            block.valley_ridge(taps, ksize, ang, kernels.shape[0], mean, stdev, norm, direction)
+            n_planes, taps, ksize, ang = ahead.result()
+            ahead = pool.submit(tables, scales_pxl[k + 1]) if k + 1 < len(scales) else None
+            block.valley_ridge(taps, ksize, ang, n_planes, mean, stdev, norm, direction)
             for array, name in zip((norm.to_host(), direction.to_host()), _valley_ridge_names(scale, mode, fact)):
                 _finish(array, ind_nans, dem_ds, name, crop, outdir, "1", results)
     finally:
+        pool.shutdown(wait=True, cancel_futures=True)
         for a in (norm, direction, smooth):
             if a is not None:
                 a.free()
