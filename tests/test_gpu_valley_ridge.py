@@ -27,12 +27,8 @@ def _case(g, tag):
 
 # both evaluations of the angle loop: the direct kernel (what these sizes take by default) and the
 # FFT route that large kernels take (TOPO_AMD_VALLEY_FFT_MIN_KERNEL is read at every launch)
-# (the FFT route on three of the cases only: every new transform length costs rocFFT a run-time
-# compilation of several seconds on a machine that has not seen it before)
-VR_FFT_TAGS = ["int_ridge_s7", "int_valley_s17", "frac_valley_s9_sig"]
-
-
-@pytest.mark.parametrize("tag, route", [(t, "direct") for t in VR_TAGS] + [(t, "fft") for t in VR_FFT_TAGS])
+@pytest.mark.parametrize("route", ["direct", "fft"])
+@pytest.mark.parametrize("tag", VR_TAGS)
 def test_valley_ridge_against_the_reference(golden, tag, route, monkeypatch):
     monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "1" if route == "fft" else "100000")
     g = golden("valley_ridge")
