@@ -1,0 +1,533 @@
+// K1 ring build: TPI with the window kept as a ring of prefix rows, 8 columns per lane.
+//
+// What the chain costs on gfx950 (tools/ubench/valu_mix.hip, profiles/r02_valu_mix_rate.txt): v_add_u32 /
+// v_sub_u32 issue in 2 cycles per wave and SIMD, every DPP form (and v_add3_u32) in 4, and a block of 12
+// waves runs like one of 16 (its waves do not spread evenly over the 4 SIMDs).  With 4 columns per lane
+// (disc_wave_impl.hpp) a 67-px disc needs 18 lane hops of 4 partial sums for 4 outputs and only 46 of
+// 64 lanes end with a full sum; a third of the VALU time is transport.  This build:
+//
+//   * gives a lane NCR = 8 adjacent columns: 10 hops of 8 partial sums for 8 outputs, 54 of 64 lanes
+//     valid (432 of 512 staged columns), each hop fused into an add (v_add_u32_dpp);
+//   * visits the runs of the disc from the rim inwards with TWO chains (one collecting the columns right
+//     of the pixel with wave_shl, one those left of it with wave_shr), so that a run's column sums are
+//     formed right before their first use and die after the last: ~120 live column sums instead of 168;
+//   * keeps the prefix rows Q in a RING of R = SIZE + B rows of LDS (B = 8 output rows per phase, one
+//     per wave).  A row is written once, where it stays until the window has passed it: no LDS -> LDS
+//     move of the carried window, no fix-up pass, no full restaging;
+//   * stages by COLUMN ownership: wave w owns staged columns 64 w .. 64 w + 63, one per lane, for the
+//     whole strip.  Each phase it loads its segment of the next 8 DEM rows (8 dword loads, in flight
+//     during the chain), and after the chain (barrier) truncates, classifies, continues its running
+//     uint32 prefix (one register) and writes 8 x ds_write_b32 over the 8 oldest rows (barrier);
+//   * takes the pixel's own value from the column sum of the outermost run (a single tap).
+//
+// Blocks are 8 waves (2 per SIMD, up to 256 VGPRs).  Tile list, XCD-contiguous runs and the
+// finalisation are those of tpi_march_kernel, so the results have the same bits.  The per-tile state
+// map (p.defer) has this build's own geometry (strips of 54 x 8 columns, tiles of 64 rows); the
+// general kernel reads it through WaveArgs::map_th / map_tw.  MODE kRingFraction is the second pass
+// over the tiles kRingMainFrac marked kNeedsFraction (the ring then holds the fractional parts in units
+// of 2^-16 m).
+#pragma once
+
+namespace topo {
+
+namespace {
+
+#ifndef RING_PRIO_SWITCH_D
+#define RING_PRIO_SWITCH_D 2
+#endif
+#ifndef RING_LEAD
+#define RING_LEAD 3
+#endif
+#ifdef RING_NOSB
+#define RING_SB()
+#else
+#define RING_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+#define DPP_WAVE_SHR1 0x138  // lane i takes lane i - 1; lane 0 takes 0 (bound_ctrl)
+
+__device__ __forceinline__ uint32_t hop_up(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_SHR1, 0xf, 0xf, true);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int SIZE, int NCR>
+struct RGeo {
+    static constexpr DiscTable<SIZE> T = make_disc_table<SIZE>();
+    static_assert(T.centre == 0 && T.off_min == -T.off_max, "odd disc sizes only");
+    static_assert(NCR % 4 == 0, "16-byte pieces");
+    static constexpr int M = T.off_max;
+    static constexpr int PARTS = NCR / 4;           // 16-byte pieces per lane and row
+    static constexpr int DL = (M + NCR - 1) / NCR;  // lane hops per side
+    static constexpr int NVL = 64 - 2 * DL;         // lanes that end up with full sums
+    static constexpr int TILE_W = NCR * NVL;        // valid output columns per strip
+    static constexpr int X0 = NCR * DL;             // staged column of the first valid output
+    static constexpr int W = 64 * NCR;              // staged columns = dwords per ring row
+    static_assert(NVL >= 16, "disc too wide for one wavefront");
+    static constexpr int NR = T.num_runs;
+    // The two-sided chain: step D (lane distance, DL .. 0) adds, for output sub-column t, the lane's own
+    // columns s at offsets di = NCR D + s - t >= 0 (right chain) and -NCR D + s - t < 0 (left chain).
+    struct Sched {
+        int first_step[SIZE];  // per run: the largest step that uses it
+        int order[SIZE];       // the runs in the order they are first needed (rim first)
+        int centre_run;        // run with lo = hi = 0 (the pixel's own row only), or -1
+    };
+    static constexpr Sched make() {
+        Sched t{};
+        for (int r = 0; r < SIZE; ++r) t.first_step[r] = -1;
+        for (int r = 0; r < SIZE; ++r) t.order[r] = 0;
+        t.centre_run = -1;
+        for (int D = 0; D <= DL; ++D)
+            for (int s = 0; s < NCR; ++s)
+                for (int q = 0; q < NCR; ++q) {
+                    const int dr = NCR * D + s - q, dl = -NCR * D + s - q;
+                    if (dr >= 0 && dr <= M) {
+                        const int r = T.run_of[dr - T.off_min];
+                        if (D > t.first_step[r]) t.first_step[r] = D;
+                    }
+                    if (dl < 0 && dl >= -M) {
+                        const int r = T.run_of[dl - T.off_min];
+                        if (D > t.first_step[r]) t.first_step[r] = D;
+                    }
+                }
+        int n = 0;
+        for (int D = DL; D >= 0; --D)
+            for (int d = M; d >= 0; --d) {  // within a step: rim first
+                const int r = T.run_of[d - T.off_min];
+                bool seen = false;
+                for (int i = 0; i < n; ++i) seen = seen || t.order[i] == r;
+                if (!seen && t.first_step[r] == D) t.order[n++] = r;
+            }
+        for (int r = 0; r < NR; ++r)
+            if (T.run_lo[r] == 0 && T.run_hi[r] == 0) t.centre_run = r;
+        return t;
+    }
+    static constexpr Sched S = make();
+    static_assert(S.centre_run >= 0, "the disc's outermost column is the pixel's own row");
+};
+
+// Ring row layout: PARTS pieces of 256 dwords; lane l keeps columns NCR l + 4 P .. + 3 at dwords
+// 256 P + 4 l .. + 3, so that every ds_read_b128 of a wave is 1 KiB of consecutive bytes.
+template <int NCR>
+__device__ __forceinline__ int ring_dword_of_column(int c) {
+    return ((c % NCR) / 4) * 256 + (c / NCR) * 4 + (c % 4);
+}
+
+// Disc sums of one output row.  ring: LDS image; s0: ring slot of the row's Q index 0 (prefix through the
+// DEM row above its window), wave-uniform; acc[t]: sum over the disc for the lane's own column NCR lane + t,
+// valid for DL <= lane < 64 - DL; ctr[t]: the staged value of the pixel itself.  The prefix rows of run
+// i + LEAD are fetched before the column sums of run i are formed.
+template <int SIZE, int NCR, int R, int LEAD>
+__device__ __forceinline__ void ring_disc_sum(const uint32_t* ring, int s0, int lane, uint32_t (&acc)[NCR],
+                                              uint32_t (&ctr)[NCR], bool young) {
+    using G = RGeo<SIZE, NCR>;
+    constexpr int NR = G::NR;
+    constexpr int DL = G::DL;
+    constexpr int M = G::M;
+    u32x4 top[NR][G::PARTS], bot[NR][G::PARTS];
+    uint32_t cv[NR][NCR];
+    uint32_t aR[NCR], aL[NCR];
+    const uint32_t* col = ring + lane * 4;
+    auto fetch = [&](int i) {
+        const int r = G::S.order[i];
+        int st = s0 + G::T.run_hi[r] + 1 + M, sb = s0 + G::T.run_lo[r] + M;
+        st = st >= R ? st - R : st;
+        sb = sb >= R ? sb - R : sb;
+#pragma unroll
+        for (int P = 0; P < G::PARTS; ++P) {
+            top[r][P] = *reinterpret_cast<const u32x4*>(col + st * G::W + P * 256);
+            bot[r][P] = *reinterpret_cast<const u32x4*>(col + sb * G::W + P * 256);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < LEAD && i < NR; ++i) fetch(i);
+    // Two waves share a SIMD and the hardware serves the older one first: waves 0-3 finish their chain in
+    // 74 % of the time of waves 4-7 (s_memtime stamps, -DRING_STAMPS) and then idle at the barrier.  Giving
+    // the younger wave priority for the first part of the chain (-DRING_PRIO) moved that around without
+    // shortening the phase (4.61 ms against 4.62 ms at 67 px), so it is off.
+#ifdef RING_PRIO
+    if (young) __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int D = DL; D >= 0; --D) {
+#ifdef RING_PRIO
+        if (D == RING_PRIO_SWITCH_D && young) __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            if (G::S.first_step[G::S.order[j]] == D) {
+                const int r = G::S.order[j];
+                if (j + LEAD < NR) fetch(j + LEAD);
+                RING_SB();
+#pragma unroll
+                for (int P = 0; P < G::PARTS; ++P)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) cv[r][4 * P + s] = top[r][P][s] - bot[r][P][s];
+                RING_SB();
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NCR; ++t) {
+            uint32_t pr = 0, pl = 0;
+            bool anyr = false, anyl = false;
+#pragma unroll
+            for (int s = 0; s < NCR; ++s) {
+                const int dr = NCR * D + s - t;
+                const int dl = -NCR * D + s - t;
+                if (dr >= 0 && dr <= M) {
+                    const uint32_t c = cv[G::T.run_of[dr - G::T.off_min]][s];
+                    pr = anyr ? pr + c : c;
+                    anyr = true;
+                }
+                if (dl < 0 && dl >= -M) {
+                    const uint32_t c = cv[G::T.run_of[dl - G::T.off_min]][s];
+                    pl = anyl ? pl + c : c;
+                    anyl = true;
+                }
+            }
+            if (D == DL) {
+                aR[t] = pr;
+                aL[t] = pl;
+            } else {
+                // the lane's own part is made opaque so that the hop's add stays a two-operand add and the
+                // DPP move folds into it (v_add_u32_dpp, 4 cycles) instead of feeding a v_add3_u32 (4 + 4)
+                if (anyr) {
+                    asm("" : "+v"(pr));
+                    aR[t] = hop(aR[t]) + pr;
+                } else {
+                    aR[t] = hop(aR[t]);
+                }
+                if (anyl) {
+                    asm("" : "+v"(pl));
+                    aL[t] = hop_up(aL[t]) + pl;
+                } else {
+                    aL[t] = hop_up(aL[t]);
+                }
+            }
+        }
+        RING_SB();
+    }
+#pragma unroll
+    for (int t = 0; t < NCR; ++t) {
+        acc[t] = aR[t] + aL[t];
+        ctr[t] = cv[G::S.centre_run][t];
+    }
+}
+
+template <int SIZE, int NCR>
+struct RingCfg {
+    using G = RGeo<SIZE, NCR>;
+    static constexpr int NW = 8;        // waves per block = output rows per phase = rows staged per phase
+    static constexpr int B = NW;
+    static constexpr int TH = 64;       // rows of a map tile
+    static constexpr int PPT = TH / B;  // phases per tile
+    static constexpr int R = SIZE + B;  // ring slots: the window of a phase (Q indices 0 .. SIZE of B rows)
+    static constexpr int HALO = SIZE - 1;
+    // stream rows above the first window row: >= 1 (Q index 0 = "through the row above"), and such that the
+    // rows staged before phase 0 are whole batches
+    static constexpr int PAD = 1 + (B - (1 + HALO + B) % B) % B;
+    static constexpr int PRO = PAD + HALO + B;               // rows staged before phase 0
+    static constexpr int NB_PRO = PRO / B;                   // as batches
+    static constexpr int HIST = (SIZE + 2 * B - 1) / B + 1;  // batches a phase's window can touch (one to spare)
+    static_assert(G::W / 64 == NW, "one staged 64-column segment per wave");
+    static constexpr size_t LDS = (size_t)R * G::W * sizeof(uint32_t) + 2 * NW * sizeof(int) + 16;
+    static_assert(TH % B == 0 && PRO % B == 0, "whole batches");
+    static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
+    static_assert(HIST <= 31, "flag history");
+};
+
+constexpr bool ring_fits(int size, int ncr) {
+    return size >= 5 && (size_t)(size + 8) * 64 * ncr * 4 + 128 <= 160 * 1024 && 64 - 2 * ((size / 2 + ncr - 1) / ncr) >= 16;
+}
+
+enum RingMode { kRingMain = 0, kRingMainFrac = 1, kRingFraction = 2 };
+
+// kRingMain: tiles with fractional samples are left to the general kernel.  kRingMainFrac: their exact sums of
+// trunc(x) go to p.sums and they are marked kNeedsFraction.  kRingFraction: the second pass over those tiles
+// (sum of the fractional parts, then TPI with the expression and operands of tpi_fraction_march_kernel).
+template <int SIZE, int NCR, int MODE>
+__global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+    using G = RGeo<SIZE, NCR>;
+    using C = RingCfg<SIZE, NCR>;
+    constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW;
+    constexpr int DL = G::DL;
+    constexpr bool FRACTION = MODE == kRingFraction;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    uint32_t* Q = lds_u;
+    int* wflags = reinterpret_cast<int*>(Q + R * G::W);  // [2 parities][NW]: what each wave saw in the batch it staged
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ntiles = tiles_x * tiles_y;
+    const int nb = gridDim.x;
+    const int per_xcd = nb >> 3;
+    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int per = (ntiles + nb - 1) / nb;  // a contiguous run of the strip-major tile list; neighbouring runs in one XCD
+    const int first = vb * per;
+    const int last = min(first + per, ntiles);
+    const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
+
+    if (FRACTION) {
+        // nothing to do on a DEM of whole metres: one flag per lane, 64 tiles per load
+        bool any = false;
+        for (int base = first; base < last; base += 64) {
+            const int mine = base + lane;
+            any = any || __builtin_amdgcn_ballot_w64(mine < last && p.defer[mine < last ? mine : first] == kNeedsFraction) != 0;
+        }
+        if (!any) return;  // the same for every thread of the block
+    }
+
+    // staging: this lane's column of this wave's segment
+    const int scol = 64 * wave + lane;                 // staged column
+    const int sdw = ring_dword_of_column<NCR>(scol);   // its dword in a ring row
+    const int rmin = max(0, p.in_row0), rmax = min(p.gny, p.in_row0 + p.in_rows);  // DEM rows this block may read
+
+#pragma unroll 1
+    for (int tile0 = first; tile0 < last;) {
+        // one run: the block's tiles of one column strip, top to bottom
+        const int ty0 = tile0 % tiles_y;
+        const int strip = tile0 / tiles_y;
+        const int run_tiles = min(last - tile0, tiles_y - ty0);
+        const int nphase = run_tiles * PPT;
+        const int ox0 = strip * G::TILE_W;
+        const int oyS = (p.out_row0 / C::TH + ty0) * C::TH;  // global multiples of TH
+        const int gx0 = ox0 - G::X0;                          // global column of staged column 0
+        // stream row n is DEM row gy0 + n; its prefix row goes to ring slot n % R, so Q index k of output row
+        // oyS + j sits in slot (j + k + PAD - 1) % R
+        const int gy0 = oyS - G::M - C::PAD;
+        const int gcol = gx0 + scol;
+        const bool col_ok = gcol >= 0 && gcol < p.nx;
+        const float* src = p.in + (col_ok ? gcol : 0);
+        auto load_batch = [&](int n0, float (&v)[B]) {
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                int gy = gy0 + n0 + r;
+                gy = min(max(gy, rmin), rmax - 1);  // a clamped row is read and thrown away
+                v[r] = src[(size_t)(gy - p.in_row0) * p.nx];
+            }
+        };
+        uint32_t run = 0;  // running prefix of this lane's column (wraps, harmlessly)
+        int wslot = 0;     // ring slot of the next row to stage
+        // Staging a batch of B rows in two halves.  convert_batch: the loaded samples -> the prefix values
+        // to write (registers) and what the wave saw; it ends with the wave's only wait on its loads, so it
+        // runs before any younger store is issued (vmcnt counts loads and stores together, in order, and a
+        // wait for the last load behind two output stores would wait for the stores too: 1300 cycles per
+        // phase in the first version).  write_batch: the B ds_write_b32 over the B oldest rows.
+        auto convert_batch = [&](int n0, const float (&v)[B], uint32_t (&q)[B]) {
+            uint32_t amax = 0;  // largest |x| seen, as float bits (NaN / inf sort above all)
+            bool frac = false;
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                const int gy = gy0 + n0 + r;
+                const bool ok = col_ok && gy >= rmin && gy < rmax;
+                const float x = ok ? v[r] : 0.0f;  // padding is staged as zero (mode="same")
+                if (FRACTION) {
+                    run += stage_value<kStF>(x, 0.0f, 0);
+                } else {
+                    // (int)x truncates towards zero; NaN -> 0 and |x| >= 2^31 saturates, both caught by amax
+                    const int xi = (int)x;
+                    frac |= x != (float)xi;
+                    amax = max(amax, __float_as_uint(x) & 0x7fffffffu);
+                    run += (uint32_t)xi;
+                }
+                q[r] = run;
+            }
+            int wf = 0;
+            if (!FRACTION) {
+                // |trunc(x)| <= kAbsLim  <=>  |x| < kAbsLim + 1
+                if (__builtin_amdgcn_ballot_w64(frac)) wf |= kTileFrac;
+                if (__builtin_amdgcn_ballot_w64(amax >= __float_as_uint(kAbsLim + 1.0f))) wf |= kTileFloat;
+            }
+            return wf;
+        };
+        auto write_batch = [&](const uint32_t (&q)[B]) {
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                int s = wslot + r;
+                s = s >= R ? s - R : s;
+                Q[s * G::W + sdw] = q[r];
+            }
+            wslot += B;
+            wslot = wslot >= R ? wslot - R : wslot;
+        };
+        auto stage_batch = [&](int n0, const float (&v)[B]) {
+            uint32_t q[B];
+            const int wf = convert_batch(n0, v, q);
+            write_batch(q);
+            return wf;
+        };
+        unsigned hist_frac = 0, hist_float = 0;
+        // every wave folds the 8 waves' flags of the batch just staged into its (identical) history
+        auto fold_flags = [&](int parity) {
+            const int4 a = *reinterpret_cast<const int4*>(wflags + parity * NW);
+            const int4 b = *reinterpret_cast<const int4*>(wflags + parity * NW + 4);
+            const int all = __builtin_amdgcn_readfirstlane(a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w);
+            hist_frac = ((hist_frac << 1) | ((all & kTileFrac) ? 1u : 0u)) & ((1u << C::HIST) - 1u);
+            hist_float = ((hist_float << 1) | ((all & kTileFloat) ? 1u : 0u)) & ((1u << C::HIST) - 1u);
+        };
+
+        // ---- prologue: the window of phase 0, two batches of loads in flight; leaves the batch that follows
+        // the prologue in va ----
+        float va[B], vb2[B];
+        int pro_flags = 0;
+        load_batch(0, va);
+#pragma unroll 1
+        for (int k = 0; k < C::NB_PRO; k += 2) {
+            load_batch((k + 1) * B, vb2);
+            pro_flags |= stage_batch(k * B, va);
+            if (k + 1 < C::NB_PRO) {
+                load_batch((k + 2) * B, va);
+                pro_flags |= stage_batch((k + 1) * B, vb2);
+            }
+        }
+        if (C::NB_PRO % 2 != 0) {
+#pragma unroll
+            for (int r = 0; r < B; ++r) va[r] = vb2[r];
+        }
+        if (lane == 0) wflags[wave] = pro_flags;
+        __syncthreads();
+        fold_flags(0);
+
+        const int ocol = gx0 + lane * NCR;  // the lane's own columns
+        const bool lane_ok = lane >= DL && lane < 64 - DL;
+        int s0 = C::PAD - 1 + wave;  // slot of Q index 0 of this wave's row in phase 0
+        int mode = kTileDone;
+#ifdef RING_STAMPS
+        long long tsum[5] = {0, 0, 0, 0, 0};
+#define RING_STAMP(i) { const long long now_ = __builtin_amdgcn_s_memtime(); tsum[i] += now_ - tlast; tlast = now_; }
+        long long tlast = __builtin_amdgcn_s_memtime();
+#else
+#define RING_STAMP(i)
+#endif
+#pragma unroll 1
+        for (int ph = 0; ph < nphase; ++ph) {
+            const int tile = tile0 + ph / PPT;
+            if (FRACTION) {
+                if (ph % PPT == 0) mode = __builtin_amdgcn_readfirstlane((int)p.defer[tile]);
+            } else {
+                const int now = hist_float ? kTileGeneral
+                                           : (hist_frac ? (MODE == kRingMainFrac ? kNeedsFraction : kTileGeneral) : kTileDone);
+                if (ph % PPT == 0) {
+                    mode = now;
+                    if (threadIdx.x == 0) p.defer[tile] = (uint8_t)mode;
+                } else if (mode != kTileGeneral && now != mode && !(mode == kNeedsFraction && now == kTileDone)) {
+                    // the tile's later rows brought in what its first phase had not seen: leave all of it
+                    mode = kTileGeneral;
+                    if (threadIdx.x == 0) p.defer[tile] = (uint8_t)kTileGeneral;
+                }
+            }
+            const bool compute = FRACTION ? mode == kNeedsFraction : mode != kTileGeneral;
+            uint32_t next_q[B];
+            int next_flags = 0;
+            bool converted = false;
+            if (compute) {
+                const int oy = oyS + ph * B + wave;
+                const bool live = lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx;
+                const bool live2 = live && ocol + 4 < p.nx;  // nx % 4 == 0: the lane's second 16 bytes may lie outside
+                const size_t o = live ? (size_t)(oy - p.out_row0) * p.nx + ocol : 0;
+                Vec4<int> sv[2];
+                Vec4<float> xs[2];
+                if (FRACTION) {
+                    const size_t xi = live ? (size_t)(oy - p.in_row0) * p.nx + ocol : 0;
+#pragma unroll
+                    for (int P = 0; P < 2; ++P) {
+                        const bool lv = P == 0 ? live : live2;
+                        sv[P] = *reinterpret_cast<const Vec4<int>*>(p.sums + (lv ? o + 4 * P : 0));
+                        xs[P] = *reinterpret_cast<const Vec4<float>*>(p.in + (lv ? xi + 4 * P : 0));
+                    }
+                }
+                uint32_t acc[NCR], ctr[NCR];
+                ring_disc_sum<SIZE, NCR, R, RING_LEAD>(Q, s0, lane, acc, ctr, wave >= NW / 2);
+                if (ph + 1 < nphase) next_flags = convert_batch(C::PRO + ph * B, va, next_q);
+                converted = true;
+                static_assert(NCR == 8, "the stores below write two 16-byte pieces per lane");
+#pragma unroll
+                for (int P = 0; P < 2; ++P) {
+                    if (P == 0 ? live : live2) {
+                        if (MODE == kRingMainFrac && mode == kNeedsFraction) {
+                            const Vec4<int> s4{{(int)acc[4 * P], (int)acc[4 * P + 1], (int)acc[4 * P + 2], (int)acc[4 * P + 3]}};
+                            *reinterpret_cast<Vec4<int>*>(p.sums + o + 4 * P) = s4;
+                        } else {
+                            Vec4<float> out_t;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                if (FRACTION) {
+                                    const double sf = (double)(int)acc[4 * P + t] * (1.0 / 65536.0);
+                                    const double s1 = (double)sv[P].v[t] + sf;
+                                    const double x_ctr = (double)xs[P].v[t];
+                                    out_t.v[t] = (float)((double)xs[P].v[t] - (s1 - x_ctr) * inv_nm1);
+                                } else {
+                                    const float x = (float)(int)ctr[4 * P + t];
+                                    const double s1 = (double)(int)acc[4 * P + t];  // sum of x over the in-domain taps, exact
+                                    const double x_ctr = (double)x;
+                                    out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+                                }
+                            }
+                            *reinterpret_cast<Vec4<float>*>(p.tpi + o + 4 * P) = out_t;
+                        }
+                    }
+                }
+            }
+            if (FRACTION && ph % PPT == PPT - 1 && mode == kNeedsFraction && threadIdx.x == 0) p.defer[tile] = kTileDone;
+            if (!converted && ph + 1 < nphase) next_flags = convert_batch(C::PRO + ph * B, va, next_q);
+            s0 += B;
+            s0 = s0 >= R ? s0 - R : s0;
+            RING_STAMP(0)
+            __syncthreads();  // every wave is done with the B oldest rows
+            RING_STAMP(1)
+            if (ph + 1 < nphase) {
+                write_batch(next_q);
+                load_batch(C::PRO + (ph + 1) * B, va);  // in flight during the next chain
+                if (lane == 0) wflags[((ph + 1) & 1) * NW + wave] = next_flags;
+            }
+            RING_STAMP(2)
+            __syncthreads();
+            RING_STAMP(3)
+            if (ph + 1 < nphase) fold_flags((ph + 1) & 1);
+        }
+#ifdef RING_STAMPS
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && MODE != kRingFraction)
+            printf("blk %d wave %d phases %d: chain %lld  barA %lld  stage %lld  barB %lld (memtime ticks)\n", (int)blockIdx.x, wave,
+                   nphase, tsum[0], tsum[1], tsum[2], tsum[3]);
+#endif
+        tile0 += run_tiles;
+    }
+}
+
+template <int SIZE, int NCR, int MODE>
+int launch_ring(const Block& b, float* tpi_out) {
+    using G = RGeo<SIZE, NCR>;
+    using C = RingCfg<SIZE, NCR>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0, 0};
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_ring_kernel<SIZE, NCR, MODE>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)tpi_ring_kernel<SIZE, NCR, MODE>,
+                                                              C::NW * 64, C::LDS));
+        blocks_per_cu = nblk < 1 ? 1 : (nblk > 4 ? 4 : nblk);  // small discs: several rings per CU
+    }
+    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
+    const int tiles_y = (b.out_row0 + b.out_rows - 1) / C::TH - b.out_row0 / C::TH + 1;
+    const long ntiles = (long)tiles_x * tiles_y;
+    const long grid = march_grid(c, blocks_per_cu, ntiles);
+    void* defer = nullptr;
+    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
+    a.defer = (uint8_t*)defer;
+    if (MODE != kRingMain) {
+        void* sums = nullptr;
+        TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
+        a.sums = (int32_t*)sums;
+    }
+    hipLaunchKernelGGL((tpi_ring_kernel<SIZE, NCR, MODE>), dim3((unsigned)grid), dim3(C::NW * 64), C::LDS, c.compute, a,
+                       tiles_x, tiles_y);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+}  // namespace
+
+}  // namespace topo

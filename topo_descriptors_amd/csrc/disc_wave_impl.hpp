@@ -54,6 +54,7 @@ struct WaveArgs {
     int32_t* sums;      // marching kernels: exact sum of trunc(x) over the disc per pixel, laid out like the outputs
     int map_th;         // general kernel: tile height of the geometry p.defer was built for (0 = its own)
     int map_tiles_y;    //                 and its number of tile rows
+    int map_tw;         //                 and its strip width when that differs too (0 = its own)
 };
 
 template <typename T>
@@ -359,8 +360,12 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
                 const int r0 = max((p.out_row0 / TH + ty) * TH, p.out_row0);
                 const int r1 = min((p.out_row0 / TH + ty) * TH + TH, p.out_row0 + p.out_rows) - 1;
                 const int base = p.out_row0 / p.map_th;
-                for (int my = r0 / p.map_th; my <= r1 / p.map_th; ++my)
-                    marked = marked || p.defer[tx * p.map_tiles_y + (my - base)] == 1;
+                // (the ring build's strips are wider than this kernel's: map_tw)
+                const int mx0 = p.map_tw ? tx * G::TILE_W / p.map_tw : tx;
+                const int mx1 = p.map_tw ? (min(tx * G::TILE_W + G::TILE_W, p.nx) - 1) / p.map_tw : tx;
+                for (int mx = mx0; mx <= mx1; ++mx)
+                    for (int my = r0 / p.map_th; my <= r1 / p.map_th; ++my)
+                        marked = marked || p.defer[mx * p.map_tiles_y + (my - base)] == 1;
             }
         }
         take = marked;
@@ -1256,7 +1261,8 @@ int launch_std_march(const Block& b, float* std_out) {
 // only_deferred: process the tiles a preceding launch_march of the same geometry marked.
 // map_th: tile height of the marching launch when it differs from TH.
 template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
-int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferred = false, int map_th = 0) {
+int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferred = false, int map_th = 0,
+                int map_tw = 0) {
     using G = Geo<SIZE>;
     Context& c = ctx();
     WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
@@ -1288,10 +1294,12 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferr
     a.scratch = (uint32_t*)scratch;
     if (only_deferred) {
         long map_tiles = ntiles;
-        if (map_th != 0 && map_th != TH) {
+        if (map_th != 0 && (map_th != TH || map_tw != 0)) {
             a.map_th = map_th;
             a.map_tiles_y = (b.out_row0 + b.out_rows - 1) / map_th - b.out_row0 / map_th + 1;
-            map_tiles = (long)tiles_x * a.map_tiles_y;
+            a.map_tw = map_tw == G::TILE_W ? 0 : map_tw;
+            const int map_tiles_x = a.map_tw ? (b.nx + a.map_tw - 1) / a.map_tw : tiles_x;
+            map_tiles = (long)map_tiles_x * a.map_tiles_y;
         }
         void* defer = nullptr;  // same size as in the marching launches, so the same allocation
         TOPO_TRY(workspace(8, (size_t)map_tiles, &defer));
@@ -1302,6 +1310,16 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferr
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
+
+}  // namespace
+
+}  // namespace topo
+
+#include "disc_ring_impl.hpp"
+
+namespace topo {
+
+namespace {
 
 // Tile heights: as tall as LDS allows (prefix rows + segment totals + border table <= 160 KiB),
 // capped at the heights that measured best for 67 px.
@@ -1332,6 +1350,18 @@ inline int tpi_march_min_size() {
 }
 // Disc size from which TPI on tiles with fractional elevations takes the two marching passes
 // (sum of trunc(x), then sum of the fractional parts) instead of the general kernel.
+// Disc size from which TPI takes the ring build (disc_ring_impl.hpp) instead of tpi_march_kernel
+// (TOPO_AMD_TPI_RING_MIN, a tuning knob: both give the same bits).
+// Measured on the 32768^2 bench DEM (tools/ring_time.py, profiles/r02_tpi_ring.txt): 2.03-2.06 ms against
+// 2.31-2.37 ms for 5 ... 11 px, level at 13-17 px, 4.6 ms against 4.4 ms at 67 px.
+inline int tpi_ring_min_size() {
+    static const int v = env_int("TOPO_AMD_TPI_RING_MIN", 5);
+    return v;
+}
+inline int tpi_ring_max_size() {
+    static const int v = env_int("TOPO_AMD_TPI_RING_MAX", 11);
+    return v;
+}
 inline int tpi_fraction_min_size() {
     static const int v = env_int("TOPO_AMD_TPI_FRACTION_MIN", 17);
     return v;
@@ -1365,6 +1395,21 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
     // TPI alone: whole-metre tiles are finished by the first marching kernel; tiles with fractional
     // elevations get their exact sum of trunc(x) there and the sum of the fractional parts in the
     // second; the general kernel takes what neither could (non-finite or absurd samples)
+    // the ring build (disc_ring_impl.hpp) is compiled for the sizes it wins at and for the headline sizes (A/B)
+    constexpr bool kRing = ring_fits(SIZE, 8) && (SIZE <= 17 || SIZE == 65 || SIZE == 67);
+    if constexpr (kRing) {
+        if (SIZE >= tpi_ring_min_size() && SIZE <= tpi_ring_max_size()) {
+            using RC = RingCfg<SIZE, 8>;
+            constexpr int map_tw = RGeo<SIZE, 8>::TILE_W;
+            if (SIZE < tpi_fraction_min_size()) {
+                TOPO_TRY((launch_ring<SIZE, 8, kRingMain>(b, tpi_out)));
+            } else {
+                TOPO_TRY((launch_ring<SIZE, 8, kRingMainFrac>(b, tpi_out)));
+                TOPO_TRY((launch_ring<SIZE, 8, kRingFraction>(b, tpi_out)));
+            }
+            return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true, RC::TH, map_tw);
+        }
+    }
     if (SIZE < tpi_fraction_min_size()) {
         // small discs: the general kernel's two passes over one tile beat two marching kernels
         TOPO_TRY((launch_march<SIZE, TH12, 12, true, false, false>(b, tpi_out)));
