@@ -41,6 +41,8 @@ extern "C" {
 #define TOPO_AMD_ENODEV (-3)   /* no usable GPU / library not initialised        */
 #define TOPO_AMD_ERCCL (-4)    /* an RCCL call failed                            */
 #define TOPO_AMD_EUNSUP (-5)   /* valid request the kernels do not cover (yet)   */
+#define TOPO_AMD_EEMPTY (-6)   /* Sx: a sector has no usable ray pixel; its plane was zero-filled and the
+                                  other sectors were computed (nanmax over nothing, topo.py:947-951) */
 
 /* descriptor ids for topo_amd_halo_rows */
 #define TOPO_AMD_DESC_TPI 0
@@ -105,8 +107,7 @@ int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int
 
 /* ndimage.gaussian_filter(dem, (sigma_y, sigma_x)), reflect boundary, truncate 4 sigma
  * (replaces topo.dem topo.py:62-80 and the pre-smoothing at topo.py:173, :298).  A sigma of
- * 0 skips that axis.  `scratch` must hold (out_rows) x nx floats or be NULL (then the
- * library uses its own workspace).                                                       */
+ * 0 skips that axis.  The intermediate plane lives in the library's own workspace.       */
 int topo_amd_gaussian_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
                           double sigma_y, double sigma_x, int out_row0, int out_rows,
                           float* out);
@@ -138,7 +139,7 @@ int topo_amd_sx_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
  * frame window[a] and writes the device plane outs[a] (outs: host array of device pointers).
  * Neighbouring sectors overlap: ray pixels shared by several sectors are scanned once.  Every
  * plane has exactly the bits topo_amd_sx_dev gives for that sector alone.  A sector without a
- * usable ray pixel is treated as by topo_amd_sx_dev (plane zero-filled, TOPO_AMD_EINVAL), but
+ * usable ray pixel is treated as by topo_amd_sx_dev (plane zero-filled, TOPO_AMD_EEMPTY), but
  * only after the other sectors are done.                                                     */
 int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int n_az,
                           const int32_t* first, const int32_t* dj, const int32_t* di,
@@ -206,9 +207,21 @@ int topo_amd_comm_destroy(void);
  * rows from the neighbours on the communication stream (ranks at the global edge skip the
  * missing side) and records an event; topo_amd_halo_wait() makes the compute stream wait
  * for it.  Every rank must call with the same halo depths.  Requires rows_local >= both.  */
+/* Loop-back mode (environment TOPO_AMD_HALO_LOOPBACK=1, communicator of ONE rank): the same
+ * ncclSend / ncclRecv pairs are issued to rank 0 itself, with periodic wrap - the block's last
+ * halo_above rows land in its top ghost rows, its first halo_below rows in its bottom ghost
+ * rows - so that pointer offsets, counts, stream ordering and the CU reservation of the
+ * exchange run on a single GPU (tests/test_gpu_halo_loopback.py).                          */
 int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_above,
                                  int halo_below);
 int topo_amd_halo_wait(void);
+/* Declares the ghost depth the shard buffers handed to topo_amd_shard_* are laid out with:
+ * [halo_above | rows_local | halo_below] rows.  A descriptor that needs fewer ghost rows uses
+ * the ones next to the owned rows; one that needs more is refused (TOPO_AMD_EINVAL) instead of
+ * reading the owned rows from the wrong offset and receiving past the end of the buffer.
+ * -1 / -1 (the default): the buffer has exactly the depth topo_amd_halo_rows gives for the
+ * descriptor of each call.                                                                 */
+int topo_amd_shard_layout(int halo_above, int halo_below);
 
 /* Sharded TPI/STD step: ghost exchange overlapped with the interior rows, then the two
  * seam strips.  `block` as above with halo_above == halo_below == topo_amd_halo_rows(TPI).

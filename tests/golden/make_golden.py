@@ -308,6 +308,58 @@ def main():
             out[f"kernels_s{size}_n{len(flats)}_rot{angle}"] = ref_topo._rotate_kernels(base, np.float32(angle))
     save("valley_ridge", **out)
 
+    # ---- batch wrappers: the reference's compute_* with its netCDF writer captured -------
+    # compute_dem / compute_tpi / compute_std / compute_gradient / compute_sx / compute_valley_ridge
+    # (topo.py:16-59, 88-141, 216-269, 534-594, 715-772, 317-386) run unmodified on a Dataset-like DEM;
+    # helpers.to_netcdf (helpers.py:34-65) is replaced by a function that keeps {NAME: array}, so the
+    # fixture pins the scale -> pixel -> sigma plumbing, the output names and the NaN re-insertion.
+    dem_b = orc.synthetic_dem(96, 112, seed=6, integer=True)
+    nyb, nxb = dem_b.shape
+    xb, yb = grid(nyb, nxb, 30.0, -30.0)
+    ds_b = FakeDataset(dem_b, xb, yb)
+    ind_nans = (np.array([3, 50, 95]), np.array([4, 60, 111]))
+    captured = {}
+
+    def capture(array, dem_ds, name, crop=None, outdir=".", units=None):
+        captured[str.upper(name)] = (np.array(array, copy=True), units)
+
+    ref_hlp.to_netcdf = capture
+    out = {"dem": dem_b, "x": xb, "y": yb, "nan_rows": ind_nans[0], "nan_cols": ind_nans[1]}
+    px_b, res_b2 = ref_hlp.scale_to_pixel([100, 200, 400, 500], ds_b)
+    out["px_100_200_400_500"] = px_b
+    calls = [
+        ("tpi", lambda: ref_topo.compute_tpi(ds_b, [200, 500], smth_factors=[None, 0.5], ind_nans=ind_nans)),
+        ("std", lambda: ref_topo.compute_std(ds_b, [200, 500], smth_factors=0.5, ind_nans=ind_nans)),
+        ("std0", lambda: ref_topo.compute_std(ds_b, 200, ind_nans=ind_nans)),
+        ("grad", lambda: ref_topo.compute_gradient(ds_b, [100, 400], sig_ratios=[1, 2], ind_nans=ind_nans)),
+        ("dem", lambda: ref_topo.compute_dem(ds_b, [400], ind_nans=ind_nans)),
+        ("sx", lambda: ref_topo.compute_sx(ds_b, 0, 300.0)),
+        ("sx225", lambda: ref_topo.compute_sx(ds_b, 225, 300.0, height=2.0, azimuth_arc=20.0, azimuth_steps=7)),
+        ("vr", lambda: ref_topo.compute_valley_ridge(ds_b, [200], "valley", smth_factors=[None], ind_nans=ind_nans)),
+    ]
+    names = []
+    for tag, fn in calls:
+        captured.clear()
+        fn()
+        for name, (array, units) in captured.items():
+            out[f"{tag}__{name}"] = array
+            names.append(f"{tag}__{name}|{units}")
+    out["names_units"] = np.array(names)
+    # float64 evaluations of the same formulas: the reference's noise floor travels with the fixture
+    sig17 = 0.5 * 17 / 4
+    out["tpi__TPI_200M_exact"] = orc.tpi_exact(dem_b, 7)
+    out["tpi__TPI_500M_SMTHFACT0.5_exact"] = orc.tpi_exact(dem_b, 17, sigma=sig17)
+    out["std__STD_200M_SMTHFACT0.5_exact"] = orc.std_exact(dem_b, 7, sigma=0.5 * 7 / 4)
+    out["std__STD_500M_SMTHFACT0.5_exact"] = orc.std_exact(dem_b, 17, sigma=sig17)
+    out["std0__STD_200M_exact"] = orc.std_exact(dem_b, 7)
+    for key in [k for k in out if k.endswith("_exact")]:
+        ref = out[key[: -len("_exact")]]
+        exact = np.array(out[key], dtype=np.float64)
+        exact[ind_nans] = np.nan  # the wrappers put the NaNs back
+        out[key] = exact
+        assert np.isnan(ref[ind_nans]).all()
+    save("batch", **out)
+
 
 if __name__ == "__main__":
     main()

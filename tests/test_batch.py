@@ -159,3 +159,114 @@ def test_the_calls_of_the_reference_example_script_at_its_large_scales():
         assert np.max(np.abs(norm[mask] - want[mask])) <= 2e-5 * np.max(want), mode
     out = batch.compute_sx(ds, 0, 1000, outdir=None)
     assert np.array_equal(out["SX_RADIUS1000_AZIMUTH0"], topo.sx(ds, 0, 1000))
+
+
+# ---- n1 pinned on the reference (task 8) --------------------------------------------
+# tests/golden/batch.npz holds what the reference's own compute_dem / compute_tpi / compute_std /
+# compute_gradient / compute_sx / compute_valley_ridge (topo.py:16-59, 88-141, 216-269, 534-594, 715-772,
+# 317-386) handed to its netCDF writer (helpers.to_netcdf, replaced by a capture function in
+# tests/golden/make_golden.py), keyed "<call>__<NAME>", plus the units string of every output.
+def _batch_fixture(golden):
+    g = golden("batch")
+    ds = FakeDataset(g["dem"], g["x"], g["y"])
+    ind_nans = (g["nan_rows"], g["nan_cols"])
+    expected = {}
+    for entry in g["names_units"]:
+        key, units = str(entry).split("|")
+        expected[key] = (g[key], units)
+    return g, ds, ind_nans, expected
+
+
+def _batch_calls(ds, ind_nans):
+    return {
+        "tpi": lambda: batch.compute_tpi(ds, [200, 500], smth_factors=[None, 0.5], ind_nans=ind_nans, outdir=None),
+        "std": lambda: batch.compute_std(ds, [200, 500], smth_factors=0.5, ind_nans=ind_nans, outdir=None),
+        "std0": lambda: batch.compute_std(ds, 200, ind_nans=ind_nans, outdir=None),
+        "grad": lambda: batch.compute_gradient(ds, [100, 400], sig_ratios=[1, 2], ind_nans=ind_nans, outdir=None),
+        "dem": lambda: batch.compute_dem(ds, [400], ind_nans=ind_nans, outdir=None),
+        "sx": lambda: batch.compute_sx(ds, 0, 300.0, outdir=None),
+        "sx225": lambda: batch.compute_sx(ds, 225, 300.0, height=2.0, azimuth_arc=20.0, azimuth_steps=7, outdir=None),
+        "vr": lambda: batch.compute_valley_ridge(ds, [200], "valley", smth_factors=[None], ind_nans=ind_nans, outdir=None),
+    }
+
+
+def test_reference_batch_fixture_plumbing(golden):
+    """CPU: the fixture's names, pixel sizes and sigmas are the ones this package's host logic derives, and
+    the oracle's scipy evaluators at those parameters reproduce the reference's wrapper outputs bit for bit
+    (NaNs put back at ind_nans)."""
+    from oracle import topo_oracle as orc
+    from topo_descriptors_amd import helpers as hlp
+
+    g, ds, ind_nans, expected = _batch_fixture(golden)
+    px, res = hlp.scale_to_pixel([100, 200, 400, 500], ds)
+    assert list(px) == list(g["px_100_200_400_500"]) == [3, 7, 13, 17]
+    sig = hlp.get_sigmas([None, 0.5], np.array([7, 17]))
+    assert sig[0] is None and sig[1] == 0.5 * 17 / 4
+    names = {
+        "tpi": [batch._tpi_name(200, None), batch._tpi_name(500, 0.5)],
+        "std": [batch._std_name(200, 0.5), batch._std_name(500, 0.5)],
+        "std0": [batch._std_name(200, None)],
+        "grad": batch._gradient_names(100, 1) + batch._gradient_names(400, 2),
+        "dem": [batch._dem_name(400)],
+        "sx": [batch._sx_name(300.0, 0)],
+        "sx225": [batch._sx_name(300.0, 225)],
+        "vr": batch._valley_ridge_names(200, "valley", None),
+    }
+    want_keys = {f"{tag}__{str.upper(n)}" for tag, ns in names.items() for n in ns}
+    assert want_keys == set(expected)
+    units = {k: u for k, (_, u) in expected.items()}
+    assert units["tpi__TPI_200M"] == "m" and units["grad__SLOPE_100M_SIGRATIO1"] == "degree"
+    assert units["grad__WE_DERIVATIVE_400M_SIGRATIO2"] == "1" and units["sx__SX_RADIUS300_AZIMUTH0"] == "degree"
+
+    dem = g["dem"]
+
+    def with_nans(a):
+        a = np.array(a, copy=True)
+        a[ind_nans] = np.nan
+        return a
+
+    assert np.array_equal(with_nans(orc.tpi_scipy(dem, 7)), expected["tpi__TPI_200M"][0], equal_nan=True)
+    assert np.array_equal(with_nans(orc.tpi_scipy(dem, 17, sigma=0.5 * 17 / 4)), expected["tpi__TPI_500M_SMTHFACT0.5"][0],
+                          equal_nan=True)
+    assert np.array_equal(with_nans(orc.std_scipy(dem, 7, sigma=0.5 * 7 / 4)), expected["std__STD_200M_SMTHFACT0.5"][0],
+                          equal_nan=True)
+    assert np.array_equal(with_nans(orc.std_scipy(dem, 7)), expected["std0__STD_200M"][0], equal_nan=True)
+    assert np.array_equal(with_nans(orc.gaussian_scipy(dem, 13 / 4)), expected["dem__DEM_400M"][0], equal_nan=True)
+    got = orc.gradient_scipy(dem, 13 / 4, res, sig_ratio=2)
+    for k, n in enumerate(batch._gradient_names(400, 2)):
+        assert np.array_equal(with_nans(got[k]), expected[f"grad__{n}"][0], equal_nan=True), n
+    got = orc.gradient_scipy(dem, 3 / 4, res, sig_ratio=1)  # sigma <= 1: the Sobel branch
+    for k, n in enumerate(batch._gradient_names(100, 1)):
+        assert np.array_equal(with_nans(got[k]), expected[f"grad__{n}"][0], equal_nan=True), n
+    assert np.max(np.abs(orc.sx(dem, g["x"], g["y"], 0, 300.0) - expected["sx__SX_RADIUS300_AZIMUTH0"][0])) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_wrappers_against_the_reference_wrappers(golden):
+    """GPU: batch.compute_* against what the reference's compute_* produced on the same Dataset - names, NaN
+    positions, values to the contract of SURVEY section 8 (STD two-sided with the stored reference floor)."""
+    from oracle import topo_oracle as orc
+
+    g, ds, ind_nans, expected = _batch_fixture(golden)
+    got = {}
+    for tag, fn in _batch_calls(ds, ind_nans).items():
+        for name, array in fn().items():
+            got[f"{tag}__{str.upper(name)}"] = array
+    assert set(got) == set(expected)
+    for key, (ref, _) in expected.items():
+        out = got[key]
+        assert out.shape == ref.shape and out.dtype == ref.dtype, (key, out.dtype, ref.dtype)
+        assert np.array_equal(np.isnan(out), np.isnan(ref)), key
+        m = ~np.isnan(ref)
+        scale = np.max(np.abs(ref[m]))
+        if "STD" in key:
+            exact, floor = g[key + "_exact"] if key + "_exact" in g else None, float(g[key + "_floor"])
+            assert np.max(np.abs(out[m] - ref[m])) <= floor + 1e-4 * scale, key
+        elif "ASPECT" in key:
+            slope = got[key.replace("ASPECT", "SLOPE")]
+            steep = m & (slope > 0.1)
+            assert np.max(orc.wrapped_angle_diff(out[steep], ref[steep])) <= 0.036, key
+        elif "VALLEY_DIR" in key:
+            assert np.mean(out[m] == ref[m]) >= 0.999, key
+        else:
+            assert np.max(np.abs(out[m] - ref[m])) <= 1e-4 * scale, (key, np.max(np.abs(out[m] - ref[m])), scale)

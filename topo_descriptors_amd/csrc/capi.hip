@@ -121,7 +121,14 @@ struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, size = 1;
     bool halo_pending = false;
+    int layout_above = -1, layout_below = -1;  // declared ghost depth of the shard buffers (topo_amd_shard_layout)
 } g_comm;
+
+// TOPO_AMD_HALO_LOOPBACK=1 with a communicator of one rank: the exchange talks to itself
+bool halo_loopback() {
+    const char* e = std::getenv("TOPO_AMD_HALO_LOOPBACK");
+    return e && e[0] == '1' && g_comm.size == 1 && g_comm.comm != nullptr;
+}
 
 #define TOPO_NCCL(call)                                                                    \
     do {                                                                                   \
@@ -684,12 +691,13 @@ int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const i
     TOPO_TRY(run.alloc(&d_out, bytes));
     run.prefault(out, bytes);
     TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
-    TOPO_TRY(topo_amd_sx_dev((const float*)d_in, ny, 0, ny, nx, dj, di, dist, n_off, window, height,
-                             0, ny, (float*)d_out));
+    const int rc = topo_amd_sx_dev((const float*)d_in, ny, 0, ny, nx, dj, di, dist, n_off, window, height, 0, ny,
+                                   (float*)d_out);
+    if (rc != TOPO_AMD_OK && rc != TOPO_AMD_EEMPTY) return rc;  // EEMPTY: the plane was zero-filled
     run.ready();
     TOPO_TRY(download(out, d_out, bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
-    return TOPO_AMD_OK;
+    return rc;
 }
 
 int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int32_t* first,
@@ -707,7 +715,7 @@ int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int3
     TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
     const int rc = topo_amd_sx_multi_dev((const float*)d_in, ny, 0, ny, nx, n_az, first, dj, di, dist, window,
                                          height, 0, ny, d_out.data());
-    if (rc != TOPO_AMD_OK && rc != TOPO_AMD_EINVAL) return rc;
+    if (rc != TOPO_AMD_OK && rc != TOPO_AMD_EEMPTY) return rc;  // EEMPTY: every plane was written
     run.ready();
     for (int k = 0; k < n_az; ++k) TOPO_TRY(download(outs[k], d_out[k], bytes));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
@@ -783,12 +791,26 @@ int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_
     // the local rows must be final before neighbours read them
     TOPO_HIP(hipEventRecord(c.input_ready, c.compute));
     TOPO_HIP(hipStreamWaitEvent(c.comm, c.input_ready, 0));
-    if (g_comm.size > 1) {
+    float* ghost_top = block;
+    float* local = block + (size_t)halo_above * nx;
+    float* ghost_bot = local + (size_t)rows_local * nx;
+    if (halo_loopback()) {
+        // the rank is its own upper and lower neighbour: same calls, same counts, periodic wrap.  Sends and
+        // receives to one peer inside a group match in order.
+        TOPO_NCCL(ncclGroupStart());
+        if (halo_above > 0) {
+            TOPO_NCCL(ncclSend(local + (size_t)(rows_local - halo_above) * nx, (size_t)halo_above * nx, ncclFloat, 0,
+                               g_comm.comm, c.comm));
+            TOPO_NCCL(ncclRecv(ghost_top, (size_t)halo_above * nx, ncclFloat, 0, g_comm.comm, c.comm));
+        }
+        if (halo_below > 0) {
+            TOPO_NCCL(ncclSend(local, (size_t)halo_below * nx, ncclFloat, 0, g_comm.comm, c.comm));
+            TOPO_NCCL(ncclRecv(ghost_bot, (size_t)halo_below * nx, ncclFloat, 0, g_comm.comm, c.comm));
+        }
+        TOPO_NCCL(ncclGroupEnd());
+    } else if (g_comm.size > 1) {
         TOPO_REQUIRE(g_comm.comm != nullptr, "halo_exchange: call topo_amd_comm_init first");
         const int up = g_comm.rank - 1, down = g_comm.rank + 1;
-        float* ghost_top = block;
-        float* local = block + (size_t)halo_above * nx;
-        float* ghost_bot = local + (size_t)rows_local * nx;
         TOPO_NCCL(ncclGroupStart());
         if (up >= 0) {
             // my first halo_below rows become the upper neighbour's bottom ghost rows
@@ -811,6 +833,15 @@ int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_
     return TOPO_AMD_OK;
 }
 
+int topo_amd_shard_layout(int halo_above, int halo_below) {
+    TOPO_REQUIRE((halo_above >= 0 && halo_below >= 0) || (halo_above == -1 && halo_below == -1),
+                 "shard_layout: ghost depths %d / %d (both >= 0, or -1 / -1 for 'as the descriptor needs')", halo_above,
+                 halo_below);
+    g_comm.layout_above = halo_above;
+    g_comm.layout_below = halo_below;
+    return TOPO_AMD_OK;
+}
+
 int topo_amd_halo_wait(void) {
     TOPO_TRY(require_ready());
     if (g_comm.halo_pending) {
@@ -828,9 +859,25 @@ namespace {
 // Geometry of one rank's haloed block inside the global DEM.
 struct Shard {
     Block whole;           // block including the ghost rows that exist
+    Block owned;           // the owned rows alone: what a launch may read while the exchange is in flight
     int row0, rows_local;  // owned rows
     int interior0, interior1;  // owned rows whose stencil stays inside the owned rows
 };
+
+// The buffer is laid out with the declared ghost depth (topo_amd_shard_layout); a descriptor that needs
+// `above` rows uses the last `above` of the declared ones.  Returns where its [above | local | below] view
+// starts.
+int shard_view(float** block, int above, int below, const char* who) {
+    TOPO_REQUIRE(*block != nullptr, "%s: NULL block", who);
+    if (g_comm.layout_above < 0) return TOPO_AMD_OK;
+    TOPO_REQUIRE(above <= g_comm.layout_above && below <= g_comm.layout_below,
+                 "%s needs %d / %d ghost rows but the shard buffers were declared with %d / %d (topo_amd_shard_layout)",
+                 who, above, below, g_comm.layout_above, g_comm.layout_below);
+    return TOPO_AMD_OK;
+}
+size_t shard_view_offset(int above, int nx) {
+    return g_comm.layout_above < 0 ? 0 : (size_t)(g_comm.layout_above - above) * nx;
+}
 
 Shard make_shard(float* block, int rows_local, int row0, int gny, int nx, int above, int below) {
     Shard s;
@@ -841,6 +888,10 @@ Shard make_shard(float* block, int rows_local, int row0, int gny, int nx, int ab
     s.whole.in_rows = rows_local + (has_up ? above : 0) + (has_down ? below : 0);
     s.whole.gny = gny;
     s.whole.nx = nx;
+    s.owned = s.whole;
+    s.owned.in = block + (size_t)above * nx;
+    s.owned.in_row0 = row0;
+    s.owned.in_rows = rows_local;
     s.row0 = row0;
     s.rows_local = rows_local;
     s.interior0 = has_up ? std::min(row0 + above, row0 + rows_local) : row0;
@@ -848,22 +899,24 @@ Shard make_shard(float* block, int rows_local, int row0, int gny, int nx, int ab
     return s;
 }
 
-// Runs `fn(out_row0, out_rows)` for the interior first, then (after the ghost rows landed)
-// for the seam strips: the exchange overlaps the interior compute.
+// Runs `fn(block, out_row0, out_rows)` for the interior first, then (after the ghost rows landed) for the
+// seam strips: the exchange overlaps the interior compute.  The interior launch gets the OWNED rows as
+// its block: the ghost rows are being written by the exchange meanwhile, and a tile-based kernel stages
+// (and classifies) every row of its block that a tile touches, not only the rows its outputs need.
 template <class Fn>
 int run_overlapped(float* block, const Shard& s, int above, int below, Fn fn) {
     TOPO_TRY(topo_amd_halo_exchange_start(block, s.rows_local, s.whole.nx, above, below));
     // the interior launch is persistent (it would otherwise hold every CU until it ends): leave
     // a few CUs to the send/recv kernels so that the exchange really runs next to it
-    ctx().reserve_cus = g_comm.size > 1 ? 16 : 0;
+    ctx().reserve_cus = (g_comm.size > 1 || halo_loopback()) ? 16 : 0;
     int rc = TOPO_AMD_OK;
-    if (s.interior1 > s.interior0) rc = fn(s.interior0, s.interior1 - s.interior0);
+    if (s.interior1 > s.interior0) rc = fn(s.owned, s.interior0, s.interior1 - s.interior0);
     ctx().reserve_cus = 0;
     if (rc != TOPO_AMD_OK) return rc;
     TOPO_TRY(topo_amd_halo_wait());
-    if (s.interior0 > s.row0) TOPO_TRY(fn(s.row0, s.interior0 - s.row0));
+    if (s.interior0 > s.row0) TOPO_TRY(fn(s.whole, s.row0, s.interior0 - s.row0));
     const int end = s.row0 + s.rows_local;
-    if (end > s.interior1) TOPO_TRY(fn(s.interior1, end - s.interior1));
+    if (end > s.interior1) TOPO_TRY(fn(s.whole, s.interior1, end - s.interior1));
     return TOPO_AMD_OK;
 }
 
@@ -880,9 +933,11 @@ int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int 
     DiscRuns disc;
     TOPO_TRY(build_disc(size, &disc));
     const int above = -disc.dj_min, below = disc.dj_max;
+    TOPO_TRY(shard_view(&block, above, below, "shard_tpi_std"));
+    block += shard_view_offset(above, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, above, below);
-    return run_overlapped(block, s, above, below, [&](int o0, int on) {
-        Block b = s.whole;
+    return run_overlapped(block, s, above, below, [&](const Block& view, int o0, int on) {
+        Block b = view;
         b.out_row0 = o0;
         b.out_rows = on;
         TOPO_TRY(check_block(b, above, below, "shard_tpi_std"));
@@ -895,9 +950,11 @@ int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int
                             float* dx_out, float* dy_out, float* slope_out, float* aspect_out) {
     TOPO_TRY(require_ready());
     const int h = gradient_halo(sigma, sig_ratio);
+    TOPO_TRY(shard_view(&block, h, h, "shard_gradient"));
+    block += shard_view_offset(h, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, h, h);
-    return run_overlapped(block, s, h, h, [&](int o0, int on) {
-        Block b = s.whole;
+    return run_overlapped(block, s, h, h, [&](const Block& view, int o0, int on) {
+        Block b = view;
         b.out_row0 = o0;
         b.out_rows = on;
         TOPO_TRY(check_block(b, h, h, "shard_gradient"));
@@ -922,9 +979,11 @@ int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx, c
         up = std::max(up, -dj[n]);
         down = std::max(down, dj[n]);
     }
+    TOPO_TRY(shard_view(&block, up, down, "shard_sx"));
+    block += shard_view_offset(up, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, up, down);
-    return run_overlapped(block, s, up, down, [&](int o0, int on) {
-        Block b = s.whole;
+    return run_overlapped(block, s, up, down, [&](const Block& view, int o0, int on) {
+        Block b = view;
         b.out_row0 = o0;
         b.out_rows = on;
         TOPO_TRY(check_block(b, up, down, "shard_sx"));
@@ -939,10 +998,12 @@ int topo_amd_shard_sx_multi(float* block, int rows_local, int row0, int gny, int
     TOPO_REQUIRE(n_az >= 1 && first && dj && di && dist && window && outs, "shard_sx_multi: NULL argument");
     int up = 0, down = 0;
     sx_multi_reach(n_az, first, dj, dist, &up, &down);
+    TOPO_TRY(shard_view(&block, up, down, "shard_sx_multi"));
+    block += shard_view_offset(up, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, up, down);
     std::vector<float*> moved(n_az);
-    return run_overlapped(block, s, up, down, [&](int o0, int on) {
-        Block b = s.whole;
+    return run_overlapped(block, s, up, down, [&](const Block& view, int o0, int on) {
+        Block b = view;
         b.out_row0 = o0;
         b.out_rows = on;
         TOPO_TRY(check_block(b, up, down, "shard_sx_multi"));
@@ -959,6 +1020,8 @@ int topo_amd_shard_valley_ridge(float* block, int rows_local, int row0, int gny,
                  "shard_valley_ridge: NULL argument");
     int above = 0, below = 0;
     (void)valley_ridge_reach(ksize, n_angles, &above, &below);
+    TOPO_TRY(shard_view(&block, above, below, "shard_valley_ridge"));
+    block += shard_view_offset(above, nx);
     // the standardisation needs the mean and standard deviation of the WHOLE DEM (topo.py:427):
     // float64 moments about 0 of the owned rows, then the one all-reduce of the whole path.
     // On a DEM of whole metres the three numbers are exact integers (< 2^53), so every sharding
@@ -978,8 +1041,8 @@ int topo_amd_shard_valley_ridge(float* block, int rows_local, int row0, int gny,
     if (var < 0.0) var = 0.0;
     const double stdev = std::sqrt(var);
     Shard s = make_shard(block, rows_local, row0, gny, nx, above, below);
-    return run_overlapped(block, s, above, below, [&](int o0, int on) {
-        Block b = s.whole;
+    return run_overlapped(block, s, above, below, [&](const Block& view, int o0, int on) {
+        Block b = view;
         b.out_row0 = o0;
         b.out_rows = on;
         TOPO_TRY(check_block(b, above, below, "shard_valley_ridge"));

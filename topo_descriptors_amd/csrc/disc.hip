@@ -362,6 +362,7 @@ __global__ __launch_bounds__(kThreads) void repitch_kernel(const float* src, int
 
 int repitch(const float* src, int src_pitch, float* dst, int dst_pitch, int width, int cols, int rows) {
     if (rows <= 0) return TOPO_AMD_OK;
+    TOPO_TRY(check_grid_rows(rows, "disc (re-pitched copy)"));
     dim3 grid((cols + kThreads - 1) / kThreads, rows);
     hipLaunchKernelGGL(repitch_kernel, grid, dim3(kThreads), 0, ctx().compute, src, src_pitch, dst, dst_pitch,
                        width, cols);

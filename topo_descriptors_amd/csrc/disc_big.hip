@@ -289,6 +289,7 @@ int launch_disc_big(const Block& b, const DiscRuns& disc, float* tpi_out, float*
     void* d_runs = nullptr;
     TOPO_TRY(upload_table(0, packed.data(), packed.size() * sizeof(int), &d_runs));
     a.runs = (const int*)d_runs;
+    TOPO_TRY(check_grid_rows(std::max(b.out_rows, b.in_rows), "disc (prefix planes)"));
     const dim3 pgrid((b.nx + kThreads - 1) / kThreads), ggrid((b.nx + kThreads - 1) / kThreads, b.out_rows);
 
     // narrow planes first; which gather follows depends on what the prefix pass saw in the block
@@ -329,6 +330,7 @@ int launch_disc_big(const Block& b, const DiscRuns& disc, float* tpi_out, float*
     hipLaunchKernelGGL(big_prefix_kernel, dim3((b.nx + kThreads - 1) / kThreads), dim3(kThreads), 0,
                        c.compute, a);
     TOPO_HIP(hipGetLastError());
+    TOPO_TRY(check_grid_rows(b.out_rows, "disc (float64 prefix planes)"));
     dim3 grid((b.nx + kThreads - 1) / kThreads, b.out_rows);
     if (tpi_out && std_out) hipLaunchKernelGGL((big_disc_kernel<true, true>), grid, dim3(kThreads), 0, c.compute, a);
     else if (tpi_out) hipLaunchKernelGGL((big_disc_kernel<true, false>), grid, dim3(kThreads), 0, c.compute, a);

@@ -931,6 +931,7 @@ int launch_sobel(const Block& b, float* dx_out, float* dy_out) {
     g.out_rows = b.out_rows;
     g.dx = dx_out;
     g.dy = dy_out;
+    TOPO_TRY(check_grid_rows(b.out_rows, "sobel / gradient epilogue"));
     dim3 grid((b.nx + kThreads - 1) / kThreads, b.out_rows);
     hipLaunchKernelGGL(sobel_kernel<false>, grid, dim3(kThreads), 0, c.compute, g);
     TOPO_HIP(hipGetLastError());
@@ -954,6 +955,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     g.dy = dy;
     g.slope = slope;
     g.aspect = aspect;
+    TOPO_TRY(check_grid_rows(b.out_rows, "sobel / gradient epilogue"));
     dim3 grid((b.nx + kThreads - 1) / kThreads, b.out_rows);
     if (sigma <= 1.0) {  // topo.py:628-629
         g.raw = b.in;

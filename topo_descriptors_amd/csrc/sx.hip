@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(float* out, int rows, i
 
 int launch_synth(float* out, int rows, int row0, int nx, uint32_t seed, bool integer_valued) {
     Context& c = ctx();
+    TOPO_TRY(check_grid_rows(rows, "synth_dem"));
     dim3 grid((nx + kThreads - 1) / kThreads, rows);
     hipLaunchKernelGGL(synth_kernel, grid, dim3(kThreads), 0, c.compute, out, rows, row0, nx, seed,
                        integer_valued);
@@ -288,7 +289,7 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
         hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(kThreads), 0, c.compute, out, total, 0.0f);
         TOPO_HIP(hipGetLastError());
         set_error("sx: no usable ray pixel (all distances NaN)");
-        return TOPO_AMD_EINVAL;
+        return TOPO_AMD_EEMPTY;
     }
     SxArgs a;
     int dj_min = 0, dj_max = 0, di_min = 0, di_max = 0;  // the target pixel itself is staged too

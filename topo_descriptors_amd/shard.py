@@ -121,11 +121,28 @@ class ShardedDEM:
 
     def __init__(self, plan, local_rows=None):
         from . import device as d
+        from . import _lib
         self.plan = plan
         plan.validate()
         self.block = d.DeviceArray(plan.buffer_rows, plan.nx)
+        # the ghost rows are read by nobody before an exchange has filled them, but a stale NaN in recycled
+        # memory should not be what a debugging session finds there
+        _lib.check(_lib.lib().topo_amd_memset(self.block.ptr, 0, self.block.nbytes), "topo_amd_memset")
         if local_rows is not None:
             self.block.upload_rows(local_rows, plan.halo_above)
+
+    def _collective(self, name, *args):
+        """Call a ``topo_amd_shard_*`` entry point with this buffer's ghost depth declared
+        (``topo_amd_shard_layout``): a descriptor that needs fewer ghost rows than the plan reserves uses the
+        ones next to the owned rows, one that needs more is refused instead of reading the owned rows from the
+        wrong offset and receiving past the end of the buffer."""
+        from . import _lib
+        lib = _lib.lib()
+        _lib.check(lib.topo_amd_shard_layout(self.plan.halo_above, self.plan.halo_below), "shard_layout")
+        try:
+            _lib.check(getattr(lib, name)(*args), name)
+        finally:
+            lib.topo_amd_shard_layout(-1, -1)
 
     @staticmethod
     def init_comm(rank, nranks, broadcast_bytes):
@@ -144,9 +161,9 @@ class ShardedDEM:
     def tpi_std(self, size, tpi=None, std=None):
         from . import _lib
         p = self.plan
-        _lib.check(_lib.lib().topo_amd_shard_tpi_std(self.block.ptr, p.rows_local, p.row0, p.gny, p.nx,
+        self._collective("topo_amd_shard_tpi_std", self.block.ptr, p.rows_local, p.row0, p.gny, p.nx,
                                                      int(size), tpi.ptr if tpi else None,
-                                                     std.ptr if std else None), "shard_tpi_std")
+                                                     std.ptr if std else None)
 
     def gradient(self, sigma, res_x, res_y, sig_ratio=1.0, dx=None, dy=None, slope=None, aspect=None):
         from . import _lib
@@ -154,10 +171,13 @@ class ShardedDEM:
         rx = np.ascontiguousarray(res_x, dtype=np.float64)
         ry = np.ascontiguousarray(res_y, dtype=np.float64)
         mode = _lib.RES_SCALAR if rx.size == 1 and ry.size == 1 else _lib.RES_1D
+        if mode == _lib.RES_1D and (rx.size != p.nx or ry.size != p.gny):
+            raise ValueError(f"1-D resolutions must have nx = {p.nx} and gny = {p.gny} entries (the rows of the "
+                             f"WHOLE DEM), got {rx.size} and {ry.size}")
         outs = [a.ptr if a else None for a in (dx, dy, slope, aspect)]
-        _lib.check(_lib.lib().topo_amd_shard_gradient(self.block.ptr, p.rows_local, p.row0, p.gny, p.nx,
+        self._collective("topo_amd_shard_gradient", self.block.ptr, p.rows_local, p.row0, p.gny, p.nx,
                                                       float(sigma), float(sig_ratio), mode,
-                                                      _lib.ptr(rx), _lib.ptr(ry), *outs), "shard_gradient")
+                                                      _lib.ptr(rx), _lib.ptr(ry), *outs)
 
     def valley_ridge(self, taps, ksize, angles, n_planes, norm, direction):
         """Collective.  The plan's halo must be ``halo_rows(DESC_VALLEY_RIDGE, ksize.max())``; the mean
@@ -167,10 +187,9 @@ class ShardedDEM:
         taps = np.ascontiguousarray(taps, dtype=np.float32)
         ksize = np.ascontiguousarray(ksize, dtype=np.int32)
         angles = np.ascontiguousarray(angles, dtype=np.float32)
-        _lib.check(_lib.lib().topo_amd_shard_valley_ridge(
-            self.block.ptr, p.rows_local, p.row0, p.gny, p.nx, taps.ctypes.data_as(_lib._vp),
+        self._collective("topo_amd_shard_valley_ridge", self.block.ptr, p.rows_local, p.row0, p.gny, p.nx, taps.ctypes.data_as(_lib._vp),
             ksize.ctypes.data_as(_lib._i32p), angles.ctypes.data_as(_lib._vp), ksize.size, int(n_planes),
-            norm.ptr, direction.ptr), "shard_valley_ridge")
+            norm.ptr, direction.ptr)
 
     def sx(self, dj, di, dist, window, height, out):
         from . import _lib
@@ -178,11 +197,11 @@ class ShardedDEM:
         dj = np.ascontiguousarray(dj, dtype=np.int32)
         di = np.ascontiguousarray(di, dtype=np.int32)
         dist = np.ascontiguousarray(dist, dtype=np.float64)
-        _lib.check(_lib.lib().topo_amd_shard_sx(self.block.ptr, p.rows_local, p.row0, p.gny, p.nx,
+        self._collective("topo_amd_shard_sx", self.block.ptr, p.rows_local, p.row0, p.gny, p.nx,
                                                 dj.ctypes.data_as(_lib._i32p),
                                                 di.ctypes.data_as(_lib._i32p),
                                                 dist.ctypes.data_as(_lib._f64p), dist.size, int(window),
-                                                float(height), out.ptr), "shard_sx")
+                                                float(height), out.ptr)
 
     def sx_multi(self, sectors, height, outs):
         """Sx of several azimuth sectors with ONE ghost-row exchange.  The plan's halo must be the
@@ -194,10 +213,9 @@ class ShardedDEM:
         p = self.plan
         first, dj, di, dist, window = pack_sectors(sectors)
         planes = (C.c_void_p * len(outs))(*[o.ptr for o in outs])
-        _lib.check(_lib.lib().topo_amd_shard_sx_multi(
-            self.block.ptr, p.rows_local, p.row0, p.gny, p.nx, len(sectors), first.ctypes.data_as(_lib._i32p),
+        self._collective("topo_amd_shard_sx_multi", self.block.ptr, p.rows_local, p.row0, p.gny, p.nx, len(sectors), first.ctypes.data_as(_lib._i32p),
             dj.ctypes.data_as(_lib._i32p), di.ctypes.data_as(_lib._i32p), dist.ctypes.data_as(_lib._f64p),
-            window.ctypes.data_as(_lib._i32p), float(height), planes), "shard_sx_multi")
+            window.ctypes.data_as(_lib._i32p), float(height), planes)
 
 
 def sx_multi_halo(sectors):
