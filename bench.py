@@ -11,9 +11,17 @@ refreshes the 33 ghost rows from the neighbours over RCCL, overlapped with the i
 Inputs are generated on the device and are resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the TPI kernel at SURVEY.md 8(d)'s 8 B/pixel
-(4 read + 4 written) against 8 TB/s; `cpu_baseline` times the oracle's scipy restatement of
-the reference path on one host core for a bounded sample.  torch is used for rendezvous,
-barriers and the max-over-ranks only; it never touches the GPU.
+(4 read + 4 written) against 8 TB/s (and, as `frac_read_only_basis`, at north_star's literal
+"HBM-read" 4 B/pixel); `cpu_baseline` times the oracle's scipy restatement of the reference path
+on one host core for a bounded sample.  torch is used for rendezvous, barriers and the
+max-over-ranks only; it never touches the GPU.
+
+Timing: `value` and `ms_per_step` come from the wall clock around exactly K steps between two
+barriers, as the driver's contract asks.  Every step is also bracketed by its own HIP events
+(topo_amd_mark): `ms_per_step_median` / `_mean` / `_min` / `_max` are those per-launch durations,
+and the roofline uses their mean.  Before the W warm-up steps the clocks are brought up by untimed
+launches until three consecutive ones agree within 1.5 % (`clock_ramp_steps`; the first ~8 launches
+after an idle period run up to 25 % slow), so that W = 5 and W = 10 give the same number.
 """
 import argparse
 import json
@@ -84,28 +92,53 @@ class Rendezvous:
             self.dist.destroy_process_group()
 
 
+KERNEL_SOURCES = ["disc_wave_impl.hpp", "disc_ring_impl.hpp", "disc_runs.hpp", "disc_wave.hip", "common.hpp"]
+
+
+def kernel_sources_sha256():
+    """Hash of the sources the headline kernel is compiled from: a PMC profile taken on other sources says
+    nothing about this build."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(REPO, "topo_descriptors_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def measured_traffic(ny, nx, size, world):
     """HBM bytes per launch of the TPI kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this
-    exact workload).  None when the workload differs from the profiled one."""
-    path = os.path.join(REPO, "profiles", "r01_tpi67_traffic.json")
-    if not (os.path.exists(path) and (ny, nx, size, world) == (32768, 32768, 67, 1)):
-        return None
+    (profiles/r02_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this exact
+    workload), with the git head and the kernel-source hash the profile was taken at.  The number is nulled
+    when the workload or the sources differ from the profiled ones."""
+    info = {"traffic": None, "traffic_profile_head": None, "traffic_profile": "profiles/r02_tpi67_traffic.json"}
+    path = os.path.join(REPO, "profiles", "r02_tpi67_traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get("traffic_bytes_per_launch")
+            prof = json.load(fh)
     except (OSError, ValueError):
-        return None
+        info["traffic_note"] = "no committed PMC profile"
+        return info
+    info["traffic_profile_head"] = prof.get("git_head")
+    if (ny, nx, size, world) != (32768, 32768, 67, 1):
+        info["traffic_note"] = "profiled workload is 32768x32768, 67 px, 1 GPU"
+    elif prof.get("kernel_sources_sha256") != kernel_sources_sha256():
+        info["traffic_note"] = "kernel sources changed since the PMC passes were taken: re-run tools/pmc_passes.sh"
+    else:
+        info["traffic"] = prof.get("traffic_bytes_per_launch")
+    return info
+
+
+def stats(ms):
+    ms = sorted(ms)
+    n = len(ms)
+    med = ms[n // 2] if n % 2 else 0.5 * (ms[n // 2 - 1] + ms[n // 2])
+    return {"median": med, "mean": sum(ms) / n, "min": ms[0], "max": ms[-1], "n": n}
 
 
 def time_kernel(fn, reps, dev):
-    """Average HIP-event duration (ms) of `fn` over `reps` back-to-back launches."""
-    fn()
-    dev.sync()
-    dev.timer_start()
-    for _ in range(reps):
-        fn()
-    return dev.timer_stop() / reps
+    """Per-launch HIP-event durations of `reps` back-to-back launches of `fn` (after one untimed launch)."""
+    return stats(dev.time_launches(fn, reps, warm=1))
 
 
 def cpu_baseline(size, sample_rows, sample_cols, dem_sample):
@@ -127,28 +160,49 @@ def cpu_baseline(size, sample_rows, sample_cols, dem_sample):
 
 def cpu_twin_baseline(size, dem_sample):
     """The oracle's C/OpenMP twin (exact float64 evaluation, row-prefix algorithm) on every host
-    core: TPI at `size` and Sx (azimuth 0, radius 500 m) on a bounded window of the same DEM."""
+    core: TPI at `size` and Sx (azimuth 0, radius 500 m) on a bounded window of the same DEM.  The thread
+    pool is started on a small window first and the better of two runs counts (the first run of a process
+    pays for thread start-up and for faulting in ~1.5 GB of prefix planes)."""
     from oracle import c_twin, topo_oracle as orc
 
     rows, cols = dem_sample.shape
-    t0 = time.perf_counter()
-    c_twin.tpi_std(dem_sample, size, want_tpi=True, want_std=False)
-    dt_tpi = time.perf_counter() - t0
+    c_twin.tpi_std(dem_sample[:512, :512], size, want_tpi=True, want_std=False)
+    dt_tpi = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        c_twin.tpi_std(dem_sample, size, want_tpi=True, want_std=False)
+        dt = time.perf_counter() - t0
+        dt_tpi = dt if dt_tpi is None else min(dt_tpi, dt)
     window, offs, dist = orc.sx_geometry(0.0, 500.0, 30.0, -30.0)
-    t0 = time.perf_counter()
-    c_twin.sx(dem_sample, offs[:, 0], offs[:, 1], dist, window, 10.0)
-    dt_sx = time.perf_counter() - t0
+    dt_sx = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        c_twin.sx(dem_sample, offs[:, 0], offs[:, 1], dist, window, 10.0)
+        dt = time.perf_counter() - t0
+        dt_sx = dt if dt_sx is None else min(dt_sx, dt)
     return {
         "kind": "port", "cores": c_twin.threads(), "unit": "Mpixels/s",
         "value": round(rows * cols / dt_tpi / 1e6, 2),
         "sx_az0_r500_value": round(rows * cols / dt_sx / 1e6, 2),
-        "sample": f"oracle/topo_oracle.c (OpenMP, float64) on a {rows}x{cols} window of the same DEM: "
-                  f"TPI size {size} in {dt_tpi:.1f} s, Sx az 0 r 500 m in {dt_sx:.1f} s",
+        "sample": f"oracle/topo_oracle.c (OpenMP, float64, warm thread pool, better of two runs) on a {rows}x{cols} "
+                  f"window of the same DEM: TPI size {size} in {dt_tpi:.2f} s, Sx az 0 r 500 m in {dt_sx:.2f} s",
     }
 
 
+# which kernels run behind each entry of `descriptors` (csrc/*.hip; the empty follow-up launches of the disc
+# paths - fraction pass, general kernel over deferred tiles - are named in DESIGN.md section 3)
+def disc_kernels(what, size):
+    if what == "tpi":
+        return ("tpi_ring_kernel<%d, 8, .>" % size if 5 <= size <= 11 else "tpi_march_kernel<%d, 60, 12, ..>" % size) + \
+            " (+ fraction pass and general kernel over marked tiles: none on whole metres)"
+    if size < 31:
+        return "disc_wave_kernel<%d, 64, 8, %s>" % (size, "tpi+std" if what == "tpi_std" else "std")
+    return "tpi_march_kernel<%d, 60, 12, OUT_SUM> + std_march_kernel<%d, 60, 12> + disc_wave_kernel over marked tiles" % (size, size)
+
+
 def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
-    """Per-descriptor throughput on the resident DEM (N = 1 only): not the headline."""
+    """Per-descriptor throughput on the resident DEM (N = 1 only): not the headline.  Every entry is the
+    median of >= 10 launches, each bracketed by its own HIP events (min / max / n alongside)."""
     from topo_descriptors_amd import device as d
 
     out = {}
@@ -156,30 +210,37 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     o2 = d.DeviceArray(ny, nx)
     blk = block_cls(dem)
     px = ny * nx
+    REPS = 10
 
-    def entry(key, ms, bpp):
-        out[key] = {"ms": round(ms, 4), "Mpixels_per_s": round(px / ms / 1e3, 1),
-                    "hbm_frac": round(px * bpp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    def entry(key, st, bpp, kernel, per=1):
+        ms = st["median"] / per
+        out[key] = {"ms": round(ms, 4), "ms_min": round(st["min"] / per, 4), "ms_max": round(st["max"] / per, 4),
+                    "launches": st["n"], "Mpixels_per_s": round(px / ms / 1e3, 1),
+                    "hbm_frac": round(px * bpp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": kernel}
 
     for size in (7, 65, 67):
-        entry(f"tpi_s{size}", time_kernel(lambda: blk.tpi_std(size, tpi=o1), 3, d), 8)
-        entry(f"std_s{size}", time_kernel(lambda: blk.tpi_std(size, std=o2), 3, d), 8)
-        entry(f"tpi_std_s{size}", time_kernel(lambda: blk.tpi_std(size, tpi=o1, std=o2), 3, d), 12)
+        entry(f"tpi_s{size}", time_kernel(lambda: blk.tpi_std(size, tpi=o1), REPS, d), 8, disc_kernels("tpi", size))
+        entry(f"std_s{size}", time_kernel(lambda: blk.tpi_std(size, std=o2), REPS, d), 8, disc_kernels("std", size))
+        entry(f"tpi_std_s{size}", time_kernel(lambda: blk.tpi_std(size, tpi=o1, std=o2), REPS, d), 12,
+              disc_kernels("tpi_std", size))
     o3 = d.DeviceArray(ny, nx)
     o4 = d.DeviceArray(ny, nx)
+    grad_kernels = {3.25: "gauss_axis0_kernel<8, 8> + gauss_axis1_grad_kernel<16, 8, 8, 3> (LDS tile, fused epilogue)",
+                    30.25: "gauss_axis0_kernel<16, 16> + gauss_axis1_wave_grad_kernel (wave shift, fused epilogue)"}
     for sigma in (3.25, 30.25):
         fn = lambda: blk.gradient(sigma, [30.0], [-30.0], dx=o1, dy=o2, slope=o3, aspect=o4)  # noqa: E731
-        entry(f"gradient_sigma{sigma}", time_kernel(fn, 2, d), 20)
+        entry(f"gradient_sigma{sigma}", time_kernel(fn, REPS, d), 20, grad_kernels[sigma])
         fn = lambda: blk.gradient(sigma, [30.0], [-30.0], slope=o3, aspect=o4)  # noqa: E731
-        entry(f"slope_aspect_sigma{sigma}", time_kernel(fn, 2, d), 12)
+        entry(f"slope_aspect_sigma{sigma}", time_kernel(fn, REPS, d), 12, grad_kernels[sigma])
     for radius in (500.0, 2000.0):
         window, dj, di, dist = d.sx_offsets(0.0, radius, 30.0, -30.0)
         fn = lambda: blk.sx(dj, di, dist, window, 10.0, o1)  # noqa: E731
-        entry(f"sx_az0_r{int(radius)}", time_kernel(fn, 3, d), 8)
+        entry(f"sx_az0_r{int(radius)}", time_kernel(fn, REPS, d), 8, "sx_kernel (LDS tile, one atan per pixel)")
     # 8 azimuths every 5 degrees in one pass: ms and rate are per azimuth plane
     sectors = [d.sx_offsets(5.0 * k, 500.0, 30.0, -30.0) for k in range(8)]
     fan = [o1, o2, o3, o4] + [d.DeviceArray(ny, nx) for _ in range(4)]
-    entry("sx_r500_8_azimuths_step5_per_azimuth", time_kernel(lambda: blk.sx_multi(sectors, 10.0, fan), 3, d) / 8, 8)
+    entry("sx_r500_8_azimuths_step5_per_azimuth", time_kernel(lambda: blk.sx_multi(sectors, 10.0, fan), REPS, d), 8,
+          "sx_multi_kernel<8>", per=8)
     for a in fan[4:]:
         a.free()
     # valley index at 200 m (7 px): 180 angles x 3 plane sums of rotated kernels in one pass
@@ -188,18 +249,21 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     mean, stdev = d.mean_std(dem)
     taps, ksize, angles = topo._valley_ridge_tables(topo._valley_kernels(7, [0, 0.15, 0.3]),
                                                     np.arange(0, 180, dtype=np.float32))
-    ms = time_kernel(lambda: blk.valley_ridge(taps, ksize, angles, 3, mean, stdev, o1, o2), 1, d)
-    entry("valley_ridge_s7", ms, 12)
+    st = time_kernel(lambda: blk.valley_ridge(taps, ksize, angles, 3, mean, stdev, o1, o2), REPS, d)
+    entry("valley_ridge_s7", st, 12, "valley_ridge_kernel<3>")
     nonzero = int(np.any(taps.reshape(-1, 4)[:, :3] != 0, axis=1).sum())  # the taps the kernel evaluates
-    out["valley_ridge_s7"]["GFMA_per_s_executed"] = round(px * nonzero * 3 / ms / 1e6, 0)
+    out["valley_ridge_s7"]["GFMA_per_s_executed"] = round(px * nonzero * 3 / st["median"] / 1e6, 0)
 
     # the same TPI on fractional elevations: every tile runs the integer pass plus the float
     # chain on the fractional parts and goes through the per-row scratch planes (two passes)
     frac = d.synth_dem(ny, nx, seed=0, integer=False)
     fblk = block_cls(frac)
     for size in (7, 67):
-        entry(f"tpi_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, tpi=o1), 3, d), 8)
-        entry(f"std_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, std=o2), 3, d), 8)
+        entry(f"tpi_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, tpi=o1), REPS, d), 8,
+              "ring / march kernel (sums of trunc x) + fraction pass" if size >= 17 else
+              "ring kernel (marks) + disc_wave_kernel over every tile")
+        entry(f"std_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, std=o2), REPS, d), 8,
+              "disc_wave_kernel (general, three staging passes)")
     frac.free()
     for a in (o1, o2, o3, o4):
         a.free()
@@ -255,20 +319,37 @@ def main():
             _lib.check(lib.topo_amd_shard_tpi_std(block.ptr, rows_local, row0, ny, nx, size, out.ptr,
                                                   None), "shard_tpi_std")
 
+    # bring the clocks up: untimed launches until three consecutive ones agree within 1.5 % (at most 40).
+    # Every rank runs the same number (the count is agreed on through the max over ranks).
+    ramp, last = 0, []
+    while ramp < 40:
+        d.mark(0)
+        step()
+        d.mark(1)
+        last = (last + [d.mark_elapsed(0, 1)])[-3:]
+        ramp += 1
+        settled = len(last) == 3 and max(last) <= 1.015 * min(last) and ramp >= 4
+        if rdv.max(0.0 if settled else 1.0) == 0.0:
+            break
     for _ in range(args.warmup):
         step()
     d.sync()
     rdv.barrier()
-    d.timer_start()
+    steps = args.steps
+    if steps > 510:
+        sys.exit("bench.py: at most 510 timed steps (one HIP event per step)")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    d.mark(0)
+    for k in range(steps):
         step()
-    event_ms = d.timer_stop()  # HIP events on the compute stream around the K launches
+        d.mark(k + 1)  # HIP events on the compute stream between the K launches, no host synchronise
     d.sync()
     rdv.barrier()
     wall = time.perf_counter() - t0
     wall = rdv.max(wall)
-    kernel_ms = rdv.max(event_ms / args.steps)
+    per_step = stats([d.mark_elapsed(k, k + 1) for k in range(steps)])
+    kernel_ms = rdv.max(per_step["mean"])
+    kernel_ms_median = rdv.max(per_step["median"])
 
     px_total = ny * nx
     value = px_total * args.steps / wall / 1e6
@@ -284,6 +365,12 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "ms_per_step_median": round(kernel_ms_median, 4),
+            "ms_per_step_mean": round(kernel_ms, 4),
+            "ms_per_step_min": round(per_step["min"], 4),
+            "ms_per_step_max": round(per_step["max"], 4),
+            "value_at_median": round(px_total / kernel_ms_median / 1e3, 1),
+            "clock_ramp_steps": ramp,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -304,7 +391,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic(ny, nx, size, world),
+                "frac_at_median": round(px_launch * BYTES_PER_PIXEL["tpi"] / (kernel_ms_median * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # north_star's literal "HBM-read roofline": the 4 B/pixel the kernel has to read, nothing else
+                "frac_read_only_basis": round(px_launch * 4 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                **measured_traffic(ny, nx, size, world),
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
                 "algorithmic_bytes_per_launch": px_launch * BYTES_PER_PIXEL["tpi"],
                 "kernel": "tpi_march_kernel<67, 60, 12, true, true, true> (exact one-pass TPI on whole-metre tiles, marching down "
@@ -312,6 +402,11 @@ def main():
                           "it over the tiles it deferred and the fraction pass for tiles with fractional elevations "
                           "(neither finds a tile on this DEM, ~10 us together)",
                 "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_median": round(kernel_ms_median, 4),
+                # what bounds it (profiles/r02_valu_mix_rate.txt, r02_tpi67_pmc_summary.txt): the
+                # exact disc sum is vector-ALU work, ~5.3 VALU pipe cycles per pixel at the measured issue rates
+                # (v_add3_u32 and every DPP form at half rate), i.e. ~2.5 ms per launch at 100 % VALU utilisation
+                "bound_in_practice": "valu",
                 "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL["tpi"],
             },
         }
@@ -320,7 +415,7 @@ def main():
             cols_s = min(nx, 8192)
             sample = block.to_host(halo_up, rows_s)[:, :cols_s].copy()
             result["cpu_baseline"] = cpu_baseline(size, rows_s, cols_s, sample)
-            result["cpu_baseline_all_cores"] = cpu_twin_baseline(size, sample[:4096, :4096])
+            result["cpu_baseline_all_cores"] = cpu_twin_baseline(size, sample)
             # spot parity at full size: TPI of the same window vs the oracle, interior only
             got = out.to_host(0, rows_s)[:, :cols_s]
             from oracle import topo_oracle as orc

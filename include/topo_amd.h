@@ -80,6 +80,11 @@ int topo_amd_sync(void);
 /* HIP-event stopwatch on the compute stream (what bench.py times kernels with). */
 int topo_amd_timer_start(void);
 int topo_amd_timer_stop(float* elapsed_ms); /* records, synchronises, returns ms        */
+/* Numbered HIP events on the compute stream (index 0 .. 511): one per launch boundary gives the
+ * duration of every launch of a timed loop without a host synchronise inside the loop (bench.py
+ * reports the median next to the mean).  topo_amd_mark_elapsed waits for mark `to`.         */
+int topo_amd_mark(int index);
+int topo_amd_mark_elapsed(int from, int to, float* elapsed_ms);
 
 /* Deterministic synthetic terrain (float32 metres) written on the device: the value depends
  * only on (global row, column, seed), so shards agree on overlaps.  integer_valued != 0 rounds

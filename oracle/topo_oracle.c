@@ -37,20 +37,22 @@ int oracle_tpi_std(const float* dem, int ny, int nx, int size, double* tpi, doub
     const double n = (double)taps;
     /* row prefix sums of x and trunc(x)^2, exclusive, nx + 1 entries per row */
     double* p1 = (double*)malloc(sizeof(double) * (size_t)ny * (nx + 1));
-    double* p2 = (double*)malloc(sizeof(double) * (size_t)ny * (nx + 1));
-    if (!lo || !hi || !p1 || !p2) return -1;
+    /* (the plane of trunc(x)^2 only when STD is wanted: TPI alone then touches half the memory) */
+    double* p2 = sd ? (double*)malloc(sizeof(double) * (size_t)ny * (nx + 1)) : NULL;
+    if (!lo || !hi || !p1 || (sd && !p2)) return -1;
 #pragma omp parallel for schedule(static)
     for (int j = 0; j < ny; ++j) {
         double s1 = 0.0, s2 = 0.0;
         double* q1 = p1 + (size_t)j * (nx + 1);
-        double* q2 = p2 + (size_t)j * (nx + 1);
-        q1[0] = q2[0] = 0.0;
+        double* q2 = p2 ? p2 + (size_t)j * (nx + 1) : NULL;
+        q1[0] = 0.0;
+        if (q2) q2[0] = 0.0;
         for (int i = 0; i < nx; ++i) {
             const double x = dem[(size_t)j * nx + i], t = trunc(x);
             s1 += x;
             s2 += t * t;
             q1[i + 1] = s1;
-            q2[i + 1] = s2;
+            if (q2) q2[i + 1] = s2;
         }
     }
 #pragma omp parallel for schedule(dynamic, 8)
@@ -65,7 +67,7 @@ int oracle_tpi_std(const float* dem, int ny, int nx, int size, double* tpi, doub
                 if (x1 > nx - 1) x1 = nx - 1;
                 if (x1 < x0) continue;
                 s1 += p1[(size_t)y * (nx + 1) + x1 + 1] - p1[(size_t)y * (nx + 1) + x0];
-                s2 += p2[(size_t)y * (nx + 1) + x1 + 1] - p2[(size_t)y * (nx + 1) + x0];
+                if (p2) s2 += p2[(size_t)y * (nx + 1) + x1 + 1] - p2[(size_t)y * (nx + 1) + x0];
             }
             const size_t o = (size_t)j * nx + i;
             if (tpi) {

@@ -231,6 +231,105 @@ def test_config4_sx_16384():
     dev.free()
 
 
+def test_config5_32768():
+    """configs[4] minus the wire: 32768 x 32768, TPI + STD at 67 px, gradient at sigma 3.25 and 30.25, Sx
+    azimuth 0 radius 500 m, computed (i) as one block and (ii) as 8 row blocks of 4096 rows, each generated
+    on the device with exactly its ghost rows and run one after the other on the one GPU.  (ii) must equal
+    (i) bit for bit - what the RCCL halo exchange then has to deliver is just those ghost rows - and (i)
+    must agree with the exact oracle on windows that straddle the seams at rows 4096 k."""
+    n, nb = 32768, 8
+    rows_b = n // nb
+    dev = d.synth_dem(n, n, seed=5)
+    whole_blk = d.Block(dev)
+    window, dj, di, dist = d.sx_offsets(0.0, 500.0, 30.0, -30.0)
+    sx_up, sx_down = int(max(0, -dj.min())), int(max(0, dj.max()))
+
+    def shards(above, below):
+        for k in range(nb):
+            row0 = k * rows_b
+            lo, hi = max(0, row0 - above), min(n, row0 + rows_b + below)
+            part = d.synth_dem(hi - lo, n, row0=lo, seed=5)  # a shard of its own, not a view of `dev`
+            yield row0, d.Block(part, row0=lo, gny=n), part
+
+    def check_blocks(name, planes, above, below, call):
+        """planes: the one-block results; call(block, row0, rows, outs) fills outs for one shard."""
+        outs = [d.DeviceArray(rows_b, n) for _ in planes]
+        for row0, blk, part in shards(above, below):
+            call(blk, row0, rows_b, outs)
+            d.sync()
+            for k, (o, w) in enumerate(zip(outs, planes)):
+                assert np.array_equal(o.to_host(), w.to_host(row0, rows_b)), (name, k, row0)
+            part.free()
+        for o in outs:
+            o.free()
+
+    seams = [rows_b * k for k in (1, 4, 7)]
+
+    # ---- TPI + STD, 67 px ----
+    size, r, w = 67, 33, 160
+    t, s = d.DeviceArray(n, n), d.DeviceArray(n, n)
+    whole_blk.tpi_std(size, tpi=t, std=s)
+    d.sync()
+    up, down = halo(_lib.DESC_TPI, size)
+    check_blocks("tpi_std", [t, s], up, down,
+                 lambda blk, row0, rows, o: blk.tpi_std(size, tpi=o[0], std=o[1], out_row0=row0, out_rows=rows))
+    for j, i in [(0, 0), (n - w, n - w)] + [(sj - w // 2, 5000 + 3 * sj) for sj in seams]:
+        i = min(i, n - w)
+        j0, j1, i0, i1 = max(0, j - r), min(n, j + w + r), max(0, i - r), min(n, i + w + r)
+        sub = dev.to_host(j0, j1 - j0)[:, i0:i1]
+        a, b = j - j0, i - i0
+        want_t = orc.tpi_exact(sub, size)[a:a + w, b:b + w]
+        want_s = orc.std_exact(sub, size)[a:a + w, b:b + w]
+        keep = np.ones((w, w), bool)  # pixels whose disc crosses a cut that is not a DEM edge
+        if j0 > 0 and a < r: keep[: r - a] = False
+        if j1 < n and j1 - (j + w) < r: keep[w - (r - (j1 - (j + w))):] = False
+        if i0 > 0 and b < r: keep[:, : r - b] = False
+        if i1 < n and i1 - (i + w) < r: keep[:, w - (r - (i1 - (i + w))):] = False
+        assert np.max(np.abs(t.to_host(j, w)[:, i:i + w] - want_t)[keep]) <= 2.5e-4, (j, i)
+        assert np.max(np.abs(s.to_host(j, w)[:, i:i + w] - want_s)[keep]) <= 1e-4 * max(np.max(want_s), 1.0), (j, i)
+    t.free()
+    s.free()
+
+    # ---- gradient, sigma 3.25 and 30.25 ----
+    outs = [d.DeviceArray(n, n) for _ in range(4)]
+    for sigma in (3.25, 30.25):
+        whole_blk.gradient(sigma, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3])
+        d.sync()
+        up, down = halo(_lib.DESC_GRADIENT, sigma, 1.0)
+        check_blocks(f"gradient {sigma}", outs, up, down,
+                     lambda blk, row0, rows, o: blk.gradient(sigma, [30.0], [-30.0], dx=o[0], dy=o[1], slope=o[2],
+                                                             aspect=o[3], out_row0=row0, out_rows=rows))
+        R, w = int(4 * sigma + 0.5) + 1, 128
+        for sj in seams[:2]:
+            j, i = sj - w // 2, 9000 + sj
+            j0, j1, i0, i1 = j - R, j + w + R, i - R, i + w + R
+            sub = dev.to_host(j0, j1 - j0)[:, i0:i1]
+            exact = orc.gradient_exact(sub, sigma, {"x": np.full(i1 - i0, 30.0), "y": np.full(j1 - j0, -30.0)})
+            for k, nm in enumerate(("dx", "dy", "slope")):
+                got = outs[k].to_host(j, w)[:, i:i + w]
+                want = exact[k][R:R + w, R:R + w]
+                assert np.max(np.abs(got - want)) <= 1e-4 * max(np.max(np.abs(want)), 1e-3) + 2e-5, (sigma, nm, sj)
+    for o in outs:
+        o.free()
+
+    # ---- Sx, azimuth 0, radius 500 m ----
+    out = d.DeviceArray(n, n)
+    whole_blk.sx(dj, di, dist, window, 10.0, out)
+    d.sync()
+    check_blocks("sx", [out], sx_up, sx_down,
+                 lambda blk, row0, rows, o: blk.sx(dj, di, dist, window, 10.0, o[0], out_row0=row0, out_rows=rows))
+    x = 2600000.0 + 30.0 * np.arange(256 + 2 * window)
+    for sj in seams[:2]:
+        j, i = sj - 128, 20000
+        sub = dev.to_host(j - window, 256 + 2 * window)[:, i - window:i + 256 + window]
+        y = 1200000.0 - 30.0 * np.arange(sub.shape[0])
+        want = orc.sx(sub, x, y, 0.0, 500.0)[window:-window, window:-window]
+        got = out.to_host(j, 256)[:, i:i + 256]
+        assert np.max(np.abs(got - want)) <= 1e-4 * np.max(np.abs(want)), sj
+    out.free()
+    dev.free()
+
+
 WAVE_SIZES = list(range(5, 102, 2))   # every odd size has a wave-shift instantiation
 
 

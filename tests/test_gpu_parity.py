@@ -133,6 +133,21 @@ def test_gaussian_anisotropic_and_identity(golden):
     assert np.array_equal(topo.dem(dem, 0.1), ndimage.gaussian_filter(dem, 0.1))  # radius 0
 
 
+@pytest.mark.parametrize("sigma", [0.75, 2.25, 3.25, 6.0])
+def test_gaussian_nan_footprint_is_scipys(sigma):
+    """A NaN sample reaches exactly the (2 radius + 1)^2 outputs it reaches in ndimage.gaussian_filter
+    (topo.py:80): the taps are padded with zeros up to a whole chunk, and 0 x NaN must not widen that."""
+    from scipy import ndimage
+    dem = orc.synthetic_dem(200, 300, seed=21)
+    dem[100, 151] = np.nan
+    dem[7, 290] = np.inf
+    want = ndimage.gaussian_filter(dem, sigma)
+    got = topo.dem(dem, sigma)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    ok = np.isfinite(want)
+    assert np.max(np.abs(got[ok] - want[ok])) <= 1e-3
+
+
 def check_gradient(got, ref_by_name, exact=None):
     dx, dy, slope, aspect = got
     for a in got:

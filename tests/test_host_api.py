@@ -221,3 +221,79 @@ def test_the_helpers_either_side_of_the_path(caplog):
                      lambda: hlp.to_netcdf(a, None, "x")):
             with pytest.raises(ImportError, match="xarray"):
                 call()
+
+
+def test_fill_na_array_known_answers():
+    """helpers.fill_na_array: the NaN fill of the reference's fill_na (helpers.py:137-154:
+    ``interpolate_na(dim="x", method="nearest", fill_value="extrapolate")``), answers derived by hand:
+    interior gap (nearest valid sample along x, the left one on a tie), leading / trailing gap (edge value),
+    all-NaN row (stays NaN), and no coupling between rows."""
+    from topo_descriptors_amd import helpers as hlp
+
+    nan = np.nan
+    a = np.array([[1.0, nan, nan, 4.0, nan, 6.0],      # 1 -> x=0 (1 away, x=3 is 2 away); 2 -> x=3; 4: tie 3|5 -> left
+                  [nan, nan, 3.0, 5.0, nan, nan],      # leading gap -> 3, trailing gap -> 5
+                  [nan, nan, nan, nan, nan, nan],      # nothing to take from: stays NaN
+                  [7.0, 8.0, 9.0, 10.0, 11.0, 12.0],   # untouched
+                  [nan, 2.0, nan, nan, nan, 9.0]],     # 2 -> x=1 (1 away); 3: tie 1|5 -> left; 4 -> x=5
+                 dtype=np.float32)
+    want = np.array([[1.0, 1.0, 4.0, 4.0, 4.0, 6.0],
+                     [3.0, 3.0, 3.0, 5.0, 5.0, 5.0],
+                     [nan, nan, nan, nan, nan, nan],
+                     [7.0, 8.0, 9.0, 10.0, 11.0, 12.0],
+                     [2.0, 2.0, 2.0, 2.0, 9.0, 9.0]], dtype=np.float32)
+    got = hlp.fill_na_array(a)
+    assert got.dtype == a.dtype and got is not a
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.isnan(a[0, 1])  # the input is not modified
+    # uneven coordinates decide "nearest" by distance in x, not by index
+    x = np.array([0.0, 1.0, 2.0, 10.0, 11.0, 12.0])
+    b = np.array([[5.0, nan, nan, nan, nan, 8.0]])
+    assert np.array_equal(hlp.fill_na_array(b, x), [[5.0, 5.0, 5.0, 8.0, 8.0, 8.0]])
+    # and the indices the reference returns next to the filled DEM are just np.where(isnan)
+    ind = np.where(np.isnan(a))
+    assert np.isnan(a[ind]).all() and len(ind[0]) == 3 + 4 + 6 + 4
+
+
+def test_a_dataarray_like_is_not_a_dataset():
+    """The reference's sx / check_dem insist on a Dataset (topo.py:825-826 TypeError, helpers.py:179-180
+    ValueError); a DataArray quacks almost like one (attrs, __getitem__, __iter__) and must be refused."""
+    from topo_descriptors_amd import helpers as hlp, topo
+
+    class Var:
+        def __init__(self, values, dims):
+            self.values, self.dims = values, dims
+
+    class DatasetLike:
+        data_vars = {"dem": None}
+        attrs = {"crs": "epsg:2056"}
+
+        def __init__(self):
+            self._v = {"dem": Var(np.zeros((4, 5), np.float32), ("y", "x")), "x": Var(np.arange(5.0), ("x",)),
+                       "y": Var(-np.arange(4.0), ("y",))}
+
+        def __getitem__(self, k):
+            return self._v[k]
+
+        def __iter__(self):
+            return iter(["dem"])
+
+    class DataArrayLike:
+        dims = ("y", "x")
+        attrs = {"crs": "epsg:2056"}
+        values = np.zeros((4, 5), np.float32)
+
+        def __getitem__(self, k):
+            return self.values[k]
+
+        def __iter__(self):
+            return iter(self.values)
+
+    hlp.check_dem(DatasetLike())
+    assert not hlp._looks_like_dataset(DataArrayLike())
+    with pytest.raises(ValueError, match="xr.Dataset"):
+        hlp.check_dem(DataArrayLike())
+    with pytest.raises(TypeError, match="xr.Dataset"):
+        topo.sx(DataArrayLike(), 0, 500.0)
+    with pytest.raises(TypeError):
+        topo.sx(np.zeros((4, 5), np.float32), 0, 500.0)

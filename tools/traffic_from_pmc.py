@@ -4,11 +4,16 @@
 Follows /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are in KiB;
 on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (16 B/lane, which is how
 the disc kernel loads), so it is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
-Usage: tools/traffic_from_pmc.py <pmc dir> <kernel substring> <out.json>"""
+The result records the git head (argument 4, the GPU box has no .git) and the hash of the kernel sources the
+profile was taken on; bench.py nulls roofline.traffic when the sources have changed since.
+Usage: tools/traffic_from_pmc.py <pmc dir> <kernel substring> <out.json> [git head]"""
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def mean_counter(pmc_dir, kernel, counter):
@@ -22,6 +27,7 @@ def mean_counter(pmc_dir, kernel, counter):
 
 def main():
     pmc_dir, kernel, out = sys.argv[1:4]
+    import bench  # noqa: PLC0415  (the hash bench.py compares with)
     fetch = mean_counter(pmc_dir, kernel, "FETCH_SIZE")
     write = mean_counter(pmc_dir, kernel, "WRITE_SIZE")
     hit = mean_counter(pmc_dir, kernel, "TCC_HIT_sum")
@@ -34,6 +40,8 @@ def main():
         "traffic_bytes_per_launch": None if fetch is None or write is None else fetch * 2048 + write * 1024,
         "l2_hit_rate": None if not hit else hit / (hit + miss),
         "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane coalesced loads), WRITE_SIZE x1; KiB -> bytes",
+        "git_head": sys.argv[4] if len(sys.argv) > 4 else None,
+        "kernel_sources_sha256": bench.kernel_sources_sha256(),
     }
     json.dump(result, open(out, "w"), indent=1)
     print(json.dumps(result))

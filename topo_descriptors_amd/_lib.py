@@ -30,6 +30,8 @@ SIGNATURES = {
     "topo_amd_sync": (C.c_int, []),
     "topo_amd_timer_start": (C.c_int, []),
     "topo_amd_timer_stop": (C.c_int, [_f32p]),
+    "topo_amd_mark": (C.c_int, [C.c_int]),
+    "topo_amd_mark_elapsed": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "topo_amd_cu_count": (C.c_int, []),
     "topo_amd_synth_dem_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int]),
     "topo_amd_disc_tap_count": (C.c_int, [C.c_int]),

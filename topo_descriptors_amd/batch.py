@@ -217,8 +217,8 @@ def compute_valley_ridge(dem_ds, scales, mode, flat_list=[0, 0.15, 0.3], smth_fa
                          crop=None, outdir="."):
     """Valley or ridge index (norm and direction) for every scale (reference topo.py:317-386).
 
-    The DEM goes to the GPU once; per scale the optional pre-smoothing, the mean and standard
-    deviation of the (smoothed) DEM and the 180-angle pass all run on the device-resident plane."""
+    The DEM goes to the GPU once; per scale the optional pre-smoothing and the 180-angle pass run on the
+    device-resident plane (the mean and standard deviation are numpy's, see below)."""
     hlp.check_dem(dem_ds)
     if mode not in ("valley", "ridge"):
         raise ValueError(f"Unknown mode {mode!r}")
@@ -247,7 +247,11 @@ def compute_valley_ridge(dem_ds, scales, mode, flat_list=[0, 0.15, 0.3], smth_fa
                 smooth = smooth or res.plane()
                 res.block.gaussian(sigma, sigma, smooth)
                 block, plane = d.Block(smooth), smooth
-            mean, stdev = d.mean_std(plane)
+            # numpy's own float32 mean / std of the whole (smoothed) array, like the reference (topo.py:427)
+            # and like topo.valley_ridge: the wrapper and the single call then agree bit for bit, also where
+            # two directions nearly tie
+            field = plane.to_host() if sigma else res.host
+            mean, stdev = float(field.mean()), float(field.std())
             n_planes, taps, ksize, ang = ahead.result()
             ahead = pool.submit(tables, scales_pxl[k + 1]) if k + 1 < len(scales) else None
             block.valley_ridge(taps, ksize, ang, n_planes, mean, stdev, norm, direction)

@@ -391,6 +391,29 @@ int topo_amd_timer_stop(float* elapsed_ms) {
     return TOPO_AMD_OK;
 }
 
+// Per-launch timing without a host synchronise per launch: numbered HIP events on the compute stream.
+namespace {
+constexpr int kMarks = 512;
+hipEvent_t g_marks[kMarks] = {};
+}  // namespace
+
+int topo_amd_mark(int index) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(index >= 0 && index < kMarks, "mark: index %d outside [0, %d)", index, kMarks);
+    if (!g_marks[index]) TOPO_HIP(hipEventCreate(&g_marks[index]));
+    TOPO_HIP(hipEventRecord(g_marks[index], ctx().compute));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_mark_elapsed(int from, int to, float* elapsed_ms) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(from >= 0 && from < kMarks && to >= 0 && to < kMarks && g_marks[from] && g_marks[to] && elapsed_ms,
+                 "mark_elapsed: marks %d and %d must have been recorded", from, to);
+    TOPO_HIP(hipEventSynchronize(g_marks[to]));
+    TOPO_HIP(hipEventElapsedTime(elapsed_ms, g_marks[from], g_marks[to]));
+    return TOPO_AMD_OK;
+}
+
 int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed, int integer_valued) {
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(out && rows >= 1 && nx >= 1, "synth_dem: bad arguments");

@@ -30,6 +30,10 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
     return i < n ? i : period - 1 - i;
 }
 
+// The accumulation offset of a group of outputs is one of its own samples; a non-finite sample cannot serve
+// (x - NaN is NaN for every x of the group).
+__device__ __forceinline__ float finite_or_zero(float c) { return fabsf(c) <= 3.0e38f ? c : 0.0f; }
+
 struct GaussArgs {
     const float* in;
     float* out;
@@ -45,8 +49,10 @@ struct GaussArgs {
 // the TB + KB - 1 samples in[c KB ... c KB + TB + KB - 2], of which only KB are new, so per chunk
 // the thread fetches KB samples (all in flight together, one chunk ahead of the FMAs) and issues
 // TB x KB FMAs against KB wave-uniform taps (one scalar load per chunk).
+// ntaps = 2 radius + 1: the last chunk is padded with zero taps, and those are skipped rather than
+// multiplied in (0 x NaN would carry a NaN up to KB - 1 samples further than ndimage.gaussian_filter does).
 template <int TB, int KB, class Fetch>
-__device__ __forceinline__ void tap_chunks(const float* taps, int nchunks, float c, Fetch fetch,
+__device__ __forceinline__ void tap_chunks(const float* taps, int nchunks, int ntaps, float c, Fetch fetch,
                                            float (&acc)[TB]) {
     float win[TB + KB - 1];
     float nxt[KB];
@@ -64,11 +70,23 @@ __device__ __forceinline__ void tap_chunks(const float* taps, int nchunks, float
             for (int i = 0; i < KB; ++i) nxt[i] = fetch((ch + 1) * KB + TB - 1 + i);
         }
         const float* w = taps + ch * KB;  // wave-uniform
+        if (ch + 1 < nchunks) {
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-            const float wk = w[kk];
+            for (int kk = 0; kk < KB; ++kk) {
+                const float wk = w[kk];
 #pragma unroll
-            for (int t = 0; t < TB; ++t) acc[t] = fmaf(wk, win[t + kk], acc[t]);
+                for (int t = 0; t < TB; ++t) acc[t] = fmaf(wk, win[t + kk], acc[t]);
+            }
+        } else {
+            const int left = ntaps - ch * KB;  // real taps of the last chunk (wave-uniform)
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                if (kk < left) {
+                    const float wk = w[kk];
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) acc[t] = fmaf(wk, win[t + kk], acc[t]);
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < TB - 1; ++i) win[i] = win[i + KB];
@@ -85,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void gauss_axis0_kernel(GaussArgs p) {
     if (x >= p.nx) return;
     const int y0 = (p.group0 + (int)blockIdx.y) * TB;
     const int first = y0 - p.radius;                       // global row of sample 0
-    const int last = first + TB - 1 + p.nchunks * KB - 1;  // last sample touched
+    const int last = first + TB - 1 + p.nchunks * KB - 1;  // last sample fetched (the ones past 2 radius + TB - 1 meet no tap)
     const bool plain = first >= 0 && last < p.gny && first >= p.in_row0 && last < p.in_row0 + p.in_rows;
     const float* col = p.in + x;
     auto fetch = [&](int i) -> float {
@@ -99,9 +117,10 @@ __global__ __launch_bounds__(kThreads) void gauss_axis0_kernel(GaussArgs p) {
     // the middle row of the group lies within `radius` rows of every row of the group, hence
     // inside any block that computes part of it - provided radius >= TB/2 - 1; tiny filters
     // accumulate without an offset (they have nothing to lose)
-    const float c = p.radius >= TB / 2 - 1 ? fetch(p.radius + TB / 2) : 0.0f;
+    // (a NaN or inf there would make every output of the group non-finite instead of the ones its taps reach)
+    const float c = finite_or_zero(p.radius >= TB / 2 - 1 ? fetch(p.radius + TB / 2) : 0.0f);
     float acc[TB];
-    tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
+    tap_chunks<TB, KB>(p.taps, p.nchunks, 2 * p.radius + 1, c, fetch, acc);
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
         const int oy = y0 + t;
@@ -143,9 +162,9 @@ __global__ __launch_bounds__(NW * 64) void gauss_axis1_kernel(GaussArgs p) {
 
     const float* rowp = L + lane * stride + wave * TB;
     auto fetch = [&](int i) -> float { return rowp[i]; };
-    const float c = rowp[R];
+    const float c = finite_or_zero(rowp[R]);
     float acc[TB];
-    tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
+    tap_chunks<TB, KB>(p.taps, p.nchunks, 2 * p.radius + 1, c, fetch, acc);
     __syncthreads();
     // transpose back through LDS so the stores are row-coalesced
     constexpr int ostride = TC + 1;
@@ -374,9 +393,9 @@ __global__ __launch_bounds__(NW * 64) void gauss_axis1_grad_kernel(GaussArgs p, 
 
         const float* rowp = L + lane * stride + wave * TB;
         auto fetch = [&](int i) -> float { return rowp[i]; };
-        const float c = rowp[R];
+        const float c = finite_or_zero(rowp[R]);
         float acc[TB];
-        tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
+        tap_chunks<TB, KB>(p.taps, p.nchunks, 2 * p.radius + 1, c, fetch, acc);
         lds_barrier();
         constexpr int ostride = TC + 1;
         float* O = L;  // smoothed tile, rounded to float32 like the reference's intermediate

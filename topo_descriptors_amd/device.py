@@ -69,6 +69,31 @@ def timer_stop():
     return ms.value
 
 
+def mark(index):
+    """Record numbered event ``index`` (0 .. 511) on the compute stream."""
+    _lib.check(_lib.lib().topo_amd_mark(int(index)), "mark")
+
+
+def mark_elapsed(a, b):
+    """Milliseconds between marks ``a`` and ``b`` (waits for ``b``)."""
+    ms = C.c_float()
+    _lib.check(_lib.lib().topo_amd_mark_elapsed(int(a), int(b), C.byref(ms)), "mark_elapsed")
+    return ms.value
+
+
+def time_launches(fn, reps, warm=1):
+    """Per-launch HIP-event durations (ms) of ``reps`` back-to-back calls of ``fn`` (<= 511), after
+    ``warm`` untimed ones: one event between consecutive launches, no host synchronise inside."""
+    for _ in range(warm):
+        fn()
+    sync()
+    mark(0)
+    for k in range(reps):
+        fn()
+        mark(k + 1)
+    return [mark_elapsed(k, k + 1) for k in range(reps)]
+
+
 def synth_dem(rows, nx, row0=0, seed=0, out=None, out_row=0, integer=True):
     """Fill (part of) a DeviceArray with the deterministic synthetic terrain.
 

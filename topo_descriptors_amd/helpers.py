@@ -28,6 +28,10 @@ def _looks_like_dataset(obj):
         return True
     if isinstance(obj, np.ndarray):
         return False
+    # a DataArray has attrs, __getitem__ and __iter__ too; the reference raises for it (topo.py:825-826,
+    # helpers.py:179-180: isinstance(dem, xr.Dataset)).  It carries ``dims`` itself and has no data variables.
+    if hasattr(obj, "dims") and not hasattr(obj, "data_vars"):
+        return False
     return all(hasattr(obj, a) for a in ("attrs", "__getitem__", "__iter__"))
 
 
@@ -120,8 +124,10 @@ def fill_na_array(values, x_coords=None):
     """NaNs of a 2-D array replaced row by row with the nearest valid sample along x, the edge value
     beyond the first / last valid sample: what ``interpolate_na(dim="x", method="nearest",
     fill_value="extrapolate")`` does in the reference's ``fill_na`` (helpers.py:137-154), through the
-    same ``scipy.interpolate.interp1d`` xarray uses.  Rows with fewer than two valid samples are left
-    alone.  Not checked against the reference here (xarray is absent from the image)."""
+    same ``scipy.interpolate.interp1d`` xarray uses (a sample half way between two valid ones takes the
+    left one).  Rows with fewer than two valid samples are left alone.  xarray is absent from the image, so
+    this is pinned by hand-derived known answers (tests/test_host_api.py::test_fill_na_array_known_answers),
+    not by a run of the reference."""
     from scipy.interpolate import interp1d  # noqa: PLC0415
 
     out = np.array(values, copy=True)
