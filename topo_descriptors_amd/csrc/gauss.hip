@@ -49,10 +49,13 @@ struct GaussArgs {
 // the TB + KB - 1 samples in[c KB ... c KB + TB + KB - 2], of which only KB are new, so per chunk
 // the thread fetches KB samples (all in flight together, one chunk ahead of the FMAs) and issues
 // TB x KB FMAs against KB wave-uniform taps (one scalar load per chunk).
-// ntaps = 2 radius + 1: the last chunk is padded with zero taps, and those are skipped rather than
-// multiplied in (0 x NaN would carry a NaN up to KB - 1 samples further than ndimage.gaussian_filter does).
+// The padded zero taps of the last chunk are multiplied in like the others: skipping them (a second copy of
+// the unrolled chunk body, bounded by the true tap count) was measured and costs 28 % of the gradient at
+// sigma 3.25 (10.9 ms against 8.5 ms at 32768^2).  What it would buy: 0 x NaN = NaN, so a non-finite sample
+// reaches up to KB - 1 outputs further along each axis (towards lower indices) than in ndimage.gaussian_filter;
+// finite data is unaffected.  tests/test_gpu_parity.py::test_gaussian_nan_footprint pins that bound.
 template <int TB, int KB, class Fetch>
-__device__ __forceinline__ void tap_chunks(const float* taps, int nchunks, int ntaps, float c, Fetch fetch,
+__device__ __forceinline__ void tap_chunks(const float* taps, int nchunks, float c, Fetch fetch,
                                            float (&acc)[TB]) {
     float win[TB + KB - 1];
     float nxt[KB];
@@ -70,23 +73,11 @@ __device__ __forceinline__ void tap_chunks(const float* taps, int nchunks, int n
             for (int i = 0; i < KB; ++i) nxt[i] = fetch((ch + 1) * KB + TB - 1 + i);
         }
         const float* w = taps + ch * KB;  // wave-uniform
-        if (ch + 1 < nchunks) {
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                const float wk = w[kk];
+        for (int kk = 0; kk < KB; ++kk) {
+            const float wk = w[kk];
 #pragma unroll
-                for (int t = 0; t < TB; ++t) acc[t] = fmaf(wk, win[t + kk], acc[t]);
-            }
-        } else {
-            const int left = ntaps - ch * KB;  // real taps of the last chunk (wave-uniform)
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                if (kk < left) {
-                    const float wk = w[kk];
-#pragma unroll
-                    for (int t = 0; t < TB; ++t) acc[t] = fmaf(wk, win[t + kk], acc[t]);
-                }
-            }
+            for (int t = 0; t < TB; ++t) acc[t] = fmaf(wk, win[t + kk], acc[t]);
         }
 #pragma unroll
         for (int i = 0; i < TB - 1; ++i) win[i] = win[i + KB];
@@ -120,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void gauss_axis0_kernel(GaussArgs p) {
     // (a NaN or inf there would make every output of the group non-finite instead of the ones its taps reach)
     const float c = finite_or_zero(p.radius >= TB / 2 - 1 ? fetch(p.radius + TB / 2) : 0.0f);
     float acc[TB];
-    tap_chunks<TB, KB>(p.taps, p.nchunks, 2 * p.radius + 1, c, fetch, acc);
+    tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
         const int oy = y0 + t;
@@ -164,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void gauss_axis1_kernel(GaussArgs p) {
     auto fetch = [&](int i) -> float { return rowp[i]; };
     const float c = finite_or_zero(rowp[R]);
     float acc[TB];
-    tap_chunks<TB, KB>(p.taps, p.nchunks, 2 * p.radius + 1, c, fetch, acc);
+    tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
     __syncthreads();
     // transpose back through LDS so the stores are row-coalesced
     constexpr int ostride = TC + 1;
@@ -294,6 +285,50 @@ __global__ __launch_bounds__(kThreads) void gradient_epilogue_kernel(GradArgs p)
     finish_gradient(p, oy, ox, dx, dy);
 }
 
+// The same, four adjacent pixels per thread: 16-byte loads of the three smoothed rows and 16-byte stores of
+// the four outputs (the one-pixel kernel moves the 20 B/pixel as dwords and ran at 3.2 TB/s).  Needs
+// nx % 4 == 0 and 16-byte aligned planes; identical arithmetic per pixel, hence identical bits.
+__global__ __launch_bounds__(kThreads) void gradient_epilogue4_kernel(GradArgs p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int ox = (blockIdx.x * kThreads + threadIdx.x) * 4;
+    const int oy = p.out_row0 + blockIdx.y;
+    if (ox >= p.nx) return;
+    const float* rowx = p.gx_src + (size_t)(oy - p.s_row0) * p.nx;
+    const f4 mid = *reinterpret_cast<const f4*>(rowx + ox);
+    const float left = ox > 0 ? rowx[ox - 1] : 0.0f, right = ox + 4 < p.nx ? rowx[ox + 4] : 0.0f;
+    const float* coly = p.gy_src + (size_t)(oy - p.s_row0) * p.nx + ox;
+    const f4 cen = *reinterpret_cast<const f4*>(coly);
+    const f4 up = oy > 0 ? *reinterpret_cast<const f4*>(coly - p.nx) : cen;
+    const f4 dn = oy < p.gny - 1 ? *reinterpret_cast<const f4*>(coly + p.nx) : cen;
+    f4 odx, ody, osl, oas;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int x = ox + t;
+        const float xm = t == 0 ? left : mid[t == 0 ? 0 : t - 1], xp = t == 3 ? right : mid[t == 3 ? 3 : t + 1];
+        // numpy.gradient: central difference / 2 inside, first-order one-sided at the edges
+        float dx;
+        if (x == 0) dx = mid[1] - mid[0];
+        else if (x == p.nx - 1) dx = mid[3] - mid[2];
+        else dx = (xp - xm) * 0.5f;
+        float dy;
+        if (oy == 0) dy = dn[t] - cen[t];
+        else if (oy == p.gny - 1) dy = cen[t] - up[t];
+        else dy = (dn[t] - up[t]) * 0.5f;
+        float rx, ry, slope, aspect;
+        resolution_at(p, oy, x, rx, ry);
+        gradient_values(dx, dy, rx, ry, slope, aspect);
+        odx[t] = dx;
+        ody[t] = dy;
+        osl[t] = slope;
+        oas[t] = aspect;
+    }
+    const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
+    if (p.dx) *reinterpret_cast<f4*>(p.dx + o) = odx;
+    if (p.dy) *reinterpret_cast<f4*>(p.dy + o) = ody;
+    if (p.slope) *reinterpret_cast<f4*>(p.slope + o) = osl;
+    if (p.aspect) *reinterpret_cast<f4*>(p.aspect + o) = oas;
+}
+
 __device__ __forceinline__ double raw_reflect(const GradArgs& p, int gy, int gx) {
     gy = reflect_index(gy, p.gny);
     gx = reflect_index(gx, p.nx);
@@ -395,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void gauss_axis1_grad_kernel(GaussArgs p, 
         auto fetch = [&](int i) -> float { return rowp[i]; };
         const float c = finite_or_zero(rowp[R]);
         float acc[TB];
-        tap_chunks<TB, KB>(p.taps, p.nchunks, 2 * p.radius + 1, c, fetch, acc);
+        tap_chunks<TB, KB>(p.taps, p.nchunks, c, fetch, acc);
         lds_barrier();
         constexpr int ostride = TC + 1;
         float* O = L;  // smoothed tile, rounded to float32 like the reference's intermediate
@@ -615,6 +650,241 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const float* in, fl
     }
 }
 
+// ---- long filters on the matrix cores: banded Toeplitz x data with v_mfma_f32_32x32x2_f32 --------------
+// out = T in, T[i][k] = w[k - i] for 0 <= k - i <= 2 R.  For a tile of 32 outputs along the filter axis the
+// band touches K = 32 + 2 R inputs, so the product spends (32 + 2 R) / (2 R + 1) of the minimum number of
+// multiply-adds (1.13 at radius 121) - but at the f32 MFMA rate, which one wave per SIMD reaches with
+// nothing but an LDS read per operand, where the vector-ALU kernels issue 2.3 instructions per useful FMA.
+// The result of a 32x32x2 f32 MFMA chain is the k-ordered fmaf chain, one rounding per product; the taps
+// outside the band are exact zeros, so an output is the fmaf chain over its own 2 R + 1 taps in ascending
+// order whatever tile it falls in (partition invariance needs no tile alignment; only the accumulation
+// offsets do: they are taken per column / per row from samples that any block covering the output holds).
+// A non-finite sample reaches every output of the tiles whose (padded) band contains it (0 x NaN), i.e. up to 47
+// rows / columns further than in ndimage.gaussian_filter.  Two accumulators (even / odd groups) were tried to
+// take the dependent-MFMA wait out: 7.9 ms against 6.9 ms for the one chain, so it stays one chain.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMfmaCols = 128;  // axis 0: columns per block (4 waves x 32)
+constexpr int kAhead = 8;       // steps an operand is fetched ahead of its MFMA
+
+// wz[n] = w[n - 31] (0 outside the filter), n in [0, K + 32): lane (i = l & 31, h = l >> 5) of step s reads
+// wz[2 s + h - i + 31], the Toeplitz entry T[i][2 s + h]
+constexpr int kWzPad = 32 + 6 * kAhead;  // zeros behind the taps: the steps a padded / prefetching loop reads past the band
+__device__ __forceinline__ void fill_toeplitz_table(float* wz, const float* taps, int R, int K) {
+    for (int n = threadIdx.x; n < K + kWzPad; n += blockDim.x) wz[n] = (n >= 31 && n - 31 <= 2 * R) ? taps[n - 31] : 0.0f;
+}
+
+// Axis 0.  The block owns columns [128 b, 128 b + 128) and a run of row tiles, top to bottom; the input
+// rows of the current window live in a ring of K + 32 LDS rows (the 32 spare ones receive the next
+// tile's rows while this tile is computed: one barrier per tile).
+__global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int tile_first, int ntiles, int tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    const int R = p.radius, K = 32 + 2 * R, RR = (K + 32 + 7) / 8 * 8;  // ring rows: a multiple of 8
+    float* ring = L;
+    float* wz = L + RR * kMfmaCols;  // K + kWzPad entries
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int x0 = blockIdx.x * kMfmaCols;
+    const int tb = blockIdx.y * tiles_per_block, te = min(tb + tiles_per_block, ntiles);
+    if (tb >= te) return;
+    fill_toeplitz_table(wz, p.taps, R, K);
+    for (int n = threadIdx.x; n < RR * kMfmaCols; n += 256) ring[n] = 0.0f;
+    __syncthreads();
+    // loader: 32 threads x 16 bytes per row, 8 rows per pass of the block
+    const int lc = min(x0 + (int)(threadIdx.x & 31) * 4, p.nx - 4);  // (columns past nx: clamped, never stored)
+    const int lr = threadIdx.x >> 5;
+    auto row_ptr = [&](int gy) {
+        gy = reflect_index(gy, p.gny);
+        gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
+        return p.in + (size_t)(gy - p.in_row0) * p.nx + lc;
+    };
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    int y0 = (tile_first + tb) * 32;
+    for (int k = lr; k < K; k += 8)
+        *reinterpret_cast<f4*>(ring + k * kMfmaCols + (threadIdx.x & 31) * 4) = *reinterpret_cast<const f4*>(row_ptr(y0 - R + k));
+    int base = 0;  // ring slot of input row y0 - R (even, like RR: a row pair never straddles the wrap)
+    __syncthreads();
+    const int xw = 32 * wave + j;
+    for (int t = tb; t < te; ++t, y0 += 32) {
+        f4 pre[4];
+        const bool more = t + 1 < te;
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[q] = *reinterpret_cast<const f4*>(row_ptr(y0 - R + K + 8 * q + lr));
+        }
+        int sc = base + R + 16;
+        sc = sc >= RR ? sc - RR : sc;
+        const float c = finite_or_zero(ring[sc * kMfmaCols + xw]);  // the column's sample at the tile's middle row
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        const float* wl = wz + (h - j + 31);
+        const float* bl = ring + h * kMfmaCols + xw;
+        // one wave per SIMD: nothing but the wave itself hides the LDS latency, so the operands of step
+        // s + kAhead are fetched before the MFMA of step s is issued
+        // The step count is padded to a multiple of 8 with zero-weight steps, so the loop has no branch: the
+        // padded steps (and the fetches past the last step) read rows of the ring beyond the window - the next
+        // tile's rows, or the zeros the ring starts with - against taps that are exactly 0.  Steps go in groups
+        // of 4 (8 ring rows: RR and base are multiples of 8, so a group never straddles the wrap and its reads
+        // are one address plus immediates), fetched one group (256 MFMA cycles) ahead of their MFMAs.
+        const int NG = (K / 2 + 7) / 8 * 2;
+        int slot = base;  // ring row of the next group to fetch
+        auto fetch = [&](int g, float (&a)[4], float (&b)[4]) {
+            const float* bp = bl + slot * kMfmaCols;
+            const float* wp = wl + 8 * g;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = wp[2 * u];
+                b[u] = bp[2 * u * kMfmaCols];
+            }
+            slot += 8;
+            slot = slot >= RR ? slot - RR : slot;
+        };
+        auto run = [&](const float (&a)[4], const float (&b)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u] - c, acc, 0, 0, 0);
+        };
+        float a0[4], b0[4], a1[4], b1[4];
+        fetch(0, a0, b0);
+        for (int g = 0; g < NG; g += 2) {
+            fetch(g + 1, a1, b1);
+            run(a0, b0);
+            fetch(g + 2, a0, b0);
+            run(a1, b1);
+            // a wave issues in order and a dependent MFMA waits 64 cycles for the one before it: the 5 or so other
+            // instructions of a step have to sit in that shadow, one step's worth behind every MFMA, not in a
+            // burst behind the last one (53 % -> ? MFMA utilisation, profiles/r02_grad30_pmc_summary.txt)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int sl = base + K + 8 * q + lr;
+                sl = sl >= RR ? sl - RR : sl;
+                *reinterpret_cast<f4*>(ring + sl * kMfmaCols + (threadIdx.x & 31) * 4) = pre[q];
+            }
+        }
+        const int ox = x0 + xw;
+        if (ox < p.nx) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int oy = y0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = c + acc[v];
+            }
+        }
+        base += 32;
+        base = base >= RR ? base - RR : base;
+        __syncthreads();
+    }
+}
+
+// Axis 1.  Every wave owns a band of 32 rows and marches along x; its window of input columns lives in a
+// ring of K + 32 LDS columns (odd row pitch: the 32 rows of an A-operand read fall into 32 banks).  Waves
+// never talk to each other.  `in` holds plane rows [0, rows); a row's result depends on that row alone.
+__global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int rows) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    const int R = p.radius, K = 32 + 2 * R, RC = (K + 32 + 7) / 8 * 8, pitch = RC + 1;  // ring columns: a multiple of 8
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* wz = L;
+    float* ring = L + (K + kWzPad) + wave * (32 * pitch + 32);
+    float* crow = ring + 32 * pitch;
+    fill_toeplitz_table(wz, p.taps, R, K);
+    for (int n = lane; n < 32 * pitch; n += 64) ring[n] = 0.0f;
+    __syncthreads();
+    const int band = blockIdx.x * 4 + wave;
+    const int r0 = band * 32;
+    if (r0 >= rows) return;
+    const int i = lane & 31, h = lane >> 5;
+    // loader: lanes 0-31 / 32-63 take two rows per pass, 32 consecutive columns
+    auto load_cols = [&](int xfirst, int q) {  // rows 2 q + h, columns xfirst + i
+        const int r = min(r0 + 2 * q + h, rows - 1);
+        const int cx = reflect_index(xfirst + i, p.nx);
+        return p.in[(size_t)r * p.nx + cx];
+    };
+    int x0 = 0;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        if (k0 + i < K) {
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + k0 + i] = load_cols(x0 - R + k0, q);
+        }
+    }
+    int base = 0;  // ring column of input column x0 - R (even, like RC)
+    const int ntile = (p.nx + 31) / 32;
+    for (int t = 0; t < ntile; ++t, x0 += 32) {
+        float pre[16];
+        const bool more = t + 1 < ntile;
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) pre[q] = load_cols(x0 - R + K, q);
+        }
+        int sc = base + R + 16;
+        sc = sc >= RC ? sc - RC : sc;
+        const float c = finite_or_zero(ring[i * pitch + sc]);  // the row's sample at the tile's middle column
+        if (h == 0) crow[i] = c;
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        const float* wl = wz + (h - i + 31);
+        const float* al = ring + i * pitch + h;
+        const int NG = (K / 2 + 7) / 8 * 2;  // groups of 4 steps, padded with zero-weight steps: see axis 0
+        int slot = base;  // ring column of the next group to fetch
+        auto fetch = [&](int g, float (&a)[4], float (&b)[4]) {
+            const float* ap = al + slot;
+            const float* wp = wl + 8 * g;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = ap[2 * u];
+                b[u] = wp[2 * u];
+            }
+            slot += 8;
+            slot = slot >= RC ? slot - RC : slot;
+        };
+        auto run = [&](const float (&a)[4], const float (&b)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u] - c, b[u], acc, 0, 0, 0);
+        };
+        float a0[4], b0[4], a1[4], b1[4];
+        fetch(0, a0, b0);
+        for (int g = 0; g < NG; g += 2) {
+            fetch(g + 1, a1, b1);
+            run(a0, b0);
+            fetch(g + 2, a0, b0);
+            run(a1, b1);
+            // a wave issues in order and a dependent MFMA waits 64 cycles for the one before it: the 5 or so other
+            // instructions of a step have to sit in that shadow, one step's worth behind every MFMA, not in a
+            // burst behind the last one (53 % -> ? MFMA utilisation, profiles/r02_grad30_pmc_summary.txt)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+            }
+        }
+        if (more) {
+            int sl = base + K + i;
+            sl = sl >= RC ? sl - RC : sl;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + sl] = pre[q];
+        }
+        const int ox = x0 + i;  // D: column = lane & 31
+        if (ox < p.nx) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int ri = (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (r0 + ri < rows) p.out[(size_t)(r0 + ri) * p.nx + ox] = crow[ri] + acc[v];
+            }
+        }
+        base += 32;
+        base = base >= RC ? base - RC : base;
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------
 int upload_weights(int slot, double sigma, int kb, GaussArgs* a) {
     const int R = gaussian_radius(sigma);
@@ -644,8 +914,94 @@ bool wide_tiling(int radius) {
     return radius >= from;
 }
 
-int run_axis0(const Block& b, double sigma, float* out, int table_slot) {
+// The MFMA kernels take the filters whose ring fits LDS (radius <= 121, sigma <= 30.3).  Same-box sweeps on the
+// 32768^2 bench DEM (tools/grad_time.py, profiles/r02_gauss_mfma.txt): for the Gaussian alone they win from the
+// smallest radius tried (sigma 3.25: 4.9 ms against 6.3 ms); for the gradient, where the vector-ALU axis-1 kernel
+// has the epilogue fused in and the MFMA route pays a separate epilogue launch, they win from radius ~30
+// (sigma 8: 10.5 against 11.5 ms; sigma 6: 10.0 against 9.6).
+bool mfma_radius(int R, int nx, bool for_gradient = false) {
+    static const int from_gauss = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_MFMA_MIN_RADIUS");
+        return e && *e ? std::atoi(e) : 12;
+    }();
+    static const int from_grad = [] {
+        const char* e = std::getenv("TOPO_AMD_GRAD_MFMA_MIN_RADIUS");
+        return e && *e ? std::atoi(e) : 30;
+    }();
+    return R >= (for_gradient ? from_grad : from_gauss) && R <= 121 && nx % 4 == 0 && nx >= 4;
+}
+
+int upload_plain_weights(int slot, double sigma, GaussArgs* a) {
+    return upload_weights(slot, sigma, 1, a);  // 2 R + 1 taps, no padding
+}
+
+int run_axis0_mfma(const Block& b, double sigma, float* out, int table_slot) {
     Context& c = ctx();
+    GaussArgs a;
+    TOPO_TRY(upload_plain_weights(table_slot, sigma, &a));
+    a.in = b.in;
+    a.out = out;
+    a.in_rows = b.in_rows;
+    a.in_row0 = b.in_row0;
+    a.gny = b.gny;
+    a.nx = b.nx;
+    a.out_row0 = b.out_row0;
+    a.out_rows = b.out_rows;
+    a.group0 = 0;
+    const int K = 32 + 2 * a.radius;
+    const size_t lds = ((size_t)((K + 32 + 7) / 8 * 8) * kMfmaCols + (K + kWzPad)) * sizeof(float);
+    static bool ready = false;
+    if (!ready) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis0_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        ready = true;
+    }
+    const int tile_first = b.out_row0 / 32;  // row tiles sit on global multiples of 32 (the accumulation offsets)
+    const int ntiles = (b.out_row0 + b.out_rows - 1) / 32 - tile_first + 1;
+    const int strips = (b.nx + kMfmaCols - 1) / kMfmaCols;
+    // one block per CU marches down its strip; with fewer strips than CUs the tile runs are cut (each cut
+    // restages 2 R rows)
+    int splits = (2 * c.num_cu + strips - 1) / strips;
+    splits = std::max(1, std::min(splits, ntiles / 8 > 0 ? ntiles / 8 : 1));
+    if (strips >= c.num_cu) splits = 1;
+    const int per = (ntiles + splits - 1) / splits;
+    TOPO_TRY(check_grid_rows((ntiles + per - 1) / per, "gaussian (matrix-core axis 0)"));
+    dim3 grid(strips, (ntiles + per - 1) / per);
+    hipLaunchKernelGGL(gauss_axis0_mfma_kernel, grid, dim3(256), lds, c.compute, a, tile_first, ntiles, per);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, int table_slot) {
+    Context& c = ctx();
+    GaussArgs a;
+    TOPO_TRY(upload_plain_weights(table_slot, sigma, &a));
+    a.in = in;
+    a.out = out;
+    a.in_rows = rows;
+    a.in_row0 = 0;
+    a.gny = rows;
+    a.nx = nx;
+    a.out_row0 = 0;
+    a.out_rows = rows;
+    a.group0 = 0;
+    const int K = 32 + 2 * a.radius;
+    const size_t lds = ((size_t)(K + kWzPad) + 4 * (size_t)(32 * ((K + 32 + 7) / 8 * 8 + 1) + 32)) * sizeof(float);
+    static bool ready = false;
+    if (!ready) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        ready = true;
+    }
+    const int bands = (rows + 31) / 32;
+    hipLaunchKernelGGL(gauss_axis1_mfma_kernel, dim3((bands + 3) / 4), dim3(256), lds, c.compute, a, rows);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+int run_axis0(const Block& b, double sigma, float* out, int table_slot, bool mfma_ok = true) {
+    Context& c = ctx();
+    if (mfma_ok && mfma_radius(gaussian_radius(sigma), b.nx)) return run_axis0_mfma(b, sigma, out, table_slot);
     const bool wide = wide_tiling(gaussian_radius(sigma));
     GaussArgs a;
     TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
@@ -693,6 +1049,7 @@ int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, c
 
 // `in` holds exactly the rows [out_row0, out_row0 + out_rows) starting at in_row0 == out_row0
 int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int table_slot) {
+    if (mfma_radius(gaussian_radius(sigma), nx)) return run_axis1_mfma(in, rows, nx, sigma, out, table_slot);
     const bool wide = wide_tiling(gaussian_radius(sigma));
     GaussArgs a;
     TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
@@ -998,7 +1355,9 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         Block rows = b;
         rows.out_row0 = s0;
         rows.out_rows = s_rows;
-        TOPO_TRY(run_axis0(rows, sigma, (float*)plane_a, 1));
+        const bool mfma = mfma_radius(gaussian_radius(sigma), b.nx, true);
+        if (mfma) TOPO_TRY(run_axis0_mfma(rows, sigma, (float*)plane_a, 1));
+        else TOPO_TRY(run_axis0(rows, sigma, (float*)plane_a, 1, false));
         // short and medium filters: LDS-tiled axis 1 (9.8 vs 13.6 ms at sigma 3.25 on 32768^2); long
         // filters: wave-shift axis 1 (26.7 vs 27.8 ms at sigma 30.25) while enough lanes produce output
         static const int fused_max = [] {
@@ -1007,14 +1366,16 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             // beyond: 2.67 vs 3.63 ms at radius 32, 3.33 vs 4.07 at 56, 4.60 vs 5.17 at 92 on 16384^2
             return e && *e ? std::atoi(e) : 92;
         }();
-        if (gaussian_radius(sigma) <= fused_max) {
-            const int r = run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);
+        if (!mfma) {
+            if (gaussian_radius(sigma) <= fused_max) {
+                const int r = run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);
+                if (r != TOPO_AMD_EUNSUP) return r;
+            }
+            const int r = run_axis1_wave_grad((const float*)plane_a, s0, s_rows, sigma, g, nullptr);
             if (r != TOPO_AMD_EUNSUP) return r;
         }
-        const int r = run_axis1_wave_grad((const float*)plane_a, s0, s_rows, sigma, g, nullptr);
-        if (r != TOPO_AMD_EUNSUP) return r;
-        // filter wider than a wavefront can chain: finish the smooth unfused (axis 1 goes through
-        // the transpose path) and difference it with the stand-alone epilogue
+        // matrix-core range (or a filter wider than a wavefront can chain): finish the smooth unfused, then the
+        // stand-alone epilogue (beyond radius 121 axis 1 goes through the wave-shift or the transpose path)
         TOPO_TRY(workspace(2, bytes, &plane_b));
         TOPO_TRY(run_axis1((const float*)plane_a, s_rows, b.nx, sigma, (float*)plane_b, 2));
         plane_a = plane_b;
@@ -1028,7 +1389,14 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     g.gy_src = (const float*)plane_b;
     g.s_row0 = s0;
     g.s_rows = s_rows;
-    hipLaunchKernelGGL(gradient_epilogue_kernel, grid, dim3(kThreads), 0, c.compute, g);
+    auto aligned16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (b.nx % 4 == 0 && b.nx >= 8 && aligned16(g.gx_src) && aligned16(g.gy_src) && aligned16(dx) && aligned16(dy) &&
+        aligned16(slope) && aligned16(aspect)) {
+        dim3 grid4((b.nx / 4 + kThreads - 1) / kThreads, b.out_rows);
+        hipLaunchKernelGGL(gradient_epilogue4_kernel, grid4, dim3(kThreads), 0, c.compute, g);
+    } else {
+        hipLaunchKernelGGL(gradient_epilogue_kernel, grid, dim3(kThreads), 0, c.compute, g);
+    }
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
