@@ -195,8 +195,9 @@ def disc_kernels(what, size):
     if what == "tpi":
         return ("tpi_ring_kernel<%d, 8, .>" % size if 5 <= size <= 11 else "tpi_march_kernel<%d, 60, 12, ..>" % size) + \
             " (+ fraction pass and general kernel over marked tiles: none on whole metres)"
-    if size < 31:
-        return "disc_wave_kernel<%d, 64, 8, %s>" % (size, "tpi+std" if what == "tpi_std" else "std")
+    if 5 <= size <= 67:
+        return "std_ring_kernel<%d, %s> (u and u^2 rings, one staging pass) + disc_wave_kernel over the marked tiles " \
+               "(DEM border, windows with more than 2 lim32 of relief)" % (size, "true" if what == "tpi_std" else "false")
     return "tpi_march_kernel<%d, 60, 12, OUT_SUM> + std_march_kernel<%d, 60, 12> + disc_wave_kernel over marked tiles" % (size, size)
 
 

@@ -117,7 +117,7 @@ __device__ __forceinline__ int ring_dword_of_column(int c) {
 // DEM row above its window), wave-uniform; acc[t]: sum over the disc for the lane's own column NCR lane + t,
 // valid for DL <= lane < 64 - DL; ctr[t]: the staged value of the pixel itself.  The prefix rows of run
 // i + LEAD are fetched before the column sums of run i are formed.
-template <int SIZE, int NCR, int R, int LEAD>
+template <int SIZE, int NCR, int R, int LEAD, int PITCH = 64 * NCR>
 __device__ __forceinline__ void ring_disc_sum(const uint32_t* ring, int s0, int lane, uint32_t (&acc)[NCR],
                                               uint32_t (&ctr)[NCR], bool young) {
     using G = RGeo<SIZE, NCR>;
@@ -135,8 +135,8 @@ __device__ __forceinline__ void ring_disc_sum(const uint32_t* ring, int s0, int 
         sb = sb >= R ? sb - R : sb;
 #pragma unroll
         for (int P = 0; P < G::PARTS; ++P) {
-            top[r][P] = *reinterpret_cast<const u32x4*>(col + st * G::W + P * 256);
-            bot[r][P] = *reinterpret_cast<const u32x4*>(col + sb * G::W + P * 256);
+            top[r][P] = *reinterpret_cast<const u32x4*>(col + st * PITCH + P * 256);
+            bot[r][P] = *reinterpret_cast<const u32x4*>(col + sb * PITCH + P * 256);
         }
     };
 #pragma unroll
@@ -525,6 +525,329 @@ int launch_ring(const Block& b, float* tpi_out) {
     hipLaunchKernelGGL((tpi_ring_kernel<SIZE, NCR, MODE>), dim3((unsigned)grid), dim3(C::NW * 64), C::LDS, c.compute, a,
                        tiles_x, tiles_y);
     TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+
+// ---- K2 ring build: STD and TPI + STD from ONE staging pass ------------------------------------------------
+// The marching pair (tpi_march_kernel<OUT_SUM> + std_march_kernel) reads the DEM twice, writes and re-reads a
+// plane of sums and runs the general kernel over what is left: 27 GB of traffic for 8.6 GB of work at 67 px.
+// Here the prefix rows of u = trunc(x) - c AND of u^2 sit side by side in one ring (2 KiB per row, 4 columns
+// per lane: two images of 8 columns per lane do not fit), both chains of an output row run in the wave that
+// owns the row, and STD (and TPI) are finalised from registers with the expressions of the other kernels:
+//   STD = std_from_int_sums(sum u, sum u^2): shift-invariant, so the bits do not depend on c;
+//   TPI = x - (sum trunc(x) - x) / (n - 1) with sum trunc(x) = sum u + c n, an exact integer.
+// 12 waves: every wave takes one row per phase (B = 12, 5 phases per 60-row map tile); waves 0-3 also own the
+// staging of 64 columns each.
+//
+// The offset c.  Everything is uint32 arithmetic modulo 2^32; the only true constraint is that the sum of u^2
+// over a disc stays below 2^32, i.e. |u| <= lim32 for the samples of the windows that are evaluated.  The
+// stagers keep, per batch of rows, the smallest and largest trunc(x) they saw; at a tile boundary the block
+// looks at the range of the rows now in the ring and ahead of it and, when c has drifted from its middle,
+// RE-BASES THE RING IN PLACE: with delta = c' - c, a prefix row of k rows transforms as
+//   Q1' = Q1 - delta k,   Q2' = Q2 - 2 delta Q1 + delta^2 k        (exact modulo 2^32; additive constants
+// in k or Q1 cancel in the differences the chains take), 79 rows x 512 dwords in about a microsecond, no reload.
+// A window whose relief exceeds 2 lim32 (2244 m at 67 px) cannot be centred: its tile goes to the general
+// kernel through the map (rows of 60, this kernel's own strips), like the tiles with fractional or non-finite
+// samples and the tiles whose discs leave the DEM (their in-domain tap counts differ from n).
+template <int SIZE>
+struct StdRingCfg {
+    using G = RGeo<SIZE, 4>;
+    static constexpr int NW = 12;
+    static constexpr int B = NW;
+    static constexpr int TH = 60;
+    static constexpr int PPT = TH / B;
+    static constexpr int R = SIZE + B;
+    static constexpr int PITCH = 2 * G::W;  // dwords per ring row: the u image, then the u^2 image
+    static constexpr int HALO = SIZE - 1;
+    static constexpr int PAD = 1 + (B - (1 + HALO + B) % B) % B;
+    static constexpr int PRO = PAD + HALO + B;
+    static constexpr int NB_PRO = PRO / B;
+    static constexpr int HIST = (SIZE + 2 * B - 1) / B + 1;
+    static constexpr int SW = G::W / 64;  // staging waves
+    static constexpr size_t LDS = (size_t)R * PITCH * sizeof(uint32_t) + 2 * NW * 4 * sizeof(int) + 16;
+    static_assert(TH % B == 0 && PRO % B == 0, "whole batches");
+    static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
+    static_assert(HIST <= 16, "flag history");
+};
+
+constexpr bool std_ring_fits(int size) {
+    return size >= 5 && size % 2 == 1 && (size_t)(size + 12) * 512 * 4 + 512 <= 160 * 1024 && 64 - 2 * ((size / 2 + 3) / 4) >= 16;
+}
+
+template <int SIZE, bool WANT_TPI>
+__global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+    using G = RGeo<SIZE, 4>;
+    using C = StdRingCfg<SIZE>;
+    constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW, PITCH = C::PITCH, HIST = C::HIST;
+    constexpr int DL = G::DL;
+    constexpr int kBig = 0x3fffffff;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    uint32_t* Q = lds_u;
+    int* wflags = reinterpret_cast<int*>(Q + R * PITCH);  // [2 parities][NW][4]: flags, min, max of the batch a wave staged
+    // more than 128 registers: the block's 12 waves then cannot sit 4 + 4 + 2 + 2 on the SIMDs
+    asm volatile("" ::: "v140");
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ntiles = tiles_x * tiles_y;
+    const int nb = gridDim.x;
+    const int per_xcd = nb >> 3;
+    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int per = (ntiles + nb - 1) / nb;
+    const int first = vb * per;
+    const int last = min(first + per, ntiles);
+    const double n = (double)G::T.taps;
+    const double inv_nm1 = 1.0 / (n - 1.0);
+    const double inv_nn1 = 1.0 / (n * (n - 1.0));
+    const int lim32 = (int)floorf(sqrtf(4294967295.0f / (float)G::T.taps));
+    const int rmin = max(0, p.in_row0), rmax = min(p.gny, p.in_row0 + p.in_rows);
+    const bool stager = wave < C::SW;
+    const int scol = 64 * wave + lane;  // staged column of a staging lane
+
+#pragma unroll 1
+    for (int tile0 = first; tile0 < last;) {
+        const int ty0 = tile0 % tiles_y;
+        const int strip = tile0 / tiles_y;
+        const int run_tiles = min(last - tile0, tiles_y - ty0);
+        const int nphase = run_tiles * PPT;
+        const int ox0 = strip * G::TILE_W;
+        const int oyS = (p.out_row0 / C::TH + ty0) * C::TH;
+        const int gx0 = ox0 - G::X0;
+        const int gy0 = oyS - G::M - C::PAD;
+        // the run starts around the sample at the centre of its first tile; it is re-based as the data drifts
+        int cy = min(max(oyS + C::TH / 2, 0), p.gny - 1);
+        cy = min(max(cy, p.in_row0), p.in_row0 + p.in_rows - 1);
+        const int cx = min(ox0 + G::TILE_W / 2, p.nx - 1);
+        float cf = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
+        if (!(fabsf(cf) <= kAbsLim)) cf = 0.0f;
+        int ci = __builtin_amdgcn_readfirstlane((int)cf);
+        const int gcol = gx0 + scol;
+        const bool col_ok = stager && gcol >= 0 && gcol < p.nx;
+        const float* src = p.in + (col_ok ? gcol : 0);
+        auto load_batch = [&](int n0, float (&v)[B]) {
+            if (!stager) return;
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                int gy = gy0 + n0 + r;
+                gy = min(max(gy, rmin), rmax - 1);
+                v[r] = src[(size_t)(gy - p.in_row0) * p.nx];
+            }
+        };
+        uint32_t run_u = 0, run_u2 = 0;
+        int wslot = 0;  // ring slot of the next row to stage = slot of the oldest row
+        // what a stager saw in a batch: flags, smallest and largest trunc(x)
+        struct Seen { int flags, lo, hi; };
+        auto convert_batch = [&](int n0, const float (&v)[B], uint32_t (&q)[B], uint32_t (&q2)[B]) {
+            Seen s{0, kBig, -kBig};
+            if (!stager) return s;
+            uint32_t amax = 0;  // largest |x| as float bits (NaN / inf sort above all)
+            bool frac = false;
+            int lo = kBig, hi = -kBig;
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                const int gy = gy0 + n0 + r;
+                const bool ok = col_ok && gy >= rmin && gy < rmax;
+                const float x = ok ? v[r] : (float)ci;  // outside: u = 0 (only tiles inside the DEM are computed)
+                const int t = (int)x;                  // truncation towards zero; NaN -> 0, caught by amax
+                frac |= x != (float)t;
+                amax = max(amax, __float_as_uint(x) & 0x7fffffffu);
+                lo = min(lo, t);
+                hi = max(hi, t);
+                const uint32_t u = (uint32_t)(t - ci);
+                run_u += u;
+                run_u2 += u * u;
+                q[r] = run_u;
+                q2[r] = run_u2;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                lo = min(lo, __shfl_xor(lo, m));
+                hi = max(hi, __shfl_xor(hi, m));
+            }
+            if (__builtin_amdgcn_ballot_w64(frac)) s.flags |= kTileFrac;
+            if (__builtin_amdgcn_ballot_w64(amax >= __float_as_uint(kAbsLim + 1.0f))) s.flags |= kTileFloat;
+            s.lo = lo;
+            s.hi = hi;
+            return s;
+        };
+        auto write_batch = [&](const uint32_t (&q)[B], const uint32_t (&q2)[B]) {
+            if (stager) {
+#pragma unroll
+                for (int r = 0; r < B; ++r) {
+                    int sl = wslot + r;
+                    sl = sl >= R ? sl - R : sl;
+                    Q[sl * PITCH + scol] = q[r];
+                    Q[sl * PITCH + G::W + scol] = q2[r];
+                }
+            }
+            wslot += B;
+            wslot = wslot >= R ? wslot - R : wslot;
+        };
+        auto publish = [&](int parity, const Seen& s) {
+            if (lane == 0 && stager) {
+                int* w = wflags + (parity * NW + wave) * 4;
+                w[0] = s.flags;
+                w[1] = s.lo;
+                w[2] = s.hi;
+            }
+        };
+        unsigned hist = 0;           // per batch: fractional / non-finite / absurd samples seen
+        int hlo[HIST], hhi[HIST];    // per batch: range of trunc(x) (index 0 = the newest batch)
+#pragma unroll
+        for (int k = 0; k < HIST; ++k) hlo[k] = kBig, hhi[k] = -kBig;
+        auto fold = [&](int parity) {
+            int fl = 0, lo = kBig, hi = -kBig;
+#pragma unroll
+            for (int w = 0; w < C::SW; ++w) {
+                const int* q = wflags + (parity * NW + w) * 4;
+                fl |= q[0];
+                lo = min(lo, q[1]);
+                hi = max(hi, q[2]);
+            }
+            fl = __builtin_amdgcn_readfirstlane(fl);
+            hist = ((hist << 1) | (fl ? 1u : 0u)) & ((1u << HIST) - 1u);
+#pragma unroll
+            for (int k = HIST - 1; k > 0; --k) hlo[k] = hlo[k - 1], hhi[k] = hhi[k - 1];
+            hlo[0] = __builtin_amdgcn_readfirstlane(lo);
+            hhi[0] = __builtin_amdgcn_readfirstlane(hi);
+        };
+
+        // prologue: the window of phase 0, one batch at a time (a run starts a handful of times per launch: the
+        // exposed load latency does not count, the registers of a second buffer would)
+        float va[B];
+        Seen pro{0, kBig, -kBig};
+#pragma unroll 1
+        for (int k = 0; k < C::NB_PRO; ++k) {
+            uint32_t q[B], q2[B];
+            load_batch(k * B, va);
+            const Seen s = convert_batch(k * B, va, q, q2);
+            pro.flags |= s.flags;
+            pro.lo = min(pro.lo, s.lo);
+            pro.hi = max(pro.hi, s.hi);
+            write_batch(q, q2);
+        }
+        load_batch(C::PRO, va);
+        publish(0, pro);
+        __syncthreads();
+        fold(0);
+
+        const int ocol = gx0 + lane * 4;
+        const bool lane_ok = lane >= DL && lane < 64 - DL;
+        // every disc of the strip's pixels stays inside the DEM's columns
+        const bool cols_inside = ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= p.nx - 1;
+        int s0 = C::PAD - 1 + wave;
+        bool general = false;
+#pragma unroll 1
+        for (int ph = 0; ph < nphase; ++ph) {
+            const int tile = tile0 + ph / PPT;
+            int wlo = kBig, whi = -kBig;  // range of the rows the windows of this phase (and a bit more) can touch
+#pragma unroll
+            for (int k = 0; k < HIST; ++k) wlo = min(wlo, hlo[k]), whi = max(whi, hhi[k]);
+            if (ph % PPT == 0) {
+                // a new tile: re-base the ring when c has drifted from the middle of the range
+                const int mid = wlo + (whi - wlo) / 2;
+                if (wlo <= whi && abs(mid - ci) > lim32 / 4) {
+                    const uint32_t delta = (uint32_t)(mid - ci);
+                    const uint32_t d2 = delta * delta;
+                    for (int idx = threadIdx.x; idx < R * G::W; idx += NW * 64) {
+                        const int sl = idx / G::W, col = idx - sl * G::W;
+                        int k = sl - wslot;  // rows since the oldest one in the ring (any offset would do)
+                        k = k < 0 ? k + R : k;
+                        uint32_t* q = Q + sl * PITCH + col;
+                        const uint32_t q1 = q[0];
+                        q[G::W] = q[G::W] - 2u * delta * q1 + d2 * (uint32_t)k;
+                        q[0] = q1 - delta * (uint32_t)k;
+                    }
+                    if (stager) {
+                        run_u2 = run_u2 - 2u * delta * run_u + d2 * (uint32_t)(R - 1);
+                        run_u = run_u - delta * (uint32_t)(R - 1);
+                    }
+                    ci = mid;
+                    __syncthreads();
+                }
+                const int oy0 = oyS + (ph / PPT) * C::TH;
+                const bool rows_inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1;
+                general = !rows_inside || !cols_inside;
+                if (threadIdx.x == 0) p.defer[tile] = general ? kTileGeneral : kTileDone;
+            }
+            // the windows of this phase hold only whole, finite samples within lim32 of c?
+            const bool fits = hist == 0 && whi - ci <= lim32 && ci - wlo <= lim32;
+            if (!general && !fits) {
+                general = true;
+                if (threadIdx.x == 0) p.defer[tile] = kTileGeneral;
+            }
+            uint32_t nq[B], nq2[B];
+            if (!general) {
+                uint32_t su[4], ctr[4], su2[4], dummy[4];
+                ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q, s0, lane, su, ctr, false);
+                ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q + G::W, s0, lane, su2, dummy, false);
+                const int oy = oyS + ph * B + wave;
+                if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
+                    const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+                    Vec4<float> out_s, out_t;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        out_s.v[t] = std_from_int_sums((double)(int)su[t], (double)su2[t], n, inv_nn1);
+                        if (WANT_TPI) {
+                            const float x = (float)((int)ctr[t] + ci);
+                            const double s1 = (double)((int)su[t] + ci * G::T.taps);  // sum of trunc(x): exact, fits int32
+                            const double x_ctr = (double)x;
+                            out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+                        }
+                    }
+                    *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+                    if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+                }
+            }
+            const Seen seen = convert_batch(C::PRO + ph * B, va, nq, nq2);
+            s0 += B;
+            s0 = s0 >= R ? s0 - R : s0;
+            __syncthreads();
+            write_batch(nq, nq2);
+            load_batch(C::PRO + (ph + 1) * B, va);
+            publish((ph + 1) & 1, seen);
+            __syncthreads();
+            fold((ph + 1) & 1);
+        }
+        tile0 += run_tiles;
+    }
+}
+
+template <int SIZE, bool WANT_TPI>
+int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
+    using G = RGeo<SIZE, 4>;
+    using C = StdRingCfg<SIZE>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0, 0};
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_kernel<SIZE, WANT_TPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)C::LDS));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_kernel<SIZE, WANT_TPI>, C::NW * 64,
+                                                              C::LDS));
+        blocks_per_cu = nblk < 1 ? 1 : (nblk > 2 ? 2 : nblk);  // small discs: two rings per CU
+    }
+    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
+    const int tiles_y = (b.out_row0 + b.out_rows - 1) / C::TH - b.out_row0 / C::TH + 1;
+    const long ntiles = (long)tiles_x * tiles_y;
+    const long grid = march_grid(c, blocks_per_cu, ntiles);
+    void* defer = nullptr;
+    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
+    a.defer = (uint8_t*)defer;
+    hipLaunchKernelGGL((std_ring_kernel<SIZE, WANT_TPI>), dim3((unsigned)grid), dim3(C::NW * 64), C::LDS, c.compute, a,
+                       tiles_x, tiles_y);
+    TOPO_HIP(hipGetLastError());
+    if (std::getenv("TOPO_AMD_DEBUG_MAP")) {  // diagnostic: how many tiles were left to the general kernel
+        std::vector<uint8_t> h((size_t)ntiles);
+        TOPO_HIP(hipMemcpyAsync(h.data(), defer, (size_t)ntiles, hipMemcpyDeviceToHost, c.compute));
+        TOPO_HIP(hipStreamSynchronize(c.compute));
+        long cnt[4] = {0, 0, 0, 0};
+        for (uint8_t v : h) ++cnt[v & 3];
+        std::fprintf(stderr, "std_ring<%d>: %ld tiles: done %ld, general %ld, other %ld\n", SIZE, ntiles, cnt[0], cnt[1], cnt[2] + cnt[3]);
+    }
     return TOPO_AMD_OK;
 }
 

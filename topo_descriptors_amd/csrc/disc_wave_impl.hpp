@@ -356,7 +356,11 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
                 // the map belongs to the marching kernels' geometry (same strips, rows of map_th): this
                 // tile is taken when a map tile that shares output rows with it is marked.  Rows of
                 // unmarked map tiles get recomputed with identical bits.
-                const int tx = mine / tiles_y, ty = mine % tiles_y;
+                // (with a map from another geometry the tile list is read row-major: a round-robin over a
+                // strip-major list whose strips are a multiple of the grid long hands every tile of the top DEM
+                // edge to block 0 and every tile of the bottom edge to the last block - 179 tiles each at 32768^2,
+                // 7 ms of a launch that has 0.8 ms of work)
+                const int tx = mine % tiles_x, ty = mine / tiles_x;
                 const int r0 = max((p.out_row0 / TH + ty) * TH, p.out_row0);
                 const int r1 = min((p.out_row0 / TH + ty) * TH + TH, p.out_row0 + p.out_rows) - 1;
                 const int base = p.out_row0 / p.map_th;
@@ -374,8 +378,9 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
     while (todo) {
         const int tile = base + __builtin_ctzll(todo) * nb;
         todo &= todo - 1;
-        const int ox0 = (tile / tiles_y) * G::TILE_W;
-        const int oy0 = (p.out_row0 / TH + tile % tiles_y) * TH;  // global multiples of TH
+        const bool row_major = p.defer != nullptr && p.map_th != 0;
+        const int ox0 = (row_major ? tile % tiles_x : tile / tiles_y) * G::TILE_W;
+        const int oy0 = (p.out_row0 / TH + (row_major ? tile / tiles_x : tile % tiles_y)) * TH;  // global multiples of TH
         const int gx = ox0 - G::X0 + lane * NC;
         const int gy0 = oy0 + G::T.off_min;
         int cy = min(max(oy0 + TH / 2, 0), p.gny - 1);
@@ -1358,6 +1363,14 @@ inline int tpi_ring_min_size() {
     static const int v = env_int("TOPO_AMD_TPI_RING_MIN", 5);
     return v;
 }
+// Disc size from which STD / TPI + STD take the one-pass ring kernel (TOPO_AMD_STD_RING_MIN; 999 = never).  Same-box
+// A/B on the 32768^2 bench DEM (tools/std_time.py, profiles/r02_std_ring.txt), ring kernel against what it replaces:
+// STD 7 px 3.10 / 5.67 ms, 17 px 3.77 / 6.40, 31 px 5.28 / 7.89, 45 px 6.76 / 9.70, 65 px 9.37 / 12.78, 67 px 10.33 /
+// 13.61; TPI + STD 67 px 10.86 / 14.22.  Identical bits (CRC-32 of both planes, whole metres and fractional DEM).
+inline int std_ring_min_size() {
+    static const int v = env_int("TOPO_AMD_STD_RING_MIN", 5);
+    return v;
+}
 inline int tpi_ring_max_size() {
     static const int v = env_int("TOPO_AMD_TPI_RING_MAX", 11);
     return v;
@@ -1373,6 +1386,16 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
     // The marching kernels take the tiles of whole metres, the general kernel the tiles they left
     // (none on a DEM of whole metres; all of them on one with fractional elevations).
     constexpr bool kFullTile = TH12 == 60;  // LDS holds the tile height the marching kernels were tuned for
+    if constexpr (std_ring_fits(SIZE)) {
+        if (std_out && SIZE >= std_ring_min_size()) {
+            // one staging pass: u and u^2 rings side by side (disc_ring_impl.hpp), then the general kernel over
+            // the tiles it marked (its map has this kernel's strips and rows of 60)
+            if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out)));
+            else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out)));
+            if (tpi_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH);
+            return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH);
+        }
+    }
     if (std_out && (SIZE < std_march_min_size() || !kFullTile)) {
         // small discs: one general kernel (two passes per tile, the second one out of L2) moves three
         // planes where the marching pair moves five, and the chains are too short to matter
