@@ -916,19 +916,21 @@ bool wide_tiling(int radius) {
 
 // The MFMA kernels take the filters whose ring fits LDS (radius <= 121, sigma <= 30.3).  Same-box sweeps on the
 // 32768^2 bench DEM (tools/grad_time.py, profiles/r02_gauss_mfma.txt): for the Gaussian alone they win from the
-// smallest radius tried (sigma 3.25: 4.9 ms against 6.3 ms); for the gradient, where the vector-ALU axis-1 kernel
+// smallest radius tried (sigma 3.25: 4.9 ms against 6.3 ms; they are used from radius 16, sigma 4); for the gradient, where the vector-ALU axis-1 kernel
 // has the epilogue fused in and the MFMA route pays a separate epilogue launch, they win from radius ~30
 // (sigma 8: 10.5 against 11.5 ms; sigma 6: 10.0 against 9.6).
 bool mfma_radius(int R, int nx, bool for_gradient = false) {
     static const int from_gauss = [] {
         const char* e = std::getenv("TOPO_AMD_GAUSS_MFMA_MIN_RADIUS");
-        return e && *e ? std::atoi(e) : 12;
+        // (not below 16: the per-column accumulation offset of an axis-0 tile is the sample 16 rows into the tile,
+        // which every row block that owns a row of the tile holds only when the halo is at least 16 rows)
+        return std::max(16, e && *e ? std::atoi(e) : 16);
     }();
     static const int from_grad = [] {
         const char* e = std::getenv("TOPO_AMD_GRAD_MFMA_MIN_RADIUS");
         return e && *e ? std::atoi(e) : 30;
     }();
-    return R >= (for_gradient ? from_grad : from_gauss) && R <= 121 && nx % 4 == 0 && nx >= 4;
+    return R >= (for_gradient ? std::max(16, from_grad) : from_gauss) && R <= 121 && nx % 4 == 0 && nx >= 4;
 }
 
 int upload_plain_weights(int slot, double sigma, GaussArgs* a) {
