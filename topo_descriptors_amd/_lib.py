@@ -6,7 +6,8 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtopo_amd.so")
+# TOPO_AMD_LIBRARY: another build of the same library (A/B runs of two builds inside one GPU session)
+LIB_PATH = os.environ.get("TOPO_AMD_LIBRARY") or os.path.join(HERE, "libtopo_amd.so")
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)

@@ -305,6 +305,11 @@ int topo_amd_shutdown(void) {
     (void)hipEventDestroy(c.t1);
     (void)hipStreamDestroy(c.compute);
     (void)hipStreamDestroy(c.comm);
+    if (c.aux) {
+        (void)hipStreamDestroy(c.aux);
+        for (auto& e : c.aux_ready) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(c.aux_done);
+    }
     c = Context();
     return TOPO_AMD_OK;
 }

@@ -663,6 +663,21 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const float* in, fl
 // rows / columns further than in ndimage.gaussian_filter.  Two accumulators (even / odd groups) were tried to
 // take the dependent-MFMA wait out: 7.9 ms against 6.9 ms for the one chain, so it stays one chain.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mfma_operands_ready() {
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// a - c on a register pair in one instruction (the compiler splits the vector subtraction into two v_add_f32
+// whenever it likes the register allocation better that way)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 c) {
+    // The hazard recogniser does not look inside inline assembly, and an MFMA that reads the pair one wait state
+    // after this instruction gets stale data (seen: wrong results with `v_pk_add_f32; s_nop 0; v_mfma`).  The
+    // callers issue the four subtractions of a phase, then mfma_operands_ready(), then the MFMAs.
+    f32x2 o;
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(c));
+    return o;
+}
 constexpr int kMfmaCols = 128;  // axis 0: columns per block (4 waves x 32)
 constexpr int kAhead = 8;       // steps an operand is fetched ahead of its MFMA
 
@@ -704,6 +719,13 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
     int base = 0;  // ring slot of input row y0 - R (even, like RR: a row pair never straddles the wrap)
     __syncthreads();
     const int xw = 32 * wave + j;
+#ifdef TOPO_GAUSS_STAMPS
+    long long st[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(n) { const long long now_ = __builtin_amdgcn_s_memtime(); st[n] += now_ - last_; last_ = now_; }
+    long long last_ = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(n)
+#endif
     for (int t = tb; t < te; ++t, y0 += 32) {
         f4 pre[4];
         const bool more = t + 1 < te;
@@ -739,28 +761,48 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
             slot += 8;
             slot = slot >= RR ? slot - RR : slot;
         };
-        auto run = [&](const float (&a)[4], const float (&b)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u] - c, acc, 0, 0, 0);
+        // every vector-ALU instruction in the MFMA stream costs the matrix pipe 8-16 cycles
+        // (tools/ubench/mfma_chain.hip, profiles/r02_mfma_chain.txt): the offsets come off two samples at a time
+        auto run = [&](const float (&a)[4], const float (&b)[4], const float (&a2)[4], const float (&b2)[4]) {
+            const f32x2 cc = {c, c};
+            const f32x2 s0 = pk_sub(f32x2{b[0], b[1]}, cc), s1 = pk_sub(f32x2{b[2], b[3]}, cc);
+            const f32x2 s2 = pk_sub(f32x2{b2[0], b2[1]}, cc), s3 = pk_sub(f32x2{b2[2], b2[3]}, cc);
+            mfma_operands_ready();
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], s0[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], s0[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], s1[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], s1[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0], s2[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1], s2[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[2], s3[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[3], s3[1], acc, 0, 0, 0);
         };
-        float a0[4], b0[4], a1[4], b1[4];
+        // A wave issues in order, a dependent MFMA waits 64 cycles for the one before it, and one wave per SIMD
+        // has nothing else to hide an LDS read behind: the operands of groups g + 2, g + 3 are requested, then the
+        // 8 MFMAs of groups g, g + 1 (fetched a phase ago) run while those reads land.  The scheduler is fenced
+        // at the phase edges: left alone it sinks each read next to its use and waits on it there (58 % MFMA
+        // utilisation, profiles/r02_grad30_pmc_summary.txt).
+        STAMP(0)
+        float a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
         fetch(0, a0, b0);
-        for (int g = 0; g < NG; g += 2) {
-            fetch(g + 1, a1, b1);
-            run(a0, b0);
-            fetch(g + 2, a0, b0);
-            run(a1, b1);
-            // a wave issues in order and a dependent MFMA waits 64 cycles for the one before it: the 5 or so other
-            // instructions of a step have to sit in that shadow, one step's worth behind every MFMA, not in a
-            // burst behind the last one (53 % -> ? MFMA utilisation, profiles/r02_grad30_pmc_summary.txt)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
-            }
+        fetch(1, a1, b1);
+        int g = 0;
+        for (; g + 4 <= NG; g += 4) {
+            fetch(g + 2, a2, b2);
+            fetch(g + 3, a3, b3);
+            __builtin_amdgcn_sched_barrier(0);
+            run(a0, b0, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(g + 4, a0, b0);
+            fetch(g + 5, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            run(a2, b2, a3, b3);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (g < NG) {  // NG is even: two groups left
+            run(a0, b0, a1, b1);
+        }
+        STAMP(1)
         if (more) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -769,24 +811,43 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
                 *reinterpret_cast<f4*>(ring + sl * kMfmaCols + (threadIdx.x & 31) * 4) = pre[q];
             }
         }
+        STAMP(2)
         const int ox = x0 + xw;
         if (ox < p.nx) {
+            if (y0 >= p.out_row0 && y0 + 32 <= p.out_row0 + p.out_rows) {
+                // whole tile inside the output rows: a scalar base per register row plus one per-lane byte offset
+                // that never changes (16 stores and their 16 additions; the guarded form below costs 1700 cycles
+                // a tile in compares and branches, 11 % of the kernel)
+                char* ub = reinterpret_cast<char*>(p.out + (size_t)(y0 - p.out_row0) * p.nx + x0);
+                const unsigned lane_off = (unsigned)(4 * h * p.nx + xw) * 4u;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int oy = y0 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = c + acc[v];
+                for (int v = 0; v < 16; ++v)
+                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + lane_off) = c + acc[v];
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int oy = y0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = c + acc[v];
+                }
             }
         }
+        STAMP(3)
         base += 32;
         base = base >= RR ? base - RR : base;
         __syncthreads();
+        STAMP(4)
     }
+#ifdef TOPO_GAUSS_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 7 && blockIdx.y == 0)
+        printf("axis0 stamps (10 ns ticks over %d tiles): head %lld  mfma %lld  ring-write %lld  store %lld  barrier %lld\n",
+               te - tb, st[0], st[1], st[2], st[3], st[4]);
+#endif
 }
 
 // Axis 1.  Every wave owns a band of 32 rows and marches along x; its window of input columns lives in a
 // ring of K + 32 LDS columns (odd row pitch: the 32 rows of an A-operand read fall into 32 banks).  Waves
 // never talk to each other.  `in` holds plane rows [0, rows); a row's result depends on that row alone.
-__global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int rows) {
+__global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int rows, int nseg) {
     extern __shared__ __attribute__((aligned(16))) float L[];
     const int R = p.radius, K = 32 + 2 * R, RC = (K + 32 + 7) / 8 * 8, pitch = RC + 1;  // ring columns: a multiple of 8
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -796,7 +857,10 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
     fill_toeplitz_table(wz, p.taps, R, K);
     for (int n = lane; n < 32 * pitch; n += 64) ring[n] = 0.0f;
     __syncthreads();
-    const int band = blockIdx.x * 4 + wave;
+    // a band's columns are cut into nseg runs of tiles, one wave each (each run restages its 2 R halo columns):
+    // 32768 rows give 1024 bands, enough for 4 waves on every CU; shorter planes need the cut to fill the chip
+    const int gw = blockIdx.x * 4 + wave;
+    const int band = gw / nseg, seg = gw - band * nseg;
     const int r0 = band * 32;
     if (r0 >= rows) return;
     const int i = lane & 31, h = lane >> 5;
@@ -806,7 +870,11 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
         const int cx = reflect_index(xfirst + i, p.nx);
         return p.in[(size_t)r * p.nx + cx];
     };
-    int x0 = 0;
+    const int ntile = (p.nx + 31) / 32;
+    const int tper = (ntile + nseg - 1) / nseg;
+    const int t_first = seg * tper, t_last = min(t_first + tper, ntile);
+    if (t_first >= t_last) return;
+    int x0 = t_first * 32;
     for (int k0 = 0; k0 < K; k0 += 32) {
         if (k0 + i < K) {
 #pragma unroll 4
@@ -814,10 +882,9 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
         }
     }
     int base = 0;  // ring column of input column x0 - R (even, like RC)
-    const int ntile = (p.nx + 31) / 32;
-    for (int t = 0; t < ntile; ++t, x0 += 32) {
+    for (int t = t_first; t < t_last; ++t, x0 += 32) {
         float pre[16];
-        const bool more = t + 1 < ntile;
+        const bool more = t + 1 < t_last;
         if (more) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) pre[q] = load_cols(x0 - R + K, q);
@@ -844,27 +911,39 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
             slot += 8;
             slot = slot >= RC ? slot - RC : slot;
         };
-        auto run = [&](const float (&a)[4], const float (&b)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u] - c, b[u], acc, 0, 0, 0);
+        auto run = [&](const float (&a)[4], const float (&b)[4], const float (&a2)[4], const float (&b2)[4]) {
+            const f32x2 cc = {c, c};  // packed subtractions: see axis 0
+            const f32x2 s0 = pk_sub(f32x2{a[0], a[1]}, cc), s1 = pk_sub(f32x2{a[2], a[3]}, cc);
+            const f32x2 s2 = pk_sub(f32x2{a2[0], a2[1]}, cc), s3 = pk_sub(f32x2{a2[2], a2[3]}, cc);
+            mfma_operands_ready();
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[0], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[1], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[0], b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[1], b[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2[0], b2[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2[1], b2[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3[0], b2[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3[1], b2[3], acc, 0, 0, 0);
         };
-        float a0[4], b0[4], a1[4], b1[4];
+        // phases fenced as in axis 0
+        float a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
         fetch(0, a0, b0);
-        for (int g = 0; g < NG; g += 2) {
-            fetch(g + 1, a1, b1);
-            run(a0, b0);
-            fetch(g + 2, a0, b0);
-            run(a1, b1);
-            // a wave issues in order and a dependent MFMA waits 64 cycles for the one before it: the 5 or so other
-            // instructions of a step have to sit in that shadow, one step's worth behind every MFMA, not in a
-            // burst behind the last one (53 % -> ? MFMA utilisation, profiles/r02_grad30_pmc_summary.txt)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
-            }
+        fetch(1, a1, b1);
+        int g = 0;
+        for (; g + 4 <= NG; g += 4) {
+            fetch(g + 2, a2, b2);
+            fetch(g + 3, a3, b3);
+            __builtin_amdgcn_sched_barrier(0);
+            run(a0, b0, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(g + 4, a0, b0);
+            fetch(g + 5, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            run(a2, b2, a3, b3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g < NG) {  // NG is even: two groups left
+            run(a0, b0, a1, b1);
         }
         if (more) {
             int sl = base + K + i;
@@ -873,11 +952,24 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
             for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + sl] = pre[q];
         }
         const int ox = x0 + i;  // D: column = lane & 31
-        if (ox < p.nx) {
+        float cr[16];  // the offsets of the 16 rows this lane holds: requested together, one wait
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int ri = (v & 3) + 8 * (v >> 2) + 4 * h;
-                if (r0 + ri < rows) p.out[(size_t)(r0 + ri) * p.nx + ox] = crow[ri] + acc[v];
+        for (int v = 0; v < 16; ++v) cr[v] = crow[(v & 3) + 8 * (v >> 2) + 4 * h];
+        __builtin_amdgcn_sched_barrier(0);
+        if (ox < p.nx) {
+            float* o = p.out + (size_t)(r0 + 4 * h) * p.nx + ox;
+            if (r0 + 32 <= rows) {  // scalar base per register row + a per-lane byte offset: see axis 0
+                char* ub = reinterpret_cast<char*>(p.out + (size_t)r0 * p.nx + x0);
+                const unsigned lane_off = (unsigned)(4 * h * p.nx + i) * 4u;
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + lane_off) = cr[v] + acc[v];
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int ri = (v & 3) + 8 * (v >> 2);
+                    if (r0 + 4 * h + ri < rows) o[(size_t)ri * p.nx] = cr[v] + acc[v];
+                }
             }
         }
         base += 32;
@@ -996,7 +1088,11 @@ int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, 
         ready = true;
     }
     const int bands = (rows + 31) / 32;
-    hipLaunchKernelGGL(gauss_axis1_mfma_kernel, dim3((bands + 3) / 4), dim3(256), lds, c.compute, a, rows);
+    const int ntile = (nx + 31) / 32;
+    int nseg = (4 * c.num_cu + bands - 1) / bands;               // enough waves for 4 per CU ...
+    nseg = std::max(1, std::min(nseg, std::max(1, ntile / 16)));  // ... while a run keeps >= 16 tiles
+    const long waves = (long)bands * nseg;
+    hipLaunchKernelGGL(gauss_axis1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, c.compute, a, rows, nseg);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
@@ -1346,6 +1442,88 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     TOPO_REQUIRE(b.gny >= 2 && b.nx >= 2,
                  "gradient: numpy.gradient needs at least 2 samples per axis (got %d x %d)",
                  b.gny, b.nx);
+    auto aligned16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    // Matrix-core route on a large block: the smooth is MFMA-bound and leaves HBM idle, the epilogue is
+    // HBM-bound and needs no LDS, so the rows go in chunks and the epilogue of chunk k runs on a second stream
+    // next to the smooth of chunk k + 1 (17.5 -> ? ms at sigma 30.25 on 32768^2).  Row chunks are row blocks:
+    // same bits.
+    static const int chunk_min = [] {
+        const char* e = std::getenv("TOPO_AMD_GRAD_CHUNK_MIN_ROWS");
+        return e && *e ? std::atoi(e) : 8192;
+    }();
+    if (sigma > 1.0 && sig_ratio == 1.0 && mfma_radius(gaussian_radius(sigma), b.nx, true) && b.out_rows >= chunk_min &&
+        b.nx % 4 == 0 && aligned16(dx) && aligned16(dy) && aligned16(slope) && aligned16(aspect)) {
+        static const int NCH = [] {
+            const char* e = std::getenv("TOPO_AMD_GRAD_CHUNKS");
+            return std::max(1, std::min(8, e && *e ? std::atoi(e) : 4));
+        }();
+        static const bool use_aux = [] {
+            const char* e = std::getenv("TOPO_AMD_GRAD_AUX");
+            return !(e && *e == '0');
+        }();
+        if (!c.aux) {
+            TOPO_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+            for (auto& e : c.aux_ready) TOPO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            TOPO_HIP(hipEventCreateWithFlags(&c.aux_done, hipEventDisableTiming));
+        }
+        // smoothed rows [s0, s1) = the output rows plus one neighbour row inside the DEM, cut at global multiples
+        // of 32 rows (the row tiles of the axis-0 kernel; a chunk of 32 k rows is also a whole number of axis-1
+        // bands); the epilogue of chunk j emits the output rows whose lower neighbour is already smoothed
+        const int s0 = b.out_row0 > 0 ? b.out_row0 - 1 : 0;
+        const int s1 = (b.out_row0 + b.out_rows + 1 < b.gny) ? b.out_row0 + b.out_rows + 1 : b.gny;
+        const int out_end = b.out_row0 + b.out_rows;
+        const size_t bytes = (size_t)(s1 - s0) * b.nx * sizeof(float);
+        void *pa = nullptr, *pb = nullptr;
+        TOPO_TRY(workspace(1, bytes, &pa));
+        TOPO_TRY(workspace(2, bytes, &pb));
+        const int per = std::max(32, ((s1 - s0 + NCH - 1) / NCH + 31) / 32 * 32);
+        int o0 = b.out_row0;
+        for (int k = 0, c0 = s0; c0 < s1; ++k) {
+            int c1 = (c0 + per) / 32 * 32;
+            if (c1 + 32 > s1) c1 = s1;  // no sliver at the end
+            Block rows = b;
+            rows.out_row0 = c0;
+            rows.out_rows = c1 - c0;
+            float* a_k = (float*)pa + (size_t)(c0 - s0) * b.nx;
+            float* b_k = (float*)pb + (size_t)(c0 - s0) * b.nx;
+            TOPO_TRY(run_axis0_mfma(rows, sigma, a_k, 1));
+            TOPO_TRY(run_axis1_mfma(a_k, c1 - c0, b.nx, sigma, b_k, 2));
+            if (use_aux) {
+                TOPO_HIP(hipEventRecord(c.aux_ready[k], c.compute));
+                TOPO_HIP(hipStreamWaitEvent(c.aux, c.aux_ready[k], 0));
+            }
+            const int o1 = c1 == s1 ? out_end : c1 - 1;
+            if (o1 > o0) {
+                GradArgs gk = g;
+                const size_t shift = (size_t)(o0 - b.out_row0) * b.nx;
+                gk.out_row0 = o0;
+                gk.out_rows = o1 - o0;
+                gk.dx = dx ? dx + shift : nullptr;
+                gk.dy = dy ? dy + shift : nullptr;
+                gk.slope = slope ? slope + shift : nullptr;
+                gk.aspect = aspect ? aspect + shift : nullptr;
+                if (res_mode == TOPO_AMD_RES_2D) {
+                    gk.res_x = g.res_x + shift;
+                    gk.res_y = g.res_y + shift;
+                }
+                gk.gx_src = (const float*)pb;
+                gk.gy_src = (const float*)pb;
+                gk.s_row0 = s0;
+                gk.s_rows = s1 - s0;
+                TOPO_TRY(check_grid_rows(o1 - o0, "gradient epilogue"));
+                dim3 grid4((b.nx / 4 + kThreads - 1) / kThreads, o1 - o0);
+                hipLaunchKernelGGL(gradient_epilogue4_kernel, grid4, dim3(kThreads), 0, use_aux ? c.aux : c.compute, gk);
+                TOPO_HIP(hipGetLastError());
+                o0 = o1;
+            }
+            c0 = c1;
+        }
+        if (use_aux) {
+            TOPO_HIP(hipEventRecord(c.aux_done, c.aux));
+            TOPO_HIP(hipStreamWaitEvent(c.compute, c.aux_done, 0));
+        }
+        return TOPO_AMD_OK;
+    }
     // smoothed rows needed: the output rows plus one neighbour row inside the DEM
     const int s0 = b.out_row0 > 0 ? b.out_row0 - 1 : 0;
     const int s1 = (b.out_row0 + b.out_rows + 1 < b.gny) ? b.out_row0 + b.out_rows + 1 : b.gny;
@@ -1391,7 +1569,6 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     g.gy_src = (const float*)plane_b;
     g.s_row0 = s0;
     g.s_rows = s_rows;
-    auto aligned16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (b.nx % 4 == 0 && b.nx >= 8 && aligned16(g.gx_src) && aligned16(g.gy_src) && aligned16(dx) && aligned16(dy) &&
         aligned16(slope) && aligned16(aspect)) {
         dim3 grid4((b.nx / 4 + kThreads - 1) / kThreads, b.out_rows);
