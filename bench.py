@@ -227,7 +227,9 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     o3 = d.DeviceArray(ny, nx)
     o4 = d.DeviceArray(ny, nx)
     grad_kernels = {3.25: "gauss_axis0_kernel<8, 8> + gauss_axis1_grad_kernel<16, 8, 8, 3> (LDS tile, fused epilogue)",
-                    30.25: "gauss_axis0_kernel<16, 16> + gauss_axis1_wave_grad_kernel (wave shift, fused epilogue)"}
+                    30.25: "8 row chunks of gauss_axis0_mfma_kernel + gauss_axis1_mfma_kernel (banded Toeplitz on the fp32 "
+                           "matrix cores), gradient_epilogue4_kernel of chunk k on a second stream beside the smooth "
+                           "of chunk k + 1"}
     for sigma in (3.25, 30.25):
         fn = lambda: blk.gradient(sigma, [30.0], [-30.0], dx=o1, dy=o2, slope=o3, aspect=o4)  # noqa: E731
         entry(f"gradient_sigma{sigma}", time_kernel(fn, REPS, d), 20, grad_kernels[sigma])
@@ -236,7 +238,7 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     for radius in (500.0, 2000.0):
         window, dj, di, dist = d.sx_offsets(0.0, radius, 30.0, -30.0)
         fn = lambda: blk.sx(dj, di, dist, window, 10.0, o1)  # noqa: E731
-        entry(f"sx_az0_r{int(radius)}", time_kernel(fn, REPS, d), 8, "sx_kernel (LDS tile, one atan per pixel)")
+        entry(f"sx_az0_r{int(radius)}", time_kernel(fn, REPS, d), 8, "sx_kernel<stride> (LDS tile, chains of 8 vertically adjacent ray pixels, one atan per pixel)")
     # 8 azimuths every 5 degrees in one pass: ms and rate are per azimuth plane
     sectors = [d.sx_offsets(5.0 * k, 500.0, 30.0, -30.0) for k in range(8)]
     fan = [o1, o2, o3, o4] + [d.DeviceArray(ny, nx) for _ in range(4)]

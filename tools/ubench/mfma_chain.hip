@@ -10,6 +10,8 @@
 //   mode 7: one chain + one v_pk_add_f32 per two MFMAs
 //   mode 8: 8 v_sub in a burst, then 8 MFMAs
 //   mode 9: one chain + an s_add per MFMA (scalar ALU)
+//   mode 10: one chain, operands rotating through 16 registers of random data (power: the constant operands of
+//            the other modes toggle nothing)
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_chain.hip -o tools/ubench/mfma_chain.bin && tools/ubench/mfma_chain.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -27,6 +29,14 @@ __global__ void k(float* out, int iters, long long* cyc) {
     float a = out[threadIdx.x], b = a + 1.0f, c = 0.5f;
     const float* p = lds + (threadIdx.x & 63);
     float r0 = a, r1 = b, r2 = a, r3 = b;
+    float rnd[16];
+    {
+        unsigned x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+        for (int n = 0; n < 16; ++n) {
+            x = x * 1664525u + 1013904223u;
+            rnd[n] = (float)(int)(x >> 8) * (1.0f / 8388608.0f) - 1.0f + (MODE == 10 ? 0.0f : a);
+        }
+    }
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -67,6 +77,8 @@ __global__ void k(float* out, int iters, long long* cyc) {
                 } else {
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(r1, b, acc0, 0, 0, 0);
                 }
+            } else if (MODE == 10) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(rnd[2 * u], rnd[2 * u + 1], acc0, 0, 0, 0);
             } else if (MODE == 9) {
                 asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc");
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
@@ -83,7 +95,7 @@ __global__ void k(float* out, int iters, long long* cyc) {
     long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.0f;
     for (int v = 0; v < 16; ++v) s += acc0[v] + acc1[v];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s + r0 + r1 + r2;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s + r0 + r1 + r2 + rnd[3];
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
@@ -126,6 +138,7 @@ int main() {
     run<7>("one chain + v_pk_add per two MFMAs", 256);
     run<8>("8 v_sub burst, then 8 MFMAs", 256);
     run<9>("one chain + s_add", 256);
+    run<10>("one chain, random operands", 256);
     run<0>("one chain (again)", 256);
     return 0;
 }

@@ -54,6 +54,12 @@ __global__ __launch_bounds__(1024) void k(unsigned* out, int iters, long long* c
 #define I_LSHLADD64(n) "v_lshl_add_u64 v[200:201], v[202:203], 2, v[204:205]\n"
 #define I_SUBS(n) "v_sub_u32 %" #n ", s4, %" #n "\n"
 #define I_MAX3(n) "v_max3_u32 %" #n ", %" #n ", %8, %9\n"
+#define I_MAXF(n) "v_max_f32 %" #n ", %" #n ", %8\n"
+#define I_MINF(n) "v_min_f32 %" #n ", %" #n ", %8\n"
+#define I_MAX3F(n) "v_max3_f32 %" #n ", %" #n ", %8, %9\n"
+#define I_MULF(n) "v_mul_f32 %" #n ", %" #n ", %8\n"
+#define I_SUBF(n) "v_sub_f32 %" #n ", %" #n ", %8\n"
+#define I_PKFMA(n) "v_pk_fma_f32 v[200:201], v[202:203], v[204:205], v[206:207]\n"
 #define I_MIX(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\nv_sub_u32 %" #n ", %" #n ", %8\n"
         if (MODE == 0) { OPS(I_ADD) }
         if (MODE == 1) { OPS(I_SUB) }
@@ -86,6 +92,12 @@ __global__ __launch_bounds__(1024) void k(unsigned* out, int iters, long long* c
         if (MODE == 28) { OPS(I_LSHLADD64) }
         if (MODE == 29) { OPS(I_SUBS) }
         if (MODE == 30) { OPS(I_MAX3) }
+        if (MODE == 31) { OPS(I_MAXF) }
+        if (MODE == 32) { OPS(I_MAX3F) }
+        if (MODE == 33) { OPS(I_MULF) }
+        if (MODE == 34) { OPS(I_SUBF) }
+        if (MODE == 35) { OPS(I_PKFMA) }
+        if (MODE == 36) { OPS(I_MINF) }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -156,6 +168,12 @@ int main() {
             run<28>("v_lshl_add_u64", d, dc, waves);
             run<29>("v_sub_u32 sgpr", d, dc, waves);
             run<30>("v_max3_u32", d, dc, waves);
+            run<31>("v_max_f32", d, dc, waves);
+            run<32>("v_max3_f32", d, dc, waves);
+            run<33>("v_mul_f32", d, dc, waves);
+            run<34>("v_sub_f32", d, dc, waves);
+            run<35>("v_pk_fma_f32", d, dc, waves);
+            run<36>("v_min_f32", d, dc, waves);
         }
     }
     return 0;

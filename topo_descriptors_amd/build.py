@@ -30,7 +30,7 @@ def _newer(target, deps):
 
 def build_library(force=False, verbose=True):
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "disc_runs.hpp"), os.path.join(CSRC, "disc_wave_impl.hpp"), os.path.join(CSRC, "disc_ring_impl.hpp"),
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "atan.hpp"), os.path.join(CSRC, "disc_runs.hpp"), os.path.join(CSRC, "disc_wave_impl.hpp"), os.path.join(CSRC, "disc_ring_impl.hpp"),
                os.path.join(os.path.dirname(HERE), "include", "topo_amd.h")]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if not force and _newer(LIB, srcs + headers):

@@ -11,6 +11,7 @@
 // axis so that one loaded sample feeds TB FMAs; samples are taken relative to a per-thread
 // offset so float32 accumulation keeps its digits on 2000 m terrain.
 #include "common.hpp"
+#include "atan.hpp"
 
 #include <cstdlib>
 
@@ -195,25 +196,6 @@ __device__ __forceinline__ float div_f32(float a, float b) {
     const float r = __builtin_amdgcn_rcpf(b);
     const float q = a * r;
     return fmaf(fmaf(-q, b, a), r, q);
-}
-
-__device__ __forceinline__ float atan_unit(float t) {  // t in [0, 1]
-    const float z = t * t;
-    float p = 0.0028662257f;
-    p = fmaf(p, z, -0.0161657367f);
-    p = fmaf(p, z, 0.0429096138f);
-    p = fmaf(p, z, -0.0752896400f);
-    p = fmaf(p, z, 0.1065626393f);
-    p = fmaf(p, z, -0.1420889944f);
-    p = fmaf(p, z, 0.1999355085f);
-    p = fmaf(p, z, -0.3333314528f);
-    return fmaf(p * z, t, t);
-}
-
-__device__ __forceinline__ float atan_pos(float s) {  // s >= 0 (or NaN)
-    const bool big = s > 1.0f;
-    const float r = atan_unit(big ? __builtin_amdgcn_rcpf(s) : s);
-    return big ? 1.5707963267948966f - r : r;
 }
 
 __device__ __forceinline__ float atan2_f32(float y, float x) {
@@ -659,11 +641,29 @@ __global__ __launch_bounds__(kThreads) void transpose_kernel(const float* in, fl
 // outside the band are exact zeros, so an output is the fmaf chain over its own 2 R + 1 taps in ascending
 // order whatever tile it falls in (partition invariance needs no tile alignment; only the accumulation
 // offsets do: they are taken per column / per row from samples that any block covering the output holds).
-// A non-finite sample reaches every output of the tiles whose (padded) band contains it (0 x NaN), i.e. up to 47
+// A non-finite sample reaches every output of the tiles whose (padded) band contains it (0 x NaN), i.e. up to 37
 // rows / columns further than in ndimage.gaussian_filter.  Two accumulators (even / odd groups) were tried to
 // take the dependent-MFMA wait out: 7.9 ms against 6.9 ms for the one chain, so it stays one chain.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The 8 LDS reads of the next phase go out two behind each of the first 4 MFMAs of this one (with the vector-ALU
+// instruction that forms their address and the scalar ring arithmetic), so the last of them has 4 MFMAs (260
+// cycles) to land before the next phase subtracts the offsets from it; then a fence.
+__device__ __forceinline__ void spread_behind_mfmas() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ void mfma_operands_ready() {
     asm volatile("s_nop 1");
     __builtin_amdgcn_sched_barrier(0);
@@ -689,14 +689,21 @@ __device__ __forceinline__ void fill_toeplitz_table(float* wz, const float* taps
 }
 
 // Axis 0.  The block owns columns [128 b, 128 b + 128) and a run of row tiles, top to bottom; the input
-// rows of the current window live in a ring of K + 32 LDS rows (the 32 spare ones receive the next
-// tile's rows while this tile is computed: one barrier per tile).
+// rows of the current window live in a ring of K8 + 32 LDS rows, K8 = K rounded up to 8 (the 32 spare ones
+// receive the next tile's rows while this tile is computed: one barrier per tile).  Everything the ring is
+// addressed with is a multiple of 8 rows, so a group of 4 MFMA steps (8 rows) and a loader pass (8 rows) never
+// straddle the wrap: the wrap is scalar arithmetic and the LDS addresses are one register plus immediates.
+//
+// One wave per SIMD issues every instruction at 4+ cycles, and every vector-ALU instruction costs the matrix
+// pipe 8-16 cycles (profiles/r02_mfma_chain.txt), so the per-tile bookkeeping is kept on the scalar unit: row
+// addresses are a scalar base plus a per-lane offset that never changes (the reflecting / clamping form only
+// where the 32 rows touch the DEM or block edge: 140 quarter-rate instructions, 950 cycles a tile).
 __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int tile_first, int ntiles, int tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) float L[];
-    const int R = p.radius, K = 32 + 2 * R, RR = (K + 32 + 7) / 8 * 8;  // ring rows: a multiple of 8
+    const int R = p.radius, K = 32 + 2 * R, K8 = (K + 7) / 8 * 8, RR = K8 + 32;
     float* ring = L;
     float* wz = L + RR * kMfmaCols;  // K + kWzPad entries
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int x0 = blockIdx.x * kMfmaCols;
     const int tb = blockIdx.y * tiles_per_block, te = min(tb + tiles_per_block, ntiles);
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
     fill_toeplitz_table(wz, p.taps, R, K);
     for (int n = threadIdx.x; n < RR * kMfmaCols; n += 256) ring[n] = 0.0f;
     __syncthreads();
-    // loader: 32 threads x 16 bytes per row, 8 rows per pass of the block
+    // loader: 32 threads x 16 bytes per row, 8 rows per pass of the block (2 per wave)
     const int lc = min(x0 + (int)(threadIdx.x & 31) * 4, p.nx - 4);  // (columns past nx: clamped, never stored)
     const int lr = threadIdx.x >> 5;
     auto row_ptr = [&](int gy) {
@@ -713,12 +720,18 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
         return p.in + (size_t)(gy - p.in_row0) * p.nx + lc;
     };
     typedef float f4 __attribute__((ext_vector_type(4)));
-    int y0 = (tile_first + tb) * 32;
-    for (int k = lr; k < K; k += 8)
-        *reinterpret_cast<f4*>(ring + k * kMfmaCols + (threadIdx.x & 31) * 4) = *reinterpret_cast<const f4*>(row_ptr(y0 - R + k));
-    int base = 0;  // ring slot of input row y0 - R (even, like RR: a row pair never straddles the wrap)
+    const unsigned in_lane_off = (unsigned)(lr * p.nx + lc) * 4u;          // bytes from the first of 8 rows
+    float* const ring_lane = ring + lr * kMfmaCols + (threadIdx.x & 31) * 4;  // this thread's slot in a group of 8 rows
+    const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
+    {
+        const int y0 = (tile_first + tb) * 32;
+        for (int k = 0; k < K8; k += 8) *reinterpret_cast<f4*>(ring_lane + k * kMfmaCols) = *reinterpret_cast<const f4*>(row_ptr(y0 - R + k + lr));
+    }
+    int base = 0;  // ring slot of input row y0 - R
     __syncthreads();
     const int xw = 32 * wave + j;
+    const unsigned out_lane_off = (unsigned)(4 * h * p.nx + xw) * 4u;
+    const int NG = K8 / 8;  // groups of 4 steps; the steps past K / 2 meet taps that are exactly 0
 #ifdef TOPO_GAUSS_STAMPS
     long long st[6] = {0, 0, 0, 0, 0, 0};
 #define STAMP(n) { const long long now_ = __builtin_amdgcn_s_memtime(); st[n] += now_ - last_; last_ = now_; }
@@ -726,12 +739,20 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
 #else
 #define STAMP(n)
 #endif
-    for (int t = tb; t < te; ++t, y0 += 32) {
+    for (int t = tb; t < te; ++t) {
+        const int y0 = (tile_first + t) * 32;
         f4 pre[4];
         const bool more = t + 1 < te;
         if (more) {
+            const int n0 = y0 - R + K8;  // the 32 rows the next tile adds
+            if (n0 >= row_lo && n0 + 32 <= row_hi) {
+                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)(n0 - p.in_row0) * p.nx);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pre[q] = *reinterpret_cast<const f4*>(row_ptr(y0 - R + K + 8 * q + lr));
+                for (int q = 0; q < 4; ++q) pre[q] = *reinterpret_cast<const f4*>(rb + (size_t)(8 * q) * p.nx * 4 + in_lane_off);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pre[q] = *reinterpret_cast<const f4*>(row_ptr(n0 + 8 * q + lr));
+            }
         }
         int sc = base + R + 16;
         sc = sc >= RR ? sc - RR : sc;
@@ -741,14 +762,6 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
         for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
         const float* wl = wz + (h - j + 31);
         const float* bl = ring + h * kMfmaCols + xw;
-        // one wave per SIMD: nothing but the wave itself hides the LDS latency, so the operands of step
-        // s + kAhead are fetched before the MFMA of step s is issued
-        // The step count is padded to a multiple of 8 with zero-weight steps, so the loop has no branch: the
-        // padded steps (and the fetches past the last step) read rows of the ring beyond the window - the next
-        // tile's rows, or the zeros the ring starts with - against taps that are exactly 0.  Steps go in groups
-        // of 4 (8 ring rows: RR and base are multiples of 8, so a group never straddles the wrap and its reads
-        // are one address plus immediates), fetched one group (256 MFMA cycles) ahead of their MFMAs.
-        const int NG = (K / 2 + 7) / 8 * 2;
         int slot = base;  // ring row of the next group to fetch
         auto fetch = [&](int g, float (&a)[4], float (&b)[4]) {
             const float* bp = bl + slot * kMfmaCols;
@@ -761,10 +774,17 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
             slot += 8;
             slot = slot >= RR ? slot - RR : slot;
         };
-        // every vector-ALU instruction in the MFMA stream costs the matrix pipe 8-16 cycles
-        // (tools/ubench/mfma_chain.hip, profiles/r02_mfma_chain.txt): the offsets come off two samples at a time
+        // the offsets come off two samples at a time (v_pk_add_f32 on the pair a ds_read2 returns)
+        const f32x2 cc = {c, c};
+        auto run1 = [&](const float (&a)[4], const float (&b)[4]) {
+            const f32x2 s0 = pk_sub(f32x2{b[0], b[1]}, cc), s1 = pk_sub(f32x2{b[2], b[3]}, cc);
+            mfma_operands_ready();
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], s0[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], s0[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], s1[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], s1[1], acc, 0, 0, 0);
+        };
         auto run = [&](const float (&a)[4], const float (&b)[4], const float (&a2)[4], const float (&b2)[4]) {
-            const f32x2 cc = {c, c};
             const f32x2 s0 = pk_sub(f32x2{b[0], b[1]}, cc), s1 = pk_sub(f32x2{b[2], b[3]}, cc);
             const f32x2 s2 = pk_sub(f32x2{b2[0], b2[1]}, cc), s3 = pk_sub(f32x2{b2[2], b2[3]}, cc);
             mfma_operands_ready();
@@ -777,52 +797,76 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[2], s3[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[3], s3[1], acc, 0, 0, 0);
         };
-        // A wave issues in order, a dependent MFMA waits 64 cycles for the one before it, and one wave per SIMD
-        // has nothing else to hide an LDS read behind: the operands of groups g + 2, g + 3 are requested, then the
-        // 8 MFMAs of groups g, g + 1 (fetched a phase ago) run while those reads land.  The scheduler is fenced
-        // at the phase edges: left alone it sinks each read next to its use and waits on it there (58 % MFMA
-        // utilisation, profiles/r02_grad30_pmc_summary.txt).
+        // A wave issues in order and a dependent MFMA waits 64 cycles for the one before it.  A phase: the offsets
+        // come off the operands of groups g, g + 1 (fetched a phase ago), then their 8 MFMAs go out with the LDS reads
+        // and the scalar bookkeeping of groups g + 2, g + 3 spread one behind each (16 issue slots of 4 cycles sit
+        // in an MFMA's shadow; bunched at the phase edge the same instructions left the pipe idle 160 cycles in
+        // 680).  The fence between phases keeps the scheduler from sinking a read next to its use.
+        auto sub = [&](const float (&d)[4], const float (&d2)[4], f32x2 (&s)[4]) {
+            s[0] = pk_sub(f32x2{d[0], d[1]}, cc);
+            s[1] = pk_sub(f32x2{d[2], d[3]}, cc);
+            s[2] = pk_sub(f32x2{d2[0], d2[1]}, cc);
+            s[3] = pk_sub(f32x2{d2[2], d2[3]}, cc);
+            mfma_operands_ready();
+        };
+        auto mm = [&](const float (&w)[4], const float (&w2)[4], const f32x2 (&s)[4]) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], s[0][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], s[0][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], s[1][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], s[1][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[0], s[2][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[1], s[2][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[2], s[3][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[3], s[3][1], acc, 0, 0, 0);
+        };
         STAMP(0)
         float a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
         fetch(0, a0, b0);
         fetch(1, a1, b1);
         int g = 0;
         for (; g + 4 <= NG; g += 4) {
+            f32x2 s[4];
+            sub(b0, b1, s);
             fetch(g + 2, a2, b2);
             fetch(g + 3, a3, b3);
-            __builtin_amdgcn_sched_barrier(0);
-            run(a0, b0, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
+            mm(a0, a1, s);
+            spread_behind_mfmas();
+            sub(b2, b3, s);
             fetch(g + 4, a0, b0);
             fetch(g + 5, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            run(a2, b2, a3, b3);
-            __builtin_amdgcn_sched_barrier(0);
+            mm(a2, a3, s);
+            spread_behind_mfmas();
         }
-        if (g < NG) {  // NG is even: two groups left
-            run(a0, b0, a1, b1);
+        {  // 0-3 groups left; a0, a1 hold the first two
+            const int rem = NG - g;
+            if (rem == 3) fetch(g + 2, a2, b2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rem >= 2) run(a0, b0, a1, b1);
+            else if (rem == 1) run1(a0, b0);
+            if (rem == 3) run1(a2, b2);
         }
         STAMP(1)
         if (more) {
+            int s8 = base + K8;  // multiples of 8 all: a pass of 8 rows never straddles the wrap
+            s8 = s8 >= RR ? s8 - RR : s8;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                int sl = base + K + 8 * q + lr;
-                sl = sl >= RR ? sl - RR : sl;
-                *reinterpret_cast<f4*>(ring + sl * kMfmaCols + (threadIdx.x & 31) * 4) = pre[q];
+                *reinterpret_cast<f4*>(ring_lane + s8 * kMfmaCols) = pre[q];
+                s8 += 8;
+                s8 = s8 >= RR ? s8 - RR : s8;
             }
         }
         STAMP(2)
         const int ox = x0 + xw;
         if (ox < p.nx) {
             if (y0 >= p.out_row0 && y0 + 32 <= p.out_row0 + p.out_rows) {
-                // whole tile inside the output rows: a scalar base per register row plus one per-lane byte offset
-                // that never changes (16 stores and their 16 additions; the guarded form below costs 1700 cycles
-                // a tile in compares and branches, 11 % of the kernel)
+                // whole tile inside the output rows: a scalar base per register row plus the per-lane byte offset
+                // (16 stores and their 16 additions; the guarded form below costs 1700 cycles a tile in compares
+                // and branches)
                 char* ub = reinterpret_cast<char*>(p.out + (size_t)(y0 - p.out_row0) * p.nx + x0);
-                const unsigned lane_off = (unsigned)(4 * h * p.nx + xw) * 4u;
 #pragma unroll
                 for (int v = 0; v < 16; ++v)
-                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + lane_off) = c + acc[v];
+                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + out_lane_off) = c + acc[v];
             } else {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
@@ -839,18 +883,18 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
     }
 #ifdef TOPO_GAUSS_STAMPS
     if (threadIdx.x == 0 && blockIdx.x == 7 && blockIdx.y == 0)
-        printf("axis0 stamps (10 ns ticks over %d tiles): head %lld  mfma %lld  ring-write %lld  store %lld  barrier %lld\n",
+        printf("axis0 stamps (clocks over %d tiles): head %lld  mfma %lld  ring-write %lld  store %lld  barrier %lld\n",
                te - tb, st[0], st[1], st[2], st[3], st[4]);
 #endif
 }
 
 // Axis 1.  Every wave owns a band of 32 rows and marches along x; its window of input columns lives in a
-// ring of K + 32 LDS columns (odd row pitch: the 32 rows of an A-operand read fall into 32 banks).  Waves
+// ring of K8 + 32 LDS columns (odd row pitch: the 32 rows of an A-operand read fall into 32 banks).  Waves
 // never talk to each other.  `in` holds plane rows [0, rows); a row's result depends on that row alone.
 __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int rows, int nseg) {
     extern __shared__ __attribute__((aligned(16))) float L[];
-    const int R = p.radius, K = 32 + 2 * R, RC = (K + 32 + 7) / 8 * 8, pitch = RC + 1;  // ring columns: a multiple of 8
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = p.radius, K = 32 + 2 * R, K8 = (K + 7) / 8 * 8, RC = K8 + 32, pitch = RC + 1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* wz = L;
     float* ring = L + (K + kWzPad) + wave * (32 * pitch + 32);
     float* crow = ring + 32 * pitch;
@@ -870,24 +914,35 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
         const int cx = reflect_index(xfirst + i, p.nx);
         return p.in[(size_t)r * p.nx + cx];
     };
+    const unsigned in_lane_off = (unsigned)(h * p.nx + i) * 4u;
+    const unsigned out_lane_off = (unsigned)(4 * h * p.nx + i) * 4u;
+    const bool full_band = r0 + 32 <= rows;
     const int ntile = (p.nx + 31) / 32;
     const int tper = (ntile + nseg - 1) / nseg;
     const int t_first = seg * tper, t_last = min(t_first + tper, ntile);
     if (t_first >= t_last) return;
-    int x0 = t_first * 32;
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        if (k0 + i < K) {
+    for (int k0 = 0; k0 < K8; k0 += 32) {
+        if (k0 + i < K8) {
 #pragma unroll 4
-            for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + k0 + i] = load_cols(x0 - R + k0, q);
+            for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + k0 + i] = load_cols(t_first * 32 - R + k0, q);
         }
     }
-    int base = 0;  // ring column of input column x0 - R (even, like RC)
-    for (int t = t_first; t < t_last; ++t, x0 += 32) {
+    int base = 0;  // ring column of input column x0 - R
+    const int NG = K8 / 8;
+    for (int t = t_first; t < t_last; ++t) {
+        const int x0 = t * 32;
         float pre[16];
         const bool more = t + 1 < t_last;
         if (more) {
+            const int n0 = x0 - R + K8;  // the 32 columns the next tile adds
+            if (full_band && n0 >= 0 && n0 + 32 <= p.nx) {  // scalar base + the per-lane byte offset: see axis 0
+                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)r0 * p.nx + n0);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) pre[q] = load_cols(x0 - R + K, q);
+                for (int q = 0; q < 16; ++q) pre[q] = *reinterpret_cast<const float*>(rb + (size_t)(2 * q) * p.nx * 4 + in_lane_off);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pre[q] = load_cols(n0, q);
+            }
         }
         int sc = base + R + 16;
         sc = sc >= RC ? sc - RC : sc;
@@ -898,7 +953,6 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
         for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
         const float* wl = wz + (h - i + 31);
         const float* al = ring + i * pitch + h;
-        const int NG = (K / 2 + 7) / 8 * 2;  // groups of 4 steps, padded with zero-weight steps: see axis 0
         int slot = base;  // ring column of the next group to fetch
         auto fetch = [&](int g, float (&a)[4], float (&b)[4]) {
             const float* ap = al + slot;
@@ -911,8 +965,16 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
             slot += 8;
             slot = slot >= RC ? slot - RC : slot;
         };
+        const f32x2 cc = {c, c};  // packed subtractions, fenced phases: see axis 0
+        auto run1 = [&](const float (&a)[4], const float (&b)[4]) {
+            const f32x2 s0 = pk_sub(f32x2{a[0], a[1]}, cc), s1 = pk_sub(f32x2{a[2], a[3]}, cc);
+            mfma_operands_ready();
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[0], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[1], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[0], b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[1], b[3], acc, 0, 0, 0);
+        };
         auto run = [&](const float (&a)[4], const float (&b)[4], const float (&a2)[4], const float (&b2)[4]) {
-            const f32x2 cc = {c, c};  // packed subtractions: see axis 0
             const f32x2 s0 = pk_sub(f32x2{a[0], a[1]}, cc), s1 = pk_sub(f32x2{a[2], a[3]}, cc);
             const f32x2 s2 = pk_sub(f32x2{a2[0], a2[1]}, cc), s3 = pk_sub(f32x2{a2[2], a2[3]}, cc);
             mfma_operands_ready();
@@ -925,28 +987,51 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3[0], b2[2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3[1], b2[3], acc, 0, 0, 0);
         };
-        // phases fenced as in axis 0
+        auto sub = [&](const float (&d)[4], const float (&d2)[4], f32x2 (&s)[4]) {
+            s[0] = pk_sub(f32x2{d[0], d[1]}, cc);
+            s[1] = pk_sub(f32x2{d[2], d[3]}, cc);
+            s[2] = pk_sub(f32x2{d2[0], d2[1]}, cc);
+            s[3] = pk_sub(f32x2{d2[2], d2[3]}, cc);
+            mfma_operands_ready();
+        };
+        auto mm = [&](const float (&w)[4], const float (&w2)[4], const f32x2 (&s)[4]) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[0][0], w[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[0][1], w[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[1][0], w[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[1][1], w[3], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[2][0], w2[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[2][1], w2[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[3][0], w2[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[3][1], w2[3], acc, 0, 0, 0);
+        };
         float a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
         fetch(0, a0, b0);
         fetch(1, a1, b1);
         int g = 0;
         for (; g + 4 <= NG; g += 4) {
+            f32x2 s[4];
+            sub(a0, a1, s);
             fetch(g + 2, a2, b2);
             fetch(g + 3, a3, b3);
-            __builtin_amdgcn_sched_barrier(0);
-            run(a0, b0, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
+            mm(b0, b1, s);
+            spread_behind_mfmas();
+            sub(a2, a3, s);
             fetch(g + 4, a0, b0);
             fetch(g + 5, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            run(a2, b2, a3, b3);
-            __builtin_amdgcn_sched_barrier(0);
+            mm(b2, b3, s);
+            spread_behind_mfmas();
         }
-        if (g < NG) {  // NG is even: two groups left
-            run(a0, b0, a1, b1);
+        {  // 0-3 groups left; a0, a1 hold the first two
+            const int rem = NG - g;
+            if (rem == 3) fetch(g + 2, a2, b2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rem >= 2) run(a0, b0, a1, b1);
+            else if (rem == 1) run1(a0, b0);
+            if (rem == 3) run1(a2, b2);
         }
         if (more) {
-            int sl = base + K + i;
+            int sl = base + K8;
+            sl = (sl >= RC ? sl - RC : sl) + i;
             sl = sl >= RC ? sl - RC : sl;
 #pragma unroll
             for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + sl] = pre[q];
@@ -957,14 +1042,13 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
         for (int v = 0; v < 16; ++v) cr[v] = crow[(v & 3) + 8 * (v >> 2) + 4 * h];
         __builtin_amdgcn_sched_barrier(0);
         if (ox < p.nx) {
-            float* o = p.out + (size_t)(r0 + 4 * h) * p.nx + ox;
-            if (r0 + 32 <= rows) {  // scalar base per register row + a per-lane byte offset: see axis 0
+            if (full_band) {
                 char* ub = reinterpret_cast<char*>(p.out + (size_t)r0 * p.nx + x0);
-                const unsigned lane_off = (unsigned)(4 * h * p.nx + i) * 4u;
 #pragma unroll
                 for (int v = 0; v < 16; ++v)
-                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + lane_off) = cr[v] + acc[v];
+                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + out_lane_off) = cr[v] + acc[v];
             } else {
+                float* o = p.out + (size_t)(r0 + 4 * h) * p.nx + ox;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int ri = (v & 3) + 8 * (v >> 2);
@@ -1089,8 +1173,22 @@ int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, 
     }
     const int bands = (rows + 31) / 32;
     const int ntile = (nx + 31) / 32;
-    int nseg = (4 * c.num_cu + bands - 1) / bands;               // enough waves for 4 per CU ...
-    nseg = std::max(1, std::min(nseg, std::max(1, ntile / 16)));  // ... while a run keeps >= 16 tiles
+    // The ring takes the whole LDS: one block of 4 waves per CU, so the chip runs 4 num_cu waves at a time and a
+    // grid one wave over that takes twice as long (171 bands x 6 runs = 1026 waves: 21.5 ms instead of 14.5 for
+    // the gradient at sigma 30.25).  Pick the cut with the least rounds x (tiles per run + the 2 R halo a run
+    // restages), runs no shorter than 16 tiles.
+    const long slots = 4L * c.num_cu;
+    const int halo_tiles = (2 * a.radius + 31) / 32;
+    int nseg = 1;
+    long best = -1;
+    for (int n = 1; n <= std::max(1, ntile / 16); ++n) {
+        const long rounds = ((long)bands * n + slots - 1) / slots;
+        const long cost = rounds * ((ntile + n - 1) / n + halo_tiles);
+        if (best < 0 || cost < best) {
+            best = cost;
+            nseg = n;
+        }
+    }
     const long waves = (long)bands * nseg;
     hipLaunchKernelGGL(gauss_axis1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, c.compute, a, rows, nseg);
     TOPO_HIP(hipGetLastError());
@@ -1445,7 +1543,8 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     auto aligned16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     // Matrix-core route on a large block: the smooth is MFMA-bound and leaves HBM idle, the epilogue is
     // HBM-bound and needs no LDS, so the rows go in chunks and the epilogue of chunk k runs on a second stream
-    // next to the smooth of chunk k + 1 (17.5 -> ? ms at sigma 30.25 on 32768^2).  Row chunks are row blocks:
+    // next to the smooth of chunk k + 1 (15.7 -> 14.5 ms at sigma 30.25 on 32768^2 with 4 -> 8 chunks; one chunk:
+    // 18.5).  Row chunks are row blocks:
     // same bits.
     static const int chunk_min = [] {
         const char* e = std::getenv("TOPO_AMD_GRAD_CHUNK_MIN_ROWS");
@@ -1455,7 +1554,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         b.nx % 4 == 0 && aligned16(dx) && aligned16(dy) && aligned16(slope) && aligned16(aspect)) {
         static const int NCH = [] {
             const char* e = std::getenv("TOPO_AMD_GRAD_CHUNKS");
-            return std::max(1, std::min(8, e && *e ? std::atoi(e) : 4));
+            return std::max(1, std::min(8, e && *e ? std::atoi(e) : 8));
         }();
         static const bool use_aux = [] {
             const char* e = std::getenv("TOPO_AMD_GRAD_AUX");
@@ -1476,7 +1575,9 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         void *pa = nullptr, *pb = nullptr;
         TOPO_TRY(workspace(1, bytes, &pa));
         TOPO_TRY(workspace(2, bytes, &pb));
-        const int per = std::max(32, ((s1 - s0 + NCH - 1) / NCH + 31) / 32 * 32);
+        // chunks of >= 4096 rows (every chunk restages the 2 R halo rows of the axis-0 ring: 6 % at radius 121)
+        const int nch = std::max(2, std::min(NCH, (s1 - s0) / 4096));
+        const int per = std::max(32, ((s1 - s0 + nch - 1) / nch + 31) / 32 * 32);
         int o0 = b.out_row0;
         for (int k = 0, c0 = s0; c0 < s1; ++k) {
             int c1 = (c0 + per) / 32 * 32;

@@ -11,6 +11,7 @@
 // along x, the offset table is wave-uniform (scalar loads), so every step is one conflict-
 // free ds_read_b32 + v_sub + v_mul + v_max per lane.
 #include "common.hpp"
+#include "atan.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -25,69 +26,216 @@ constexpr int kThreads = 256;
 constexpr int kTileW = 64;
 constexpr int kTileH = 32;  // 8 output rows per thread
 
+// Table entries: chains of ray pixels that are neighbours along the chain axis (rows for sectors that point
+// north / south, columns for those that point east / west).
+struct SxChain8 {
+    int off;       // LDS index of the first ray pixel of the chain, relative to the target pixel's tile origin
+    int pad[7];
+    float inv[8];  // 1 / distance in metres of pixel m of the chain; NaN past the end of a shorter chain
+};
+struct SxChain2 {
+    int off;
+    float inv[2];
+    int pad;
+};
+static_assert(sizeof(SxChain8) == 64 && sizeof(SxChain2) == 16, "scalar-load friendly entries");
+
 struct SxArgs {
     const float* in;
     float* out;
-    const int* lds_off;     // per unique offset: (dj - dj_min) * stride + (di - di_min)
-    const float* inv_dist;  // 1 / distance in metres
-    int n_off;
+    const SxChain8* tab8;
+    const SxChain2* tab2;
+    int n8, n2;
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
     int window;
-    int dj_min, di_min, rows_l, cols_l, stride;
+    int dj_min, di_min, rows_l, cols_l;
     float height;
 };
 
+constexpr int kSxTile = 64;                     // output tile: 64 x 64 pixels
+constexpr int kSxOwn = kSxTile / (kThreads / 64);  // consecutive pixels per lane along the chain axis
+
+// A lane owns kSxOwn consecutive pixels along the chain axis (ALONG_X false: 16 rows of one column, lanes along x;
+// true: 16 columns of one row, lanes along y).  The ray pixels of a sector are dense in (dj, di): along the axis
+// the sector points in they come in long runs of neighbours, and the sample a lane needs for (own pixel k, ray
+// pixel m + 1) is the one it needs for (own pixel k + 1, ray pixel m).  So the table holds chains of 8 (and, for
+// what is left of a run, 2) neighbouring ray pixels: 8 + kSxOwn - 1 LDS reads feed 8 kSxOwn comparisons (0.18
+// reads per comparison; one read each made the kernel LDS-bound: ds_read_b32 moves 128 B/clk/CU, 25 ms of reads
+// at radius 2000 m).  What is left is the arithmetic, 3 issue slots per pixel and ray point: v_sub, v_mul, and one
+// v_max3 per two points (v_max_f32 / v_max3_f32 issue at half rate on gfx950, profiles/r02_valu_mix_rate.txt).
+// The LDS row stride is a template parameter so that the samples of a chain are immediates on one address
+// register.  A chain shorter than its table entry ends in NaN weights: the products are NaN and max3 drops them
+// like nanmax; what such a chain reads past the tile is spare LDS.
+template <int STRIDE, bool ALONG_X>
 __global__ __launch_bounds__(kThreads) void sx_kernel(SxArgs p) {
     extern __shared__ __attribute__((aligned(16))) float L[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int ox0 = blockIdx.x * kTileW;
-    const int oy0 = p.out_row0 + blockIdx.y * kTileH;
+    const int ox0 = blockIdx.x * kSxTile;
+    const int oy0 = p.out_row0 + blockIdx.y * kSxTile;
 
     // stage tile + offset bounding box; pixels outside the DEM are never used by interior
-    // outputs (the zero frame is exactly as wide as the reach of the rays)
-    for (int r = wave; r < p.rows_l; r += kThreads / 64) {
-        const int gy = oy0 + p.dj_min + r;
-        const int by = gy - p.in_row0;
-        const bool row_ok = gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
-        float* dst = L + r * p.stride;
-        for (int k = lane; k < p.cols_l; k += 64) {
-            const int gx = ox0 + p.di_min + k;
-            dst[k] = (row_ok && gx >= 0 && gx < p.nx) ? p.in[(size_t)by * p.nx + gx] : 0.0f;
+    // outputs (the zero frame is exactly as wide as the reach of the rays).  Four rows per wave in flight.
+    for (int r0 = 0; r0 < p.rows_l; r0 += 16) {
+        for (int k0 = 0; k0 < p.cols_l; k0 += 64) {
+            const int k = k0 + lane, gx = ox0 + p.di_min + k;
+            const bool col_ok = k < p.cols_l && gx >= 0 && gx < p.nx;
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + wave + 4 * u;
+                const int gy = oy0 + p.dj_min + r, by = gy - p.in_row0;
+                const bool ok = col_ok && r < p.rows_l && gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
+                v[u] = ok ? p.in[(size_t)by * p.nx + gx] : 0.0f;
+            }
+            if (k < p.cols_l) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + wave + 4 * u;
+                    if (r < p.rows_l) L[r * STRIDE + k] = v[u];
+                }
+            }
         }
     }
     __syncthreads();
 
-    const int ox = ox0 + lane;
-    constexpr int NOUT = kTileH / (kThreads / 64);
-    float best[NOUT], centre[NOUT];
-    const int self = -p.dj_min * p.stride - p.di_min + lane;
+    constexpr int S = ALONG_X ? 1 : STRIDE;  // LDS step along the chain axis
+    float best[kSxOwn], centre[kSxOwn];
+    // own pixel k of this lane at LDS index Lw + k S (+ the offset of a ray pixel)
+    const float* Lw = ALONG_X ? L + lane * STRIDE + wave * kSxOwn : L + wave * kSxOwn * STRIDE + lane;
+    const int self = -p.dj_min * STRIDE - p.di_min;
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) {
+    for (int k = 0; k < kSxOwn; ++k) {
         best[k] = -INFINITY;
-        centre[k] = L[self + (wave + 4 * k) * p.stride] + p.height;
+        centre[k] = Lw[self + k * S] + p.height;
     }
-    for (int n = 0; n < p.n_off; ++n) {
-        const int off = p.lds_off[n] + lane;  // wave-uniform table entries
-        const float inv = p.inv_dist[n];
+    for (int c = 0; c < p.n8; ++c) {
+        const SxChain8 e = p.tab8[c];  // wave-uniform: scalar loads
+        const float* q = Lw + e.off;
+        float w[kSxOwn + 7];
 #pragma unroll
-        for (int k = 0; k < NOUT; ++k) {
-            const float z = L[off + (wave + 4 * k) * p.stride] - centre[k];
-            best[k] = fmaxf(best[k], z * inv);  // fmaxf drops NaN operands like nanmax
+        for (int j = 0; j < kSxOwn + 7; ++j) w[j] = q[j * S];
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) {
+#pragma unroll
+            for (int k = 0; k < kSxOwn; ++k) {
+                const float z0 = (w[m + k] - centre[k]) * e.inv[m];
+                const float z1 = (w[m + 1 + k] - centre[k]) * e.inv[m + 1];
+                // max3 drops (quiet) NaN operands like nanmax; spelled out because the compiler turns
+                // fmaxf(best, fmaxf(z0, z1)) into v_max(z0, z1) pairs folded by a later v_max3: 1.5 instead of 1
+                // half-rate instruction per two products
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(best[k]) : "v"(z0), "v"(z1));
+            }
         }
     }
-    if (ox >= p.nx) return;
-    const float rad2deg = 57.29577951308232f;
+    for (int c = 0; c < p.n2; c += 4) {  // four entries per scalar load (the table is padded to a multiple of 4)
+        struct Quad {
+            SxChain2 e[4];
+        };
+        const Quad g = *reinterpret_cast<const Quad*>(p.tab2 + c);
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) {
-        const int oy = oy0 + wave + 4 * k;
+        for (int u = 0; u < 4; ++u) {
+            const float* q = Lw + g.e[u].off;
+            float w[kSxOwn + 1];
+#pragma unroll
+            for (int j = 0; j < kSxOwn + 1; ++j) w[j] = q[j * S];
+#pragma unroll
+            for (int k = 0; k < kSxOwn; ++k) {
+                const float z0 = (w[k] - centre[k]) * g.e[u].inv[0];
+                const float z1 = (w[1 + k] - centre[k]) * g.e[u].inv[1];
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(best[k]) : "v"(z0), "v"(z1));
+            }
+        }
+    }
+    const float rad2deg = 57.29577951308232f;
+    if (ALONG_X) {
+        // lanes run along y here: the tile goes through LDS once more so that the stores are row segments
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSxOwn; ++k) L[lane * (kSxTile + 1) + wave * kSxOwn + k] = best[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSxOwn; ++k) best[k] = L[(wave * kSxOwn + k) * (kSxTile + 1) + lane];
+    }
+    const int ox = ox0 + lane;
+    if (ox >= p.nx) return;
+#pragma unroll
+    for (int k = 0; k < kSxOwn; ++k) {
+        const int oy = oy0 + wave * kSxOwn + k;
         if (oy >= p.out_row0 + p.out_rows) continue;
         const bool inside = oy >= p.window && oy < p.gny - p.window && ox >= p.window &&
                             ox < p.nx - p.window;
         float v = 0.0f;
-        if (inside) v = best[k] == -INFINITY ? NAN : atanf(best[k]) * rad2deg;
+        if (inside) v = best[k] == -INFINITY ? NAN : atan_signed(best[k]) * rad2deg;
         p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = v;
+    }
+}
+
+// the strides the kernel is built for: the smallest one that holds the tile's columns is used
+constexpr int kSxStrides[] = {67, 71, 75, 81, 89, 97, 105, 113, 129, 145, 161, 177, 193, 209, 225, 257};
+constexpr int kSxStrideCount = sizeof(kSxStrides) / sizeof(kSxStrides[0]);
+
+template <int I = 0>
+int launch_sx_stride(int stride, bool along_x, dim3 grid, size_t lds, hipStream_t stream, const SxArgs& a) {
+    if constexpr (I < kSxStrideCount) {
+        if (stride == kSxStrides[I]) {
+            auto go = [&](auto kernel) -> int {
+                TOPO_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, a);
+                TOPO_HIP(hipGetLastError());
+                return TOPO_AMD_OK;
+            };
+            return along_x ? go(sx_kernel<kSxStrides[I], true>) : go(sx_kernel<kSxStrides[I], false>);
+        }
+        return launch_sx_stride<I + 1>(stride, along_x, grid, lds, stream, a);
+    } else {
+        set_error("sx: no kernel for LDS stride %d", stride);
+        return TOPO_AMD_EUNSUP;
+    }
+}
+
+int sx_stride_for(int cols_l) {
+    for (int s : kSxStrides)
+        if (s >= cols_l) return s;
+    return 0;
+}
+
+// Cut the unique ray pixels into chains along one axis: runs of neighbours in eights, what is left of a run (or
+// a run shorter than 5) in twos.  `along_x`: chains run along di (same dj), else along dj (same di).
+typedef std::vector<std::pair<std::pair<int, int>, double>> SxPoints;
+void sx_chains(SxPoints pts, bool along_x, int stride, int dj_min, int di_min, std::vector<SxChain8>* t8,
+               std::vector<SxChain2>* t2) {
+    auto line = [&](const SxPoints::value_type& q) { return along_x ? q.first.first : q.first.second; };
+    auto pos = [&](const SxPoints::value_type& q) { return along_x ? q.first.second : q.first.first; };
+    std::sort(pts.begin(), pts.end(), [&](const auto& x, const auto& y) {
+        return std::make_pair(line(x), pos(x)) < std::make_pair(line(y), pos(y));
+    });
+    t8->clear();
+    t2->clear();
+    for (size_t n = 0; n < pts.size();) {
+        size_t run = 1;
+        while (n + run < pts.size() && line(pts[n + run]) == line(pts[n]) && pos(pts[n + run]) == pos(pts[n]) + (int)run) ++run;
+        for (size_t done = 0; done < run;) {
+            const size_t left = run - done, first = n + done;
+            const int off = (pts[first].first.first - dj_min) * stride + (pts[first].first.second - di_min);
+            if (left >= 5) {
+                SxChain8 e{};
+                e.off = off;
+                const size_t m = std::min<size_t>(8, left);
+                for (size_t z = 0; z < 8; ++z) e.inv[z] = z < m ? (float)(1.0 / pts[first + z].second) : std::nanf("");
+                t8->push_back(e);
+                done += m;
+            } else {
+                SxChain2 e{};
+                e.off = off;
+                e.inv[0] = (float)(1.0 / pts[first].second);
+                e.inv[1] = left >= 2 ? (float)(1.0 / pts[first + 1].second) : std::nanf("");
+                t2->push_back(e);
+                done += std::min<size_t>(2, left);
+            }
+        }
+        n += run;
     }
 }
 
@@ -180,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void sx_multi_kernel(SxMultiArgs p) {
             if (oy >= p.out_row0 + p.out_rows) continue;
             const bool inside = oy >= w && oy < p.gny - w && ox >= w && ox < p.nx - w;
             float v = 0.0f;
-            if (inside) v = best[a][k] == -INFINITY ? NAN : atanf(best[a][k]) * rad2deg;
+            if (inside) v = best[a][k] == -INFINITY ? NAN : atan_signed(best[a][k]) * rad2deg;
             p.out[a][(size_t)(oy - p.out_row0) * p.nx + ox] = v;
         }
     }
@@ -216,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void sx_global_kernel(SxGlobalArgs p) {
         const float v = p.in[(size_t)(oy + p.dj[n] - p.in_row0) * p.nx + ox + p.di[n]];
         best = fmaxf(best, (v - centre) * p.inv_dist[n]);
     }
-    p.out[o] = best == -INFINITY ? NAN : atanf(best) * 57.29577951308232f;
+    p.out[o] = best == -INFINITY ? NAN : atan_signed(best) * 57.29577951308232f;
 }
 
 __global__ __launch_bounds__(kThreads) void fill_kernel(float* out, size_t n, float value) {
@@ -301,11 +449,13 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     }
     a.dj_min = dj_min;
     a.di_min = di_min;
-    a.rows_l = kTileH + dj_max - dj_min;
-    a.cols_l = kTileW + di_max - di_min;
-    a.stride = a.cols_l | 1;
-    const size_t lds = (size_t)a.rows_l * a.stride * sizeof(float);
-    if (lds > 160 * 1024) {
+    a.rows_l = kSxTile + dj_max - dj_min;
+    a.cols_l = kSxTile + di_max - di_min;
+    const int stride = sx_stride_for(a.cols_l);
+    // spare LDS behind the tile: a chain shorter than its table entry reads up to 7 samples past its run (7 rows
+    // when the chains run along y)
+    const size_t lds = (size_t)(a.rows_l + 8) * stride * sizeof(float);
+    if (stride == 0 || lds > 160 * 1024) {
         std::vector<int> vdj(pts.size()), vdi(pts.size());
         std::vector<float> vinv(pts.size());
         for (size_t n = 0; n < pts.size(); ++n) {
@@ -324,20 +474,29 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
         TOPO_HIP(hipGetLastError());
         return TOPO_AMD_OK;
     }
-    std::vector<int> off(pts.size());
-    std::vector<float> inv(pts.size());
-    for (size_t n = 0; n < pts.size(); ++n) {
-        off[n] = (pts[n].first.first - dj_min) * a.stride + (pts[n].first.second - di_min);
-        inv[n] = (float)(1.0 / pts[n].second);
+    // chains along the axis that needs fewer comparisons (padding included)
+    std::vector<SxChain8> t8[2];
+    std::vector<SxChain2> t2[2];
+    for (int ax = 0; ax < 2; ++ax) sx_chains(pts, ax == 1, stride, dj_min, di_min, &t8[ax], &t2[ax]);
+    const bool along_x = 8 * t8[1].size() + 2 * t2[1].size() < 8 * t8[0].size() + 2 * t2[0].size();
+    const std::vector<SxChain8>& c8 = t8[along_x];
+    std::vector<SxChain2>& c2 = t2[along_x];
+    while (c2.size() % 4) {  // the kernel takes four at a time: entries whose products are all NaN
+        SxChain2 e{};
+        e.inv[0] = e.inv[1] = std::nanf("");
+        c2.push_back(e);
     }
-    void *d_off = nullptr, *d_inv = nullptr;
-    TOPO_TRY(upload_table(0, off.data(), off.size() * sizeof(int), &d_off));
-    TOPO_TRY(upload_table(1, inv.data(), inv.size() * sizeof(float), &d_inv));
+    const SxChain8 none8{};
+    const SxChain2 none2{};
+    void *d_t8 = nullptr, *d_t2 = nullptr;  // (an empty table still uploads one entry; its count stays 0)
+    TOPO_TRY(upload_table(0, c8.empty() ? &none8 : c8.data(), std::max<size_t>(1, c8.size()) * sizeof(SxChain8), &d_t8));
+    TOPO_TRY(upload_table(1, c2.empty() ? &none2 : c2.data(), std::max<size_t>(1, c2.size()) * sizeof(SxChain2), &d_t2));
     a.in = b.in;
     a.out = out;
-    a.lds_off = (const int*)d_off;
-    a.inv_dist = (const float*)d_inv;
-    a.n_off = (int)pts.size();
+    a.tab8 = (const SxChain8*)d_t8;
+    a.tab2 = (const SxChain2*)d_t2;
+    a.n8 = (int)c8.size();
+    a.n2 = (int)c2.size();
     a.in_rows = b.in_rows;
     a.in_row0 = b.in_row0;
     a.gny = b.gny;
@@ -346,12 +505,8 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     a.out_rows = b.out_rows;
     a.window = window;
     a.height = (float)height;
-    dim3 grid((b.nx + kTileW - 1) / kTileW, (b.out_rows + kTileH - 1) / kTileH);
-    TOPO_HIP(hipFuncSetAttribute((const void*)sx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-    hipLaunchKernelGGL(sx_kernel, grid, dim3(kThreads), lds, c.compute, a);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
+    dim3 grid((b.nx + kSxTile - 1) / kSxTile, (b.out_rows + kSxTile - 1) / kSxTile);
+    return launch_sx_stride(stride, along_x, grid, lds, c.compute, a);
 }
 
 namespace {
