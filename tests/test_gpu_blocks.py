@@ -2,6 +2,7 @@
 results bit-identical to the single-block run (last row), and the
 full-size configurations of BASELINE.json must agree with the oracle on sampled windows."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -557,4 +558,31 @@ def test_widths_that_are_not_multiples_of_four(nx, size):
     e = orc.std_exact(dem, size)
     assert np.max(np.abs(got_s - e)) <= 1e-4 * max(np.max(e), 1.0)
     for a in (dev, t, s, devw, tw, sw):
-        a.free()
+        a.free()@pytest.mark.gpu
+def test_gradient_row_chunks_bit_identical(tmp_path):
+    """From 8192 rows on, the matrix-core gradient goes in row chunks with the epilogue of a chunk on a second
+    stream beside the smooth of the next one (csrc/gauss.hip launch_gradient).  Chunks are row blocks: the bits
+    must not depend on the cut.  The threshold is read once per process, hence two child processes."""
+    import subprocess
+    import sys
+    script = (
+        "import os, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import topo_oracle as orc\n"
+        "import topo_descriptors_amd.topo as topo\n"
+        "dem = orc.synthetic_dem(700, 512, seed=5)\n"
+        "np.save(sys.argv[1], np.stack(topo.gradient(dem, 9.0, {'x': 50.0, 'y': -50.0})))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, rows in (("chunked", "64"), ("whole", "100000000")):
+        out = str(tmp_path / (name + ".npy"))
+        env = dict(os.environ, TOPO_AMD_GRAD_CHUNK_MIN_ROWS=rows)
+        subprocess.check_call([sys.executable, "-c", script, out], env=env)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+    dem = orc.synthetic_dem(700, 512, seed=5)
+    exact = orc.gradient_exact(dem, 9.0, {"x": 50.0, "y": -50.0})
+    assert np.max(np.abs(outs[0][2] - exact[2])) <= 1e-4 * max(1.0, float(np.max(np.abs(exact[2]))))
+
+
+
