@@ -23,8 +23,6 @@ namespace topo {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTileW = 64;
-constexpr int kTileH = 32;  // 8 output rows per thread
 
 // Table entries: chains of ray pixels that are neighbours along the chain axis (rows for sectors that point
 // north / south, columns for those that point east / west).
@@ -252,59 +250,104 @@ struct SxMultiArgs {
     const float* in;
     float* out[kMaxAz];
     int window[kMaxAz];
-    const int* lds_off;     // per unique ray pixel, sorted by class
-    const float* inv_dist;
-    const int* cls_first;   // n_cls + 1 entries
+    const SxChain8* tab8;   // chains sorted by class
+    const SxChain2* tab2;   // (every class padded to a multiple of 4 entries)
+    const int* cls_first8;  // n_cls + 1 entries each
+    const int* cls_first2;
     const int* cls_mask;    // bit a: sector a contains the class
     int n_cls, n_az;
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
-    int dj_min, di_min, rows_l, cols_l, stride;
+    int dj_min, di_min, rows_l, cols_l;
     float height;
 };
 
-template <int NA>
+constexpr int kSxMultiOwn = 8;                                  // pixels per lane along the chain axis
+constexpr int kSxMultiSpan = kSxMultiOwn * (kThreads / 64);     // tile extent along the chain axis (32)
+
+// Tile kSxMultiSpan x 64: ALONG_X false: 32 rows x 64 columns, lanes along x; true: 64 rows x 32 columns, lanes
+// along y.  The scan of a class is the chain scan of sx_kernel into a class maximum.
+template <int STRIDE, bool ALONG_X, int NA>
 __global__ __launch_bounds__(kThreads) void sx_multi_kernel(SxMultiArgs p) {
     extern __shared__ __attribute__((aligned(16))) float L[];
+    constexpr int OWN = kSxMultiOwn;
+    constexpr int TW = ALONG_X ? kSxMultiSpan : 64, TH = ALONG_X ? 64 : kSxMultiSpan;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int ox0 = blockIdx.x * kTileW;
-    const int oy0 = p.out_row0 + blockIdx.y * kTileH;
+    const int ox0 = blockIdx.x * TW;
+    const int oy0 = p.out_row0 + blockIdx.y * TH;
 
-    for (int r = wave; r < p.rows_l; r += kThreads / 64) {
-        const int gy = oy0 + p.dj_min + r;
-        const int by = gy - p.in_row0;
-        const bool row_ok = gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
-        float* dst = L + r * p.stride;
-        for (int k = lane; k < p.cols_l; k += 64) {
-            const int gx = ox0 + p.di_min + k;
-            dst[k] = (row_ok && gx >= 0 && gx < p.nx) ? p.in[(size_t)by * p.nx + gx] : 0.0f;
+    for (int r0 = 0; r0 < p.rows_l; r0 += 16) {
+        for (int k0 = 0; k0 < p.cols_l; k0 += 64) {
+            const int k = k0 + lane, gx = ox0 + p.di_min + k;
+            const bool col_ok = k < p.cols_l && gx >= 0 && gx < p.nx;
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + wave + 4 * u;
+                const int gy = oy0 + p.dj_min + r, by = gy - p.in_row0;
+                const bool ok = col_ok && r < p.rows_l && gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
+                v[u] = ok ? p.in[(size_t)by * p.nx + gx] : 0.0f;
+            }
+            if (k < p.cols_l) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + wave + 4 * u;
+                    if (r < p.rows_l) L[r * STRIDE + k] = v[u];
+                }
+            }
         }
     }
     __syncthreads();
 
-    const int ox = ox0 + lane;
-    constexpr int NOUT = kTileH / (kThreads / 64);
-    float best[NA][NOUT], centre[NOUT];
-    const int self = -p.dj_min * p.stride - p.di_min + lane;
+    constexpr int S = ALONG_X ? 1 : STRIDE;
+    float best[NA][OWN], centre[OWN];
+    const float* Lw = ALONG_X ? L + lane * STRIDE + wave * OWN : L + wave * OWN * STRIDE + lane;
+    const int self = -p.dj_min * STRIDE - p.di_min;
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) {
-        centre[k] = L[self + (wave + 4 * k) * p.stride] + p.height;
+    for (int k = 0; k < OWN; ++k) {
+        centre[k] = Lw[self + k * S] + p.height;
 #pragma unroll
         for (int a = 0; a < NA; ++a) best[a][k] = -INFINITY;
     }
     for (int c = 0; c < p.n_cls; ++c) {
-        float top[NOUT];
+        float top[OWN];
 #pragma unroll
-        for (int k = 0; k < NOUT; ++k) top[k] = -INFINITY;
-        const int n1 = p.cls_first[c + 1];
-        for (int n = p.cls_first[c]; n < n1; ++n) {
-            const int off = p.lds_off[n] + lane;  // wave-uniform table entries
-            const float inv = p.inv_dist[n];
+        for (int k = 0; k < OWN; ++k) top[k] = -INFINITY;
+        const int e8 = p.cls_first8[c + 1], e2 = p.cls_first2[c + 1];
+        for (int n = p.cls_first8[c]; n < e8; ++n) {
+            const SxChain8 e = p.tab8[n];
+            const float* q = Lw + e.off;
+            float w[OWN + 7];
 #pragma unroll
-            for (int k = 0; k < NOUT; ++k) {
-                const float z = L[off + (wave + 4 * k) * p.stride] - centre[k];
-                top[k] = fmaxf(top[k], z * inv);  // fmaxf drops NaN operands like nanmax
+            for (int j = 0; j < OWN + 7; ++j) w[j] = q[j * S];
+#pragma unroll
+            for (int m = 0; m < 8; m += 2) {
+#pragma unroll
+                for (int k = 0; k < OWN; ++k) {
+                    const float z0 = (w[m + k] - centre[k]) * e.inv[m];
+                    const float z1 = (w[m + 1 + k] - centre[k]) * e.inv[m + 1];
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(top[k]) : "v"(z0), "v"(z1));
+                }
+            }
+        }
+        for (int n = p.cls_first2[c]; n < e2; n += 4) {
+            struct Quad {
+                SxChain2 e[4];
+            };
+            const Quad g = *reinterpret_cast<const Quad*>(p.tab2 + n);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* q = Lw + g.e[u].off;
+                float w[OWN + 1];
+#pragma unroll
+                for (int j = 0; j < OWN + 1; ++j) w[j] = q[j * S];
+#pragma unroll
+                for (int k = 0; k < OWN; ++k) {
+                    const float z0 = (w[k] - centre[k]) * g.e[u].inv[0];
+                    const float z1 = (w[1 + k] - centre[k]) * g.e[u].inv[1];
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(top[k]) : "v"(z0), "v"(z1));
+                }
             }
         }
         const int mask = p.cls_mask[c];
@@ -312,24 +355,47 @@ __global__ __launch_bounds__(kThreads) void sx_multi_kernel(SxMultiArgs p) {
         for (int a = 0; a < NA; ++a) {
             if (mask >> a & 1) {
 #pragma unroll
-                for (int k = 0; k < NOUT; ++k) best[a][k] = fmaxf(best[a][k], top[k]);
+                for (int k = 0; k < OWN; ++k) best[a][k] = fmaxf(best[a][k], top[k]);
             }
         }
     }
-    if (ox >= p.nx) return;
     const float rad2deg = 57.29577951308232f;
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-        if (a >= p.n_az) break;
+        if (a >= p.n_az) break;  // uniform
         const int w = p.window[a];
+        if (ALONG_X) {
+            // lanes run along y: each plane's tile goes through LDS so that the stores are row segments.  Lane l
+            // then takes column l & 31 of rows 2 k + (l >> 5) of the wave's 16 rows.
+            __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NOUT; ++k) {
-            const int oy = oy0 + wave + 4 * k;
-            if (oy >= p.out_row0 + p.out_rows) continue;
-            const bool inside = oy >= w && oy < p.gny - w && ox >= w && ox < p.nx - w;
-            float v = 0.0f;
-            if (inside) v = best[a][k] == -INFINITY ? NAN : atan_signed(best[a][k]) * rad2deg;
-            p.out[a][(size_t)(oy - p.out_row0) * p.nx + ox] = v;
+            for (int k = 0; k < OWN; ++k) L[lane * (TW + 1) + wave * OWN + k] = best[a][k];
+            __syncthreads();
+            const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+            for (int k = 0; k < OWN; ++k) {
+                const int row = wave * 16 + 2 * k + half;
+                const float t = L[row * (TW + 1) + col];
+                const int ox = ox0 + col, oy = oy0 + row;
+                if (ox >= p.nx || oy >= p.out_row0 + p.out_rows) continue;
+                const bool inside = oy >= w && oy < p.gny - w && ox >= w && ox < p.nx - w;
+                float v = 0.0f;
+                if (inside) v = t == -INFINITY ? NAN : atan_signed(t) * rad2deg;
+                p.out[a][(size_t)(oy - p.out_row0) * p.nx + ox] = v;
+            }
+        } else {
+            const int ox = ox0 + lane;
+            if (ox < p.nx) {
+#pragma unroll
+                for (int k = 0; k < OWN; ++k) {
+                    const int oy = oy0 + wave * OWN + k;
+                    if (oy >= p.out_row0 + p.out_rows) continue;
+                    const bool inside = oy >= w && oy < p.gny - w && ox >= w && ox < p.nx - w;
+                    float v = 0.0f;
+                    if (inside) v = best[a][k] == -INFINITY ? NAN : atan_signed(best[a][k]) * rad2deg;
+                    p.out[a][(size_t)(oy - p.out_row0) * p.nx + ox] = v;
+                }
+            }
         }
     }
 }
@@ -511,14 +577,48 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
 
 namespace {
 
+template <int I = 0>
+int launch_sx_multi_stride(int stride, bool along_x, dim3 grid, size_t lds, hipStream_t stream, const SxMultiArgs& a) {
+    if constexpr (I < kSxStrideCount) {
+        if (stride == kSxStrides[I]) {
+            auto go = [&](auto kernel) -> int {
+                TOPO_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, a);
+                TOPO_HIP(hipGetLastError());
+                return TOPO_AMD_OK;
+            };
+            constexpr int ST = kSxStrides[I];
+            if (a.n_az <= 2) return along_x ? go(sx_multi_kernel<ST, true, 2>) : go(sx_multi_kernel<ST, false, 2>);
+            if (a.n_az <= 4) return along_x ? go(sx_multi_kernel<ST, true, 4>) : go(sx_multi_kernel<ST, false, 4>);
+            return along_x ? go(sx_multi_kernel<ST, true, kMaxAz>) : go(sx_multi_kernel<ST, false, kMaxAz>);
+        }
+        return launch_sx_multi_stride<I + 1>(stride, along_x, grid, lds, stream, a);
+    } else {
+        set_error("sx_multi: no kernel for LDS stride %d", stride);
+        return TOPO_AMD_EUNSUP;
+    }
+}
+
+}  // namespace
+
+namespace {
+
 struct SectorPoints {
     std::vector<std::pair<std::pair<int, int>, double>> pts;  // unique usable (dj, di), distance
     int dj_min = 0, dj_max = 0, di_min = 0, di_max = 0;       // box, the target pixel included
 };
 
+// LDS of the multi-azimuth tile for one orientation (0 when no compiled stride holds its columns)
+size_t sx_multi_tile_bytes(int dj_min, int dj_max, int di_min, int di_max, bool along_x) {
+    const int tw = along_x ? kSxMultiSpan : 64, th = along_x ? 64 : kSxMultiSpan;
+    const int stride = sx_stride_for(tw + di_max - di_min);
+    return stride ? (size_t)(th + dj_max - dj_min + 8) * stride * sizeof(float) : 0;
+}
+// what decides whether sectors share a launch: the larger of the two orientations (the launch picks one later)
 size_t sx_tile_bytes(int dj_min, int dj_max, int di_min, int di_max) {
-    const int rows_l = kTileH + dj_max - dj_min, cols_l = kTileW + di_max - di_min;
-    return (size_t)rows_l * (cols_l | 1) * sizeof(float);
+    const size_t v = sx_multi_tile_bytes(dj_min, dj_max, di_min, di_max, false);
+    const size_t h = sx_multi_tile_bytes(dj_min, dj_max, di_min, di_max, true);
+    return (v == 0 || h == 0) ? (size_t)1 << 30 : std::max(v, h);
 }
 
 // one launch of sx_multi_kernel for sectors [a0, a1)
@@ -548,34 +648,70 @@ int launch_sx_group(const Block& b, const std::vector<SectorPoints>& sec, int a0
     all.resize(w);
     std::stable_sort(all.begin(), all.end(),
                      [](const auto& x, const auto& y) { return x.second.first < y.second.first; });
-    a.rows_l = kTileH + dj_max - a.dj_min;
-    a.cols_l = kTileW + di_max - a.di_min;
-    a.stride = a.cols_l | 1;
-    const size_t lds = (size_t)a.rows_l * a.stride * sizeof(float);
-    std::vector<int> off(all.size()), first, mask;
-    std::vector<float> inv(all.size());
+    // classes of equal membership, each cut into chains along both axes; the axis with fewer comparisons wins
+    std::vector<int> mask;
+    std::vector<SxPoints> cls;
     for (size_t n = 0; n < all.size(); ++n) {
-        off[n] = (all[n].first.first - a.dj_min) * a.stride + (all[n].first.second - a.di_min);
-        inv[n] = (float)(1.0 / all[n].second.second);
         if (n == 0 || all[n].second.first != all[n - 1].second.first) {
-            first.push_back((int)n);
             mask.push_back(all[n].second.first);
+            cls.emplace_back();
         }
+        cls.back().push_back({all[n].first, all[n].second.second});
     }
-    first.push_back((int)all.size());
-    void *d_off = nullptr, *d_inv = nullptr, *d_first = nullptr, *d_mask = nullptr;
-    TOPO_TRY(upload_table(0, off.data(), off.size() * sizeof(int), &d_off));
-    TOPO_TRY(upload_table(1, inv.data(), inv.size() * sizeof(float), &d_inv));
-    TOPO_TRY(upload_table(2, first.data(), first.size() * sizeof(int), &d_first));
-    TOPO_TRY(upload_table(3, mask.data(), mask.size() * sizeof(int), &d_mask));
+    bool along_x = false;
+    {
+        size_t work[2] = {0, 0};
+        std::vector<SxChain8> t8;
+        std::vector<SxChain2> t2;
+        for (int ax = 0; ax < 2; ++ax)
+            for (auto& pts : cls) {
+                sx_chains(pts, ax == 1, 1, a.dj_min, a.di_min, &t8, &t2);
+                work[ax] += 8 * t8.size() + 2 * ((t2.size() + 3) / 4 * 4);
+            }
+        along_x = work[1] < work[0];
+    }
+    const int tw = along_x ? kSxMultiSpan : 64, th = along_x ? 64 : kSxMultiSpan;
+    a.rows_l = th + dj_max - a.dj_min;
+    a.cols_l = tw + di_max - a.di_min;
+    const int stride = sx_stride_for(a.cols_l);
+    TOPO_REQUIRE(stride != 0, "sx_multi: no kernel for a tile of %d columns", a.cols_l);
+    const size_t lds = (size_t)(a.rows_l + 8) * stride * sizeof(float);
+    std::vector<SxChain8> tab8;
+    std::vector<SxChain2> tab2;
+    std::vector<int> first8, first2;
+    for (auto& pts : cls) {
+        std::vector<SxChain8> t8;
+        std::vector<SxChain2> t2;
+        sx_chains(pts, along_x, stride, a.dj_min, a.di_min, &t8, &t2);
+        while (t2.size() % 4) {
+            SxChain2 e{};
+            e.inv[0] = e.inv[1] = std::nanf("");
+            t2.push_back(e);
+        }
+        first8.push_back((int)tab8.size());
+        first2.push_back((int)tab2.size());
+        tab8.insert(tab8.end(), t8.begin(), t8.end());
+        tab2.insert(tab2.end(), t2.begin(), t2.end());
+    }
+    first8.push_back((int)tab8.size());
+    first2.push_back((int)tab2.size());
+    if (tab8.empty()) tab8.push_back(SxChain8{});
+    if (tab2.empty()) tab2.push_back(SxChain2{});
+    void *d_t8 = nullptr, *d_t2 = nullptr, *d_f8 = nullptr, *d_f2 = nullptr, *d_mask = nullptr;
+    TOPO_TRY(upload_table(0, tab8.data(), tab8.size() * sizeof(SxChain8), &d_t8));
+    TOPO_TRY(upload_table(1, tab2.data(), tab2.size() * sizeof(SxChain2), &d_t2));
+    TOPO_TRY(upload_table(2, first8.data(), first8.size() * sizeof(int), &d_f8));
+    TOPO_TRY(upload_table(3, first2.data(), first2.size() * sizeof(int), &d_f2));
+    TOPO_TRY(upload_table(4, mask.data(), mask.size() * sizeof(int), &d_mask));
     a.in = b.in;
     for (int k = 0; k < kMaxAz; ++k) {
         a.out[k] = k < a1 - a0 ? outs[a0 + k] : nullptr;
         a.window[k] = k < a1 - a0 ? window[a0 + k] : 0;
     }
-    a.lds_off = (const int*)d_off;
-    a.inv_dist = (const float*)d_inv;
-    a.cls_first = (const int*)d_first;
+    a.tab8 = (const SxChain8*)d_t8;
+    a.tab2 = (const SxChain2*)d_t2;
+    a.cls_first8 = (const int*)d_f8;
+    a.cls_first2 = (const int*)d_f2;
     a.cls_mask = (const int*)d_mask;
     a.n_cls = (int)mask.size();
     a.n_az = a1 - a0;
@@ -586,16 +722,8 @@ int launch_sx_group(const Block& b, const std::vector<SectorPoints>& sec, int a0
     a.out_row0 = b.out_row0;
     a.out_rows = b.out_rows;
     a.height = (float)height;
-    dim3 grid((b.nx + kTileW - 1) / kTileW, (b.out_rows + kTileH - 1) / kTileH);
-    auto go = [&](auto kernel) -> int {
-        TOPO_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, c.compute, a);
-        TOPO_HIP(hipGetLastError());
-        return TOPO_AMD_OK;
-    };
-    if (a.n_az <= 2) return go(sx_multi_kernel<2>);
-    if (a.n_az <= 4) return go(sx_multi_kernel<4>);
-    return go(sx_multi_kernel<kMaxAz>);
+    dim3 grid((b.nx + tw - 1) / tw, (b.out_rows + th - 1) / th);
+    return launch_sx_multi_stride(stride, along_x, grid, lds, c.compute, a);
 }
 
 }  // namespace
