@@ -558,7 +558,9 @@ def test_widths_that_are_not_multiples_of_four(nx, size):
     e = orc.std_exact(dem, size)
     assert np.max(np.abs(got_s - e)) <= 1e-4 * max(np.max(e), 1.0)
     for a in (dev, t, s, devw, tw, sw):
-        a.free()@pytest.mark.gpu
+        a.free()
+
+
 def test_gradient_row_chunks_bit_identical(tmp_path):
     """From 8192 rows on, the matrix-core gradient goes in row chunks with the epilogue of a chunk on a second
     stream beside the smooth of the next one (csrc/gauss.hip launch_gradient).  Chunks are row blocks: the bits

@@ -634,6 +634,27 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                 v[r] = src[(size_t)(gy - p.in_row0) * p.nx];
             }
         };
+        {
+            // On a DEM with fractional elevations every tile ends up with the general kernel, and staging the
+            // strip for nothing cost 3 ms at 67 px (20.4 -> 23.5 ms).  Four rows spread over the run are probed
+            // first (64 columns each, the same in every wave, so the block agrees): when all four hold a
+            // fractional or non-finite sample the run is handed over unstaged.  A run that is only partly
+            // fractional and slips through is still exact: its tiles are marked one by one below.
+            int odd = 0;
+            const int pc = min(max(ox0 + 4 * lane, 0), p.nx - 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int gy = oyS + ((2 * u + 1) * run_tiles * C::TH) / 8;
+                gy = min(max(gy, rmin), rmax - 1);
+                const float x = p.in[(size_t)(gy - p.in_row0) * p.nx + pc];
+                odd += __builtin_amdgcn_ballot_w64(!(x == truncf(x))) != 0 ? 1 : 0;
+            }
+            if (odd == 4) {
+                for (int t = tile0 + (int)threadIdx.x; t < tile0 + run_tiles; t += NW * 64) p.defer[t] = kTileGeneral;
+                tile0 += run_tiles;
+                continue;
+            }
+        }
         uint32_t run_u = 0, run_u2 = 0;
         int wslot = 0;  // ring slot of the next row to stage = slot of the oldest row
         // what a stager saw in a batch: flags, smallest and largest trunc(x)
