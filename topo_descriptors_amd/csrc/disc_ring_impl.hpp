@@ -306,6 +306,24 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
                 v[r] = src[(size_t)(gy - p.in_row0) * p.nx];
             }
         };
+        if (MODE == kRingMain) {
+            // Below 17 px a tile with fractional elevations goes to the general kernel: a run whose four probed
+            // rows all hold fractional or non-finite samples is handed over unstaged (see std_ring_kernel)
+            int odd = 0;
+            const int pc = min(max(ox0 + 4 * lane, 0), p.nx - 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int gy = oyS + ((2 * u + 1) * run_tiles * C::TH) / 8;
+                gy = min(max(gy, rmin), rmax - 1);
+                const float x = p.in[(size_t)(gy - p.in_row0) * p.nx + pc];
+                odd += __builtin_amdgcn_ballot_w64(!(x == truncf(x))) != 0 ? 1 : 0;
+            }
+            if (odd == 4) {
+                for (int t = tile0 + (int)threadIdx.x; t < tile0 + run_tiles; t += NW * 64) p.defer[t] = kTileGeneral;
+                tile0 += run_tiles;
+                continue;
+            }
+        }
         uint32_t run = 0;  // running prefix of this lane's column (wraps, harmlessly)
         int wslot = 0;     // ring slot of the next row to stage
         // Staging a batch of B rows in two halves.  convert_batch: the loaded samples -> the prefix values
