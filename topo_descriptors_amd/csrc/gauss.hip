@@ -1092,9 +1092,11 @@ bool wide_tiling(int radius) {
 
 // The MFMA kernels take the filters whose ring fits LDS (radius <= 121, sigma <= 30.3).  Same-box sweeps on the
 // 32768^2 bench DEM (tools/grad_time.py, profiles/r02_gauss_mfma.txt): for the Gaussian alone they win from the
-// smallest radius tried (sigma 3.25: 4.9 ms against 6.3 ms; they are used from radius 16, sigma 4); for the gradient, where the vector-ALU axis-1 kernel
-// has the epilogue fused in and the MFMA route pays a separate epilogue launch, they win from radius ~30
-// (sigma 8: 10.5 against 11.5 ms; sigma 6: 10.0 against 9.6).
+// smallest radius tried (sigma 3.25: 4.9 ms against 6.3 ms; they are used from radius 16, sigma 4).  For the gradient
+// the vector-ALU axis-1 kernel has the epilogue fused in while the MFMA route pays a separate epilogue: with
+// the first MFMA kernels of the round the crossover was radius ~30 (sigma 8: 10.5 against 11.5 ms; sigma 6: 10.0
+// against 9.6); with the final ones and the epilogue overlapped by row chunks they win from radius 16 on
+// (sigma 4: 7.85 against 9.26 ms, sigma 5.5: 8.0 against 9.7, sigma 7: 8.2 against 9.8).
 bool mfma_radius(int R, int nx, bool for_gradient = false) {
     static const int from_gauss = [] {
         const char* e = std::getenv("TOPO_AMD_GAUSS_MFMA_MIN_RADIUS");
@@ -1104,7 +1106,7 @@ bool mfma_radius(int R, int nx, bool for_gradient = false) {
     }();
     static const int from_grad = [] {
         const char* e = std::getenv("TOPO_AMD_GRAD_MFMA_MIN_RADIUS");
-        return e && *e ? std::atoi(e) : 30;
+        return e && *e ? std::atoi(e) : 16;
     }();
     return R >= (for_gradient ? std::max(16, from_grad) : from_gauss) && R <= 121 && nx % 4 == 0 && nx >= 4;
 }
