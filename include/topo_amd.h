@@ -179,6 +179,13 @@ int topo_amd_tpi_f32(const float* dem, int ny, int nx, int size, double sigma, f
 int topo_amd_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
 int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigma,
                          float* tpi_out, float* std_out);
+/* Several scales of TPI and / or STD from ONE upload of the DEM (the loop over scales of the reference's
+ * compute_tpi / compute_std, topo.py:88-141 and :216-269, which calls tpi / std once per scale): sizes[k],
+ * sigmas[k] (0 = no pre-smoothing) -> tpi_outs[k], std_outs[k], each a host plane [ny x nx] or NULL (either
+ * array of planes may itself be NULL).  Plane k has the bits of topo_amd_tpi_std_f32(sizes[k], sigmas[k]);
+ * the call moves (1 + planes) x ny x nx x 4 bytes over PCIe instead of (scales + planes) x that.          */
+int topo_amd_tpi_std_multi_f32(const float* dem, int ny, int nx, int n_scales, const int32_t* sizes,
+                               const double* sigmas, float* const* tpi_outs, float* const* std_outs);
 int topo_amd_gauss_f32(const float* dem, int ny, int nx, double sigma_y, double sigma_x,
                        float* out);
 int topo_amd_sobel_f32(const float* dem, int ny, int nx, float* dx_out, float* dy_out);

@@ -107,6 +107,23 @@ def test_tpi_size_one_non_finite():
     assert not np.any(np.isfinite(topo.tpi(dem, 1)))
 
 
+def test_tpi_std_multi_scale_is_the_single_calls():
+    """Several scales from one upload (topo_amd_tpi_std_multi_f32): every plane has the bits of the
+    single call - ring kernel, marching kernel and general kernel sizes, with and without pre-smoothing."""
+    dem = orc.synthetic_dem(300, 260, seed=17)
+    dem[::7, ::5] += 0.25  # some fractional tiles
+    sizes, sigmas = [5, 17, 33, 67, 6], [None, 1.5, None, None, None]
+    tpis, stds = topo.tpi_std_multi(dem, sizes, sigmas)
+    for k, (size, sigma) in enumerate(zip(sizes, sigmas)):
+        t, s = topo.tpi_std(dem, size, sigma)
+        assert np.array_equal(tpis[k], t, equal_nan=True), size
+        assert np.array_equal(stds[k], s, equal_nan=True), size
+    only_t, none = topo.tpi_std_multi(dem, [9, 67], want_std=False)
+    assert none is None and np.array_equal(only_t[1], topo.tpi(dem, 67))
+    none, only_s = topo.tpi_std_multi(dem, [9], want_tpi=False)
+    assert none is None and np.array_equal(only_s[0], topo.std(dem, 9))
+
+
 @pytest.mark.parametrize("key,src", [("gauss_int_0.75", "dem_int"), ("gauss_int_2.25", "dem_int"),
                                      ("gauss_int_3.25", "dem_int"), ("gauss_big_30.25", "dem_big"),
                                      ("gauss_small_8.0", "dem_small")])

@@ -59,6 +59,7 @@ SIGNATURES = {
     "topo_amd_tpi_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp]),
     "topo_amd_std_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp]),
     "topo_amd_tpi_std_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp]),
+    "topo_amd_tpi_std_multi_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _i32p, _f64p, _vp, _vp]),
     "topo_amd_gauss_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, _vp]),
     "topo_amd_sobel_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "topo_amd_gradient_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,

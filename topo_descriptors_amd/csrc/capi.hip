@@ -627,6 +627,43 @@ int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigm
     return TOPO_AMD_OK;
 }
 
+int topo_amd_tpi_std_multi_f32(const float* dem, int ny, int nx, int n_scales, const int32_t* sizes,
+                               const double* sigmas, float* const* tpi_outs, float* const* std_outs) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dem && ny >= 1 && nx >= 1, "tpi_std_multi: bad DEM");
+    TOPO_REQUIRE(n_scales >= 1 && sizes, "tpi_std_multi: no scales");
+    TOPO_REQUIRE(tpi_outs || std_outs, "tpi_std_multi: both output lists are NULL");
+    bool any_tpi = false, any_std = false;
+    for (int k = 0; k < n_scales; ++k) {
+        const bool t = tpi_outs && tpi_outs[k], s = std_outs && std_outs[k];
+        TOPO_REQUIRE(t || s, "tpi_std_multi: scale %d has no output plane", k);
+        any_tpi |= t;
+        any_std |= s;
+    }
+    const size_t bytes = (size_t)ny * nx * sizeof(float);
+    HostRun run;
+    void *d_in = nullptr, *d_tpi = nullptr, *d_std = nullptr;
+    TOPO_TRY(run.alloc(&d_in, bytes));
+    if (any_tpi) TOPO_TRY(run.alloc(&d_tpi, bytes));
+    if (any_std) TOPO_TRY(run.alloc(&d_std, bytes));
+    for (int k = 0; k < n_scales; ++k) {
+        if (tpi_outs && tpi_outs[k]) run.prefault(tpi_outs[k], bytes);
+        if (std_outs && std_outs[k]) run.prefault(std_outs[k], bytes);
+    }
+    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
+    Block b{(const float*)d_in, ny, 0, ny, nx, 0, ny};
+    for (int k = 0; k < n_scales; ++k) {
+        float* t = tpi_outs && tpi_outs[k] ? (float*)d_tpi : nullptr;
+        float* s = std_outs && std_outs[k] ? (float*)d_std : nullptr;
+        TOPO_TRY(tpi_std_block(b, sizes[k], sigmas ? sigmas[k] : 0.0, t, s));
+        if (k == 0) run.ready();
+        if (t) TOPO_TRY(download(tpi_outs[k], d_tpi, bytes));  // stream-ordered: the next scale's kernels wait for it
+        if (s) TOPO_TRY(download(std_outs[k], d_std, bytes));
+    }
+    TOPO_HIP(hipStreamSynchronize(ctx().compute));
+    return TOPO_AMD_OK;
+}
+
 int topo_amd_tpi_f32(const float* dem, int ny, int nx, int size, double sigma, float* out) {
     TOPO_REQUIRE(out != nullptr, "tpi: NULL output");
     return topo_amd_tpi_std_f32(dem, ny, nx, size, sigma, out, nullptr);

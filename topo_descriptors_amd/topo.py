@@ -105,6 +105,39 @@ def tpi_std(dem, size, sigma=None):
     return t, s.astype(np.float64)
 
 
+def tpi_std_multi(dem, sizes, sigmas=None, want_tpi=True, want_std=True):
+    """TPI and / or STD for several disc sizes from one upload of the DEM (the multi-scale half):
+    what the reference's ``compute_tpi`` / ``compute_std`` loops do scale by scale (topo.py:88-141, :216-269).
+    Returns ``(tpis, stds)``, lists of planes in the order of ``sizes`` (``None`` for the kind not asked
+    for); every plane has the bits of the single call."""
+    import ctypes as C
+    values, _ = _unwrap(dem)
+    _check_2d(values, "tpi_std_multi")
+    src = _lib.as_f32(values)
+    sizes = np.ascontiguousarray(np.atleast_1d(sizes), dtype=np.int32)
+    n = int(sizes.size)
+    if sigmas is None:
+        sig = np.zeros(n, dtype=np.float64)
+    else:
+        sig = np.array([_sigma_arg(v) for v in np.broadcast_to(np.asarray(sigmas, dtype=object), (n,))],
+                       dtype=np.float64)
+    tpis = [np.empty_like(src) for _ in range(n)] if want_tpi else None
+    stds = [np.empty_like(src) for _ in range(n)] if want_std else None
+
+    def plane_list(planes):
+        if planes is None:
+            return None
+        return (C.c_void_p * n)(*[p.ctypes.data for p in planes])
+
+    lib = _lib.lib()
+    t_arg, s_arg = plane_list(tpis), plane_list(stds)
+    _lib.check(lib.topo_amd_tpi_std_multi_f32(_lib.ptr(src), src.shape[0], src.shape[1], n,
+                                              sizes.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              sig.ctypes.data_as(C.POINTER(C.c_double)), t_arg, s_arg),
+               "topo_amd_tpi_std_multi_f32")
+    return tpis, ([s.astype(np.float64) for s in stds] if stds is not None else None)
+
+
 # ---- Gaussian, Sobel, gradient ------------------------------------------------------------------
 def dem(dem, sigma):
     """Gaussian-smoothed DEM, reflect boundary, 4-sigma truncation (reference topo.py:62-80).
