@@ -100,7 +100,11 @@ int topo_amd_disc_mask(int size, float* mask);
 /* Ghost rows a row block needs above / below its output rows for one descriptor.
  * p0: size (TPI/STD) | sigma_axis0 (GAUSS/GRADIENT: max of the two axis-0 sigmas)
  * p1: pre-smoothing sigma (TPI/STD, 0 = none) | unused
- * For SX pass the extremes of the offset table instead: p0 = -min(dj), p1 = max(dj).   */
+ * For SX pass the extremes of the offset table instead: p0 = -min(dj), p1 = max(dj).
+ * For Gaussian radii int(4 sigma + 0.5) of 4 ... 15 (gradient: 8 ... 15; also the pre-smoothing of TPI / STD) the
+ * answer is 16 rows (gradient: 17) rather than the radius: the matrix-core kernels used there take a per-tile
+ * offset sample 16 rows into their 32-row tiles.  A block with fewer ghost rows (but at least the radius) is still
+ * computed correctly, by the vector-ALU kernels; only bit-identity with other partitions is lost.              */
 int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* below);
 
 /* ---- descriptors, device row-block form --------------------------------------------- */

@@ -454,17 +454,24 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
         case TOPO_AMD_DESC_STD: {
             DiscRuns d;
             TOPO_TRY(build_disc((int)p0, &d));
-            const int R = p1 > 0.0 ? gaussian_radius(p1) : 0;
+            int R = p1 > 0.0 ? gaussian_radius(p1) : 0;
+            if (R >= mfma_min_radius(false) && R < 16) R = 16;  // pre-smoothing on the matrix cores: see DESC_GAUSS
             *above = -d.dj_min + R;
             *below = d.dj_max + R;
             return TOPO_AMD_OK;
         }
-        case TOPO_AMD_DESC_GAUSS:
-            *above = *below = gaussian_radius(p0);
+        case TOPO_AMD_DESC_GAUSS: {
+            // (radius mfma_min_radius .. 15: the matrix-core kernels want the accumulation-offset row of every
+            // 32-row tile inside the block, 16 rows from the tile's first row: gauss.hip, mfma_rows_ok)
+            const int R = gaussian_radius(p0);
+            *above = *below = (R >= mfma_min_radius(false) && R < 16) ? 16 : R;
             return TOPO_AMD_OK;
-        case TOPO_AMD_DESC_GRADIENT:
-            *above = *below = p0 <= 1.0 ? 1 : gaussian_radius(p0) + 1;
+        }
+        case TOPO_AMD_DESC_GRADIENT: {
+            const int R = gaussian_radius(p0);
+            *above = *below = p0 <= 1.0 ? 1 : ((R >= mfma_min_radius(true) && R < 16) ? 17 : R + 1);
             return TOPO_AMD_OK;
+        }
         case TOPO_AMD_DESC_SOBEL:
             *above = *below = 1;
             return TOPO_AMD_OK;

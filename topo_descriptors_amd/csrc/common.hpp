@@ -101,7 +101,9 @@ int launch_disc_wave(const Block& b, int size, float* tpi_out, float* std_out);
 bool disc_wave_covers(int size);  // a specialisation exists for this disc size
 // any size: float64 column prefix sums in HBM (slow, exact)
 int launch_disc_big(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out);
-int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out);
+int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out, bool small_ok = true);
+// smallest radius that takes the matrix-core Gaussian kernels (>= 8); below 16 they want 16 ghost rows
+int mfma_min_radius(bool for_gradient);
 int launch_sobel(const Block& b, float* dx_out, float* dy_out);
 int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode,
                     const void* res_x, const void* res_y, float* dx, float* dy, float* slope,

@@ -1091,24 +1091,45 @@ bool wide_tiling(int radius) {
 }
 
 // The MFMA kernels take the filters whose ring fits LDS (radius <= 121, sigma <= 30.3).  Same-box sweeps on the
-// 32768^2 bench DEM (tools/grad_time.py, profiles/r02_gauss_mfma.txt): for the Gaussian alone they win from the
-// smallest radius tried (sigma 3.25: 4.9 ms against 6.3 ms; they are used from radius 16, sigma 4).  For the gradient
-// the vector-ALU axis-1 kernel has the epilogue fused in while the MFMA route pays a separate epilogue: with
-// the first MFMA kernels of the round the crossover was radius ~30 (sigma 8: 10.5 against 11.5 ms; sigma 6: 10.0
-// against 9.6); with the final ones and the epilogue overlapped by row chunks they win from radius 16 on
-// (sigma 4: 7.85 against 9.26 ms, sigma 5.5: 8.0 against 9.7, sigma 7: 8.2 against 9.8).
-bool mfma_radius(int R, int nx, bool for_gradient = false) {
+// 32768^2 bench DEM (tools/grad_time.py, profiles/r02_gauss_mfma.txt).  Gaussian alone: they win at every radius
+// tried, down to 4 (sigma 1.1 ... 1.75: 3.5-3.6 ms against 5.6 ms for the vector-ALU pair; sigma 2 ... 3.75: 3.9-4.2
+// against 6.0-6.5; sigma 30.25: 11.3 against 23.0).  Gradient: the vector-ALU axis-1 kernel has the epilogue fused
+// in while the MFMA route pays a separate epilogue (36 instead of 28 B/pixel of HBM traffic, ~8.3 ms whatever the
+// radius); with the final kernels and the epilogue overlapped by row chunks the MFMA route wins from radius 8
+// (sigma 2 ... 3.75: 8.3-8.4 against 8.7-10.5 ms, the fused kernel being bimodal from box to box; sigma 4: 7.85
+// against 9.26; sigma 7: 8.2 against 9.8) and loses below (sigma 1.1 ... 1.75: 8.3 against 7.65).
+// Below radius 16 the kernels need more of the caller: the per-column accumulation offset of an axis-0 tile is the
+// sample 16 rows into the (global) 32-row tile, and a row block holds that row for every tile it computes only
+// when it carries 16 ghost rows (17 for the gradient) instead of R (R + 1).  topo_amd_halo_rows asks for them;
+// a block that comes with less takes the vector-ALU kernels (mfma_rows_ok), whose results differ from the
+// matrix-core ones in the last bits: row-block bit-identity holds for ghost depths of topo_amd_halo_rows or more
+// (the pre-smoothing of topo.tpi / topo.std included).  The two smooths of an anisotropic gradient keep the
+// radius-16 floor: they have two radii and one ghost depth.
+constexpr int kMfmaSmallFloor = 4;
+int mfma_min_radius_impl(bool for_gradient) {
     static const int from_gauss = [] {
         const char* e = std::getenv("TOPO_AMD_GAUSS_MFMA_MIN_RADIUS");
-        // (not below 16: the per-column accumulation offset of an axis-0 tile is the sample 16 rows into the tile,
-        // which every row block that owns a row of the tile holds only when the halo is at least 16 rows)
-        return std::max(16, e && *e ? std::atoi(e) : 16);
+        return std::max(kMfmaSmallFloor, e && *e ? std::atoi(e) : 4);
     }();
     static const int from_grad = [] {
         const char* e = std::getenv("TOPO_AMD_GRAD_MFMA_MIN_RADIUS");
-        return e && *e ? std::atoi(e) : 16;
+        return std::max(kMfmaSmallFloor, e && *e ? std::atoi(e) : 8);
     }();
-    return R >= (for_gradient ? std::max(16, from_grad) : from_gauss) && R <= 121 && nx % 4 == 0 && nx >= 4;
+    return for_gradient ? from_grad : from_gauss;
+}
+
+bool mfma_radius(int R, int nx, bool for_gradient = false, bool small_ok = true) {
+    return R >= std::max(small_ok ? kMfmaSmallFloor : 16, mfma_min_radius_impl(for_gradient)) && R <= 121 && nx % 4 == 0 && nx >= 4;
+}
+
+// the accumulation-offset row of every axis-0 tile that holds one of the block's output rows is inside the block
+// (or the block reaches the DEM edge there)
+bool mfma_rows_ok(const Block& b, int R) {
+    if (R >= 16) return true;
+    const int y_first = b.out_row0 / 32 * 32 + 16, y_last = (b.out_row0 + b.out_rows - 1) / 32 * 32 + 16;
+    const bool top = b.in_row0 <= 0 || y_first >= b.in_row0;
+    const bool bottom = b.in_row0 + b.in_rows >= b.gny || y_last <= b.in_row0 + b.in_rows - 1;
+    return top && bottom;
 }
 
 int upload_plain_weights(int slot, double sigma, GaussArgs* a) {
@@ -1197,9 +1218,10 @@ int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, 
     return TOPO_AMD_OK;
 }
 
-int run_axis0(const Block& b, double sigma, float* out, int table_slot, bool mfma_ok = true) {
+int run_axis0(const Block& b, double sigma, float* out, int table_slot, bool mfma_ok = true, bool small_ok = true) {
     Context& c = ctx();
-    if (mfma_ok && mfma_radius(gaussian_radius(sigma), b.nx)) return run_axis0_mfma(b, sigma, out, table_slot);
+    if (mfma_ok && mfma_radius(gaussian_radius(sigma), b.nx, false, small_ok) && mfma_rows_ok(b, gaussian_radius(sigma)))
+        return run_axis0_mfma(b, sigma, out, table_slot);
     const bool wide = wide_tiling(gaussian_radius(sigma));
     GaussArgs a;
     TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
@@ -1246,8 +1268,8 @@ int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, c
                         float* smooth_out);
 
 // `in` holds exactly the rows [out_row0, out_row0 + out_rows) starting at in_row0 == out_row0
-int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int table_slot) {
-    if (mfma_radius(gaussian_radius(sigma), nx)) return run_axis1_mfma(in, rows, nx, sigma, out, table_slot);
+int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int table_slot, bool small_ok = true) {
+    if (mfma_radius(gaussian_radius(sigma), nx, false, small_ok)) return run_axis1_mfma(in, rows, nx, sigma, out, table_slot);
     const bool wide = wide_tiling(gaussian_radius(sigma));
     GaussArgs a;
     TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
@@ -1439,7 +1461,7 @@ int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, c
 
 // Full 2-D smooth of rows [row0, row0+rows) into `out`; ws_slot names the scratch plane.
 int smooth_rows(const Block& src, double sigma_y, double sigma_x, int row0, int rows, float* out,
-                int ws_slot, int table_slot) {
+                int ws_slot, int table_slot, bool small_ok = true) {
     Context& c = ctx();
     const bool do_y = sigma_y > 1e-15, do_x = sigma_x > 1e-15;
     Block b = src;
@@ -1449,13 +1471,13 @@ int smooth_rows(const Block& src, double sigma_y, double sigma_x, int row0, int 
     if (do_y && do_x) {
         void* tmp = nullptr;
         TOPO_TRY(workspace(ws_slot, bytes, &tmp));
-        TOPO_TRY(run_axis0(b, sigma_y, (float*)tmp, table_slot));
-        TOPO_TRY(run_axis1((const float*)tmp, rows, src.nx, sigma_x, out, table_slot + 1));
+        TOPO_TRY(run_axis0(b, sigma_y, (float*)tmp, table_slot, true, small_ok));
+        TOPO_TRY(run_axis1((const float*)tmp, rows, src.nx, sigma_x, out, table_slot + 1, small_ok));
     } else if (do_y) {
-        TOPO_TRY(run_axis0(b, sigma_y, out, table_slot));
+        TOPO_TRY(run_axis0(b, sigma_y, out, table_slot, true, small_ok));
     } else if (do_x) {
         const float* first = src.in + (size_t)(row0 - src.in_row0) * src.nx;
-        TOPO_TRY(run_axis1(first, rows, src.nx, sigma_x, out, table_slot + 1));
+        TOPO_TRY(run_axis1(first, rows, src.nx, sigma_x, out, table_slot + 1, small_ok));
     } else {
         const float* first = src.in + (size_t)(row0 - src.in_row0) * src.nx;
         TOPO_HIP(hipMemcpyAsync(out, first, bytes, hipMemcpyDeviceToDevice, c.compute));
@@ -1489,8 +1511,10 @@ int upload_resolution(int res_mode, const void* res_x, const void* res_y, int nx
 
 int gaussian_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
 
-int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out) {
-    return smooth_rows(b, sigma_y, sigma_x, b.out_row0, b.out_rows, out, 0, 1);
+int mfma_min_radius(bool for_gradient) { return mfma_min_radius_impl(for_gradient); }
+
+int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out, bool small_ok) {
+    return smooth_rows(b, sigma_y, sigma_x, b.out_row0, b.out_rows, out, 0, 1, small_ok);
 }
 
 int launch_sobel(const Block& b, float* dx_out, float* dy_out) {
@@ -1511,6 +1535,17 @@ int launch_sobel(const Block& b, float* dx_out, float* dy_out) {
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
+
+namespace {
+// the rows the gradient smooths: the output rows plus one neighbour row inside the DEM
+Block smoothed_rows_block(const Block& b) {
+    Block r = b;
+    r.out_row0 = b.out_row0 > 0 ? b.out_row0 - 1 : 0;
+    const int s1 = (b.out_row0 + b.out_rows + 1 < b.gny) ? b.out_row0 + b.out_rows + 1 : b.gny;
+    r.out_rows = s1 - r.out_row0;
+    return r;
+}
+}  // namespace
 
 int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode,
                     const void* res_x, const void* res_y, float* dx, float* dy, float* slope,
@@ -1552,7 +1587,8 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         const char* e = std::getenv("TOPO_AMD_GRAD_CHUNK_MIN_ROWS");
         return e && *e ? std::atoi(e) : 8192;
     }();
-    if (sigma > 1.0 && sig_ratio == 1.0 && mfma_radius(gaussian_radius(sigma), b.nx, true) && b.out_rows >= chunk_min &&
+    if (sigma > 1.0 && sig_ratio == 1.0 && mfma_radius(gaussian_radius(sigma), b.nx, true) &&
+        mfma_rows_ok(smoothed_rows_block(b), gaussian_radius(sigma)) && b.out_rows >= chunk_min &&
         b.nx % 4 == 0 && aligned16(dx) && aligned16(dy) && aligned16(slope) && aligned16(aspect)) {
         static const int NCH = [] {
             const char* e = std::getenv("TOPO_AMD_GRAD_CHUNKS");
@@ -1638,7 +1674,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         Block rows = b;
         rows.out_row0 = s0;
         rows.out_rows = s_rows;
-        const bool mfma = mfma_radius(gaussian_radius(sigma), b.nx, true);
+        const bool mfma = mfma_radius(gaussian_radius(sigma), b.nx, true) && mfma_rows_ok(rows, gaussian_radius(sigma));
         if (mfma) TOPO_TRY(run_axis0_mfma(rows, sigma, (float*)plane_a, 1));
         else TOPO_TRY(run_axis0(rows, sigma, (float*)plane_a, 1, false));
         // short and medium filters: LDS-tiled axis 1 (9.8 vs 13.6 ms at sigma 3.25 on 32768^2); long
@@ -1665,8 +1701,10 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     } else {  // topo.py:633-635
         const double perp = sigma * sig_ratio;
         TOPO_TRY(workspace(2, bytes, &plane_b));
-        TOPO_TRY(smooth_rows(b, perp, sigma, s0, s_rows, (float*)plane_a, 0, 1));
-        TOPO_TRY(smooth_rows(b, sigma, perp, s0, s_rows, (float*)plane_b, 0, 1));
+        // (two radii, one ghost depth: the matrix-core kernels only from radius 16, where they need no more
+        // ghost rows than the filter itself)
+        TOPO_TRY(smooth_rows(b, perp, sigma, s0, s_rows, (float*)plane_a, 0, 1, /*small_ok=*/false));
+        TOPO_TRY(smooth_rows(b, sigma, perp, s0, s_rows, (float*)plane_b, 0, 1, /*small_ok=*/false));
     }
     g.gx_src = (const float*)plane_a;
     g.gy_src = (const float*)plane_b;
