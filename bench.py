@@ -226,10 +226,9 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
               disc_kernels("tpi_std", size))
     o3 = d.DeviceArray(ny, nx)
     o4 = d.DeviceArray(ny, nx)
-    grad_kernels = {3.25: "gauss_axis0_kernel<8, 8> + gauss_axis1_grad_kernel<16, 8, 8, 3> (LDS tile, fused epilogue)",
-                    30.25: "8 row chunks of gauss_axis0_mfma_kernel + gauss_axis1_mfma_kernel (banded Toeplitz on the fp32 "
-                           "matrix cores), gradient_epilogue4_kernel of chunk k on a second stream beside the smooth "
-                           "of chunk k + 1"}
+    mfma_route = ("8 row chunks of gauss_axis0_mfma_kernel + gauss_axis1_mfma_kernel (banded Toeplitz on the fp32 "
+                  "matrix cores), gradient_epilogue4_kernel of chunk k on a second stream beside the smooth of chunk k + 1")
+    grad_kernels = {3.25: mfma_route, 30.25: mfma_route}
     for sigma in (3.25, 30.25):
         fn = lambda: blk.gradient(sigma, [30.0], [-30.0], dx=o1, dy=o2, slope=o3, aspect=o4)  # noqa: E731
         entry(f"gradient_sigma{sigma}", time_kernel(fn, REPS, d), 20, grad_kernels[sigma])
