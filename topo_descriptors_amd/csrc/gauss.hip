@@ -679,11 +679,10 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 c) {
     return o;
 }
 constexpr int kMfmaCols = 128;  // axis 0: columns per block (4 waves x 32)
-constexpr int kAhead = 8;       // steps an operand is fetched ahead of its MFMA
 
 // wz[n] = w[n - 31] (0 outside the filter), n in [0, K + 32): lane (i = l & 31, h = l >> 5) of step s reads
 // wz[2 s + h - i + 31], the Toeplitz entry T[i][2 s + h]
-constexpr int kWzPad = 32 + 6 * kAhead;  // zeros behind the taps: the steps a padded / prefetching loop reads past the band
+constexpr int kWzPad = 80;  // zeros behind the taps: what the padded steps and the fetches two groups ahead read past the band (<= 60)
 __device__ __forceinline__ void fill_toeplitz_table(float* wz, const float* taps, int R, int K) {
     for (int n = threadIdx.x; n < K + kWzPad; n += blockDim.x) wz[n] = (n >= 31 && n - 31 <= 2 * R) ? taps[n - 31] : 0.0f;
 }
