@@ -442,7 +442,10 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
                 // which c the tile happened to use
                 const double s1 = (su + cd * m) + sf;
                 if (WANT_STD) {
-                    if (!use_float && !frac && m == n) {
+                    // (per pixel, not per tile: a window of whole metres inside a tile that has fractional samples
+                    // elsewhere must get the bits the ring kernel, whose flags cover a batch of rows, gives it; found
+                    // by the randomised row-block check once a run's hand-over depended on the run's extent)
+                    if (!use_float && m == n && q3.v[t] == 0) {
                         out_s.v[t] = std_from_int_sums(su, su2, n, inv_nn1);
                     } else {
                         const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
