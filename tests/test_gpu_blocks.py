@@ -435,6 +435,33 @@ def test_very_large_discs(size):
         assert not np.isfinite(w[~np.isfinite(q)]).any()  # the split run is NaN only where the whole one is
 
 
+@pytest.mark.parametrize("size", [7, 19, 67])
+@pytest.mark.parametrize("band", [(0, 700), (300, 1100), (900, 1500), (640, 700)])
+def test_std_row_blocks_on_a_dem_with_a_fractional_band(size, band):
+    """STD / TPI+STD on rows of whole metres next to rows with fractional elevations.  The ring kernels hand a run
+    whose probed rows are all fractional to the general kernel unstaged, so which kernel computes a pixel depends
+    on the run's extent, i.e. on the row block: both must give a window of whole metres the same bits (the
+    general kernel picks its variance expression per pixel; a per-tile choice failed the randomised check once
+    in 72 206 cases)."""
+    ny, nx = 1500, 512
+    dem = orc.synthetic_dem(ny, nx, seed=23, integer=True).astype(np.float32)
+    dem[band[0]:band[1]] += np.float32(0.37)
+    up, down = halo(_lib.DESC_STD, size)
+
+    def call(blk, row0, rows):
+        t, s = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+        blk.tpi_std(size, tpi=t, std=s, out_row0=row0, out_rows=rows)
+        return [t, s]
+
+    whole = run_blocks(dem, 1, up, down, call)
+    for nb in (3, 4):
+        parts = run_blocks(dem, nb, up, down, call)
+        assert np.array_equal(whole[0], parts[0]), nb
+        assert np.array_equal(whole[1], parts[1]), nb
+    e = orc.std_exact(dem, size)
+    assert np.max(np.abs(whole[1] - e)) <= 1e-4 * max(float(np.max(e)), 1.0)
+
+
 @pytest.mark.parametrize("layout", ["fractional_first", "fractional_band", "fractional_rows"])
 def test_tpi_fast_and_deferred_tiles_on_a_mixed_dem(layout):
     """TPI alone runs as a fast build plus a deferred pass over the tiles that need the fractional /
