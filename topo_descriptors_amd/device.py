@@ -206,13 +206,4 @@ def pack_sectors(sectors):
 def sx_offsets(azimuth, radius, dx, dy, azimuth_arc=10.0, azimuth_steps=15, radius_min=0.0):
     """(window, dj, di, dist) for the C ABI from Sx parameters and mean grid spacing."""
     from . import topo  # noqa: PLC0415
-    if azimuth_arc == 0:
-        azimuth_steps = 1
-    az = np.linspace(azimuth - azimuth_arc / 2, azimuth + azimuth_arc / 2, azimuth_steps)
-    wd = topo._sx_distance(radius, dx, dy)
-    wd[wd < radius_min] = np.nan
-    centre = np.floor(np.array(wd.shape) / 2)
-    src = (centre + topo._sx_source_idx_delta(az, radius, dx, dy)).astype(int)
-    lines = topo._sx_bresenhamlines(src, centre).astype(np.int64)
-    window = int(wd.shape[0] / 2)
-    return window, lines[:, 0] - window, lines[:, 1] - window, wd[lines[:, 0], lines[:, 1]]
+    return topo._sx_sector(azimuth, radius, dx, dy, azimuth_arc, azimuth_steps, radius_min)

@@ -245,31 +245,53 @@ def _sx_bresenhamlines(start, end):
     return pts[keep]
 
 
-def _sx_rolling(dem, distance, blines, height):
-    """Max elevation angle (degrees) over the ray pixels for every DEM pixel; a frame of
-    ``int(W/2)`` pixels stays 0 (reference topo.py:928-953).  Runs as kernel K6."""
+def _sx_scan(dem, reach, rows, cols, metres, height):
+    """Kernel K6 on a host array: for every pixel the largest elevation angle (degrees) towards the ray pixels
+    ``(rows[k], cols[k])`` (offsets from the pixel) at ``metres[k]`` horizontal distance, seen from ``height``
+    above the pixel.  NaN distances are skipped; a frame of ``reach`` pixels stays 0."""
     dem = np.asarray(dem)
     _check_2d(dem, "_sx_rolling")
-    window = int(distance.shape[0] / 2)
-    blines = np.asarray(blines, dtype=np.int64).reshape(-1, 2)
-    dist = np.ascontiguousarray(distance[blines[:, 0], blines[:, 1]], dtype=np.float64)
-    dj = np.ascontiguousarray(blines[:, 0] - window, dtype=np.int32)
-    di = np.ascontiguousarray(blines[:, 1] - window, dtype=np.int32)
+    metres = np.ascontiguousarray(metres, dtype=np.float64)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
     src = _lib.as_f32(dem)
     out = np.zeros_like(src)
     ny, nx = src.shape
-    if ny <= 2 * window or nx <= 2 * window:
+    if ny <= 2 * reach or nx <= 2 * reach:  # nothing but frame
         return out.astype(dem.dtype, copy=False)
-    if dist.size == 0 or np.all(np.isnan(dist)):
+    if metres.size == 0 or np.all(np.isnan(metres)):
         # nanmax over an empty / all-NaN set: NaN inside the frame, like numpy
-        out[window : ny - window, window : nx - window] = np.nan
+        out[reach : ny - reach, reach : nx - reach] = np.nan
         return out.astype(dem.dtype, copy=False)
     lib = _lib.lib()
-    _lib.check(lib.topo_amd_sx_f32(_lib.ptr(src), ny, nx, dj.ctypes.data_as(_lib._i32p),
-                                   di.ctypes.data_as(_lib._i32p), dist.ctypes.data_as(_lib._f64p),
-                                   int(dist.size), window, float(height), _lib.ptr(out)),
+    _lib.check(lib.topo_amd_sx_f32(_lib.ptr(src), ny, nx, rows.ctypes.data_as(_lib._i32p),
+                                   cols.ctypes.data_as(_lib._i32p), metres.ctypes.data_as(_lib._f64p),
+                                   int(metres.size), int(reach), float(height), _lib.ptr(out)),
                "topo_amd_sx_f32")
     return out.astype(dem.dtype, copy=False)
+
+
+def _sx_rolling(dem, distance, blines, height):
+    """The reference's private entry (topo.py:928-953): ``distance`` is the square table of distances around
+    the pixel, ``blines`` the (row, column) cells of that table the rays cross."""
+    reach = int(distance.shape[0] / 2)
+    cells = np.asarray(blines, dtype=np.int64).reshape(-1, 2)
+    return _sx_scan(dem, reach, cells[:, 0] - reach, cells[:, 1] - reach, distance[cells[:, 0], cells[:, 1]], height)
+
+
+def _sx_sector(azimuth, radius, spacing_x, spacing_y, azimuth_arc=10.0, azimuth_steps=15, radius_min=0.0):
+    """The ray pixels of one sector as ``(reach, rows, cols, metres)``: offsets from the target pixel and their
+    distances (NaN where closer than ``radius_min``), built from the reference's three geometry helpers so that
+    the set is the reference's (topo.py:825-853)."""
+    n_rays = 1 if azimuth_arc == 0 else azimuth_steps
+    ray_azimuths = np.linspace(azimuth - azimuth_arc / 2, azimuth + azimuth_arc / 2, n_rays)
+    table = _sx_distance(radius, spacing_x, spacing_y)
+    table[table < radius_min] = np.nan
+    middle = np.floor(np.array(table.shape) / 2)
+    far_ends = (middle + _sx_source_idx_delta(ray_azimuths, radius, spacing_x, spacing_y)).astype(int)
+    cells = np.asarray(_sx_bresenhamlines(far_ends, middle), dtype=np.int64).reshape(-1, 2)
+    reach = int(table.shape[0] / 2)
+    return reach, cells[:, 0] - reach, cells[:, 1] - reach, table[cells[:, 0], cells[:, 1]]
 
 
 def sx(dem_ds, azimuth, radius, height=10.0, azimuth_arc=10.0, azimuth_steps=15, radius_min=0.0):
@@ -281,21 +303,10 @@ def sx(dem_ds, azimuth, radius, height=10.0, azimuth_arc=10.0, azimuth_steps=15,
     instrument height added to the target pixel."""
     if not hlp._looks_like_dataset(dem_ds):
         raise TypeError("Argument 'dem_ds' must be a xr.Dataset.")
-    if azimuth_arc == 0:
-        azimuth_steps = 1
-    azimuths = np.linspace(azimuth - azimuth_arc / 2, azimuth + azimuth_arc / 2, azimuth_steps)
-
-    _, res_meters = hlp.scale_to_pixel(radius, dem_ds)
-    dx = res_meters["x"].mean()
-    dy = res_meters["y"].mean()
-
-    window_distance = _sx_distance(radius, dx, dy)
-    window_distance[window_distance < radius_min] = np.nan
-
-    window_center = np.floor(np.array(window_distance.shape) / 2)
-    source = (window_center + _sx_source_idx_delta(azimuths, radius, dx, dy)).astype(int)
-    lines_indices = _sx_bresenhamlines(source, window_center)
-    return _sx_rolling(hlp.get_da(dem_ds).values, window_distance, lines_indices, height)
+    spacing = hlp.scale_to_pixel(radius, dem_ds)[1]
+    sector = _sx_sector(azimuth, radius, spacing["x"].mean(), spacing["y"].mean(), azimuth_arc, azimuth_steps,
+                        radius_min)
+    return _sx_scan(hlp.get_da(dem_ds).values, *sector, height)
 
 
 def sx_multi(dem_ds, azimuths, radius, height=10.0, azimuth_arc=10.0, azimuth_steps=15, radius_min=0.0):
