@@ -10,6 +10,13 @@ N contiguous row blocks - the total work is fixed (strong scaling) - and every s
 refreshes the 33 ghost rows from the neighbours over RCCL, overlapped with the interior rows.
 Inputs are generated on the device and are resident in HBM before the timed region.
 
+With N > 1 the line also carries `descriptors`: STD and TPI+STD at 67 px, the gradient at sigma 3.25 and 30.25 and Sx
+(azimuth 0, radius 500 m) through the sharded entry points (topo_amd_shard_*), each with its own ghost-row exchange
+per step - BASELINE.json's "per descriptor" metric for configs[4].  TOPO_AMD_HALO_LOOPBACK=1 with one rank
+(`python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`) runs the same sharded steps on ONE GPU
+as the middle shard of three whose neighbours are itself: the exchange is real (ncclSend / ncclRecv on the
+communication stream), the scaling is not.
+
 Rank 0 prints ONE JSON line.  `roofline` prices the TPI kernel at SURVEY.md 8(d)'s 8 B/pixel
 (4 read + 4 written) against 8 TB/s (and, as `frac_read_only_basis`, at north_star's literal
 "HBM-read" 4 B/pixel); `cpu_baseline` times the oracle's scipy restatement of the reference path
@@ -271,6 +278,48 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     return out
 
 
+SHARD_KEYS = ("tpi_s67", "std_s67", "tpi_std_s67", "gradient_sigma3.25", "gradient_sigma30.25", "sx_az0_r500")
+SHARD_BYTES = {"tpi_s67": 8, "std_s67": 8, "tpi_std_s67": 12, "gradient_sigma3.25": 20, "gradient_sigma30.25": 20,
+               "sx_az0_r500": 8}
+
+
+def sharded_steps(sd, d, rows_local, nx):
+    """One collective step per descriptor of BASELINE configs[4] on this rank's shard: {key: (callable, outputs)}.
+    Every call refreshes the descriptor's own ghost rows over RCCL (overlapped with the interior rows) and then
+    computes the seam strips."""
+    outs = [d.DeviceArray(rows_local, nx) for _ in range(4)]
+    window, dj, di, dist = d.sx_offsets(0.0, 500.0, 30.0, -30.0)
+    return outs, {
+        "tpi_s67": lambda: sd.tpi_std(67, tpi=outs[0]),
+        "std_s67": lambda: sd.tpi_std(67, std=outs[1]),
+        "tpi_std_s67": lambda: sd.tpi_std(67, tpi=outs[0], std=outs[1]),
+        "gradient_sigma3.25": lambda: sd.gradient(3.25, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2],
+                                                  aspect=outs[3]),
+        "gradient_sigma30.25": lambda: sd.gradient(30.25, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2],
+                                                   aspect=outs[3]),
+        "sx_az0_r500": lambda: sd.sx(dj, di, dist, window, 10.0, outs[0]),
+    }
+
+
+def sharded_descriptors(rdv, steps, time_launches, px_total, world, reps=10):
+    """Per-descriptor table of the row-sharded run: every rank times its own launches with HIP events, the slowest
+    rank's median counts (a step is over when the last shard is), and the rate is the whole DEM over that time.
+    Collective: every rank calls it with the same keys in the same order."""
+    out = {}
+    for key in SHARD_KEYS:
+        st = stats(time_launches(steps[key], reps, 2))
+        ms = rdv.max(st["median"])
+        ms_min, ms_max = -rdv.max(-st["min"]), rdv.max(st["max"])
+        bpp = SHARD_BYTES[key]
+        out[key] = {"ms": round(ms, 4), "ms_min": round(ms_min, 4), "ms_max": round(ms_max, 4), "launches": st["n"],
+                    "Mpixels_per_s": round(px_total / ms / 1e3, 1),
+                    # fraction of the aggregate roofline of the GPUs that took part
+                    "hbm_frac": round(px_total * bpp / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                    "entry_point": "topo_amd_shard_" + ("tpi_std" if "s67" in key else
+                                                         "gradient" if key.startswith("gradient") else "sx")}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -297,28 +346,41 @@ def main():
     up, down = ctypes.c_int32(), ctypes.c_int32()
     _lib.check(lib.topo_amd_halo_rows(_lib.DESC_TPI, float(size), 0.0, ctypes.byref(up),
                                       ctypes.byref(down)), "halo_rows")
-    halo_up, halo_dn = (up.value, down.value) if world > 1 else (0, 0)
-    if world > 1:
-        uid = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
-        if rank == 0:
-            _lib.check(lib.topo_amd_comm_unique_id(uid), "comm_unique_id")
-        payload = rdv.bcast_bytes(uid.raw)
-        _lib.check(lib.topo_amd_comm_init(rank, world, payload), "comm_init")
+    loopback = world == 1 and os.environ.get("TOPO_AMD_HALO_LOOPBACK") == "1"
+    sharded = world > 1 or loopback
+    sd = None
+    if sharded:
+        from topo_descriptors_amd import shard as shard_mod
 
-    block = d.DeviceArray(halo_up + rows_local + halo_dn, nx)
-    d.synth_dem(rows_local, nx, row0=row0, seed=0, out=block, out_row=halo_up)
+        shard_mod.ShardedDEM.init_comm(rank, world, rdv.bcast_bytes)
+        # one buffer for every descriptor of the table: ghost zones as deep as the deepest asks for (the gradient
+        # at sigma 30.25: 122 rows); each call uses the rows next to the owned ones (topo_amd_shard_layout)
+        deep = max(max(shard_mod.halo_rows(_lib.DESC_TPI, size)),
+                   0 if args.no_extras else max(shard_mod.halo_rows(_lib.DESC_GRADIENT, 30.25, 1.0)))
+        if loopback:  # the middle shard of three; its neighbours are itself
+            plan = shard_mod.RowShardPlan(3 * ny, nx, 3, 1, deep, deep)
+        else:
+            plan = shard_mod.RowShardPlan(ny, nx, world, rank, deep, deep)
+        assert loopback or (plan.row0, plan.rows_local) == (row0, rows_local)
+        sd = shard_mod.ShardedDEM(plan)
+        block = sd.block
+        halo_up, halo_dn = up.value, down.value
+        first_row = plan.halo_above
+    else:
+        halo_up = halo_dn = first_row = 0
+        block = d.DeviceArray(rows_local, nx)
+    d.synth_dem(rows_local, nx, row0=row0, seed=0, out=block, out_row=first_row)
     out = d.DeviceArray(rows_local, nx)
     d.sync()
 
-    if world == 1:
+    if not sharded:
         blk = d.Block(block)
 
         def step():
             blk.tpi_std(size, tpi=out)
     else:
         def step():
-            _lib.check(lib.topo_amd_shard_tpi_std(block.ptr, rows_local, row0, ny, nx, size, out.ptr,
-                                                  None), "shard_tpi_std")
+            sd.tpi_std(size, tpi=out)
 
     # bring the clocks up: untimed launches until three consecutive ones agree within 1.5 % (at most 40).
     # Every rank runs the same number (the count is agreed on through the max over ranks).
@@ -374,6 +436,11 @@ def main():
             "clock_ramp_steps": ramp,
             "higher_is_better": True,
             "scaling": "strong",
+            "exchange": ("none (one block)" if not sharded else
+                         "loop-back: ncclSend / ncclRecv of the ghost rows to this same GPU (both ends of every link "
+                         "are one device: the exchange is exercised, not a scaling number)" if loopback else
+                         "ncclSend / ncclRecv of the ghost rows to the neighbour ranks over RCCL, overlapped with "
+                         "the interior rows"),
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -395,7 +462,7 @@ def main():
                 "frac_at_median": round(px_launch * BYTES_PER_PIXEL["tpi"] / (kernel_ms_median * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 # north_star's literal "HBM-read roofline": the 4 B/pixel the kernel has to read, nothing else
                 "frac_read_only_basis": round(px_launch * 4 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                **measured_traffic(ny, nx, size, world),
+                **measured_traffic(ny, nx, size, 0 if loopback else world),
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
                 "algorithmic_bytes_per_launch": px_launch * BYTES_PER_PIXEL["tpi"],
                 "kernel": "tpi_march_kernel<67, 60, 12, true, true, true> (exact one-pass TPI on whole-metre tiles, marching down "
@@ -411,10 +478,10 @@ def main():
                 "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL["tpi"],
             },
         }
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and not sharded:
             rows_s = min(ny, 16384)  # ~4 s of scipy on one core + ~6 s of the C twin on all of them
             cols_s = min(nx, 16384)
-            sample = block.to_host(halo_up, rows_s)[:, :cols_s].copy()
+            sample = block.to_host(first_row, rows_s)[:, :cols_s].copy()
             result["cpu_baseline"] = cpu_baseline(size, rows_s, cols_s, sample)
             result["cpu_baseline_all_cores"] = cpu_twin_baseline(size, sample)
             # spot parity at full size: TPI of the same window vs the oracle, interior only
@@ -428,11 +495,23 @@ def main():
                                                       want[: rows_s - r, : cols_s - r]))),
                 "window": [rows_s - r, cols_s - r],
             }
-        if not args.no_extras and world == 1:
+        if not args.no_extras and not sharded:
             result["descriptors"] = extras(d, _lib, args, d.Block, block, ny, nx)
+    if not args.no_extras and sharded:  # collective: every rank takes part, rank 0 reports
+        outs, steps_by_key = sharded_steps(sd, d, rows_local, nx)
+        table = sharded_descriptors(rdv, steps_by_key, d.time_launches, px_total, world)
+        d.sync()
+        for a in outs:
+            a.free()
+        if rank == 0:
+            result["descriptors"] = table
+            result["descriptors_note"] = (
+                "row-sharded entry points (topo_amd_shard_*), one ghost-row exchange per step and descriptor; ms = "
+                "median of 10 launches on the slowest rank; Mpixels_per_s = the whole DEM over that time; hbm_frac "
+                "against n_gpus x 8 TB/s")
     out.free()
     block.free()
-    if world > 1:
+    if sharded:
         _lib.check(lib.topo_amd_comm_destroy(), "comm_destroy")
     rdv.close()
     if rank == 0:

@@ -98,8 +98,9 @@ int topo_amd_disc_tap_count(int size);
 /* Writes the size x size 0/1 mask (row-major float32).                                 */
 int topo_amd_disc_mask(int size, float* mask);
 /* Ghost rows a row block needs above / below its output rows for one descriptor.
- * p0: size (TPI/STD) | sigma_axis0 (GAUSS/GRADIENT: max of the two axis-0 sigmas)
- * p1: pre-smoothing sigma (TPI/STD, 0 = none) | unused
+ * p0: size (TPI/STD) | sigma (GAUSS: of axis 0; GRADIENT: the `sigma` argument of the gradient)
+ * p1: pre-smoothing sigma (TPI/STD, 0 = none) | sig_ratio (GRADIENT; 0 or 1 = isotropic) | unused
+ * GRADIENT answers exactly the depth topo_amd_shard_gradient(sigma, sig_ratio) lays its block out with.
  * For SX pass the extremes of the offset table instead: p0 = -min(dj), p1 = max(dj).
  * For Gaussian radii int(4 sigma + 0.5) of 4 ... 15 (gradient: 8 ... 15; also the pre-smoothing of TPI / STD) the
  * answer is 16 rows (gradient: 17) rather than the radius: the matrix-core kernels used there take a per-tile
@@ -236,8 +237,11 @@ int topo_amd_halo_wait(void);
  * the ones next to the owned rows; one that needs more is refused (TOPO_AMD_EINVAL) instead of
  * reading the owned rows from the wrong offset and receiving past the end of the buffer.
  * -1 / -1 (the default): the buffer has exactly the depth topo_amd_halo_rows gives for the
- * descriptor of each call.                                                                 */
+ * descriptor of each call.  The declaration belongs to the CALLING THREAD (thread-local), so
+ * concurrent drivers of differently laid-out shards do not disturb each other;
+ * topo_amd_shard_layout_get reads it back (to save and restore around a call).              */
 int topo_amd_shard_layout(int halo_above, int halo_below);
+int topo_amd_shard_layout_get(int* halo_above, int* halo_below);
 
 /* Sharded TPI/STD step: ghost exchange overlapped with the interior rows, then the two
  * seam strips.  `block` as above with halo_above == halo_below == topo_amd_halo_rows(TPI).

@@ -95,3 +95,198 @@ def test_a_plan_too_shallow_for_the_descriptor_is_refused(loopback_comm):
     d.sync()
     t.free()
     sd.block.free()
+
+
+# ---- every topo_amd_shard_* entry point under the live exchange (task 1) ---------------------------
+def _middle_shard(local, up, down, extra=(0, 0)):
+    """ShardedDEM of the middle third of `local` stacked three times, ghost rows poisoned (0xFF = NaN bit pattern)
+    so that a row the exchange fails to deliver shows up in the outputs."""
+    rows, nx = local.shape
+    plan = shard.RowShardPlan(3 * rows, nx, 3, 1, up + extra[0], down + extra[1])
+    sd = shard.ShardedDEM(plan)
+    _lib.check(_lib.lib().topo_amd_memset(sd.block.ptr, 0xFF, sd.block.nbytes), "memset")
+    sd.block.upload_rows(local, plan.halo_above)
+    return sd
+
+
+def _poison_ghosts(sd):
+    p = sd.plan
+    lib = _lib.lib()
+    if p.halo_above:
+        _lib.check(lib.topo_amd_memset(sd.block.ptr, 0xFF, p.halo_above * p.nx * 4), "memset")
+    if p.halo_below:
+        _lib.check(lib.topo_amd_memset(sd.block.row_ptr(p.halo_above + p.rows_local), 0xFF, p.halo_below * p.nx * 4),
+                   "memset")
+
+
+# sigma 0.75: Sobel, 1 ghost row.  2.25 / 3.25: matrix-core route below radius 16, 17 ghost rows (ADVICE r02, high:
+# the shard used to be laid out with R + 1).  1.5: vector-ALU route (radius 6).  7.0: matrix cores, radius 28.
+# (3.25, 2.0): anisotropic, two smooths.  30.25 on 8800 local rows: row chunks + the epilogue on the second stream
+# inside run_overlapped.
+@pytest.mark.parametrize("sigma,ratio,rows,nx", [(0.75, 1.0, 256, 512), (1.5, 1.0, 256, 512), (2.25, 1.0, 300, 512),
+                                                 (3.25, 1.0, 300, 512), (3.25, 1.0, 263, 516), (7.0, 1.0, 300, 512),
+                                                 (3.25, 2.0, 300, 512), (30.25, 1.0, 8800, 512)])
+def test_shard_gradient_under_the_live_exchange(loopback_comm, sigma, ratio, rows, nx):
+    local = orc.synthetic_dem(rows, nx, seed=17)
+    stacked = np.concatenate([local, local, local], axis=0)
+    up, down = shard.halo_rows(_lib.DESC_GRADIENT, sigma, ratio)
+    x = 2600000.0 + 30.0 * np.arange(nx)
+    y = 1200000.0 - 30.0 * np.arange(3 * rows)
+    res = orc.grid_resolution(x, y)
+    sd = _middle_shard(local, up, down, extra=(3, 0) if rows < 1000 else (0, 0))
+    outs = [d.DeviceArray(rows, nx) for _ in range(4)]
+    for _ in range(2):
+        _poison_ghosts(sd)
+        sd.gradient(sigma, res["x"], res["y"], sig_ratio=ratio, dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3])
+    d.sync()
+    whole = d.DeviceArray.from_host(stacked)
+    want = [d.DeviceArray(rows, nx) for _ in range(4)]
+    d.Block(whole).gradient(sigma, res["x"], res["y"], sig_ratio=ratio, dx=want[0], dy=want[1], slope=want[2],
+                            aspect=want[3], out_row0=rows, out_rows=rows)
+    d.sync()
+    for k, name in enumerate(("dx", "dy", "slope", "aspect")):
+        assert np.array_equal(outs[k].to_host(), want[k].to_host()), (sigma, ratio, name)
+    for a in outs + want + [whole, sd.block]:
+        a.free()
+
+
+def test_c_caller_with_the_default_layout_gets_the_same_gradient(loopback_comm):
+    """A C caller that lays its block out with exactly topo_amd_halo_rows(GRADIENT) ghost rows and never calls
+    topo_amd_shard_layout."""
+    lib = loopback_comm
+    rows, nx, sigma = 288, 512, 3.25
+    local = orc.synthetic_dem(rows, nx, seed=23)
+    stacked = np.concatenate([local, local, local], axis=0)
+    up, down = shard.halo_rows(_lib.DESC_GRADIENT, sigma, 1.0)
+    assert (up, down) == (17, 17)
+    buf = d.DeviceArray(up + rows + down, nx)
+    _lib.check(lib.topo_amd_memset(buf.ptr, 0xFF, buf.nbytes), "memset")
+    buf.upload_rows(local, up)
+    rx, ry = np.array([30.0]), np.array([-30.0])
+    outs = [d.DeviceArray(rows, nx) for _ in range(4)]
+    _lib.check(lib.topo_amd_shard_gradient(buf.ptr, rows, rows, 3 * rows, nx, sigma, 1.0, _lib.RES_SCALAR, _lib.ptr(rx),
+                                           _lib.ptr(ry), *[o.ptr for o in outs]), "shard_gradient")
+    d.sync()
+    whole = d.DeviceArray.from_host(stacked)
+    want = [d.DeviceArray(rows, nx) for _ in range(4)]
+    d.Block(whole).gradient(sigma, rx, ry, dx=want[0], dy=want[1], slope=want[2], aspect=want[3], out_row0=rows,
+                            out_rows=rows)
+    d.sync()
+    for k in range(4):
+        assert np.array_equal(outs[k].to_host(), want[k].to_host()), k
+    for a in outs + want + [whole, buf]:
+        a.free()
+
+
+@pytest.mark.parametrize("azimuth", [0.0, 180.0, 135.0, 275.0])
+def test_shard_sx_under_the_live_exchange(loopback_comm, azimuth):
+    """One-sided ghost zones: at azimuth 0 on a north-up grid only the north neighbour sends."""
+    rows, nx = 320, 512
+    local = orc.synthetic_dem(rows, nx, seed=29)
+    stacked = np.concatenate([local, local, local], axis=0)
+    window, dj, di, dist = d.sx_offsets(azimuth, 500.0, 30.0, -30.0)
+    up, down = shard.halo_rows(_lib.DESC_SX, max(0, -dj.min()), max(0, dj.max()))
+    if azimuth == 0.0:
+        assert up > 0 and down == 0
+    if azimuth == 180.0:
+        assert up == 0 and down > 0
+    sd = _middle_shard(local, up, down)
+    out = d.DeviceArray(rows, nx)
+    for _ in range(2):
+        _poison_ghosts(sd)
+        sd.sx(dj, di, dist, window, 10.0, out)
+    d.sync()
+    whole = d.DeviceArray.from_host(stacked)
+    want = d.DeviceArray(rows, nx)
+    d.Block(whole).sx(dj, di, dist, window, 10.0, want, out_row0=rows, out_rows=rows)
+    d.sync()
+    got, ref = out.to_host(), want.to_host()
+    assert np.array_equal(got, ref), azimuth
+    assert np.isfinite(got).all()
+    for a in (out, want, whole, sd.block):
+        a.free()
+
+
+def test_shard_sx_multi_north_and_south_rays_in_one_exchange(loopback_comm):
+    rows, nx = 320, 512
+    local = orc.synthetic_dem(rows, nx, seed=31)
+    stacked = np.concatenate([local, local, local], axis=0)
+    sectors = [d.sx_offsets(a, 400.0, 30.0, -30.0) for a in (350.0, 0.0, 10.0, 170.0, 180.0, 190.0, 90.0)]
+    up, down = shard.sx_multi_halo(sectors)
+    assert up > 0 and down > 0
+    sd = _middle_shard(local, up, down)
+    outs = [d.DeviceArray(rows, nx) for _ in sectors]
+    for _ in range(2):
+        _poison_ghosts(sd)
+        sd.sx_multi(sectors, 10.0, outs)
+    d.sync()
+    whole = d.DeviceArray.from_host(stacked)
+    blk = d.Block(whole)
+    for sec, o in zip(sectors, outs):
+        want = d.DeviceArray(rows, nx)
+        blk.sx(sec[1], sec[2], sec[3], sec[0], 10.0, want, out_row0=rows, out_rows=rows)
+        d.sync()
+        assert np.array_equal(o.to_host(), want.to_host())
+        want.free()
+        o.free()
+    whole.free()
+    sd.block.free()
+
+
+@pytest.mark.parametrize("route", ["direct", "fft"])
+def test_shard_valley_ridge_under_the_live_exchange(loopback_comm, route, monkeypatch):
+    """The moments of the middle third are those of the stack (the same samples three times; whole metres: exact),
+    so the standardisation agrees and the direct kernel must give the single block's bits."""
+    from topo_descriptors_amd import topo
+    monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "1" if route == "fft" else "100000")
+    rows, nx = 160, 256
+    local = orc.synthetic_dem(rows, nx, seed=37)
+    stacked = np.concatenate([local, local, local], axis=0)
+    size, flats = 7, [0, 0.15, 0.3]
+    angles_in = np.arange(0, 180, 9, dtype=np.float32)
+    taps, ksize, angles = topo._valley_ridge_tables(topo._valley_kernels(size, flats), angles_in)
+    up, down = shard.halo_rows(_lib.DESC_VALLEY_RIDGE, int(ksize.max()))
+    sd = _middle_shard(local, up, down)
+    n, a = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+    for _ in range(2):
+        _poison_ghosts(sd)
+        sd.valley_ridge(taps, ksize, angles, len(flats), n, a)
+    d.sync()
+    whole = d.DeviceArray.from_host(stacked)
+    mean, stdev = d.mean_std(whole)
+    n2, a2 = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+    d.Block(whole).valley_ridge(taps, ksize, angles, len(flats), mean, stdev, n2, a2, out_row0=rows, out_rows=rows)
+    d.sync()
+    norm, direction = n.to_host(), a.to_host()
+    assert np.isfinite(norm).all()
+    if route == "direct":
+        assert np.array_equal(norm, n2.to_host()) and np.array_equal(direction, a2.to_host())
+    else:
+        scale = float(np.max(np.abs(n2.to_host())))
+        assert np.max(np.abs(norm - n2.to_host())) <= 1e-5 * scale
+        assert np.mean(direction == a2.to_host()) >= 0.995
+    for x in (n, a, n2, a2, whole, sd.block):
+        x.free()
+
+
+def test_shard_tpi_std_fractional_dem_under_the_live_exchange(loopback_comm):
+    """Fractional elevations take other kernels (fraction march / general kernel) than whole metres: the seam
+    strips must agree with the single block there too."""
+    rows, nx, size = 384, 768, 33
+    local = orc.synthetic_dem(rows, nx, seed=41, integer=False)
+    stacked = np.concatenate([local, local, local], axis=0)
+    up, down = shard.halo_rows(_lib.DESC_TPI, size)
+    sd = _middle_shard(local, up, down)
+    t, s = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+    for _ in range(2):
+        _poison_ghosts(sd)
+        sd.tpi_std(size, tpi=t, std=s)
+    d.sync()
+    whole = d.DeviceArray.from_host(stacked)
+    wt, ws = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+    d.Block(whole).tpi_std(size, tpi=wt, std=ws, out_row0=rows, out_rows=rows)
+    d.sync()
+    assert np.array_equal(t.to_host(), wt.to_host())
+    assert np.array_equal(s.to_host(), ws.to_host())
+    for a in (t, s, wt, ws, whole, sd.block):
+        a.free()

@@ -131,7 +131,8 @@ def test_halo_rows_contract():
              (_lib.DESC_STD, 7, 0.75, 3 + 3, 3 + 3), (_lib.DESC_STD, 7, 5.0, 3 + 20, 3 + 20),
              (_lib.DESC_GAUSS, 30.25, 0, 121, 121), (_lib.DESC_GAUSS, 3.25, 0, 16, 16), (_lib.DESC_GAUSS, 0.75, 0, 3, 3),
              (_lib.DESC_GRADIENT, 30.25, 0, 122, 122), (_lib.DESC_GRADIENT, 3.25, 0, 17, 17),
-             (_lib.DESC_GRADIENT, 1.5, 0, 7, 7),
+             (_lib.DESC_GRADIENT, 1.5, 0, 7, 7), (_lib.DESC_GRADIENT, 3.25, 1.0, 17, 17),
+             (_lib.DESC_GRADIENT, 3.25, 2.0, 27, 27), (_lib.DESC_GRADIENT, 2.25, 0.5, 10, 10),
              (_lib.DESC_GRADIENT, 0.75, 0, 1, 1), (_lib.DESC_SOBEL, 0, 0, 1, 1),
              (_lib.DESC_SX, 17, 0, 17, 0)]
     for desc, p0, p1, a, b in cases:

@@ -198,6 +198,24 @@ def _rendezvous_worker(rank, world, port, fail):
         assert payload == bytes(range(128))       # the ncclUniqueId travels like this
         rdv.barrier()
         assert rdv.max(float(rank)) == float(world - 1)
+        # the per-descriptor table of the sharded run (BASELINE configs[4]): a collective over the same control
+        # plane; the slowest rank's median counts.  Stand-ins for the GPU steps and their HIP-event timer.
+        calls = []
+        steps = {k: (lambda k=k: calls.append(k)) for k in bench.SHARD_KEYS}
+
+        def fake_timer(fn, reps, warm):
+            for _ in range(reps + warm):
+                fn()
+            return [1.0 + rank + 0.01 * i for i in range(reps)]
+
+        table = bench.sharded_descriptors(rdv, steps, fake_timer, 32768 * 32768, world, reps=4)
+        assert tuple(table) == bench.SHARD_KEYS and calls == [k for k in bench.SHARD_KEYS for _ in range(6)]
+        for key, row in table.items():
+            assert abs(row["ms"] - (world + 0.015)) < 1e-9, row        # median of the slowest rank
+            assert row["ms_min"] == 1.0 and abs(row["ms_max"] - (world + 0.03)) < 1e-9
+            assert row["Mpixels_per_s"] == round(32768 * 32768 / row["ms"] / 1e3, 1)
+            assert row["entry_point"].startswith("topo_amd_shard_")
+            assert 0 < row["hbm_frac"] < 1
         rdv.close()
     except Exception as exc:  # noqa: BLE001
         fail.put(f"rank {rank}: {type(exc).__name__}: {exc}")

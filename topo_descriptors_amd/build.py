@@ -39,8 +39,24 @@ def build_library(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
 
+    def deps(path, seen):
+        """`path` and every quoted include it reaches (csrc/ and include/)."""
+        if path in seen or not os.path.exists(path):
+            return seen
+        seen.add(path)
+        with open(path) as fh:
+            for line in fh:
+                line = line.strip()
+                if line.startswith("#include \""):
+                    name = line.split("\"")[1]
+                    for base in (os.path.dirname(path), CSRC, os.path.join(os.path.dirname(HERE), "include")):
+                        deps(os.path.join(base, name), seen)
+        return seen
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
+        if not force and _newer(obj, sorted(deps(src, set())) + [__file__]):
+            return obj  # object newer than its source and every header it includes
         cmd = [cc, f"--offload-arch={ARCH}", *FLAGS, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

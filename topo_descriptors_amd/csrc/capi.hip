@@ -121,8 +121,10 @@ struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, size = 1;
     bool halo_pending = false;
-    int layout_above = -1, layout_below = -1;  // declared ghost depth of the shard buffers (topo_amd_shard_layout)
 } g_comm;
+// declared ghost depth of the shard buffers (topo_amd_shard_layout): per calling thread, so that two threads (or an
+// application and a ShardedDEM inside it) that drive shards with different buffer layouts do not see each other's
+thread_local int t_layout_above = -1, t_layout_below = -1;
 
 // TOPO_AMD_HALO_LOOPBACK=1 with a communicator of one rank: the exchange talks to itself
 bool halo_loopback() {
@@ -167,10 +169,24 @@ int tpi_std_block(const Block& b, int size, double sigma, float* tpi_out, float*
     return launch_tpi_std(d, disc, tpi_out, std_out);
 }
 
+// ghost rows the gradient cannot do without: the filter radius plus the row of the central difference
 int gradient_halo(double sigma, double sig_ratio) {
     if (sigma <= 1.0) return 1;
     const double s_max = sig_ratio == 1.0 ? sigma : std::max(sigma, sigma * sig_ratio);
     return gaussian_radius(s_max) + 1;
+}
+
+// ghost rows a row SHARD of the gradient is laid out with and exchanges: what topo_amd_halo_rows(GRADIENT)
+// answers and what topo_amd_shard_gradient uses (one function, so the two cannot drift apart).  Radii
+// mfma_min_radius(true) .. 15 of the isotropic smooth ask for 17 rows: the matrix-core kernels take their
+// accumulation offsets 16 rows into a 32-row tile (gauss.hip, mfma_rows_ok), and with R + 1 rows the interior and
+// the seam strips of a shard would mix matrix-core and vector-ALU kernels depending on row0 % 32.
+int gradient_shard_halo(double sigma, double sig_ratio) {
+    if (sigma <= 1.0) return 1;
+    if (sig_ratio == 0.0) sig_ratio = 1.0;
+    if (sig_ratio != 1.0) return gradient_halo(sigma, sig_ratio);
+    const int R = gaussian_radius(sigma);
+    return (R >= mfma_min_radius(true) && R < 16) ? 17 : R + 1;
 }
 
 // RAII-less helper for the host-buffer entry points
@@ -282,6 +298,12 @@ int topo_amd_init(int device) {
     return TOPO_AMD_OK;
 }
 
+// Per-launch timing without a host synchronise per launch: numbered HIP events on the compute stream.
+namespace {
+constexpr int kMarks = 512;
+hipEvent_t g_marks[kMarks] = {};
+}  // namespace
+
 int topo_amd_shutdown(void) {
     Context& c = ctx();
     if (!c.ready) return TOPO_AMD_OK;
@@ -298,6 +320,10 @@ int topo_amd_shutdown(void) {
         if (g_slots[i].pinned) (void)hipHostFree(g_slots[i].pinned);
         if (g_slots[i].copied) (void)hipEventDestroy(g_slots[i].copied);
         g_slots[i] = TableSlot();
+    }
+    for (auto& e : g_marks) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
     }
     (void)hipEventDestroy(c.halo_done);
     (void)hipEventDestroy(c.input_ready);
@@ -396,11 +422,6 @@ int topo_amd_timer_stop(float* elapsed_ms) {
     return TOPO_AMD_OK;
 }
 
-// Per-launch timing without a host synchronise per launch: numbered HIP events on the compute stream.
-namespace {
-constexpr int kMarks = 512;
-hipEvent_t g_marks[kMarks] = {};
-}  // namespace
 
 int topo_amd_mark(int index) {
     TOPO_TRY(require_ready());
@@ -467,11 +488,9 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
             *above = *below = (R >= mfma_min_radius(false) && R < 16) ? 16 : R;
             return TOPO_AMD_OK;
         }
-        case TOPO_AMD_DESC_GRADIENT: {
-            const int R = gaussian_radius(p0);
-            *above = *below = p0 <= 1.0 ? 1 : ((R >= mfma_min_radius(true) && R < 16) ? 17 : R + 1);
+        case TOPO_AMD_DESC_GRADIENT:
+            *above = *below = gradient_shard_halo(p0, p1);
             return TOPO_AMD_OK;
-        }
         case TOPO_AMD_DESC_SOBEL:
             *above = *below = 1;
             return TOPO_AMD_OK;
@@ -909,8 +928,15 @@ int topo_amd_shard_layout(int halo_above, int halo_below) {
     TOPO_REQUIRE((halo_above >= 0 && halo_below >= 0) || (halo_above == -1 && halo_below == -1),
                  "shard_layout: ghost depths %d / %d (both >= 0, or -1 / -1 for 'as the descriptor needs')", halo_above,
                  halo_below);
-    g_comm.layout_above = halo_above;
-    g_comm.layout_below = halo_below;
+    t_layout_above = halo_above;
+    t_layout_below = halo_below;
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_shard_layout_get(int* halo_above, int* halo_below) {
+    TOPO_REQUIRE(halo_above && halo_below, "shard_layout_get: NULL output");
+    *halo_above = t_layout_above;
+    *halo_below = t_layout_below;
     return TOPO_AMD_OK;
 }
 
@@ -941,14 +967,14 @@ struct Shard {
 // starts.
 int shard_view(float** block, int above, int below, const char* who) {
     TOPO_REQUIRE(*block != nullptr, "%s: NULL block", who);
-    if (g_comm.layout_above < 0) return TOPO_AMD_OK;
-    TOPO_REQUIRE(above <= g_comm.layout_above && below <= g_comm.layout_below,
+    if (t_layout_above < 0) return TOPO_AMD_OK;
+    TOPO_REQUIRE(above <= t_layout_above && below <= t_layout_below,
                  "%s needs %d / %d ghost rows but the shard buffers were declared with %d / %d (topo_amd_shard_layout)",
-                 who, above, below, g_comm.layout_above, g_comm.layout_below);
+                 who, above, below, t_layout_above, t_layout_below);
     return TOPO_AMD_OK;
 }
 size_t shard_view_offset(int above, int nx) {
-    return g_comm.layout_above < 0 ? 0 : (size_t)(g_comm.layout_above - above) * nx;
+    return t_layout_above < 0 ? 0 : (size_t)(t_layout_above - above) * nx;
 }
 
 Shard make_shard(float* block, int rows_local, int row0, int gny, int nx, int above, int below) {
@@ -1021,7 +1047,7 @@ int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int
                             double sig_ratio, int res_mode, const void* res_x, const void* res_y,
                             float* dx_out, float* dy_out, float* slope_out, float* aspect_out) {
     TOPO_TRY(require_ready());
-    const int h = gradient_halo(sigma, sig_ratio);
+    const int h = gradient_shard_halo(sigma, sig_ratio);  // == topo_amd_halo_rows(GRADIENT, sigma, sig_ratio)
     TOPO_TRY(shard_view(&block, h, h, "shard_gradient"));
     block += shard_view_offset(h, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, h, h);

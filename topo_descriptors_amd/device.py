@@ -84,6 +84,8 @@ def mark_elapsed(a, b):
 def time_launches(fn, reps, warm=1):
     """Per-launch HIP-event durations (ms) of ``reps`` back-to-back calls of ``fn`` (<= 511), after
     ``warm`` untimed ones: one event between consecutive launches, no host synchronise inside."""
+    if not 1 <= reps <= 511:
+        raise ValueError(f"time_launches: reps = {reps} outside 1 .. 511 (the library keeps 512 numbered events)")
     for _ in range(warm):
         fn()
     sync()

@@ -136,13 +136,19 @@ class ShardedDEM:
         (``topo_amd_shard_layout``): a descriptor that needs fewer ghost rows than the plan reserves uses the
         ones next to the owned rows, one that needs more is refused instead of reading the owned rows from the
         wrong offset and receiving past the end of the buffer."""
+        import ctypes as C
+
         from . import _lib
         lib = _lib.lib()
+        # the declaration is per thread in the library; whatever this thread had declared before (the application
+        # may drive shards of its own through the C ABI) is put back afterwards
+        was_up, was_down = C.c_int32(), C.c_int32()
+        _lib.check(lib.topo_amd_shard_layout_get(C.byref(was_up), C.byref(was_down)), "shard_layout_get")
         _lib.check(lib.topo_amd_shard_layout(self.plan.halo_above, self.plan.halo_below), "shard_layout")
         try:
             _lib.check(getattr(lib, name)(*args), name)
         finally:
-            lib.topo_amd_shard_layout(-1, -1)
+            lib.topo_amd_shard_layout(was_up.value, was_down.value)
 
     @staticmethod
     def init_comm(rank, nranks, broadcast_bytes):
