@@ -117,7 +117,9 @@ __device__ __forceinline__ int ring_dword_of_column(int c) {
 // DEM row above its window), wave-uniform; acc[t]: sum over the disc for the lane's own column NCR lane + t,
 // valid for DL <= lane < 64 - DL; ctr[t]: the staged value of the pixel itself.  The prefix rows of run
 // i + LEAD are fetched before the column sums of run i are formed.
-template <int SIZE, int NCR, int R, int LEAD, int PITCH = 64 * NCR>
+// P0 / P1 (CHAIN_PRIO, disc_wave_impl.hpp): issue priority of the wave for the first and the second half of the
+// chain's steps (-1: leave it alone), so that the waves sharing a SIMD advance together instead of one after the other.
+template <int SIZE, int NCR, int R, int LEAD, int PITCH = 64 * NCR, int P0 = -1, int P1 = -1>
 __device__ __forceinline__ void ring_disc_sum(const uint32_t* ring, int s0, int lane, uint32_t (&acc)[NCR],
                                               uint32_t (&ctr)[NCR], bool young) {
     using G = RGeo<SIZE, NCR>;
@@ -127,16 +129,23 @@ __device__ __forceinline__ void ring_disc_sum(const uint32_t* ring, int s0, int 
     u32x4 top[NR][G::PARTS], bot[NR][G::PARTS];
     uint32_t cv[NR][NCR];
     uint32_t aR[NCR], aL[NCR];
-    const uint32_t* col = ring + lane * 4;
+    const char* col = reinterpret_cast<const char*>(ring + lane * 4);
+    // The slot of a prefix row is wave-uniform: its byte offset is formed on the scalar unit and reaches the address
+    // with ONE full-rate v_add_u32 (sgpr + lane base); the pieces of a row are immediates.  (Left to the compiler
+    // the slot index went through a v_lshl_add_u32 per read and the lower row of a pair through a further add of
+    // a literal: three half- and full-rate vector instructions per run and chain, 126 per row of std_ring_kernel.)
+    // byte offset of ring slot s0, and the wrap: (b0 + d) mod RB as min(b0 + d, b0 + d - RB) in unsigned arithmetic
+    // (3 scalar instructions per row address)
+    constexpr uint32_t RB = (uint32_t)R * PITCH * 4;
+    const uint32_t b0 = (uint32_t)s0 * (PITCH * 4);
     auto fetch = [&](int i) {
         const int r = G::S.order[i];
-        int st = s0 + G::T.run_hi[r] + 1 + M, sb = s0 + G::T.run_lo[r] + M;
-        st = st >= R ? st - R : st;
-        sb = sb >= R ? sb - R : sb;
+        const uint32_t dt = (uint32_t)(G::T.run_hi[r] + 1 + M) * (PITCH * 4), db = (uint32_t)(G::T.run_lo[r] + M) * (PITCH * 4);
+        const uint32_t ot = min(b0 + dt, b0 + dt - RB), ob = min(b0 + db, b0 + db - RB);
 #pragma unroll
         for (int P = 0; P < G::PARTS; ++P) {
-            top[r][P] = *reinterpret_cast<const u32x4*>(col + st * PITCH + P * 256);
-            bot[r][P] = *reinterpret_cast<const u32x4*>(col + sb * PITCH + P * 256);
+            top[r][P] = *reinterpret_cast<const u32x4*>(col + ot + P * 1024);
+            bot[r][P] = *reinterpret_cast<const u32x4*>(col + ob + P * 1024);
         }
     };
 #pragma unroll
@@ -153,6 +162,7 @@ __device__ __forceinline__ void ring_disc_sum(const uint32_t* ring, int s0, int 
 #ifdef RING_PRIO
         if (D == RING_PRIO_SWITCH_D && young) __builtin_amdgcn_s_setprio(0);
 #endif
+        if (P1 >= 0 && D == DL / 2) CHAIN_SETPRIO(P1);
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             if (G::S.first_step[G::S.order[j]] == D) {
@@ -695,7 +705,9 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                 hi = max(hi, t);
                 const uint32_t u = (uint32_t)(t - ci);
                 run_u += u;
-                run_u2 += u * u;
+                // (24-bit multiply, full rate: a sample that passes the classification has |trunc(x)| <= 2^18 and the
+                // offset follows the data, so |u| < 2^23; what a flagged sample leaves in the ring is never used)
+                run_u2 += (uint32_t)__mul24((int)u, (int)u);
                 q[r] = run_u;
                 q2[r] = run_u2;
             }
@@ -819,15 +831,18 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
             uint32_t nq[B], nq2[B];
             if (!general) {
                 uint32_t su[4], ctr[4], su2[4], dummy[4];
-                ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q, s0, lane, su, ctr, false);
-                ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q + G::W, s0, lane, su2, dummy, false);
+// progress-based issue priority (CHAIN_PRIO, disc_wave_impl.hpp) from 25 px: 67 px 10.19 -> 9.37 ms, 31 px
+                // 5.31 -> 5.03 ms; at 7 px the chains are too short for it (3.10 -> 3.28 ms)
+                constexpr int kP = SIZE >= 25 ? 0 : -4;
+                ring_disc_sum<SIZE, 4, R, 2, PITCH, 3 + kP, 2 + kP>(Q, s0, lane, su, ctr, false);
+                ring_disc_sum<SIZE, 4, R, 2, PITCH, 1 + kP, 0 + kP>(Q + G::W, s0, lane, su2, dummy, false);
                 const int oy = oyS + ph * B + wave;
                 if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
                     const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
                     Vec4<float> out_s, out_t;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        out_s.v[t] = std_from_int_sums((double)(int)su[t], (double)su2[t], n, inv_nn1);
+                        out_s.v[t] = std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1);
                         if (WANT_TPI) {
                             const float x = (float)((int)ctr[t] + ci);
                             const double s1 = (double)((int)su[t] + ci * G::T.taps);  // sum of trunc(x): exact, fits int32

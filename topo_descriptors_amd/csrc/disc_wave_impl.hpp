@@ -83,6 +83,22 @@ __device__ __forceinline__ uint32_t hop(uint32_t x) {
 // itself the scheduler does that in the kernels with registers to spare, and in the ones at the
 // 168-VGPR limit it waits for every pair of reads before issuing the next (21 exposed LDS
 // latencies per row).
+// CHAIN_PRIO (default on; used by the ring kernels, disc_ring_impl.hpp): a wave lowers its own issue priority as it
+// gets through its row.  The hardware serves the oldest wave of a SIMD first, so in a kernel whose waves each take
+// ONE row between two barriers the three waves that share a SIMD finish one after the other and the last one runs
+// alone, with nothing to hide its LDS latencies behind; with the laggard always ahead in priority they advance
+// together (std_ring_kernel<67>: 10.19 -> 9.37 ms, TPI + STD 10.61 -> 9.85 ms on the 32768^2 bench DEM).  The
+// marching kernels, whose waves draw rows from a queue (MARCH_DYN_ROWS), lose with it (4.44 -> 4.76 ms at 67 px):
+// wave_disc_sum leaves the priority alone.
+#ifndef CHAIN_PRIO
+#define CHAIN_PRIO 1
+#endif
+#if CHAIN_PRIO
+#define CHAIN_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define CHAIN_SETPRIO(x)
+#endif
+
 template <int SIZE, typename T, int HALF = 0, bool PIPE = false>
 __device__ __forceinline__ void wave_disc_sum(const T* Q, int jj, int lane, T (&acc)[NC]) {
     using ACC = T;
@@ -191,14 +207,17 @@ __device__ __forceinline__ float std_from_sums(double s1, double s2, double inv_
     return sqrtf((float)var);
 }
 // The same for a pixel whose n taps are all inside the DEM, on a tile of the integer path:
-// n s2 - s1^2 = n Su2 - Su^2 whatever offset c the sums were taken with, and n Su2, Su^2 and their
-// difference are integers below 2^53 (|u| <= 8006 on that path), hence exact in float64.  One
-// rounding (the multiply by 1/(n(n-1))) instead of a cancelling difference, 6 f64 instructions
-// instead of ~15, and identical bits from kernels that used different offsets.
-__device__ __forceinline__ float std_from_int_sums(double su, double su2, double n, double inv_nn1) {
-    double var = (n * su2 - su * su) * inv_nn1;
-    if (var < 0.0) var = 0.0;
-    return sqrtf((float)var);
+// n s2 - s1^2 = n Su2 - Su^2 whatever offset c the sums were taken with, a non-negative integer below 2^62 that
+// 64-bit integer arithmetic forms exactly (one v_mad_u64_u32 and one v_mad_i64_i32 when Su2 fits 32 bits), hence
+// identical bits from kernels that used different offsets.  It is rounded to float32 once (high word x 2^32 + low
+// word in one fma: within 1.2e-7 relative), scaled by 1 / (n (n - 1)) and rooted with the hardware's v_sqrt_f32
+// (1 ulp): 3e-7 relative in all, against the 1e-4 of the contract, in 8 instructions where the float64 form with a
+// correctly rounded sqrtf took about 20 per pixel (a tenth of std_ring_kernel's vector instructions).  Every
+// wave-shift and ring kernel uses this one function for such pixels, so they agree bit for bit.
+__device__ __forceinline__ float std_from_int_sums(int su, uint64_t su2, uint32_t n, float inv_nn1) {
+    const uint64_t num = (uint64_t)n * su2 - (uint64_t)((int64_t)su * (int64_t)su);
+    const float f = fmaf((float)(uint32_t)(num >> 32), 4294967296.0f, (float)(uint32_t)num);
+    return __builtin_amdgcn_sqrtf(f * inv_nn1);
 }
 enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4 };
 
@@ -446,7 +465,8 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
                     // elsewhere must get the bits the ring kernel, whose flags cover a batch of rows, gives it; found
                     // by the randomised row-block check once a run's hand-over depended on the run's extent)
                     if (!use_float && m == n && q3.v[t] == 0) {
-                        out_s.v[t] = std_from_int_sums(su, su2, n, inv_nn1);
+                        out_s.v[t] = std_from_int_sums((int)q0.v[t], ((uint64_t)q2.v[t] << 16) + q1.v[t], (uint32_t)G::T.taps,
+                                                       (float)inv_nn1);
                     } else {
                         const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
                         out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
@@ -589,8 +609,28 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
 // such tiles in a row the block marks the rest of its run without staging it.
 // FRACTION: stage the fractional parts (integers in units of 2^-16 m, stage_value<kStF>) instead of
 // trunc(x), without classifying: the window was classified when its trunc(x) sums were formed.
+// -DMARCH_STAMPS: s_memtime stamps around the phases of a marched tile, summed per wave and printed by two blocks
+// (diagnostic build of tools/ubench/tpi_lab.hip; the product is built without it)
+#ifdef MARCH_STAMPS
+#define MARCH_STAMP(i) { const long long now_ = __builtin_amdgcn_s_memtime(); tsum[i] += now_ - tlast; tlast = now_; }
+#define MARCH_STAMP_ARGS , long long (&tsum)[8], long long& tlast
+#define MARCH_STAMP_PASS , tsum, tlast
+#else
+#define MARCH_STAMP(i)
+#define MARCH_STAMP_ARGS
+#define MARCH_STAMP_PASS
+#endif
+
+// MARCH_DYN_ROWS (default on): the waves of a block draw the output rows of a tile from a ticket counter in LDS
+// (flag_word[1]) instead of owning every NWAVES-th row, so a wave that the SIMD's arbitration held back takes
+// fewer rows and the tile's row loop ends for all waves within a row's time.  Which wave computes a row does not
+// change its bits.
+#ifndef MARCH_DYN_ROWS
+#define MARCH_DYN_ROWS 1
+#endif
+
 template <int SIZE, int TH, int NWAVES, bool FRACTION = false>
-__device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* flag_word, int gy0, int gx) {
+__device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* flag_word, int gy0, int gx MARCH_STAMP_ARGS) {
     constexpr int NROWS = TH + SIZE - 1;
     constexpr int KEEP = NROWS + 1 - TH;  // prefix rows carried over: those of window rows TH-1 .. NROWS-1
     constexpr int RW = TH / NWAVES;       // new rows per wave
@@ -599,7 +639,7 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
     constexpr int MOVES = (MOVE4 + NT - 1) / NT;
     uint32_t* TOT = Q + (NROWS + 1) * ROWW;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r0 = KEEP - 1 + wave * RW;  // first new window row of this wave
     Vec4<float> v[RW];
 #pragma unroll
@@ -615,7 +655,10 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
         const int idx = (int)threadIdx.x + s * NT;
         m[s] = src[idx < MOVE4 ? idx : MOVE4 - 1];
     }
+    MARCH_STAMP(0)
     __syncthreads();
+    MARCH_STAMP(1)
+    if (MARCH_DYN_ROWS && threadIdx.x == 0) flag_word[1] = 0;  // every wave has left the previous tile's row loop
     int4v* dst = reinterpret_cast<int4v*>(Q);
 #pragma unroll
     for (int s = 0; s < MOVES; ++s) {
@@ -649,14 +692,26 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
         if (__builtin_amdgcn_ballot_w64(amax > __float_as_uint(kAbsLim))) wf |= kTileFloat;
         if (lane == 0 && wf) atomicOr(flag_word, wf);
     }
+    MARCH_STAMP(2)
     __syncthreads();
+    MARCH_STAMP(3)
     const int all = FRACTION ? 0 : *flag_word;
     // every wave adds the carried prefix (row KEEP-1) and the totals of the waves above it
     Vec4<uint32_t> off = *reinterpret_cast<const Vec4<uint32_t>*>(Q + (KEEP - 1) * ROWW + lane * NC);
-    for (int w = 0; w < wave; ++w) {
-        const Vec4<uint32_t> t = *reinterpret_cast<const Vec4<uint32_t>*>(TOT + w * ROWW + lane * NC);
+    {
+        // the totals of the waves above: all NWAVES - 1 reads are issued at once (the rows past this wave's own are
+        // read and dropped); a loop with the wave number as its trip count waited for every read in turn, and the
+        // last wave's eleven round trips were the longest stretch of the tile's staging (1 700 of ~6 900 cycles)
+        Vec4<uint32_t> tot[NWAVES - 1];
 #pragma unroll
-        for (int s = 0; s < NC; ++s) off.v[s] += t.v[s];
+        for (int w = 0; w < NWAVES - 1; ++w) tot[w] = *reinterpret_cast<const Vec4<uint32_t>*>(TOT + w * ROWW + lane * NC);
+#pragma unroll
+        for (int w = 0; w < NWAVES - 1; ++w) {
+            if (w < wave) {  // wave-uniform: a scalar branch
+#pragma unroll
+                for (int s = 0; s < NC; ++s) off.v[s] += tot[w].v[s];
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
@@ -666,7 +721,9 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
         for (int s = 0; s < NC; ++s) x.v[s] += off.v[s];
         *q = x;
     }
+    MARCH_STAMP(4)
     __syncthreads();
+    MARCH_STAMP(5)
     return all;
 }
 
@@ -715,6 +772,10 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
     constexpr int kHist = (SIZE - 1 + TH - 1) / TH;
     unsigned frac_hist = 0;
     int deferred_in_a_row = 0;
+#ifdef MARCH_STAMPS
+    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
     for (int tile = first; tile < last; ++tile) {
         if (deferred_in_a_row >= kGiveUp) {
@@ -729,10 +790,15 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
         if (ty == 0) carry = false;  // top of a strip
         int flags;
         if (carry) {
-            flags = stage_march<SIZE, TH, NWAVES>(p, Q, flag_word, gy0, gx);
+            MARCH_STAMP(7)
+            flags = stage_march<SIZE, TH, NWAVES>(p, Q, flag_word, gy0, gx MARCH_STAMP_PASS);
         } else {
             __syncthreads();  // the image and the flag word of the previous tile are done with
+            if (MARCH_DYN_ROWS && threadIdx.x == 0) flag_word[1] = 0;
             flags = stage_prefix<SIZE, TH, NWAVES, kStU, int, true>(p, lds_u, flag_word, gy0, gx, 0.0f, 0, 0.0f, 0.0f);
+#ifdef MARCH_STAMPS
+            tlast = __builtin_amdgcn_s_memtime();  // full stagings (run starts) are not in the sums
+#endif
         }
         const bool leave = (flags & (ALLOW_FRAC ? kTileFloat : (kTileFloat | kTileFrac))) != 0;
         if (ALLOW_FRAC) {
@@ -759,9 +825,18 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
         // that the whole-metre copy is exactly the loop of the kernel without ALLOW_FRAC
         auto rows = [&](auto fraction_tag) {
             constexpr bool SUMS_ONLY = decltype(fraction_tag)::value;  // fractional tile: sums now, TPI later
+            // the next row of the tile that nobody has taken yet (MARCH_DYN_ROWS), drawn one row ahead so that the
+            // LDS atomic's round trip is behind the chain
+            auto draw = [&]() {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(&flag_word[1], 1);
+                return __builtin_amdgcn_readfirstlane(t);
+            };
+            int next_row = MARCH_DYN_ROWS ? draw() : wave;
 #pragma unroll 1
-            for (int k = 0; k < RW; ++k) {
-                const int jj = wave + k * NWAVES;
+            while (next_row < TH) {
+                const int jj = next_row;
+                next_row = MARCH_DYN_ROWS ? draw() : jj + NWAVES;
                 uint32_t acc[NC];  // sum of trunc(x) over the disc modulo 2^32; the true value fits int32
                 wave_disc_sum<SIZE, uint32_t, 0, (SIZE >= 41)>(Q, jj, lane, acc);
                 const int oy = oy0 + jj;
@@ -793,7 +868,14 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
         } else {
             rows(std::false_type{});
         }
+        MARCH_STAMP(6)
     }
+#ifdef MARCH_STAMPS
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && (wave == 0 || wave == 5 || wave == 11))
+        printf("blk %3d wave %2d tiles %d: loads+move reads %lld | barrier %lld | move writes+scan+write %lld | barrier %lld | "
+               "fix-up %lld | barrier %lld | rows (chain+finalise+store) %lld | tile set-up %lld   (memtime ticks, 100 MHz)\n",
+               (int)blockIdx.x, wave, last - first, tsum[0], tsum[1], tsum[2], tsum[3], tsum[4], tsum[5], tsum[6], tsum[7]);
+#endif
 }
 
 // Grid of the marching launches: persistent blocks, whole XCD rounds, never more blocks than tiles.
@@ -897,7 +979,10 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveArg
         const int gy0 = oy0 + G::T.off_min;
         if (ty == 0) carry = false;
         if (carry) {
-            (void)stage_march<SIZE, TH, NWAVES, true>(p, Q, flag_word, gy0, gx);
+#ifdef MARCH_STAMPS
+            long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
+            (void)stage_march<SIZE, TH, NWAVES, true>(p, Q, flag_word, gy0, gx MARCH_STAMP_PASS);
         } else {
             __syncthreads();  // the previous tile's image is done with
             (void)stage_prefix<SIZE, TH, NWAVES, kStF, uint32_t>(p, lds_u, flag_word, gy0, gx, 0.0f, 0, 0.0f, 0.0f);
@@ -1212,8 +1297,7 @@ __global__ __launch_bounds__(NWAVES * 64) void std_march_kernel(WaveArgs p, int 
                     }
                     if (!BORDER || m == n) {
                         // sum of u, what the general kernel's first chain yields: |ci n| < 2^30, |su| < 2^25
-                        const double su = (double)(sv.v[t] - ci * G::T.taps);
-                        out_s.v[t] = std_from_int_sums(su, su2, n, inv_nn1);
+                        out_s.v[t] = std_from_int_sums(sv.v[t] - ci * G::T.taps, (uint64_t)acc[t], (uint32_t)G::T.taps, (float)inv_nn1);
                     } else {
                         const double s1 = (double)sv.v[t];
                         const double su = s1 - cd * m;
