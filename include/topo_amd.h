@@ -115,6 +115,13 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
 int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int size,
                          int out_row0, int out_rows, float* tpi_out, float* std_out);
 
+/* TPI for several disc sizes of one resident block (the scale loop of compute_tpi, reference
+ * topo.py:132-141, and of scripts/compute_topo_descriptors.py:25-38): sizes that have a two-disc
+ * kernel (pairs out of 5, 7, 9, 11 px) are evaluated two at a time from ONE pass over the DEM,
+ * the rest one by one; every plane has the bits of topo_amd_tpi_std_dev for its size.
+ * tpi_outs[k] receives the plane of sizes[k] (out_rows x nx each).                         */
+int topo_amd_tpi_multi_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int n_sizes,
+                           const int32_t* sizes, int out_row0, int out_rows, float* const* tpi_outs);
 /* ndimage.gaussian_filter(dem, (sigma_y, sigma_x)), reflect boundary, truncate 4 sigma
  * (replaces topo.dem topo.py:62-80 and the pre-smoothing at topo.py:173, :298).  A sigma of
  * 0 skips that axis.  The intermediate plane lives in the library's own workspace.       */

@@ -49,6 +49,8 @@ SIGNATURES = {
                                         _vp, _vp]),
     "topo_amd_sx_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p,
                                   C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _vp]),
+    "topo_amd_tpi_multi_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int, C.c_int,
+                                         C.POINTER(_vp)]),
     "topo_amd_sx_multi_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p,
                                         _f64p, _i32p, C.c_double, C.c_int, C.c_int, C.POINTER(_vp)]),
     "topo_amd_valley_ridge_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _i32p, _vp, C.c_int,

@@ -127,8 +127,28 @@ def _tpi_std(dem_ds, scales, smth_factors, ind_nans, crop, outdir, want):
     res = _ResidentDem(hlp.get_da(dem_ds).values)
     out, smooth, results = res.plane(), None, {}
     try:
-        for scale, px, fact, sigma in zip(scales, scales_pxl, smth_factors, sigmas):
+        # un-smoothed TPI at two small scales shares one pass over the DEM (Block.tpi_multi): the
+        # planes of such pairs are made ahead of the loop, which then only names and writes them
+        ahead = {}
+        if want == "tpi":
+            small = {}
+            for k, (px, sigma) in enumerate(zip(scales_pxl, sigmas)):
+                if not sigma and int(px) in (5, 7, 9, 11):
+                    small.setdefault(int(px), k)
+            sizes = sorted(small)
+            if len(sizes) >= 2:
+                second = res.plane()
+                try:
+                    for a, b in zip(sizes[0::2], sizes[1::2]):
+                        res.block.tpi_multi([a, b], [out, second])
+                        ahead[small[a]], ahead[small[b]] = out.to_host(), second.to_host()
+                finally:
+                    second.free()
+        for k, (scale, px, fact, sigma) in enumerate(zip(scales, scales_pxl, smth_factors, sigmas)):
             logger.info("Computing scale %s meters with smoothing factor %s ...", scale, fact)
+            if k in ahead:
+                _finish(ahead.pop(k), ind_nans, dem_ds, _tpi_name(scale, fact), crop, outdir, "m", results)
+                continue
             block = res.block
             if sigma:  # pre-smoothing (reference topo.py:172-173, :297-298)
                 smooth = smooth or res.plane()

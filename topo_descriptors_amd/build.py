@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtopo_amd.so")
-SOURCES = [f"disc_wave_g{g}.hip" for g in range(10)] + ["disc.hip", "disc_wave.hip", "disc_big.hip", "gauss.hip",
+SOURCES = [f"disc_wave_g{g}.hip" for g in range(10)] + ["disc.hip", "disc_wave.hip", "disc_pair.hip", "disc_big.hip", "gauss.hip",
                                                            "sx.hip", "valley.hip", "valley_fft.hip", "capi.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -2,6 +2,7 @@
 // and host-buffer descriptor entry points, and RCCL ghost-row exchange for row shards.
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -516,6 +517,40 @@ int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int
     TOPO_TRY(require_ready());
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     return tpi_std_block(b, size, 0.0, tpi_out, std_out);
+}
+
+int topo_amd_tpi_multi_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int n_sizes, const int32_t* sizes,
+                           int out_row0, int out_rows, float* const* tpi_outs) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(n_sizes >= 1 && sizes && tpi_outs, "tpi_multi: no sizes");
+    for (int k = 0; k < n_sizes; ++k) TOPO_REQUIRE(tpi_outs[k], "tpi_multi: NULL output plane %d", k);
+    Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    // sizes that have a two-disc kernel (disc_pair.hip) go through it in pairs - the smallest with the next one up,
+    // so that the shared ring is no larger than it has to be - the rest one by one
+    std::vector<int> order(n_sizes), left;
+    for (int k = 0; k < n_sizes; ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return sizes[x] < sizes[y]; });
+    std::vector<char> done(n_sizes, 0);
+    static const bool pairs_on = [] {
+        const char* e = std::getenv("TOPO_AMD_TPI_PAIRS");  // 0 switches the two-disc kernel off (A/B runs)
+        return !(e && e[0] == '0');
+    }();
+    for (int i = 0; i + 1 < n_sizes && pairs_on; ++i) {
+        const int a = order[i], c = order[i + 1];
+        if (done[a] || done[c] || !tpi_pair_covers(sizes[a], sizes[c])) continue;
+        DiscRuns da, dc;
+        TOPO_TRY(build_disc(sizes[a], &da));
+        TOPO_TRY(build_disc(sizes[c], &dc));
+        TOPO_TRY(check_block(b, -dc.dj_min, dc.dj_max, "tpi_multi"));
+        const int rc = launch_tpi_pair(b, sizes[a], tpi_outs[a], sizes[c], tpi_outs[c]);
+        if (rc == TOPO_AMD_EUNSUP) break;  // planes the 16-byte row accesses cannot take: single launches handle them
+        if (rc != TOPO_AMD_OK) return rc;
+        done[a] = done[c] = 1;
+        ++i;
+    }
+    for (int k = 0; k < n_sizes; ++k)
+        if (!done[k]) TOPO_TRY(tpi_std_block(b, sizes[k], 0.0, tpi_outs[k], nullptr));
+    return TOPO_AMD_OK;
 }
 
 int topo_amd_gaussian_dev(const float* in, int in_rows, int in_row0, int gny, int nx,

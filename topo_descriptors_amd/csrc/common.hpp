@@ -99,6 +99,9 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
 // size-specialised wave-shift kernels; TOPO_AMD_EUNSUP = not covered, use the generic kernel
 int launch_disc_wave(const Block& b, int size, float* tpi_out, float* std_out);
 bool disc_wave_covers(int size);  // a specialisation exists for this disc size
+// TPI of two small disc sizes from one pass over the DEM (disc_pair.hip); TOPO_AMD_EUNSUP = pair not covered
+int launch_tpi_pair(const Block& b, int size_a, float* out_a, int size_b, float* out_b);
+bool tpi_pair_covers(int size_a, int size_b);
 // any size: float64 column prefix sums in HBM (slow, exact)
 int launch_disc_big(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out);
 int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out, bool small_ok = true);

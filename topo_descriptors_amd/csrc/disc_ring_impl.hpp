@@ -255,8 +255,14 @@ enum RingMode { kRingMain = 0, kRingMainFrac = 1, kRingFraction = 2 };
 // kRingMain: tiles with fractional samples are left to the general kernel.  kRingMainFrac: their exact sums of
 // trunc(x) go to p.sums and they are marked kNeedsFraction.  kRingFraction: the second pass over those tiles
 // (sum of the fractional parts, then TPI with the expression and operands of tpi_fraction_march_kernel).
-template <int SIZE, int NCR, int MODE>
+// SIZE2 (0 = none): a second, smaller disc evaluated from the same ring in the same pass (several
+// scales from one read of the DEM).  The window of the smaller disc is inside the larger one's, so the staging, the
+// ring and the tile classification are those of SIZE; its chain runs over its own run table with the ring slot of its
+// own first row, and TPI of SIZE2 goes to p.tpi2 with the expression of the single call, hence with its bits.  A tile
+// the pass leaves to the general kernel is left for both sizes (kRingMain only: discs below 17 px).
+template <int SIZE, int NCR, int MODE, int SIZE2 = 0>
 __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+    static_assert(SIZE2 == 0 || (SIZE2 < SIZE && SIZE2 >= 5 && SIZE2 % 2 == 1 && MODE == kRingMain), "pair: a smaller odd disc, main pass");
     using G = RGeo<SIZE, NCR>;
     using C = RingCfg<SIZE, NCR>;
     constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW;
@@ -465,6 +471,30 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
                     }
                 }
                 uint32_t acc[NCR], ctr[NCR];
+                if constexpr (SIZE2 != 0) {
+                    // the smaller disc first (its sums are converted and stored before the larger chain needs the registers)
+                    using G2 = RGeo<SIZE2, NCR>;
+                    constexpr int kShift = G::M - G2::M;  // its window starts this many rows further down
+                    int s2 = s0 + kShift;
+                    s2 = s2 >= R ? s2 - R : s2;
+                    uint32_t acc2[NCR], ctr2[NCR];
+                    ring_disc_sum<SIZE2, NCR, R, RING_LEAD>(Q, s2, lane, acc2, ctr2, wave >= NW / 2);
+                    const double inv_nm1_2 = 1.0 / ((double)G2::T.taps - 1.0);
+#pragma unroll
+                    for (int P = 0; P < 2; ++P) {
+                        if (P == 0 ? live : live2) {
+                            Vec4<float> out_t;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const float x = (float)(int)ctr2[4 * P + t];
+                                const double s1 = (double)(int)acc2[4 * P + t];
+                                const double x_ctr = (double)x;
+                                out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1_2);
+                            }
+                            *reinterpret_cast<Vec4<float>*>(p.tpi2 + o + 4 * P) = out_t;
+                        }
+                    }
+                }
                 ring_disc_sum<SIZE, NCR, R, RING_LEAD>(Q, s0, lane, acc, ctr, wave >= NW / 2);
                 if (ph + 1 < nphase) next_flags = convert_batch(C::PRO + ph * B, va, next_q);
                 converted = true;
@@ -522,19 +552,19 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
     }
 }
 
-template <int SIZE, int NCR, int MODE>
-int launch_ring(const Block& b, float* tpi_out) {
+template <int SIZE, int NCR, int MODE, int SIZE2 = 0>
+int launch_ring(const Block& b, float* tpi_out, float* tpi2_out = nullptr) {
     using G = RGeo<SIZE, NCR>;
     using C = RingCfg<SIZE, NCR>;
     Context& c = ctx();
     WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
-               nullptr, nullptr, nullptr, 0, 0, 0};
+               nullptr, nullptr, nullptr, 0, 0, 0, tpi2_out};
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_ring_kernel<SIZE, NCR, MODE>,
+        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_ring_kernel<SIZE, NCR, MODE, SIZE2>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         int nblk = 0;
-        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)tpi_ring_kernel<SIZE, NCR, MODE>,
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)tpi_ring_kernel<SIZE, NCR, MODE, SIZE2>,
                                                               C::NW * 64, C::LDS));
         blocks_per_cu = nblk < 1 ? 1 : (nblk > 4 ? 4 : nblk);  // small discs: several rings per CU
     }
@@ -550,7 +580,7 @@ int launch_ring(const Block& b, float* tpi_out) {
         TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
         a.sums = (int32_t*)sums;
     }
-    hipLaunchKernelGGL((tpi_ring_kernel<SIZE, NCR, MODE>), dim3((unsigned)grid), dim3(C::NW * 64), C::LDS, c.compute, a,
+    hipLaunchKernelGGL((tpi_ring_kernel<SIZE, NCR, MODE, SIZE2>), dim3((unsigned)grid), dim3(C::NW * 64), C::LDS, c.compute, a,
                        tiles_x, tiles_y);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;

@@ -55,6 +55,7 @@ struct WaveArgs {
     int map_th;         // general kernel: tile height of the geometry p.defer was built for (0 = its own)
     int map_tiles_y;    //                 and its number of tile rows
     int map_tw;         //                 and its strip width when that differs too (0 = its own)
+    float* tpi2;        // ring kernel for a pair of disc sizes: TPI of the smaller disc
 };
 
 template <typename T>
@@ -698,20 +699,10 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
     const int all = FRACTION ? 0 : *flag_word;
     // every wave adds the carried prefix (row KEEP-1) and the totals of the waves above it
     Vec4<uint32_t> off = *reinterpret_cast<const Vec4<uint32_t>*>(Q + (KEEP - 1) * ROWW + lane * NC);
-    {
-        // the totals of the waves above: all NWAVES - 1 reads are issued at once (the rows past this wave's own are
-        // read and dropped); a loop with the wave number as its trip count waited for every read in turn, and the
-        // last wave's eleven round trips were the longest stretch of the tile's staging (1 700 of ~6 900 cycles)
-        Vec4<uint32_t> tot[NWAVES - 1];
+    for (int w = 0; w < wave; ++w) {
+        const Vec4<uint32_t> t = *reinterpret_cast<const Vec4<uint32_t>*>(TOT + w * ROWW + lane * NC);
 #pragma unroll
-        for (int w = 0; w < NWAVES - 1; ++w) tot[w] = *reinterpret_cast<const Vec4<uint32_t>*>(TOT + w * ROWW + lane * NC);
-#pragma unroll
-        for (int w = 0; w < NWAVES - 1; ++w) {
-            if (w < wave) {  // wave-uniform: a scalar branch
-#pragma unroll
-                for (int s = 0; s < NC; ++s) off.v[s] += tot[w].v[s];
-            }
-        }
+        for (int s = 0; s < NC; ++s) off.v[s] += t.v[s];
     }
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
@@ -741,7 +732,6 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
     static_assert(G::T.centre == 0, "odd disc sizes only: the zeroed tap is the pixel itself");
     static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
     constexpr int NROWS = TH + SIZE - 1;
-    constexpr int RW = TH / NWAVES;
     constexpr int kGiveUp = 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
     uint32_t* Q = lds_u;  // uint32 prefix sums of trunc(x): wrap-around is defined and harmless

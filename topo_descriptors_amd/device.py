@@ -131,6 +131,17 @@ class Block:
                                                    tpi.ptr if tpi else None,
                                                    std.ptr if std else None), "tpi_std_dev")
 
+    def tpi_multi(self, sizes, outs, out_row0=None, out_rows=None):
+        """TPI for several disc sizes; pairs of small sizes (5 ... 11 px) share one pass over the DEM
+        (``topo_amd_tpi_multi_dev``).  outs: one DeviceArray per size.  Same bits as ``tpi_std`` per size."""
+        o0, on = self._range(out_row0, out_rows)
+        sz = np.ascontiguousarray(np.atleast_1d(sizes), dtype=np.int32)
+        if sz.size != len(outs):
+            raise ValueError(f"{sz.size} sizes but {len(outs)} output planes")
+        planes = (C.c_void_p * len(outs))(*[o.ptr for o in outs])
+        _lib.check(_lib.lib().topo_amd_tpi_multi_dev(*self._head(), int(sz.size), sz.ctypes.data_as(_lib._i32p), o0, on,
+                                                     planes), "tpi_multi_dev")
+
     def gaussian(self, sigma_y, sigma_x, out, out_row0=None, out_rows=None):
         o0, on = self._range(out_row0, out_rows)
         _lib.check(_lib.lib().topo_amd_gaussian_dev(*self._head(), float(sigma_y), float(sigma_x),

@@ -66,7 +66,12 @@ def circular_kernel(size):
 def tpi(dem, size, sigma=None):
     """Topographic position index: elevation minus the mean of the disc neighbourhood of
     diameter ``size`` pixels, centre excluded; optional Gaussian pre-smoothing ``sigma``
-    (reference topo.py:145-181).  float32 in, float32 out; DataArray in, DataArray out."""
+    (reference topo.py:145-181).  float32 in, float32 out; DataArray in, DataArray out.
+
+    With ``sigma`` the pre-smoothing is :func:`dem`'s: see there for how far a non-finite sample reaches (further
+    than in the reference's ``ndimage.gaussian_filter``).  Without it a NaN reaches the windows that contain it and
+    some more pixels of its tile (it travels down the column prefix sums); the reference's FFT convolution makes the
+    whole array NaN."""
     values, rewrap = _unwrap(dem)
     _check_2d(values, "tpi")
     src = _lib.as_f32(values)
@@ -79,7 +84,8 @@ def tpi(dem, size, sigma=None):
 
 def std(dem, size, sigma=None):
     """Sample standard deviation inside the disc window, with the reference's int32
-    truncation of the squared term (reference topo.py:273-307).  Returns float64."""
+    truncation of the squared term (reference topo.py:273-307).  Returns float64.  Non-finite samples: as for
+    :func:`tpi` (and :func:`dem` when ``sigma`` is given)."""
     values, _ = _unwrap(dem)
     _check_2d(values, "std")
     src = _lib.as_f32(values)
@@ -141,7 +147,16 @@ def tpi_std_multi(dem, sizes, sigmas=None, want_tpi=True, want_std=True):
 # ---- Gaussian, Sobel, gradient ------------------------------------------------------------------
 def dem(dem, sigma):
     """Gaussian-smoothed DEM, reflect boundary, 4-sigma truncation (reference topo.py:62-80).
-    ``sigma`` may be a scalar or an (axis0, axis1) pair."""
+    ``sigma`` may be a scalar or an (axis0, axis1) pair.
+
+    Non-finite samples: a NaN / inf in the DEM makes NaN at least every output whose window contains it, as in the
+    reference, and - unlike ``scipy.ndimage.gaussian_filter`` - up to 37 pixels beyond it along each axis when the
+    smoothing runs on the matrix cores (Gaussian radius ``int(4 sigma + 0.5)`` of 4 ... 121 and a DEM width that is a
+    multiple of 4): those kernels evaluate 32 outputs at a time against a zero-padded band of taps, and 0 x NaN is
+    NaN.  Fill or mask nodata before calling (``helpers.fill_na`` / ``fill_na_array``), as the reference's driver
+    does (scripts/compute_topo_descriptors.py:21-22); ``tests/test_gpu_parity.py::test_gaussian_nan_footprint`` pins
+    the bound.
+    """
     values, rewrap = _unwrap(dem)
     _check_2d(values, "dem")
     sig = np.broadcast_to(np.asarray(sigma, dtype=np.float64), (2,))
@@ -191,7 +206,8 @@ def gradient(dem, sigma, res_meters, sig_ratio=1):
     ``sigma <= 1`` uses the Sobel pair; ``sig_ratio != 1`` smooths with ``sigma*sig_ratio``
     perpendicular to each derivative.  Derivatives are divided by the signed grid
     resolution ``res_meters`` (second return of :func:`helpers.scale_to_pixel`); slope in
-    degrees; aspect in [0, 360) with north-facing = 0 and east-facing = 90."""
+    degrees; aspect in [0, 360) with north-facing = 0 and east-facing = 90.  Non-finite samples reach as far as in
+    :func:`dem` (plus the one pixel of the finite difference)."""
     values, _ = _unwrap(dem)
     _check_2d(values, "gradient")
     src = _lib.as_f32(values)
