@@ -166,10 +166,11 @@ def cpu_baseline(size, sample_rows, sample_cols, dem_sample):
 
 
 def cpu_twin_baseline(size, dem_sample):
-    """The oracle's C/OpenMP twin (exact float64 evaluation, row-prefix algorithm) on every host
-    core: TPI at `size` and Sx (azimuth 0, radius 500 m) on a bounded window of the same DEM.  The thread
-    pool is started on a small window first and the better of two runs counts (the first run of a process
-    pays for thread start-up and for faulting in ~1.5 GB of prefix planes)."""
+    """The oracle's C/OpenMP twin (exact float64 evaluation; row prefix sums in thread-private tiles, pixel loop
+    innermost and vectorised) on every host core: TPI at `size` and Sx (azimuth 0, radius 500 m; the distinct ray
+    pixels once each, one atan per pixel) on a bounded window of the same DEM.  The thread pool is started on a
+    small window first and the better of two runs counts (the first run of a process pays for thread start-up and
+    for faulting in the float64 result plane)."""
     from oracle import c_twin, topo_oracle as orc
 
     rows, cols = dem_sample.shape
@@ -181,7 +182,7 @@ def cpu_twin_baseline(size, dem_sample):
         dt = time.perf_counter() - t0
         dt_tpi = dt if dt_tpi is None else min(dt_tpi, dt)
     window, offs, dist = orc.sx_geometry(0.0, 500.0, 30.0, -30.0)
-    sx_sample = np.ascontiguousarray(dem_sample[:8192, :8192])  # ~14 s on 256 threads; the pool is warm by now
+    sx_sample = np.ascontiguousarray(dem_sample[:8192, :8192])  # the pool is warm by now
     t0 = time.perf_counter()
     c_twin.sx(sx_sample, offs[:, 0], offs[:, 1], dist, window, 10.0)
     dt_sx = time.perf_counter() - t0

@@ -17,7 +17,7 @@ def build(force=False):
     gcc = shutil.which("gcc")
     if gcc is None:
         raise RuntimeError("gcc not found")
-    cmd = [gcc, "-O3", "-fopenmp", "-shared", "-fPIC", "-o", LIB, SRC, "-lm"]
+    cmd = [gcc, "-O3", "-mavx2", "-mfma", "-fopenmp", "-shared", "-fPIC", "-o", LIB, SRC, "-lm"]
     print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
     return LIB
