@@ -108,6 +108,19 @@ struct RGeo {
 
 // Ring row layout: PARTS pieces of 256 dwords; lane l keeps columns NCR l + 4 P .. + 3 at dwords
 // 256 P + 4 l .. + 3, so that every ds_read_b128 of a wave is 1 KiB of consecutive bytes.
+// min (MAX = false) or max of an int over the wavefront, the same value in every lane (wave-uniform)
+template <bool MAX>
+__device__ __forceinline__ int wave_min_max(int v) {
+    auto op = [](int a, int b) { return MAX ? max(a, b) : min(a, b); };
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));  // row_ror:1
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));  // row_ror:2
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));  // row_ror:4
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));  // row_ror:8
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return op(op(r0, r1), op(r2, r3));
+}
+
 template <int NCR>
 __device__ __forceinline__ int ring_dword_of_column(int c) {
     return ((c % NCR) / 4) * 256 + (c / NCR) * 4 + (c % 4);
@@ -250,11 +263,23 @@ constexpr bool ring_fits(int size, int ncr) {
     return size >= 5 && (size_t)(size + 8) * 64 * ncr * 4 + 128 <= 160 * 1024 && 64 - 2 * ((size / 2 + ncr - 1) / ncr) >= 16;
 }
 
-enum RingMode { kRingMain = 0, kRingMainFrac = 1, kRingFraction = 2 };
+enum RingMode { kRingMain = 0, kRingMainFrac = 1, kRingFraction = 2, kRingMark = 3, kRingBoth = 4 };
+
+// the two-image pass (kRingBoth) fits LDS and has its strips?  (5 ... 31 px with 8 columns per lane)
+constexpr bool ring_both_fits(int size) {
+    return size >= 5 && size % 2 == 1 && (size_t)(size + 8) * 64 * 8 * 4 * 2 + 128 <= 160 * 1024;
+}
 
 // kRingMain: tiles with fractional samples are left to the general kernel.  kRingMainFrac: their exact sums of
 // trunc(x) go to p.sums and they are marked kNeedsFraction.  kRingFraction: the second pass over those tiles
 // (sum of the fractional parts, then TPI with the expression and operands of tpi_fraction_march_kernel).
+// kRingMark + kRingBoth: the pair for small discs on DEMs with fractional elevations.  kRingMark is kRingMain except
+// that a tile with fractional samples is marked kNeedsFraction (and not computed) instead of going to the general
+// kernel; kRingBoth then takes those tiles in ONE pass with two rings side by side - the prefix rows of trunc(x) and of
+// the fractional parts in units of 2^-16 m - runs both chains and finalises with the expression and operands of
+// kRingFraction (sum of trunc(x) as an exact integer, plus 2^-16 x the integer sum of the parts), hence with the bits
+// of the fraction passes and of the general kernel.  One read of the DEM and one write of TPI instead of the sums
+// plane going out and coming back between two passes.
 // SIZE2 (0 = none): a second, smaller disc evaluated from the same ring in the same pass (several
 // scales from one read of the DEM).  The window of the smaller disc is inside the larger one's, so the staging, the
 // ring and the tile classification are those of SIZE; its chain runs over its own run table with the ring slot of its
@@ -268,9 +293,13 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
     constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW;
     constexpr int DL = G::DL;
     constexpr bool FRACTION = MODE == kRingFraction;
+    constexpr bool BOTH = MODE == kRingBoth;
+    constexpr bool SECOND = FRACTION || BOTH;  // a second pass: works on the tiles the map names
+    static_assert(!BOTH || SIZE2 == 0, "the two-image pass takes one disc");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
     uint32_t* Q = lds_u;
-    int* wflags = reinterpret_cast<int*>(Q + R * G::W);  // [2 parities][NW]: what each wave saw in the batch it staged
+    uint32_t* F = Q + R * G::W;  // kRingBoth: the ring of the fractional parts
+    int* wflags = reinterpret_cast<int*>(Q + (BOTH ? 2 : 1) * R * G::W);  // [2 parities][NW]: what each wave saw in the batch it staged
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -283,7 +312,7 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
     const int last = min(first + per, ntiles);
     const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
 
-    if (FRACTION) {
+    if (SECOND) {
         // nothing to do on a DEM of whole metres: one flag per lane, 64 tiles per load
         bool any = false;
         for (int base = first; base < last; base += 64) {
@@ -322,9 +351,10 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
                 v[r] = src[(size_t)(gy - p.in_row0) * p.nx];
             }
         };
-        if (MODE == kRingMain) {
-            // Below 17 px a tile with fractional elevations goes to the general kernel: a run whose four probed
-            // rows all hold fractional or non-finite samples is handed over unstaged (see std_ring_kernel)
+        if (MODE == kRingMain || MODE == kRingMark) {
+            // A tile with fractional elevations is not for this pass (kRingMain: the general kernel's; kRingMark:
+            // the two-image pass's): a run whose four probed rows all hold fractional or non-finite samples is
+            // handed over unstaged (see std_ring_kernel)
             int odd = 0;
             const int pc = min(max(ox0 + 4 * lane, 0), p.nx - 1);
 #pragma unroll
@@ -335,19 +365,33 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
                 odd += __builtin_amdgcn_ballot_w64(!(x == truncf(x))) != 0 ? 1 : 0;
             }
             if (odd == 4) {
-                for (int t = tile0 + (int)threadIdx.x; t < tile0 + run_tiles; t += NW * 64) p.defer[t] = kTileGeneral;
+                for (int t = tile0 + (int)threadIdx.x; t < tile0 + run_tiles; t += NW * 64)
+                    p.defer[t] = MODE == kRingMark ? kNeedsFraction : kTileGeneral;
                 tile0 += run_tiles;
                 continue;
             }
         }
-        uint32_t run = 0;  // running prefix of this lane's column (wraps, harmlessly)
+        if (SECOND) {
+            // a run without a tile for this pass is not staged (a DEM that is fractional in places only)
+            bool any = false;
+            for (int base = tile0; base < tile0 + run_tiles; base += 64) {
+                const int mine = base + lane;
+                any = any || __builtin_amdgcn_ballot_w64(mine < tile0 + run_tiles && p.defer[mine < tile0 + run_tiles ? mine : tile0] == kNeedsFraction) != 0;
+            }
+            if (!any) {
+                tile0 += run_tiles;
+                continue;
+            }
+        }
+        uint32_t run = 0;    // running prefix of this lane's column (wraps, harmlessly)
+        uint32_t run_f = 0;  // kRingBoth: the same for the fractional parts
         int wslot = 0;     // ring slot of the next row to stage
         // Staging a batch of B rows in two halves.  convert_batch: the loaded samples -> the prefix values
         // to write (registers) and what the wave saw; it ends with the wave's only wait on its loads, so it
         // runs before any younger store is issued (vmcnt counts loads and stores together, in order, and a
         // wait for the last load behind two output stores would wait for the stores too: 1300 cycles per
         // phase in the first version).  write_batch: the B ds_write_b32 over the B oldest rows.
-        auto convert_batch = [&](int n0, const float (&v)[B], uint32_t (&q)[B]) {
+        auto convert_batch = [&](int n0, const float (&v)[B], uint32_t (&q)[B], uint32_t (&qf)[BOTH ? B : 1]) {
             uint32_t amax = 0;  // largest |x| seen, as float bits (NaN / inf sort above all)
             bool frac = false;
 #pragma unroll
@@ -363,6 +407,10 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
                     frac |= x != (float)xi;
                     amax = max(amax, __float_as_uint(x) & 0x7fffffffu);
                     run += (uint32_t)xi;
+                    if (BOTH) {
+                        run_f += stage_value<kStF>(x, 0.0f, 0);
+                        qf[r] = run_f;
+                    }
                 }
                 q[r] = run;
             }
@@ -374,20 +422,21 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
             }
             return wf;
         };
-        auto write_batch = [&](const uint32_t (&q)[B]) {
+        auto write_batch = [&](const uint32_t (&q)[B], const uint32_t (&qf)[BOTH ? B : 1]) {
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 int s = wslot + r;
                 s = s >= R ? s - R : s;
                 Q[s * G::W + sdw] = q[r];
+                if (BOTH) F[s * G::W + sdw] = qf[r];
             }
             wslot += B;
             wslot = wslot >= R ? wslot - R : wslot;
         };
         auto stage_batch = [&](int n0, const float (&v)[B]) {
-            uint32_t q[B];
-            const int wf = convert_batch(n0, v, q);
-            write_batch(q);
+            uint32_t q[B], qf[BOTH ? B : 1];
+            const int wf = convert_batch(n0, v, q, qf);
+            write_batch(q, qf);
             return wf;
         };
         unsigned hist_frac = 0, hist_float = 0;
@@ -436,22 +485,33 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
 #pragma unroll 1
         for (int ph = 0; ph < nphase; ++ph) {
             const int tile = tile0 + ph / PPT;
-            if (FRACTION) {
+            if (SECOND) {
                 if (ph % PPT == 0) mode = __builtin_amdgcn_readfirstlane((int)p.defer[tile]);
+                if (BOTH && hist_float && mode == kNeedsFraction) {
+                    // (a run the first pass handed over unstaged was not classified there) non-finite or absurd
+                    // samples in the window: the whole tile is the general kernel's
+                    mode = kTileGeneral;
+                    if (threadIdx.x == 0) p.defer[tile] = (uint8_t)kTileGeneral;
+                }
             } else {
-                const int now = hist_float ? kTileGeneral
-                                           : (hist_frac ? (MODE == kRingMainFrac ? kNeedsFraction : kTileGeneral) : kTileDone);
+                constexpr bool kFracLater = MODE == kRingMainFrac || MODE == kRingMark;  // fractional tiles have a pass of their own
+                const int now = hist_float ? kTileGeneral : (hist_frac ? (kFracLater ? kNeedsFraction : kTileGeneral) : kTileDone);
                 if (ph % PPT == 0) {
                     mode = now;
                     if (threadIdx.x == 0) p.defer[tile] = (uint8_t)mode;
+                } else if (MODE == kRingMark && mode == kTileDone && now == kNeedsFraction) {
+                    // fractional rows further down the tile: all of it goes to the two-image pass (the rows written
+                    // so far are written again there, with the same bits)
+                    mode = kNeedsFraction;
+                    if (threadIdx.x == 0) p.defer[tile] = (uint8_t)kNeedsFraction;
                 } else if (mode != kTileGeneral && now != mode && !(mode == kNeedsFraction && now == kTileDone)) {
                     // the tile's later rows brought in what its first phase had not seen: leave all of it
                     mode = kTileGeneral;
                     if (threadIdx.x == 0) p.defer[tile] = (uint8_t)kTileGeneral;
                 }
             }
-            const bool compute = FRACTION ? mode == kNeedsFraction : mode != kTileGeneral;
-            uint32_t next_q[B];
+            const bool compute = SECOND ? mode == kNeedsFraction : (MODE == kRingMark ? mode == kTileDone : mode != kTileGeneral);
+            uint32_t next_q[B], next_qf[BOTH ? B : 1];
             int next_flags = 0;
             bool converted = false;
             if (compute) {
@@ -461,12 +521,12 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
                 const size_t o = live ? (size_t)(oy - p.out_row0) * p.nx + ocol : 0;
                 Vec4<int> sv[2];
                 Vec4<float> xs[2];
-                if (FRACTION) {
+                if (SECOND) {
                     const size_t xi = live ? (size_t)(oy - p.in_row0) * p.nx + ocol : 0;
 #pragma unroll
                     for (int P = 0; P < 2; ++P) {
                         const bool lv = P == 0 ? live : live2;
-                        sv[P] = *reinterpret_cast<const Vec4<int>*>(p.sums + (lv ? o + 4 * P : 0));
+                        if (FRACTION) sv[P] = *reinterpret_cast<const Vec4<int>*>(p.sums + (lv ? o + 4 * P : 0));
                         xs[P] = *reinterpret_cast<const Vec4<float>*>(p.in + (lv ? xi + 4 * P : 0));
                     }
                 }
@@ -486,17 +546,21 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
                             Vec4<float> out_t;
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                const float x = (float)(int)ctr2[4 * P + t];
-                                const double s1 = (double)(int)acc2[4 * P + t];
-                                const double x_ctr = (double)x;
-                                out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1_2);
+                                const int xi = (int)ctr2[4 * P + t];
+                                out_t.v[t] = (float)((double)xi - (double)((int)acc2[4 * P + t] - xi) * inv_nm1_2);
                             }
                             *reinterpret_cast<Vec4<float>*>(p.tpi2 + o + 4 * P) = out_t;
                         }
                     }
                 }
                 ring_disc_sum<SIZE, NCR, R, RING_LEAD>(Q, s0, lane, acc, ctr, wave >= NW / 2);
-                if (ph + 1 < nphase) next_flags = convert_batch(C::PRO + ph * B, va, next_q);
+                if (BOTH) {
+                    // the sum of trunc(x) takes the place of the first pass's plane of sums; then the fractional parts
+#pragma unroll
+                    for (int t = 0; t < NCR; ++t) sv[t / 4].v[t % 4] = (int)acc[t];
+                    ring_disc_sum<SIZE, NCR, R, RING_LEAD>(F, s0, lane, acc, ctr, wave >= NW / 2);
+                }
+                if (ph + 1 < nphase) next_flags = convert_batch(C::PRO + ph * B, va, next_q, next_qf);
                 converted = true;
                 static_assert(NCR == 8, "the stores below write two 16-byte pieces per lane");
 #pragma unroll
@@ -509,16 +573,14 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
                             Vec4<float> out_t;
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                if (FRACTION) {
+                                if (SECOND) {
                                     const double sf = (double)(int)acc[4 * P + t] * (1.0 / 65536.0);
                                     const double s1 = (double)sv[P].v[t] + sf;
                                     const double x_ctr = (double)xs[P].v[t];
                                     out_t.v[t] = (float)((double)xs[P].v[t] - (s1 - x_ctr) * inv_nm1);
                                 } else {
-                                    const float x = (float)(int)ctr[4 * P + t];
-                                    const double s1 = (double)(int)acc[4 * P + t];  // sum of x over the in-domain taps, exact
-                                    const double x_ctr = (double)x;
-                                    out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+                                    const int xi = (int)ctr[4 * P + t];  // integers: see tpi_march_kernel
+                                    out_t.v[t] = (float)((double)xi - (double)((int)acc[4 * P + t] - xi) * inv_nm1);
                                 }
                             }
                             *reinterpret_cast<Vec4<float>*>(p.tpi + o + 4 * P) = out_t;
@@ -526,15 +588,15 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
                     }
                 }
             }
-            if (FRACTION && ph % PPT == PPT - 1 && mode == kNeedsFraction && threadIdx.x == 0) p.defer[tile] = kTileDone;
-            if (!converted && ph + 1 < nphase) next_flags = convert_batch(C::PRO + ph * B, va, next_q);
+            if (SECOND && ph % PPT == PPT - 1 && mode == kNeedsFraction && threadIdx.x == 0) p.defer[tile] = kTileDone;
+            if (!converted && ph + 1 < nphase) next_flags = convert_batch(C::PRO + ph * B, va, next_q, next_qf);
             s0 += B;
             s0 = s0 >= R ? s0 - R : s0;
             RING_STAMP(0)
             __syncthreads();  // every wave is done with the B oldest rows
             RING_STAMP(1)
             if (ph + 1 < nphase) {
-                write_batch(next_q);
+                write_batch(next_q, next_qf);
                 load_batch(C::PRO + (ph + 1) * B, va);  // in flight during the next chain
                 if (lane == 0) wflags[((ph + 1) & 1) * NW + wave] = next_flags;
             }
@@ -559,13 +621,15 @@ int launch_ring(const Block& b, float* tpi_out, float* tpi2_out = nullptr) {
     Context& c = ctx();
     WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
                nullptr, nullptr, nullptr, 0, 0, 0, tpi2_out};
+    constexpr size_t kLds = C::LDS + (MODE == kRingBoth ? (size_t)C::R * G::W * sizeof(uint32_t) : 0);
+    static_assert(kLds <= 160 * 1024, "the two rings do not fit LDS");
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
         TOPO_HIP(hipFuncSetAttribute((const void*)tpi_ring_kernel<SIZE, NCR, MODE, SIZE2>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
         int nblk = 0;
         TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)tpi_ring_kernel<SIZE, NCR, MODE, SIZE2>,
-                                                              C::NW * 64, C::LDS));
+                                                              C::NW * 64, kLds));
         blocks_per_cu = nblk < 1 ? 1 : (nblk > 4 ? 4 : nblk);  // small discs: several rings per CU
     }
     const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
@@ -575,12 +639,12 @@ int launch_ring(const Block& b, float* tpi_out, float* tpi2_out = nullptr) {
     void* defer = nullptr;
     TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
     a.defer = (uint8_t*)defer;
-    if (MODE != kRingMain) {
+    if (MODE == kRingMainFrac || MODE == kRingFraction) {
         void* sums = nullptr;
         TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
         a.sums = (int32_t*)sums;
     }
-    hipLaunchKernelGGL((tpi_ring_kernel<SIZE, NCR, MODE, SIZE2>), dim3((unsigned)grid), dim3(C::NW * 64), C::LDS, c.compute, a,
+    hipLaunchKernelGGL((tpi_ring_kernel<SIZE, NCR, MODE, SIZE2>), dim3((unsigned)grid), dim3(C::NW * 64), kLds, c.compute, a,
                        tiles_x, tiles_y);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
@@ -741,11 +805,11 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                 q[r] = run_u;
                 q2[r] = run_u2;
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                lo = min(lo, __shfl_xor(lo, m));
-                hi = max(hi, __shfl_xor(hi, m));
-            }
+            // wave-wide min / max: four rotations inside the rows of 16 lanes (DPP), then the four rows through the
+            // scalar unit.  (Twelve __shfl_xor, i.e. LDS round trips one after the other, sat on the staging waves'
+            // path to the barrier every phase.)
+            lo = wave_min_max<false>(lo);
+            hi = wave_min_max<true>(hi);
             if (__builtin_amdgcn_ballot_w64(frac)) s.flags |= kTileFrac;
             if (__builtin_amdgcn_ballot_w64(amax >= __float_as_uint(kAbsLim + 1.0f))) s.flags |= kTileFloat;
             s.lo = lo;
@@ -874,10 +938,9 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                     for (int t = 0; t < 4; ++t) {
                         out_s.v[t] = std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1);
                         if (WANT_TPI) {
-                            const float x = (float)((int)ctr[t] + ci);
-                            const double s1 = (double)((int)su[t] + ci * G::T.taps);  // sum of trunc(x): exact, fits int32
-                            const double x_ctr = (double)x;
-                            out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+                            const int xi = (int)ctr[t] + ci;  // integers: see tpi_march_kernel
+                            // sum of trunc(x) = su + c n: exact, fits int32
+                            out_t.v[t] = (float)((double)xi - (double)((int)su[t] + ci * G::T.taps - xi) * inv_nm1);
                         }
                     }
                     *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;

@@ -844,10 +844,11 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
                     Vec4<float> out_t;
 #pragma unroll
                     for (int t = 0; t < NC; ++t) {
-                        const float x = (float)(int)(hi.v[t] - lo.v[t]);
-                        const double s1 = (double)(int)acc[t];  // sum of x over the in-domain taps, exact
-                        const double x_ctr = (double)x;
-                        out_t.v[t] = (float)((double)x - (s1 - x_ctr) * inv_nm1);
+                        // x and (sum of x over the in-domain taps) - x are integers: the difference is taken in int32
+                        // and each goes to float64 with one conversion (the values, hence the bits, of the form
+                        // (double)(float)x - ((double)s1 - (double)(float)x) * inv_nm1, two conversions less per pixel)
+                        const int xi = (int)(hi.v[t] - lo.v[t]);
+                        out_t.v[t] = (float)((double)xi - (double)((int)acc[t] - xi) * inv_nm1);
                     }
                     *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
                 }
@@ -1435,7 +1436,10 @@ inline int tpi_march_min_size() {
 // Disc size from which TPI takes the ring build (disc_ring_impl.hpp) instead of tpi_march_kernel
 // (TOPO_AMD_TPI_RING_MIN, a tuning knob: both give the same bits).
 // Measured on the 32768^2 bench DEM (tools/ring_time.py, profiles/r02_tpi_ring.txt): 2.03-2.06 ms against
-// 2.31-2.37 ms for 5 ... 11 px, level at 13-17 px, 4.6 ms against 4.4 ms at 67 px.
+// 2.31-2.37 ms for 5 ... 11 px, level at 13-17 px, 4.6 ms against 4.4 ms at 67 px.  Round 3: the ring sizes go up
+// to 17 px, because with fractional elevations the two-image pass (kRingBoth) halves the time there (7 px 5.36 ->
+// 2.48 ms, 13 px 5.82 -> 3.60, 17 px 6.00 -> 3.79, profiles/r03_tpi_ring_both.txt) while whole metres cost the
+// same to 15 px and 5 % more at 17 (2.43 against 2.32 ms).
 inline int tpi_ring_min_size() {
     static const int v = env_int("TOPO_AMD_TPI_RING_MIN", 5);
     return v;
@@ -1449,8 +1453,13 @@ inline int std_ring_min_size() {
     return v;
 }
 inline int tpi_ring_max_size() {
-    static const int v = env_int("TOPO_AMD_TPI_RING_MAX", 11);
+    static const int v = env_int("TOPO_AMD_TPI_RING_MAX", 17);
     return v;
+}
+// TOPO_AMD_TPI_RING_BOTH=0: fractional tiles of the ring sizes go the older ways (A/B runs; same bits)
+inline bool tpi_ring_both() {
+    static const int v = env_int("TOPO_AMD_TPI_RING_BOTH", 1);
+    return v != 0;
 }
 inline int tpi_fraction_min_size() {
     static const int v = env_int("TOPO_AMD_TPI_FRACTION_MIN", 17);
@@ -1501,6 +1510,17 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
         if (SIZE >= tpi_ring_min_size() && SIZE <= tpi_ring_max_size()) {
             using RC = RingCfg<SIZE, 8>;
             constexpr int map_tw = RGeo<SIZE, 8>::TILE_W;
+            if constexpr (ring_both_fits(SIZE) && SIZE <= 17) {
+                // whole-metre tiles in the first pass; tiles with fractional elevations in ONE second pass with two
+                // rings (trunc(x) and the fractional parts); what neither could take in the general kernel.  On the
+                // 32768^2 bench DEM with fractional elevations: 7 px 5.36 -> 2.48 ms, 17 px 5.31 -> 3.79 ms
+                // (profiles/r03_tpi_ring_both.txt), bit for bit the planes of the older routes
+                if (tpi_ring_both()) {
+                    TOPO_TRY((launch_ring<SIZE, 8, kRingMark>(b, tpi_out)));
+                    TOPO_TRY((launch_ring<SIZE, 8, kRingBoth>(b, tpi_out)));
+                    return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true, RC::TH, map_tw);
+                }
+            }
             if (SIZE < tpi_fraction_min_size()) {
                 TOPO_TRY((launch_ring<SIZE, 8, kRingMain>(b, tpi_out)));
             } else {
