@@ -696,12 +696,30 @@ struct StdRingCfg {
 constexpr bool std_ring_fits(int size) {
     return size >= 5 && size % 2 == 1 && (size_t)(size + 12) * 512 * 4 + 512 <= 160 * 1024 && 64 - 2 * ((size / 2 + 3) / 4) >= 16;
 }
+// three images (u, u^2 and the fractional parts) fit: 5 ... 41 px
+constexpr bool std_ring_both_fits(int size) {
+    return std_ring_fits(size) && (size_t)(size + 12) * 768 * 4 + 512 <= 160 * 1024;
+}
 
-template <int SIZE, bool WANT_TPI>
+// kStdMain: what the comment above describes (tiles with fractional samples are left to what follows).
+// kStdBoth, the second pass for DEMs with fractional elevations (discs up to 41 px): it takes the tiles kStdMain left
+// that lie inside the DEM (the border tiles need the in-domain tap counts: general kernel) with a THIRD image in the
+// ring, the prefix rows of the fractional parts in units of 2^-16 m, runs the three chains and finalises every pixel
+// with the general kernel's choice and expressions (the integer form when the window's fractional sum is exactly 0,
+// else s1 = (sum u + c n) + 2^-16 sum g, s2 = sum u^2 + 2 c sum u + c^2 n in float64: exact integers whatever c is),
+// hence with its bits.  A tile it cannot take either (non-finite samples, more relief than the u^2 sums hold) stays
+// marked for the general kernel.  One read of the DEM instead of the general kernel's three staging passes:
+// 32768^2 with fractional elevations, STD 7 px 6.97 -> 4.10 ms, 17 px 8.34 -> 5.18, 31 px 10.88 -> 7.99, 41 px
+// 12.56 -> 10.81 (profiles/r03_std_ring_both.txt).
+enum StdRingMode { kStdMain = 0, kStdBoth = 2 };
+
+template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
 __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, int tiles_y) {
     using G = RGeo<SIZE, 4>;
     using C = StdRingCfg<SIZE>;
-    constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW, PITCH = C::PITCH, HIST = C::HIST;
+    constexpr bool BOTH = MODE == kStdBoth;
+    constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW, HIST = C::HIST;
+    constexpr int PITCH = (BOTH ? 3 : 2) * G::W;  // dwords per ring row: the u image, the u^2 image (and the image of the fractional parts)
     constexpr int DL = G::DL;
     constexpr int kBig = 0x3fffffff;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
@@ -720,11 +738,29 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
     const int first = vb * per;
     const int last = min(first + per, ntiles);
     const double n = (double)G::T.taps;
+    const double inv_n = 1.0 / n;
     const double inv_nm1 = 1.0 / (n - 1.0);
     const double inv_nn1 = 1.0 / (n * (n - 1.0));
     const int lim32 = (int)floorf(sqrtf(4294967295.0f / (float)G::T.taps));
     const int rmin = max(0, p.in_row0), rmax = min(p.gny, p.in_row0 + p.in_rows);
     const bool stager = wave < C::SW;
+    // kStdBoth: a tile the first pass left, with every disc of its pixels inside the DEM
+    auto candidate = [&](int t) {
+        const int ty = t % tiles_y, strip = t / tiles_y;
+        const int oy0 = (p.out_row0 / C::TH + ty) * C::TH, ox0 = strip * G::TILE_W;
+        const bool inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1 && ox0 - G::M >= 0 &&
+                            ox0 + G::TILE_W - 1 + G::M <= p.nx - 1;
+        return inside && p.defer[t] == kTileGeneral;
+    };
+    if (BOTH) {
+        // nothing to do on a DEM of whole metres: one tile per lane, 64 tiles per ballot
+        bool any = false;
+        for (int base = first; base < last; base += 64) {
+            const int mine = base + lane;
+            any = any || __builtin_amdgcn_ballot_w64(mine < last && candidate(mine < last ? mine : first)) != 0;
+        }
+        if (!any) return;  // the same for every thread of the block
+    }
     const int scol = 64 * wave + lane;  // staged column of a staging lane
 
 #pragma unroll 1
@@ -756,7 +792,18 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                 v[r] = src[(size_t)(gy - p.in_row0) * p.nx];
             }
         };
-        {
+        if (BOTH) {
+            // a run without a tile for this pass is not staged
+            bool any = false;
+            for (int base = tile0; base < tile0 + run_tiles; base += 64) {
+                const int mine = base + lane;
+                any = any || __builtin_amdgcn_ballot_w64(mine < tile0 + run_tiles && candidate(mine < tile0 + run_tiles ? mine : tile0)) != 0;
+            }
+            if (!any) {
+                tile0 += run_tiles;
+                continue;
+            }
+        } else {
             // On a DEM with fractional elevations every tile ends up with the general kernel, and staging the
             // strip for nothing cost 3 ms at 67 px (20.4 -> 23.5 ms).  Four rows spread over the run are probed
             // first (64 columns each, the same in every wave, so the block agrees): when all four hold a
@@ -777,11 +824,11 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                 continue;
             }
         }
-        uint32_t run_u = 0, run_u2 = 0;
+        uint32_t run_u = 0, run_u2 = 0, run_f = 0;
         int wslot = 0;  // ring slot of the next row to stage = slot of the oldest row
         // what a stager saw in a batch: flags, smallest and largest trunc(x)
         struct Seen { int flags, lo, hi; };
-        auto convert_batch = [&](int n0, const float (&v)[B], uint32_t (&q)[B], uint32_t (&q2)[B]) {
+        auto convert_batch = [&](int n0, const float (&v)[B], uint32_t (&q)[B], uint32_t (&q2)[B], uint32_t (&qf)[BOTH ? B : 1]) {
             Seen s{0, kBig, -kBig};
             if (!stager) return s;
             uint32_t amax = 0;  // largest |x| as float bits (NaN / inf sort above all)
@@ -804,6 +851,10 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                 run_u2 += (uint32_t)__mul24((int)u, (int)u);
                 q[r] = run_u;
                 q2[r] = run_u2;
+                if (BOTH) {
+                    run_f += stage_value<kStF>(ok ? x : 0.0f, 0.0f, 0);
+                    qf[r] = run_f;
+                }
             }
             // wave-wide min / max: four rotations inside the rows of 16 lanes (DPP), then the four rows through the
             // scalar unit.  (Twelve __shfl_xor, i.e. LDS round trips one after the other, sat on the staging waves'
@@ -816,7 +867,7 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
             s.hi = hi;
             return s;
         };
-        auto write_batch = [&](const uint32_t (&q)[B], const uint32_t (&q2)[B]) {
+        auto write_batch = [&](const uint32_t (&q)[B], const uint32_t (&q2)[B], const uint32_t (&qf)[BOTH ? B : 1]) {
             if (stager) {
 #pragma unroll
                 for (int r = 0; r < B; ++r) {
@@ -824,6 +875,7 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                     sl = sl >= R ? sl - R : sl;
                     Q[sl * PITCH + scol] = q[r];
                     Q[sl * PITCH + G::W + scol] = q2[r];
+                    if (BOTH) Q[sl * PITCH + 2 * G::W + scol] = qf[r];
                 }
             }
             wslot += B;
@@ -837,7 +889,7 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                 w[2] = s.hi;
             }
         };
-        unsigned hist = 0;           // per batch: fractional / non-finite / absurd samples seen
+        unsigned hist = 0;           // per batch: fractional / non-finite / absurd samples seen (kStdBoth: the last two only)
         int hlo[HIST], hhi[HIST];    // per batch: range of trunc(x) (index 0 = the newest batch)
 #pragma unroll
         for (int k = 0; k < HIST; ++k) hlo[k] = kBig, hhi[k] = -kBig;
@@ -851,7 +903,8 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                 hi = max(hi, q[2]);
             }
             fl = __builtin_amdgcn_readfirstlane(fl);
-            hist = ((hist << 1) | (fl ? 1u : 0u)) & ((1u << HIST) - 1u);
+            constexpr int kStops = BOTH ? kTileFloat : (kTileFrac | kTileFloat);
+            hist = ((hist << 1) | ((fl & kStops) ? 1u : 0u)) & ((1u << HIST) - 1u);
 #pragma unroll
             for (int k = HIST - 1; k > 0; --k) hlo[k] = hlo[k - 1], hhi[k] = hhi[k - 1];
             hlo[0] = __builtin_amdgcn_readfirstlane(lo);
@@ -864,13 +917,13 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
         Seen pro{0, kBig, -kBig};
 #pragma unroll 1
         for (int k = 0; k < C::NB_PRO; ++k) {
-            uint32_t q[B], q2[B];
+            uint32_t q[B], q2[B], qf[BOTH ? B : 1];
             load_batch(k * B, va);
-            const Seen s = convert_batch(k * B, va, q, q2);
+            const Seen s = convert_batch(k * B, va, q, q2, qf);
             pro.flags |= s.flags;
             pro.lo = min(pro.lo, s.lo);
             pro.hi = max(pro.hi, s.hi);
-            write_batch(q, q2);
+            write_batch(q, q2, qf);
         }
         load_batch(C::PRO, va);
         publish(0, pro);
@@ -882,7 +935,7 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
         // every disc of the strip's pixels stays inside the DEM's columns
         const bool cols_inside = ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= p.nx - 1;
         int s0 = C::PAD - 1 + wave;
-        bool general = false;
+        int tmode = kTileDone;  // what the map says about the current tile
 #pragma unroll 1
         for (int ph = 0; ph < nphase; ++ph) {
             const int tile = tile0 + ph / PPT;
@@ -902,7 +955,7 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                         uint32_t* q = Q + sl * PITCH + col;
                         const uint32_t q1 = q[0];
                         q[G::W] = q[G::W] - 2u * delta * q1 + d2 * (uint32_t)k;
-                        q[0] = q1 - delta * (uint32_t)k;
+                        q[0] = q1 - delta * (uint32_t)k;  // (the fractional parts do not depend on c)
                     }
                     if (stager) {
                         run_u2 = run_u2 - 2u * delta * run_u + d2 * (uint32_t)(R - 1);
@@ -911,19 +964,26 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                     ci = mid;
                     __syncthreads();
                 }
-                const int oy0 = oyS + (ph / PPT) * C::TH;
-                const bool rows_inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1;
-                general = !rows_inside || !cols_inside;
-                if (threadIdx.x == 0) p.defer[tile] = general ? kTileGeneral : kTileDone;
+                if (BOTH) {
+                    tmode = candidate(tile) ? kNeedsFraction : kTileDone;  // (kTileDone here: not this pass's)
+                } else {
+                    const int oy0 = oyS + (ph / PPT) * C::TH;
+                    const bool rows_inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1;
+                    tmode = !rows_inside || !cols_inside ? kTileGeneral : kTileDone;
+                    if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
+                }
             }
-            // the windows of this phase hold only whole, finite samples within lim32 of c?
+            // the windows of this phase hold only finite samples within lim32 of c (kStdMain: and whole ones)?
             const bool fits = hist == 0 && whi - ci <= lim32 && ci - wlo <= lim32;
-            if (!general && !fits) {
-                general = true;
+            if (BOTH) {
+                if (tmode == kNeedsFraction && !fits) tmode = kTileGeneral;  // the mark stays: general kernel
+            } else if (tmode != kTileGeneral && !fits) {
+                tmode = kTileGeneral;
                 if (threadIdx.x == 0) p.defer[tile] = kTileGeneral;
             }
-            uint32_t nq[B], nq2[B];
-            if (!general) {
+            const bool compute = BOTH ? tmode == kNeedsFraction : tmode == kTileDone;
+            uint32_t nq[B], nq2[B], nqf[BOTH ? B : 1];
+            if (compute) {
                 uint32_t su[4], ctr[4], su2[4], dummy[4];
 // progress-based issue priority (CHAIN_PRIO, disc_wave_impl.hpp) from 25 px: 67 px 10.19 -> 9.37 ms, 31 px
                 // 5.31 -> 5.03 ms; at 7 px the chains are too short for it (3.10 -> 3.28 ms)
@@ -931,7 +991,33 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                 ring_disc_sum<SIZE, 4, R, 2, PITCH, 3 + kP, 2 + kP>(Q, s0, lane, su, ctr, false);
                 ring_disc_sum<SIZE, 4, R, 2, PITCH, 1 + kP, 0 + kP>(Q + G::W, s0, lane, su2, dummy, false);
                 const int oy = oyS + ph * B + wave;
-                if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
+                if (BOTH) {
+                    uint32_t sfi[4];
+                    ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q + 2 * G::W, s0, lane, sfi, dummy, false);
+                    if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
+                        const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+                        Vec4<float> xs{{0.f, 0.f, 0.f, 0.f}};
+                        if (WANT_TPI) xs = *reinterpret_cast<const Vec4<float>*>(p.in + (size_t)(oy - p.in_row0) * p.nx + ocol);
+                        Vec4<float> out_s, out_t;
+                        const double cd = (double)ci;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            // the general kernel's expressions (disc_wave_kernel, finalise_row) on the same exact sums
+                            const double dsu = (double)(int)su[t], dsu2 = (double)su2[t];
+                            const double sf = (double)(int)sfi[t] * (1.0 / 65536.0);
+                            const double s1 = (dsu + cd * n) + sf;
+                            if (sfi[t] == 0) {
+                                out_s.v[t] = std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1);
+                            } else {
+                                const double s2 = dsu2 + 2.0 * cd * dsu + cd * cd * n;
+                                out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
+                            }
+                            if (WANT_TPI) out_t.v[t] = (float)((double)xs.v[t] - (s1 - (double)xs.v[t]) * inv_nm1);
+                        }
+                        *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+                        if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+                    }
+                } else if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
                     const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
                     Vec4<float> out_s, out_t;
 #pragma unroll
@@ -947,11 +1033,12 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
                     if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
                 }
             }
-            const Seen seen = convert_batch(C::PRO + ph * B, va, nq, nq2);
+            if (BOTH && ph % PPT == PPT - 1 && tmode == kNeedsFraction && threadIdx.x == 0) p.defer[tile] = kTileDone;
+            const Seen seen = convert_batch(C::PRO + ph * B, va, nq, nq2, nqf);
             s0 += B;
             s0 = s0 >= R ? s0 - R : s0;
             __syncthreads();
-            write_batch(nq, nq2);
+            write_batch(nq, nq2, nqf);
             load_batch(C::PRO + (ph + 1) * B, va);
             publish((ph + 1) & 1, seen);
             __syncthreads();
@@ -961,20 +1048,22 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
     }
 }
 
-template <int SIZE, bool WANT_TPI>
+template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
 int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
     using G = RGeo<SIZE, 4>;
     using C = StdRingCfg<SIZE>;
+    constexpr size_t kLds = C::LDS + (MODE == kStdBoth ? (size_t)C::R * G::W * sizeof(uint32_t) : 0);
+    static_assert(kLds <= 160 * 1024, "the three images do not fit LDS");
     Context& c = ctx();
     WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
                nullptr, nullptr, nullptr, 0, 0, 0};
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_kernel<SIZE, WANT_TPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)C::LDS));
+        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_kernel<SIZE, WANT_TPI, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kLds));
         int nblk = 0;
-        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_kernel<SIZE, WANT_TPI>, C::NW * 64,
-                                                              C::LDS));
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_kernel<SIZE, WANT_TPI, MODE>, C::NW * 64,
+                                                              kLds));
         blocks_per_cu = nblk < 1 ? 1 : (nblk > 2 ? 2 : nblk);  // small discs: two rings per CU
     }
     const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
@@ -984,7 +1073,7 @@ int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
     void* defer = nullptr;
     TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
     a.defer = (uint8_t*)defer;
-    hipLaunchKernelGGL((std_ring_kernel<SIZE, WANT_TPI>), dim3((unsigned)grid), dim3(C::NW * 64), C::LDS, c.compute, a,
+    hipLaunchKernelGGL((std_ring_kernel<SIZE, WANT_TPI, MODE>), dim3((unsigned)grid), dim3(C::NW * 64), kLds, c.compute, a,
                        tiles_x, tiles_y);
     TOPO_HIP(hipGetLastError());
     if (std::getenv("TOPO_AMD_DEBUG_MAP")) {  // diagnostic: how many tiles were left to the general kernel

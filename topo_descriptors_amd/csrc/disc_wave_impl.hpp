@@ -1456,7 +1456,11 @@ inline int tpi_ring_max_size() {
     static const int v = env_int("TOPO_AMD_TPI_RING_MAX", 17);
     return v;
 }
-// TOPO_AMD_TPI_RING_BOTH=0: fractional tiles of the ring sizes go the older ways (A/B runs; same bits)
+// TOPO_AMD_STD_RING_BOTH=0 / TOPO_AMD_TPI_RING_BOTH=0: fractional tiles of the ring sizes go the older ways (A/B runs; same bits)
+inline bool std_ring_both() {
+    static const int v = env_int("TOPO_AMD_STD_RING_BOTH", 1);
+    return v != 0;
+}
 inline bool tpi_ring_both() {
     static const int v = env_int("TOPO_AMD_TPI_RING_BOTH", 1);
     return v != 0;
@@ -1478,6 +1482,14 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
             // the tiles it marked (its map has this kernel's strips and rows of 60)
             if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out)));
             else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out)));
+            if constexpr (std_ring_both_fits(SIZE)) {
+                // tiles with fractional elevations: one more pass of the ring kernel with a third image (the
+                // fractional parts) instead of the general kernel's three staging passes
+                if (std_ring_both()) {
+                    if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true, kStdBoth>(b, tpi_out, std_out)));
+                    else TOPO_TRY((launch_std_ring<SIZE, false, kStdBoth>(b, nullptr, std_out)));
+                }
+            }
             if (tpi_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH);
             return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH);
         }
