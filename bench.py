@@ -115,11 +115,11 @@ def kernel_sources_sha256():
 
 def measured_traffic(ny, nx, size, world):
     """HBM bytes per launch of the TPI kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this exact
+    (profiles/r03_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this exact
     workload), with the git head and the kernel-source hash the profile was taken at.  The number is nulled
     when the workload or the sources differ from the profiled ones."""
-    info = {"traffic": None, "traffic_profile_head": None, "traffic_profile": "profiles/r02_tpi67_traffic.json"}
-    path = os.path.join(REPO, "profiles", "r02_tpi67_traffic.json")
+    info = {"traffic": None, "traffic_profile_head": None, "traffic_profile": "profiles/r03_tpi67_traffic.json"}
+    path = os.path.join(REPO, "profiles", "r03_tpi67_traffic.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -133,6 +133,29 @@ def measured_traffic(ny, nx, size, world):
         info["traffic_note"] = "kernel sources changed since the PMC passes were taken: re-run tools/pmc_passes.sh"
     else:
         info["traffic"] = prof.get("traffic_bytes_per_launch")
+    return info
+
+
+def valu_bound(ny, nx, size, world, kernel_ms):
+    """What bounds the kernel in practice: vector-ALU issue.  profiles/r03_tpi67_valu_bound.json (tools/valu_bound.py)
+    prices the kernel's own instruction stream - the row loop's instructions by issue class from the ISA, the rest
+    from the launch's SQ_INSTS_VALU counter - with the issue costs measured on the GPU; the fraction is that time
+    over the measured one.  Nulled when the workload or the kernel sources differ from the profiled ones."""
+    info = {"valu_bound_ms": None, "frac_of_valu_bound": None, "valu_bound_profile": "profiles/r03_tpi67_valu_bound.json"}
+    try:
+        with open(os.path.join(REPO, "profiles", "r03_tpi67_valu_bound.json")) as fh:
+            prof = json.load(fh)
+    except (OSError, ValueError):
+        info["valu_bound_note"] = "no committed profile"
+        return info
+    if (ny, nx, size, world) != (32768, 32768, 67, 1):
+        info["valu_bound_note"] = "profiled workload is 32768x32768, 67 px, 1 GPU"
+    elif prof.get("kernel_sources_sha256") != kernel_sources_sha256():
+        info["valu_bound_note"] = "kernel sources changed since tools/valu_bound.py ran"
+    else:
+        info["valu_bound_ms"] = prof.get("valu_bound_ms")
+        info["frac_of_valu_bound"] = round(prof["valu_bound_ms"] / kernel_ms, 4) if prof.get("valu_bound_ms") else None
+        info["valu_row_loop"] = prof.get("row_loop_instructions")
     return info
 
 
@@ -472,10 +495,12 @@ def main():
                           "(neither finds a tile on this DEM, ~10 us together)",
                 "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_median": round(kernel_ms_median, 4),
-                # what bounds it (profiles/r02_valu_mix_rate.txt, r02_tpi67_pmc_summary.txt): the
-                # exact disc sum is vector-ALU work, ~5.3 VALU pipe cycles per pixel at the measured issue rates
-                # (v_add3_u32 and every DPP form at half rate), i.e. ~2.5 ms per launch at 100 % VALU utilisation
+                # what bounds it (profiles/r02_valu_mix_rate.txt, r03_valu_mix2_rate.txt, r03_tpi67_valu_bound.json,
+                # DESIGN.md K1): the exact disc sum is vector-ALU work - 315 vector instructions per wave and output row,
+                # 171 of them at half rate (every DPP form, v_add3_u32, converts, float64) - i.e. ~3.1 ms per launch at
+                # 100 % VALU utilisation; valu_bound_ms / frac_of_valu_bound below
                 "bound_in_practice": "valu",
+                **valu_bound(ny, nx, size, 0 if loopback else world, kernel_ms),
                 "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL["tpi"],
             },
         }
