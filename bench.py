@@ -264,10 +264,15 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
         entry(f"gradient_sigma{sigma}", time_kernel(fn, REPS, d), 20, grad_kernels[sigma])
         fn = lambda: blk.gradient(sigma, [30.0], [-30.0], slope=o3, aspect=o4)  # noqa: E731
         entry(f"slope_aspect_sigma{sigma}", time_kernel(fn, REPS, d), 12, grad_kernels[sigma])
-    for radius in (500.0, 2000.0):
-        window, dj, di, dist = d.sx_offsets(0.0, radius, 30.0, -30.0)
+    # azimuth 45: the weak case (diagonal sectors cut into short chains)
+    for azimuth, radius in ((0.0, 500.0), (0.0, 2000.0), (45.0, 500.0), (45.0, 2000.0)):
+        window, dj, di, dist = d.sx_offsets(azimuth, radius, 30.0, -30.0)
         fn = lambda: blk.sx(dj, di, dist, window, 10.0, o1)  # noqa: E731
-        entry(f"sx_az0_r{int(radius)}", time_kernel(fn, REPS, d), 8, "sx_kernel<stride> (LDS tile, chains of 8 vertically adjacent ray pixels, one atan per pixel)")
+        entry(f"sx_az{int(azimuth)}_r{int(radius)}", time_kernel(fn, REPS, d), 8, "sx_kernel<stride> (LDS tile, chains of 8 neighbouring ray pixels along the sector's axis, one atan per pixel)")
+    # two small discs in one pass over the DEM: ms for the pair, rate and fraction per plane
+    st = time_kernel(lambda: blk.tpi_multi([7, 11], [o1, o2]), REPS, d)
+    entry("tpi_s7_s11_one_pass_per_plane", st, 6, "tpi_ring_kernel<11, 8, kRingMain, 7> (one staging pass, one ring, two chains; 4 B read + 8 B "
+          "written per pixel = 6 B per plane)", per=2)
     # 8 azimuths every 5 degrees in one pass: ms and rate are per azimuth plane
     sectors = [d.sx_offsets(5.0 * k, 500.0, 30.0, -30.0) for k in range(8)]
     fan = [o1, o2, o3, o4] + [d.DeviceArray(ny, nx) for _ in range(4)]
