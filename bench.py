@@ -198,12 +198,14 @@ def cpu_twin_baseline(size, dem_sample):
 
     rows, cols = dem_sample.shape
     c_twin.tpi_std(dem_sample[:512, :512], size, want_tpi=True, want_std=False)
+    plane = np.zeros(dem_sample.shape, np.float64)  # the result plane, touched once: not part of the timing
     dt_tpi = None
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
-        c_twin.tpi_std(dem_sample, size, want_tpi=True, want_std=False)
+        c_twin.tpi_std(dem_sample, size, want_tpi=True, want_std=False, out_tpi=plane)
         dt = time.perf_counter() - t0
         dt_tpi = dt if dt_tpi is None else min(dt_tpi, dt)
+    del plane
     window, offs, dist = orc.sx_geometry(0.0, 500.0, 30.0, -30.0)
     sx_sample = np.ascontiguousarray(dem_sample[:8192, :8192])  # the pool is warm by now
     t0 = time.perf_counter()
@@ -214,7 +216,7 @@ def cpu_twin_baseline(size, dem_sample):
         "value": round(rows * cols / dt_tpi / 1e6, 2),
         "sx_az0_r500_value": round(sx_sample.shape[0] * sx_sample.shape[1] / dt_sx / 1e6, 2),
         "sample": f"oracle/topo_oracle.c (OpenMP, float64, warm thread pool) on windows of the same DEM: TPI size {size} on "
-                  f"{rows}x{cols} in {dt_tpi:.2f} s (better of two runs), Sx az 0 r 500 m on "
+                  f"{rows}x{cols} in {dt_tpi:.2f} s (best of three runs into one result plane), Sx az 0 r 500 m on "
                   f"{sx_sample.shape[0]}x{sx_sample.shape[1]} in {dt_sx:.2f} s",
     }
 

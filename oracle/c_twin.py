@@ -26,10 +26,15 @@ def threads():
     return lib().oracle_threads()
 
 
-def tpi_std(dem, size, want_tpi=True, want_std=True):
+def tpi_std(dem, size, want_tpi=True, want_std=True, out_tpi=None, out_std=None):
+    """out_tpi / out_std: float64 arrays to write into (a timing loop passes the same, already touched, arrays every
+    time: a fresh 2 GB result array is faulted in page by page under the kernel's address-space lock, which on 256
+    threads costs more than the computation)."""
     dem = np.ascontiguousarray(dem, dtype=np.float32)
-    t = np.empty(dem.shape, np.float64) if want_tpi else None
-    s = np.empty(dem.shape, np.float64) if want_std else None
+    t = (out_tpi if out_tpi is not None else np.empty(dem.shape, np.float64)) if want_tpi else None
+    s = (out_std if out_std is not None else np.empty(dem.shape, np.float64)) if want_std else None
+    for a in (t, s):
+        assert a is None or (a.shape == dem.shape and a.dtype == np.float64 and a.flags.c_contiguous)
     rc = lib().oracle_tpi_std(dem.ctypes.data, dem.shape[0], dem.shape[1], int(size),
                               t.ctypes.data if want_tpi else None, s.ctypes.data if want_std else None)
     assert rc == 0

@@ -50,7 +50,7 @@ struct Context {
     hipStream_t compute = nullptr;   // every kernel goes here
     hipStream_t comm = nullptr;      // RCCL ghost-row traffic
     hipStream_t aux = nullptr;       // bandwidth-bound epilogues running next to matrix-core kernels (created on first use)
-    hipEvent_t aux_ready[12] = {};    // compute -> aux, one per chunk
+    hipEvent_t aux_ready[64] = {};    // compute -> aux, one per chunk
     hipEvent_t aux_done = nullptr;   // aux -> compute
     hipEvent_t halo_done = nullptr;  // comm -> compute dependency
     hipEvent_t input_ready = nullptr;  // compute -> comm dependency

@@ -1584,14 +1584,20 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     // same bits.
     static const int chunk_min = [] {
         const char* e = std::getenv("TOPO_AMD_GRAD_CHUNK_MIN_ROWS");
-        return e && *e ? std::atoi(e) : 8192;
+        return e && *e ? std::atoi(e) : 4096;  // (a 4096-row shard of the 8-GPU split goes in two chunks)
     }();
     if (sigma > 1.0 && sig_ratio == 1.0 && mfma_radius(gaussian_radius(sigma), b.nx, true) &&
         mfma_rows_ok(smoothed_rows_block(b), gaussian_radius(sigma)) && b.out_rows >= chunk_min &&
         b.nx % 4 == 0 && aligned16(dx) && aligned16(dy) && aligned16(slope) && aligned16(aspect)) {
         static const int NCH = [] {
             const char* e = std::getenv("TOPO_AMD_GRAD_CHUNKS");
-            return std::max(1, std::min(8, e && *e ? std::atoi(e) : 8));
+            return std::max(1, std::min(64, e && *e ? std::atoi(e) : 16));
+        }();
+        static const int chunk_rows = [] {  // smallest chunk (rows); a chunk's planes should fit the 256 MB Infinity Cache
+            const char* e = std::getenv("TOPO_AMD_GRAD_CHUNK_ROWS");
+            // 32768^2, chunks x rows (profiles/r03_gradient_chunks.txt): 8 x 4096 8.04 / 13.70 ms at sigma 3.25 / 30.25,
+            // 16 x 2048 7.77 / 13.50, 32 x 1024 8.27 / 14.55, 64 x 512 8.54 / 16.16
+            return std::max(256, e && *e ? std::atoi(e) : 2048);
         }();
         static const bool use_aux = [] {
             const char* e = std::getenv("TOPO_AMD_GRAD_AUX");
@@ -1612,8 +1618,8 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         void *pa = nullptr, *pb = nullptr;
         TOPO_TRY(workspace(1, bytes, &pa));
         TOPO_TRY(workspace(2, bytes, &pb));
-        // chunks of >= 4096 rows (every chunk restages the 2 R halo rows of the axis-0 ring: 6 % at radius 121)
-        const int nch = std::max(2, std::min(NCH, (s1 - s0) / 4096));
+        // chunks of >= 2048 rows (every chunk restages the 2 R halo rows of the axis-0 ring: 12 % at radius 121)
+        const int nch = std::max(2, std::min(NCH, (s1 - s0) / chunk_rows));
         const int per = std::max(32, ((s1 - s0 + nch - 1) / nch + 31) / 32 * 32);
         int o0 = b.out_row0;
         for (int k = 0, c0 = s0; c0 < s1; ++k) {
