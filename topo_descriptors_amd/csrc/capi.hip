@@ -1041,7 +1041,14 @@ int run_overlapped(float* block, const Shard& s, int above, int below, Fn fn) {
     TOPO_TRY(topo_amd_halo_exchange_start(block, s.rows_local, s.whole.nx, above, below));
     // the interior launch is persistent (it would otherwise hold every CU until it ends): leave
     // a few CUs to the send/recv kernels so that the exchange really runs next to it
-    ctx().reserve_cus = (g_comm.size > 1 || halo_loopback()) ? 16 : 0;
+    static const int kReserve = [] {
+        const char* e = std::getenv("TOPO_AMD_RESERVE_CUS");  // tuning knob (0 ... 64)
+        // one 4096 x 32768 shard in loop-back, ms per TPI / STD step (profiles/r03_reserve_cus.txt): 32 CUs 0.724 / 1.579,
+        // 16 0.688 / 1.447, 8 0.681 / 1.430, 4 0.680 / 1.428, 0 0.654 / 1.386 (in loop-back the copy needs no link;
+        // with real neighbours an exchange that finds no free CU starts when the interior launch ends)
+        return e && *e ? std::max(0, std::min(64, std::atoi(e))) : 8;
+    }();
+    ctx().reserve_cus = (g_comm.size > 1 || halo_loopback()) ? kReserve : 0;
     int rc = TOPO_AMD_OK;
     if (s.interior1 > s.interior0) rc = fn(s.owned, s.interior0, s.interior1 - s.interior0);
     ctx().reserve_cus = 0;

@@ -1584,7 +1584,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     // same bits.
     static const int chunk_min = [] {
         const char* e = std::getenv("TOPO_AMD_GRAD_CHUNK_MIN_ROWS");
-        return e && *e ? std::atoi(e) : 4096;  // (a 4096-row shard of the 8-GPU split goes in two chunks)
+        return e && *e ? std::atoi(e) : 2048;  // (the interior of a 4096-row shard of the 8-GPU split goes in two chunks)
     }();
     if (sigma > 1.0 && sig_ratio == 1.0 && mfma_radius(gaussian_radius(sigma), b.nx, true) &&
         mfma_rows_ok(smoothed_rows_block(b), gaussian_radius(sigma)) && b.out_rows >= chunk_min &&
