@@ -1060,265 +1060,6 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
     }
 }
 
-// Axis 1 FUSED with the gradient epilogue, for short filters (K8 = 64: radius <= 16, sigma <= 4).  The unfused
-// matrix-core route writes the smoothed plane and reads it back in gradient_epilogue4_kernel: 36 B/pixel of HBM
-// traffic for 20 algorithmic, and at these radii the route is bound by exactly that traffic (round 2: 38.6 GB in
-// 7.9 ms).  Here a wave owns a band of 32 smoothed rows that OVERLAPS its neighbours by two rows and yields 30 rows
-// of the gradient (+6.7 % matrix work); the 32 x 32 smoothed tile goes from the accumulators into a small LDS
-// buffer next to the last two columns of the previous tile, and the lanes difference it there (numpy.gradient:
-// central differences, one-sided at the DEM's edges) and finish with the expressions of the stand-alone epilogue
-// (finish_gradient), so the four planes have the bits of the unfused route: a smoothed value depends on its own row
-// and on the GLOBAL 32-column tile grid only, not on the band it is computed in.  The gradient columns of a tile lag
-// its smoothed columns by one (x0 - 1 ... x0 + 30: the right neighbour of column x0 + 31 is the next tile's), a
-// run of tiles that does not start at the DEM's left edge computes one tile ahead of its first without emitting,
-// and the last run adds one step past the right edge to emit column nx - 1.  17 KB of LDS per wave: two blocks
-// per CU, so one wave's epilogue arithmetic runs beside another's MFMAs.
-constexpr int kGradBandRows = 30;
-constexpr int kGbPrev = 5;    // columns of the previous tile kept in front of the current one
-constexpr int kGbPitch = 37;  // kGbPrev + 32 (odd: conflict-free column walks)
-
-// Global accesses with a scalar row base and a per-lane byte offset that never changes, written as instructions so
-// that the compiler's memory-counter bookkeeping does not see them.  With ~190 live registers it recycles the 64-bit
-// address pairs of ordinary loads and stores within a few instructions and, to do that safely, waits for the
-// operation that used them: the next tile's MFMA loop then starts behind the previous tile's 60 stores and its own
-// 16 loads (13.5 ms for the gradient at sigma 3.25 where the unfused route takes 7.8).  The loads are waited for by
-// hand (tile_loads_landed) before the ring write that consumes them; a dword store reads its data register at issue
-// (no hazard on gfx9 for <= 64 bits of data), so nothing waits for the stores.
-__device__ __forceinline__ float load_row_lane(const void* row_base, unsigned lane_off) {
-    float v;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(lane_off), "s"(row_base));
-    return v;
-}
-__device__ __forceinline__ void store_row_lane(void* row_base, unsigned lane_off, float v) {
-    asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_off), "v"(v), "s"(row_base));
-}
-// 16 bytes per lane; the data registers of a store wider than 8 bytes may not be written in the next cycle (gfx9
-// hazard the compiler pads on its own stores): hence the s_nop behind it
-__device__ __forceinline__ void store_row_lane4(void* row_base, unsigned lane_off, float a, float b, float c, float d) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const f4 v = {a, b, c, d};
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(lane_off), "v"(v), "s"(row_base));
-}
-__device__ __forceinline__ void tile_loads_landed(float (&v)[16]) {
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
-                 :
-                 : "memory");
-}
-
-__global__ __launch_bounds__(256) void gauss_axis1_mfma_grad_kernel(GaussArgs p, GradArgs g, int nbands, int nseg) {
-    extern __shared__ __attribute__((aligned(16))) float L[];
-    const int R = p.radius, K = 32 + 2 * R, K8 = (K + 7) / 8 * 8, RC = K8 + 32, pitch = RC + 1;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* wz = L;
-    float* ring = L + (K + kWzPad) + wave * (32 * pitch + 32 + 32 * kGbPitch);
-    float* crow = ring + 32 * pitch;
-    float* gb = crow + 32;  // [32 smoothed rows][2 + 32 columns]
-    fill_toeplitz_table(wz, p.taps, R, K);
-    for (int n = lane; n < 32 * pitch + 32 + 32 * kGbPitch; n += 64) ring[n] = 0.0f;
-    __syncthreads();
-    const int gw = blockIdx.x * 4 + wave;
-    // (wave-uniform, and said so: the division runs on the vector unit, and a band index the compiler takes for
-    // per-lane turns every row address below into a 64-bit register pair that the next instructions overwrite -
-    // behind a wait for the load or store that still holds it: 13.5 ms instead of 6)
-    const int band = __builtin_amdgcn_readfirstlane(gw / nseg), seg = gw - band * nseg;
-    if (band >= nbands) return;
-    const int out_end = g.out_row0 + g.out_rows;
-    const int G0 = g.out_row0 + kGradBandRows * band;  // first gradient row of the band; smoothed row r of the band
-    auto plane_row = [&](int r) {                      // is global row G0 - 1 + r, clamped into the DEM (and, past
-        const int y = min(max(G0 - 1 + r, 0), g.gny - 1);  // the rows this launch emits, into the smoothed plane)
-        return min(max(y - g.s_row0, 0), g.s_rows - 1);
-    };
-    const int i = lane & 31, h = lane >> 5;
-    auto load_cols = [&](int xfirst, int q) {  // band rows 2 q + h, columns xfirst + i
-        const int cx = reflect_index(xfirst + i, p.nx);
-        return p.in[(size_t)plane_row(2 * q + h) * p.nx + cx];
-    };
-    const unsigned in_lane_off = (unsigned)(h * p.nx + i) * 4u;
-    const int pr0 = G0 - 1 - g.s_row0;
-    const bool full_band = G0 - 1 >= 0 && G0 + 30 <= g.gny - 1 && pr0 >= 0 && pr0 + 32 <= g.s_rows;  // 32 distinct, consecutive rows
-    const int ntile = (p.nx + 31) / 32;
-    const int tper = (ntile + nseg - 1) / nseg;
-    const int t_first = seg * tper, t_last = min(t_first + tper, ntile);
-    if (t_first >= t_last) return;
-    const int t_start = t_first > 0 ? t_first - 1 : 0;             // one tile ahead, not emitted
-    const int t_stop = t_last == ntile ? ntile + 1 : t_last;      // one step past the edge: column nx - 1
-    for (int k0 = 0; k0 < K8; k0 += 32) {
-        if (k0 + i < K8) {
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + k0 + i] = load_cols(t_start * 32 - R + k0, q);
-        }
-    }
-    int base = 0;  // ring column of input column x0 - R
-    const int NG = K8 / 8;
-#ifdef TOPO_GAUSS_STAMPS
-    long long st[6] = {0, 0, 0, 0, 0, 0};
-    long long last_ = __builtin_amdgcn_s_memtime();
-#define GSTAMP(n) { const long long now_ = __builtin_amdgcn_s_memtime(); st[n] += now_ - last_; last_ = now_; }
-#else
-#define GSTAMP(n)
-#endif
-    // emission: a lane takes four adjacent columns of one row per round (8 rows x 8 groups of 4 columns per round, four
-    // rounds for the band's 30 rows), so that a row's eight lanes store one aligned 128-byte line per plane
-    const int rloc = lane >> 3, gidx = lane & 7;
-    const unsigned emit_lane_off = (unsigned)(rloc * g.nx + 4 * gidx) * 4u;
-    for (int t = t_start; t < t_stop; ++t) {
-        const int x0 = t * 32;
-        float pre[16];
-        const bool more = t + 1 < t_stop;
-        if (more) {
-            const int n0 = x0 - R + K8;  // the 32 columns the next tile adds
-            if (full_band && n0 >= 0 && n0 + 32 <= p.nx) {
-                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)pr0 * p.nx + n0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) pre[q] = load_row_lane(rb + (size_t)(2 * q) * p.nx * 4, in_lane_off);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) pre[q] = load_cols(n0, q);
-            }
-        }
-        GSTAMP(0)
-        int sc = base + R + 16;
-        sc = sc >= RC ? sc - RC : sc;
-        const float c = finite_or_zero(ring[i * pitch + sc]);  // the row's sample at the tile's middle column
-        if (h == 0) crow[i] = c;
-        f32x16 acc;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-        const float* wl = wz + (h - i + 31);
-        const float* al = ring + i * pitch + h;
-        int slot = base;
-        auto fetch = [&](int gi, float (&a)[4], float (&b)[4]) {
-            const float* ap = al + slot;
-            const float* wp = wl + 8 * gi;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = ap[2 * u];
-                b[u] = wp[2 * u];
-            }
-            slot += 8;
-            slot = slot >= RC ? slot - RC : slot;
-        };
-        const f32x2 cc = {c, c};
-        auto run1 = [&](const float (&a)[4], const float (&b)[4]) {
-            const f32x2 s0 = pk_sub(f32x2{a[0], a[1]}, cc), s1 = pk_sub(f32x2{a[2], a[3]}, cc);
-            mfma_operands_ready();
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[0], b[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[1], b[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[0], b[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[1], b[3], acc, 0, 0, 0);
-        };
-        auto run = [&](const float (&a)[4], const float (&b)[4], const float (&a2)[4], const float (&b2)[4]) {
-            const f32x2 s0 = pk_sub(f32x2{a[0], a[1]}, cc), s1 = pk_sub(f32x2{a[2], a[3]}, cc);
-            const f32x2 s2 = pk_sub(f32x2{a2[0], a2[1]}, cc), s3 = pk_sub(f32x2{a2[2], a2[3]}, cc);
-            mfma_operands_ready();
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[0], b[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[1], b[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[0], b[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[1], b[3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2[0], b2[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2[1], b2[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3[0], b2[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3[1], b2[3], acc, 0, 0, 0);
-        };
-        // the same products in the same order as gauss_axis1_mfma_kernel (hence the same bits): groups of 4 steps,
-        // two groups per call
-        float a0[4], b0[4], a1[4], b1[4];
-        int gi = 0;
-        for (; gi + 2 <= NG; gi += 2) {
-            fetch(gi, a0, b0);
-            fetch(gi + 1, a1, b1);
-            run(a0, b0, a1, b1);
-        }
-        if (gi < NG) {
-            fetch(gi, a0, b0);
-            run1(a0, b0);
-        }
-        GSTAMP(1)
-        if (more) {
-            tile_loads_landed(pre);
-            int sl = base + K8;
-            sl = (sl >= RC ? sl - RC : sl) + i;
-            sl = sl >= RC ? sl - RC : sl;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + sl] = pre[q];
-        }
-        GSTAMP(2)
-        // the smoothed tile -> the gradient buffer, behind the previous tile's last kGbPrev columns
-        {
-            float keep[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int e = lane + 64 * u;  // 32 rows x kGbPrev columns
-                keep[u] = e < 32 * kGbPrev ? gb[(e / kGbPrev) * kGbPitch + 32 + e % kGbPrev] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int e = lane + 64 * u;
-                if (e < 32 * kGbPrev) gb[(e / kGbPrev) * kGbPitch + e % kGbPrev] = keep[u];
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int row = (v & 3) + 8 * (v >> 2) + 4 * h;
-            gb[row * kGbPitch + kGbPrev + i] = crow[row] + acc[v];
-        }
-        GSTAMP(3)
-        // buffer column cb holds DEM column x0 - kGbPrev + cb; this step emits DEM columns x0 - 4 ... x0 + 27
-        const int gx0 = x0 - 4 + 4 * gidx;
-        if (t >= t_first && gx0 >= 0 && gx0 < p.nx) {
-#pragma unroll
-            for (int rd = 0; rd < 4; ++rd) {
-                const int rr = 1 + 8 * rd + rloc;  // band row
-                const int gy = G0 - 1 + rr;
-                if (rr <= kGradBandRows && gy < out_end) {
-                    const float* cp = gb + rr * kGbPitch + 1 + 4 * gidx;  // the first of the item's four columns
-                    float cen[6], up[4], dn[4];
-#pragma unroll
-                    for (int u = 0; u < 6; ++u) cen[u] = cp[u - 1];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        up[u] = cp[u - kGbPitch];
-                        dn[u] = cp[u + kGbPitch];
-                    }
-                    float odx[4], ody[4], osl[4], oas[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int gx = gx0 + u;
-                        float dx, dy;  // numpy.gradient: central difference / 2 inside, first-order one-sided at the edges
-                        if (gx == 0) dx = cen[u + 2] - cen[u + 1];
-                        else if (gx == p.nx - 1) dx = cen[u + 1] - cen[u];
-                        else dx = (cen[u + 2] - cen[u]) * 0.5f;
-                        if (gy == 0) dy = dn[u] - cen[u + 1];
-                        else if (gy == g.gny - 1) dy = cen[u + 1] - up[u];
-                        else dy = (dn[u] - up[u]) * 0.5f;
-                        float rx, ry;
-                        resolution_at(g, gy, gx, rx, ry);
-                        gradient_values(dx, dy, rx, ry, osl[u], oas[u]);  // finish_gradient's arithmetic
-                        odx[u] = dx;
-                        ody[u] = dy;
-                    }
-                    // a scalar base per round plus a per-lane byte offset that never changes
-                    const size_t ob = ((size_t)(G0 + 8 * rd - g.out_row0) * g.nx + (size_t)x0) * 4 - 16;
-                    if (g.dx) store_row_lane4(reinterpret_cast<char*>(g.dx) + ob, emit_lane_off, odx[0], odx[1], odx[2], odx[3]);
-                    if (g.dy) store_row_lane4(reinterpret_cast<char*>(g.dy) + ob, emit_lane_off, ody[0], ody[1], ody[2], ody[3]);
-                    if (g.slope) store_row_lane4(reinterpret_cast<char*>(g.slope) + ob, emit_lane_off, osl[0], osl[1], osl[2], osl[3]);
-                    if (g.aspect) store_row_lane4(reinterpret_cast<char*>(g.aspect) + ob, emit_lane_off, oas[0], oas[1], oas[2], oas[3]);
-                }
-            }
-        }
-        GSTAMP(4)
-        base += 32;
-        base = base >= RC ? base - RC : base;
-    }
-#ifdef TOPO_GAUSS_STAMPS
-    if (lane == 0 && (gw == 5 || gw == 1000))
-        printf("axis1+epilogue wave %d: %d tiles: loads issue %lld  mfma %lld  wait+ring write %lld  buffer %lld  emission %lld (clocks)\n",
-               gw, t_stop - t_start, st[0], st[1], st[2], st[3], st[4]);
-#endif
-}
-
 // ---- host side -----------------------------------------------------------------------------
 int upload_weights(int slot, double sigma, int kb, GaussArgs* a) {
     const int R = gaussian_radius(sigma);
@@ -1472,52 +1213,6 @@ int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, 
     }
     const long waves = (long)bands * nseg;
     hipLaunchKernelGGL(gauss_axis1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, c.compute, a, rows, nseg);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
-}
-
-// the fused axis-1 + epilogue kernel covers the filters whose ring is 64 + 32 columns (radius <= 16) on planes the
-// 16-byte accesses of the matrix-core route take; TOPO_AMD_GRAD_FUSED_MFMA=0 switches it off (A/B: same bits)
-bool mfma_grad_fused(int R, int nx) {
-    static const bool on = [] {
-        const char* e = std::getenv("TOPO_AMD_GRAD_FUSED_MFMA");
-        return !(e && *e == '0');
-    }();
-    return on && R <= 16 && (32 + 2 * R + 7) / 8 * 8 == 64 && nx % 4 == 0 && nx >= 64;
-}
-
-// Gradient rows g.out_row0 ... + g.out_rows from the axis-0 plane `in` (rows g.s_row0 ... + g.s_rows of the DEM), on
-// `stream`: axis 1 on the matrix cores with the epilogue fused in (gauss_axis1_mfma_grad_kernel).
-int run_axis1_mfma_grad(const float* in, double sigma, const GradArgs& g, int table_slot, hipStream_t stream) {
-    Context& c = ctx();
-    GaussArgs a;
-    TOPO_TRY(upload_plain_weights(table_slot, sigma, &a));
-    a.in = in;
-    a.out = nullptr;
-    a.in_rows = g.s_rows;
-    a.in_row0 = g.s_row0;
-    a.gny = g.gny;
-    a.nx = g.nx;
-    a.out_row0 = g.out_row0;
-    a.out_rows = g.out_rows;
-    a.group0 = 0;
-    const int K = 32 + 2 * a.radius, K8 = (K + 7) / 8 * 8;
-    const size_t lds = ((size_t)(K + kWzPad) + 4 * (size_t)(32 * (K8 + 32 + 1) + 32 + 32 * kGbPitch)) * sizeof(float);
-    static bool ready = false;
-    if (!ready) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_mfma_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-        ready = true;
-    }
-    const int bands = (g.out_rows + kGradBandRows - 1) / kGradBandRows;
-    const int ntile = (g.nx + 31) / 32;
-    // two blocks of 4 waves per CU; a short plane is cut into runs of tiles (each run computes one tile ahead of
-    // its first) until the chip is full, runs no shorter than 16 tiles
-    const long slots = 8L * c.num_cu;
-    int nseg = 1;
-    while ((long)bands * nseg < slots && ntile / (nseg + 1) >= 16) ++nseg;
-    const long waves = (long)bands * nseg;
-    hipLaunchKernelGGL(gauss_axis1_mfma_grad_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, stream, a, g, bands, nseg);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
@@ -1935,34 +1630,14 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             rows.out_rows = c1 - c0;
             float* a_k = (float*)pa + (size_t)(c0 - s0) * b.nx;
             float* b_k = (float*)pb + (size_t)(c0 - s0) * b.nx;
-            const bool fused = mfma_grad_fused(gaussian_radius(sigma), b.nx);
             TOPO_TRY(run_axis0_mfma(rows, sigma, a_k, 1));
-            if (!fused) TOPO_TRY(run_axis1_mfma(a_k, c1 - c0, b.nx, sigma, b_k, 2));
+            TOPO_TRY(run_axis1_mfma(a_k, c1 - c0, b.nx, sigma, b_k, 2));
             if (use_aux) {
                 TOPO_HIP(hipEventRecord(c.aux_ready[k], c.compute));
                 TOPO_HIP(hipStreamWaitEvent(c.aux, c.aux_ready[k], 0));
             }
             const int o1 = c1 == s1 ? out_end : c1 - 1;
-            if (o1 > o0 && fused) {
-                // axis 1 and the epilogue in one kernel, from the axis-0 plane (rows s0 ... c1 are there), beside the
-                // axis-0 pass of the next chunk
-                GradArgs gk = g;
-                const size_t shift = (size_t)(o0 - b.out_row0) * b.nx;
-                gk.out_row0 = o0;
-                gk.out_rows = o1 - o0;
-                gk.dx = dx ? dx + shift : nullptr;
-                gk.dy = dy ? dy + shift : nullptr;
-                gk.slope = slope ? slope + shift : nullptr;
-                gk.aspect = aspect ? aspect + shift : nullptr;
-                if (res_mode == TOPO_AMD_RES_2D) {
-                    gk.res_x = g.res_x + shift;
-                    gk.res_y = g.res_y + shift;
-                }
-                gk.s_row0 = s0;
-                gk.s_rows = c1 - s0;
-                TOPO_TRY(run_axis1_mfma_grad((const float*)pa, sigma, gk, 2, use_aux ? c.aux : c.compute));
-                o0 = o1;
-            } else if (o1 > o0) {
+            if (o1 > o0) {
                 GradArgs gk = g;
                 const size_t shift = (size_t)(o0 - b.out_row0) * b.nx;
                 gk.out_row0 = o0;
@@ -2007,11 +1682,6 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         const bool mfma = mfma_radius(gaussian_radius(sigma), b.nx, true) && mfma_rows_ok(rows, gaussian_radius(sigma));
         if (mfma) TOPO_TRY(run_axis0_mfma(rows, sigma, (float*)plane_a, 1));
         else TOPO_TRY(run_axis0(rows, sigma, (float*)plane_a, 1, false));
-        if (mfma && mfma_grad_fused(gaussian_radius(sigma), b.nx)) {
-            g.s_row0 = s0;
-            g.s_rows = s_rows;
-            return run_axis1_mfma_grad((const float*)plane_a, sigma, g, 2, c.compute);
-        }
         // short and medium filters: LDS-tiled axis 1 (9.8 vs 13.6 ms at sigma 3.25 on 32768^2); long
         // filters: wave-shift axis 1 (26.7 vs 27.8 ms at sigma 30.25) while enough lanes produce output
         static const int fused_max = [] {
