@@ -46,6 +46,34 @@ class FakeDataset:
 
 
 @pytest.mark.gpu
+def test_compute_tpi_pairs_small_scales_in_one_pass():
+    """Un-smoothed TPI at small scales goes two sizes per pass over the DEM (Block.tpi_multi); the planes, their
+    names and the NaN re-insertion are those of the scale-by-scale loop (reference topo.py:132-141)."""
+    from oracle import topo_oracle as orc
+    from topo_descriptors_amd import helpers as hlp, topo
+
+    ny, nx = 200, 256
+    dem = orc.synthetic_dem(ny, nx, seed=11, integer=False)
+    x = 2600000.0 + 30.0 * np.arange(nx)
+    y = 1200000.0 - 30.0 * np.arange(ny)
+    ds = FakeDataset(dem, x, y)
+    scales = [150, 200, 500, 260, 330, 200]        # 5, 7, 17, 9, 11 px, and 7 px once more
+    px, _ = hlp.scale_to_pixel(scales, ds)
+    assert list(px) == [5, 7, 17, 9, 11, 7]
+    ind_nans = (np.array([3, 50]), np.array([4, 60]))
+    out = batch.compute_tpi(ds, scales, smth_factors=[None, None, None, None, None, 1], ind_nans=ind_nans, outdir=None)
+    assert set(out) == {"TPI_150M", "TPI_200M", "TPI_500M", "TPI_260M", "TPI_330M", "TPI_200M_SMTHFACT1"}
+    for scale, size in zip(scales[:5], px[:5]):
+        got, want = out[f"TPI_{scale}M"], topo.tpi(dem, int(size))
+        assert np.isnan(got[3, 4]) and np.isnan(got[50, 60])
+        want[ind_nans] = np.nan
+        assert np.array_equal(got, want, equal_nan=True), scale
+    want = topo.tpi(dem, 7, sigma=7 / 4)
+    want[ind_nans] = np.nan
+    assert np.array_equal(out["TPI_200M_SMTHFACT1"], want, equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_wrappers_equal_the_single_calls(tmp_path):
     from oracle import topo_oracle as orc
     from topo_descriptors_amd import helpers as hlp, topo

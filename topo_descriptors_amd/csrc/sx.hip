@@ -31,19 +31,25 @@ struct SxChain8 {
     int pad[7];
     float inv[8];  // 1 / distance in metres of pixel m of the chain; NaN past the end of a shorter chain
 };
+struct SxChain4 {
+    int off;
+    float inv[4];
+    int pad[3];
+};
 struct SxChain2 {
     int off;
     float inv[2];
     int pad;
 };
-static_assert(sizeof(SxChain8) == 64 && sizeof(SxChain2) == 16, "scalar-load friendly entries");
+static_assert(sizeof(SxChain8) == 64 && sizeof(SxChain4) == 32 && sizeof(SxChain2) == 16, "scalar-load friendly entries");
 
 struct SxArgs {
     const float* in;
     float* out;
     const SxChain8* tab8;
+    const SxChain4* tab4;
     const SxChain2* tab2;
-    int n8, n2;
+    int n8, n4, n2;
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
     int window;
@@ -131,6 +137,24 @@ __global__ __launch_bounds__(NW * 64) void sx_kernel(SxArgs p) {
             }
         }
     }
+    // chains of 4 (round 3): the runs of 3 ... 6 neighbours that diagonal sectors are made of went in twos (or in a
+    // padded eight) before: 460 comparisons for the 358 ray pixels of azimuth 45 at radius 2000 m
+    for (int c = 0; c < p.n4; ++c) {
+        const SxChain4 e = p.tab4[c];
+        const float* q = Lw + e.off;
+        float w[kSxOwn + 3];
+#pragma unroll
+        for (int j = 0; j < kSxOwn + 3; ++j) w[j] = q[j * S];
+#pragma unroll
+        for (int m = 0; m < 4; m += 2) {
+#pragma unroll
+            for (int k = 0; k < kSxOwn; ++k) {
+                const float z0 = (w[m + k] - centre[k]) * e.inv[m];
+                const float z1 = (w[m + 1 + k] - centre[k]) * e.inv[m + 1];
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(best[k]) : "v"(z0), "v"(z1));
+            }
+        }
+    }
     for (int c = 0; c < p.n2; c += 4) {  // four entries per scalar load (the table is padded to a multiple of 4)
         struct Quad {
             SxChain2 e[4];
@@ -205,16 +229,17 @@ int sx_stride_for(int cols_l) {
 }
 
 // Cut the unique ray pixels into chains along one axis: runs of neighbours in eights, what is left of a run (or
-// a run shorter than 5) in twos.  `along_x`: chains run along di (same dj), else along dj (same di).
+// a run shorter than 7) in fours and twos, so that at most one comparison per run is padding.  `along_x`: chains run along di (same dj), else along dj (same di).
 typedef std::vector<std::pair<std::pair<int, int>, double>> SxPoints;
 void sx_chains(SxPoints pts, bool along_x, int stride, int dj_min, int di_min, std::vector<SxChain8>* t8,
-               std::vector<SxChain2>* t2) {
+               std::vector<SxChain4>* t4, std::vector<SxChain2>* t2) {
     auto line = [&](const SxPoints::value_type& q) { return along_x ? q.first.first : q.first.second; };
     auto pos = [&](const SxPoints::value_type& q) { return along_x ? q.first.second : q.first.first; };
     std::sort(pts.begin(), pts.end(), [&](const auto& x, const auto& y) {
         return std::make_pair(line(x), pos(x)) < std::make_pair(line(y), pos(y));
     });
     t8->clear();
+    t4->clear();
     t2->clear();
     for (size_t n = 0; n < pts.size();) {
         size_t run = 1;
@@ -222,12 +247,19 @@ void sx_chains(SxPoints pts, bool along_x, int stride, int dj_min, int di_min, s
         for (size_t done = 0; done < run;) {
             const size_t left = run - done, first = n + done;
             const int off = (pts[first].first.first - dj_min) * stride + (pts[first].first.second - di_min);
-            if (left >= 5) {
+            if (left >= 7) {
                 SxChain8 e{};
                 e.off = off;
                 const size_t m = std::min<size_t>(8, left);
                 for (size_t z = 0; z < 8; ++z) e.inv[z] = z < m ? (float)(1.0 / pts[first + z].second) : std::nanf("");
                 t8->push_back(e);
+                done += m;
+            } else if (left >= 3) {  // 3 ... 6: a four (and a two for what is left of 5 or 6)
+                SxChain4 e{};
+                e.off = off;
+                const size_t m = std::min<size_t>(4, left);
+                for (size_t z = 0; z < 4; ++z) e.inv[z] = z < m ? (float)(1.0 / pts[first + z].second) : std::nanf("");
+                t4->push_back(e);
                 done += m;
             } else {
                 SxChain2 e{};
@@ -256,8 +288,10 @@ struct SxMultiArgs {
     float* out[kMaxAz];
     int window[kMaxAz];
     const SxChain8* tab8;   // chains sorted by class
+    const SxChain4* tab4;
     const SxChain2* tab2;   // (every class padded to a multiple of 4 entries)
     const int* cls_first8;  // n_cls + 1 entries each
+    const int* cls_first4;
     const int* cls_first2;
     const int* cls_mask;    // bit a: sector a contains the class
     int n_cls, n_az;
@@ -319,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void sx_multi_kernel(SxMultiArgs p) {
         float top[OWN];
 #pragma unroll
         for (int k = 0; k < OWN; ++k) top[k] = -INFINITY;
-        const int e8 = p.cls_first8[c + 1], e2 = p.cls_first2[c + 1];
+        const int e8 = p.cls_first8[c + 1], e4 = p.cls_first4[c + 1], e2 = p.cls_first2[c + 1];
         for (int n = p.cls_first8[c]; n < e8; ++n) {
             const SxChain8 e = p.tab8[n];
             const float* q = Lw + e.off;
@@ -328,6 +362,22 @@ __global__ __launch_bounds__(kThreads) void sx_multi_kernel(SxMultiArgs p) {
             for (int j = 0; j < OWN + 7; ++j) w[j] = q[j * S];
 #pragma unroll
             for (int m = 0; m < 8; m += 2) {
+#pragma unroll
+                for (int k = 0; k < OWN; ++k) {
+                    const float z0 = (w[m + k] - centre[k]) * e.inv[m];
+                    const float z1 = (w[m + 1 + k] - centre[k]) * e.inv[m + 1];
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(top[k]) : "v"(z0), "v"(z1));
+                }
+            }
+        }
+        for (int n = p.cls_first4[c]; n < e4; ++n) {
+            const SxChain4 e = p.tab4[n];
+            const float* q = Lw + e.off;
+            float w[OWN + 3];
+#pragma unroll
+            for (int j = 0; j < OWN + 3; ++j) w[j] = q[j * S];
+#pragma unroll
+            for (int m = 0; m < 4; m += 2) {
 #pragma unroll
                 for (int k = 0; k < OWN; ++k) {
                     const float z0 = (w[m + k] - centre[k]) * e.inv[m];
@@ -547,10 +597,12 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     }
     // chains along the axis that needs fewer comparisons (padding included)
     std::vector<SxChain8> t8[2];
+    std::vector<SxChain4> t4[2];
     std::vector<SxChain2> t2[2];
-    for (int ax = 0; ax < 2; ++ax) sx_chains(pts, ax == 1, stride, dj_min, di_min, &t8[ax], &t2[ax]);
-    const bool along_x = 8 * t8[1].size() + 2 * t2[1].size() < 8 * t8[0].size() + 2 * t2[0].size();
+    for (int ax = 0; ax < 2; ++ax) sx_chains(pts, ax == 1, stride, dj_min, di_min, &t8[ax], &t4[ax], &t2[ax]);
+    const bool along_x = 8 * t8[1].size() + 4 * t4[1].size() + 2 * t2[1].size() < 8 * t8[0].size() + 4 * t4[0].size() + 2 * t2[0].size();
     const std::vector<SxChain8>& c8 = t8[along_x];
+    const std::vector<SxChain4>& c4 = t4[along_x];
     std::vector<SxChain2>& c2 = t2[along_x];
     while (c2.size() % 4) {  // the kernel takes four at a time: entries whose products are all NaN
         SxChain2 e{};
@@ -558,15 +610,19 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
         c2.push_back(e);
     }
     const SxChain8 none8{};
+    const SxChain4 none4{};
     const SxChain2 none2{};
-    void *d_t8 = nullptr, *d_t2 = nullptr;  // (an empty table still uploads one entry; its count stays 0)
+    void *d_t8 = nullptr, *d_t4 = nullptr, *d_t2 = nullptr;  // (an empty table still uploads one entry; its count stays 0)
     TOPO_TRY(upload_table(0, c8.empty() ? &none8 : c8.data(), std::max<size_t>(1, c8.size()) * sizeof(SxChain8), &d_t8));
     TOPO_TRY(upload_table(1, c2.empty() ? &none2 : c2.data(), std::max<size_t>(1, c2.size()) * sizeof(SxChain2), &d_t2));
+    TOPO_TRY(upload_table(2, c4.empty() ? &none4 : c4.data(), std::max<size_t>(1, c4.size()) * sizeof(SxChain4), &d_t4));
     a.in = b.in;
     a.out = out;
     a.tab8 = (const SxChain8*)d_t8;
+    a.tab4 = (const SxChain4*)d_t4;
     a.tab2 = (const SxChain2*)d_t2;
     a.n8 = (int)c8.size();
+    a.n4 = (int)c4.size();
     a.n2 = (int)c2.size();
     a.in_rows = b.in_rows;
     a.in_row0 = b.in_row0;
@@ -580,7 +636,7 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     // 128-row tiles with 8 waves while two such blocks share a CU
     int waves = 4;
     size_t lds_used = lds;
-    if (!along_x && b.out_rows >= 2 * kSxTile && 8 * c8.size() + 2 * c2.size() >= 256) {
+    if (!along_x && b.out_rows >= 2 * kSxTile && 8 * c8.size() + 4 * c4.size() + 2 * c2.size() >= 256) {
         const size_t lds8 = (size_t)(a.rows_l + kSxTile + 8) * stride * sizeof(float);
         if (lds8 <= 80 * 1024) {
             waves = 8;
@@ -680,11 +736,12 @@ int launch_sx_group(const Block& b, const std::vector<SectorPoints>& sec, int a0
     {
         size_t work[2] = {0, 0};
         std::vector<SxChain8> t8;
+        std::vector<SxChain4> t4;
         std::vector<SxChain2> t2;
         for (int ax = 0; ax < 2; ++ax)
             for (auto& pts : cls) {
-                sx_chains(pts, ax == 1, 1, a.dj_min, a.di_min, &t8, &t2);
-                work[ax] += 8 * t8.size() + 2 * ((t2.size() + 3) / 4 * 4);
+                sx_chains(pts, ax == 1, 1, a.dj_min, a.di_min, &t8, &t4, &t2);
+                work[ax] += 8 * t8.size() + 4 * t4.size() + 2 * ((t2.size() + 3) / 4 * 4);
             }
         along_x = work[1] < work[0];
     }
@@ -695,31 +752,42 @@ int launch_sx_group(const Block& b, const std::vector<SectorPoints>& sec, int a0
     TOPO_REQUIRE(stride != 0, "sx_multi: no kernel for a tile of %d columns", a.cols_l);
     const size_t lds = (size_t)(a.rows_l + 8) * stride * sizeof(float);
     std::vector<SxChain8> tab8;
+    std::vector<SxChain4> tab4;
     std::vector<SxChain2> tab2;
-    std::vector<int> first8, first2;
+    std::vector<int> first8, first4, first2;
     for (auto& pts : cls) {
         std::vector<SxChain8> t8;
+        std::vector<SxChain4> t4;
         std::vector<SxChain2> t2;
-        sx_chains(pts, along_x, stride, a.dj_min, a.di_min, &t8, &t2);
+        sx_chains(pts, along_x, stride, a.dj_min, a.di_min, &t8, &t4, &t2);
         while (t2.size() % 4) {
             SxChain2 e{};
             e.inv[0] = e.inv[1] = std::nanf("");
             t2.push_back(e);
         }
         first8.push_back((int)tab8.size());
+        first4.push_back((int)tab4.size());
         first2.push_back((int)tab2.size());
         tab8.insert(tab8.end(), t8.begin(), t8.end());
+        tab4.insert(tab4.end(), t4.begin(), t4.end());
         tab2.insert(tab2.end(), t2.begin(), t2.end());
     }
     first8.push_back((int)tab8.size());
+    first4.push_back((int)tab4.size());
     first2.push_back((int)tab2.size());
     if (tab8.empty()) tab8.push_back(SxChain8{});
+    if (tab4.empty()) tab4.push_back(SxChain4{});
     if (tab2.empty()) tab2.push_back(SxChain2{});
-    void *d_t8 = nullptr, *d_t2 = nullptr, *d_f8 = nullptr, *d_f2 = nullptr, *d_mask = nullptr;
+    // one table for the three lists of class boundaries (six table slots in all)
+    const size_t nf = first8.size();
+    std::vector<int> firsts(first8);
+    firsts.insert(firsts.end(), first4.begin(), first4.end());
+    firsts.insert(firsts.end(), first2.begin(), first2.end());
+    void *d_t8 = nullptr, *d_t4 = nullptr, *d_t2 = nullptr, *d_f = nullptr, *d_mask = nullptr;
     TOPO_TRY(upload_table(0, tab8.data(), tab8.size() * sizeof(SxChain8), &d_t8));
     TOPO_TRY(upload_table(1, tab2.data(), tab2.size() * sizeof(SxChain2), &d_t2));
-    TOPO_TRY(upload_table(2, first8.data(), first8.size() * sizeof(int), &d_f8));
-    TOPO_TRY(upload_table(3, first2.data(), first2.size() * sizeof(int), &d_f2));
+    TOPO_TRY(upload_table(2, firsts.data(), firsts.size() * sizeof(int), &d_f));
+    TOPO_TRY(upload_table(3, tab4.data(), tab4.size() * sizeof(SxChain4), &d_t4));
     TOPO_TRY(upload_table(4, mask.data(), mask.size() * sizeof(int), &d_mask));
     a.in = b.in;
     for (int k = 0; k < kMaxAz; ++k) {
@@ -727,9 +795,11 @@ int launch_sx_group(const Block& b, const std::vector<SectorPoints>& sec, int a0
         a.window[k] = k < a1 - a0 ? window[a0 + k] : 0;
     }
     a.tab8 = (const SxChain8*)d_t8;
+    a.tab4 = (const SxChain4*)d_t4;
     a.tab2 = (const SxChain2*)d_t2;
-    a.cls_first8 = (const int*)d_f8;
-    a.cls_first2 = (const int*)d_f2;
+    a.cls_first8 = (const int*)d_f;
+    a.cls_first4 = (const int*)d_f + nf;
+    a.cls_first2 = (const int*)d_f + 2 * nf;
     a.cls_mask = (const int*)d_mask;
     a.n_cls = (int)mask.size();
     a.n_az = a1 - a0;
