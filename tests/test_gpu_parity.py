@@ -150,26 +150,64 @@ def test_gaussian_anisotropic_and_identity(golden):
     assert np.array_equal(topo.dem(dem, 0.1), ndimage.gaussian_filter(dem, 0.1))  # radius 0
 
 
-@pytest.mark.parametrize("sigma", [0.75, 2.25, 3.25, 6.0])
+@pytest.mark.parametrize("sigma", [0.75, 2.25, 3.25, 6.0, 12.0])
 def test_gaussian_nan_footprint(sigma):
-    """A non-finite sample makes non-finite every output ndimage.gaussian_filter (topo.py:80) makes non-finite,
-    and at most 37 more outputs along each axis: the filter is evaluated in tiles against taps padded with
-    exact zeros (vector-ALU kernels: up to a whole chunk of 8 or 16 taps; matrix-core kernels from radius 16:
-    a banded 32-row Toeplitz tile whose window is padded to a multiple of 8 samples), and 0 x NaN = NaN.  The
-    accumulation offsets must not spread it further (a non-finite offset falls back to 0), and the finite
-    outputs keep their accuracy."""
+    """A non-finite sample makes non-finite every output ndimage.gaussian_filter (topo.py:80) makes non-finite.  On
+    the matrix cores (radius int(4 sigma + 0.5) from 4, width a multiple of 4) EXACTLY those: the kernels evaluate 32
+    outputs against a zero-padded band of taps (0 x NaN = NaN), mark the tiles that came out non-finite, and a repair
+    pass takes them again over each output's own window (round 3; before, up to 37 more outputs along each axis).
+    The vector-ALU kernels (radius below 4) pad their taps to a chunk of 8: up to 7 more outputs towards lower
+    indices.  The accumulation offsets must not spread it further (a non-finite offset falls back to 0), and the
+    finite outputs keep their accuracy."""
     from scipy import ndimage
     dem = orc.synthetic_dem(200, 300, seed=21)
     dem[100, 151] = np.nan
     dem[7, 290] = np.inf
+    dem[150:153, 40] = -np.inf
     want = ndimage.gaussian_filter(dem, sigma)
     got = topo.dem(dem, sigma)
     bad_ref, bad = ~np.isfinite(want), ~np.isfinite(got)
     assert not np.any(bad_ref & ~bad)
-    allowed = ndimage.binary_dilation(bad_ref, structure=np.ones((75, 75), bool))
-    assert not np.any(bad & ~allowed)
+    if int(4 * sigma + 0.5) >= 4:
+        assert np.array_equal(bad, bad_ref), int(np.sum(bad & ~bad_ref))
+        assert np.array_equal(np.isnan(got), np.isnan(want))  # and NaN where the reference has NaN, inf where it has inf
+    else:
+        allowed = ndimage.binary_dilation(bad_ref, structure=np.ones((17, 17), bool))
+        assert not np.any(bad & ~allowed)
     ok = ~bad
     assert np.max(np.abs(got[ok] - want[ok])) <= 1e-3
+
+
+def test_gaussian_nan_repair_is_partition_invariant():
+    """Row blocks with the ghost rows the library asks for give the single block's bits around non-finite samples
+    too (the repair pass works on the global tile grid like the kernels it follows)."""
+    from topo_descriptors_amd import _lib, device as d, shard
+    gny, nx, sigma = 420, 512, 3.25
+    dem = orc.synthetic_dem(gny, nx, seed=77)
+    dem[139, 200] = np.nan     # next to a block seam for 3 blocks (rows 140, 280)
+    dem[300, 31:34] = np.nan   # across a 32-column tile boundary
+    dev = d.DeviceArray.from_host(dem)
+    whole = d.DeviceArray(gny, nx)
+    d.Block(dev).gaussian(sigma, sigma, whole)
+    d.sync()
+    w = whole.to_host()
+    up, down = shard.halo_rows(_lib.DESC_GAUSS, sigma)
+    for nb in (2, 3):
+        parts = []
+        for row0, rows in shard.split_rows(gny, nb):
+            lo, hi = max(0, row0 - up), min(gny, row0 + rows + down)
+            part = d.DeviceArray.from_host(dem[lo:hi])
+            out = d.DeviceArray(rows, nx)
+            d.Block(part, row0=lo, gny=gny).gaussian(sigma, sigma, out, out_row0=row0, out_rows=rows)
+            d.sync()
+            parts.append(out.to_host())
+            part.free()
+            out.free()
+        assert np.array_equal(np.concatenate(parts), w, equal_nan=True), nb
+    from scipy import ndimage
+    assert np.array_equal(np.isnan(w), np.isnan(ndimage.gaussian_filter(dem, sigma)))
+    dev.free()
+    whole.free()
 
 
 @pytest.mark.parametrize("sigma", [4.0, 4.25, 5.25, 6.25, 9.0, 30.25])

@@ -314,7 +314,7 @@ int topo_amd_shutdown(void) {
         g_comm = Comm();
     }
     valley_fft_release();  // FFT plans hold the stream that goes away below
-    for (int i = 0; i < 10; ++i)
+    for (int i = 0; i < 12; ++i)
         if (c.ws[i]) (void)hipFree(c.ws[i]);
     for (int i = 0; i < 6; ++i) {
         if (c.tab[i]) (void)hipFree(c.tab[i]);

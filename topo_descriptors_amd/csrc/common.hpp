@@ -56,8 +56,8 @@ struct Context {
     hipEvent_t input_ready = nullptr;  // compute -> comm dependency
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // grow-only device workspaces (never freed between calls: no hipMalloc in the hot path)
-    void* ws[10] = {};
-    size_t ws_bytes[10] = {};
+    void* ws[12] = {};
+    size_t ws_bytes[12] = {};
     // small parameter tables (disc runs, gaussian taps, sx offsets, resolutions)
     void* tab[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t tab_bytes[6] = {0, 0, 0, 0, 0, 0};

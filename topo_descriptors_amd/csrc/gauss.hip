@@ -43,6 +43,7 @@ struct GaussArgs {
     int out_row0, out_rows;
     int radius, nchunks;
     int group0;  // axis 0: first row group (global numbering) that intersects the output rows
+    unsigned char* flags;  // matrix-core kernels: one byte per 32 x 32 output tile, 1 = an output is not finite
 };
 
 // Register tiling shared by both axes: a thread produces TB consecutive outputs along the
@@ -856,6 +857,15 @@ __global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int 
             }
         }
         STAMP(2)
+        {
+            // A non-finite sample anywhere in the tile's padded band makes EVERY output of its column non-finite (the
+            // taps outside an output's window are zeros, and 0 x NaN = 0 x inf = NaN), so one accumulator per lane
+            // tells: the tile is marked for gauss_mfma_repair_kernel.  (An output that is non-finite by right - its own
+            // window holds the sample - marks the tile too and is recomputed to the same value.)
+            const bool bad = !(fabsf(acc[0] + c) <= 3.0e38f);
+            const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
+            if (lane == 0) p.flags[((size_t)t * gridDim.x + blockIdx.x) * 4 + wave] = any != 0 ? 1 : 0;
+        }
         const int ox = x0 + xw;
         if (ox < p.nx) {
             if (y0 >= p.out_row0 && y0 + 32 <= p.out_row0 + p.out_rows) {
@@ -1035,6 +1045,16 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
 #pragma unroll
             for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + sl] = pre[q];
         }
+        {
+            // Here a non-finite sample spoils its own ROW of the tile (the data is the A operand), and a lane holds
+            // 16 rows of one column: NaN and inf survive a sum, so 15 additions and one class test stand for 16 tests.
+            float ssum = acc[0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) ssum += acc[v];
+            const bool bad = !(fabsf(ssum + c) <= 3.0e38f);
+            const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
+            if (lane == 0) p.flags[(size_t)band * ntile + t] = any != 0 ? 1 : 0;
+        }
         const int ox = x0 + i;  // D: column = lane & 31
         float cr[16];  // the offsets of the 16 rows this lane holds: requested together, one wait
 #pragma unroll
@@ -1057,6 +1077,63 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
         }
         base += 32;
         base = base >= RC ? base - RC : base;
+    }
+}
+
+// Repair pass of the matrix-core Gaussian.  The banded-Toeplitz products multiply the zero taps
+// outside an output's own 2 R + 1 window in like the others, and 0 x NaN is NaN: a non-finite sample spoils all 32
+// outputs of every tile whose padded band holds it, up to 31 + 6 rows / columns beyond what
+// ndimage.gaussian_filter spoils (reference topo.py:80).  The MFMA kernels mark such tiles; this kernel takes the
+// marked ones again tap by tap - the same offset c, the same differences x - c, the ascending chain of fused
+// multiply-adds over the output's own window only - so an output is NaN exactly where its window holds a
+// non-finite sample, as in the reference, and a finite window gets the value the matrix cores give it.  On a DEM
+// without non-finite samples the launch is a scan of the flag bytes (64 per ballot).
+template <bool AXIS1>
+__global__ __launch_bounds__(64) void gauss_mfma_repair_kernel(GaussArgs p, int units_a, int units_b, int first_a, int rows_plane) {
+    // AXIS1 false: unit (a, b) = row tile first_a + a (32 rows on the global grid), columns 32 b ... 32 b + 31
+    // AXIS1 true:  unit (a, b) = band a (plane rows 32 a ...), columns 32 b ...
+    const int lane = threadIdx.x;
+    const long units = (long)units_a * units_b;
+    const int R = p.radius;
+    for (long base = (long)blockIdx.x * 64; base < units; base += (long)gridDim.x * 64) {
+        const long mine = base + lane;
+        unsigned long long marked = __builtin_amdgcn_ballot_w64(mine < units && p.flags[mine < units ? mine : 0] != 0);
+        while (marked) {
+            const int bit = __builtin_ctzll(marked);
+            marked &= marked - 1;
+            const long u = base + bit;
+            const int a = (int)(u / units_b), b = (int)(u % units_b);
+            const int j = lane & 31, h = lane >> 5;  // lane: column (axis 0) or row (axis 1) j, 16 outputs each
+            if (!AXIS1) {
+                const int y0 = (first_a + a) * 32, x = 32 * b + j;
+                if (x >= p.nx) continue;
+                auto in_at = [&](int gy) {
+                    gy = reflect_index(gy, p.gny);
+                    gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
+                    return p.in[(size_t)(gy - p.in_row0) * p.nx + x];
+                };
+                const float c = finite_or_zero(in_at(y0 + 16));
+                for (int k = 0; k < 16; ++k) {
+                    const int oy = y0 + 16 * h + k;
+                    if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
+                    float acc = 0.0f;
+                    for (int q = 0; q <= 2 * R; ++q) acc = fmaf(p.taps[q], in_at(oy - R + q) - c, acc);
+                    p.out[(size_t)(oy - p.out_row0) * p.nx + x] = c + acc;
+                }
+            } else {
+                const int r = 32 * a + j, x0 = 32 * b;
+                if (r >= rows_plane) continue;
+                const float* row = p.in + (size_t)r * p.nx;
+                const float c = finite_or_zero(row[reflect_index(x0 + 16, p.nx)]);
+                for (int k = 0; k < 16; ++k) {
+                    const int ox = x0 + 16 * h + k;
+                    if (ox >= p.nx) continue;
+                    float acc = 0.0f;
+                    for (int q = 0; q <= 2 * R; ++q) acc = fmaf(p.taps[q], row[reflect_index(ox - R + q, p.nx)] - c, acc);
+                    p.out[(size_t)r * p.nx + ox] = c + acc;
+                }
+            }
+        }
     }
 }
 
@@ -1167,7 +1244,15 @@ int run_axis0_mfma(const Block& b, double sigma, float* out, int table_slot) {
     const int per = (ntiles + splits - 1) / splits;
     TOPO_TRY(check_grid_rows((ntiles + per - 1) / per, "gaussian (matrix-core axis 0)"));
     dim3 grid(strips, (ntiles + per - 1) / per);
+    // one flag byte per 32 x 32 output tile (every tile writes its own: nothing to clear), then the repair pass
+    const long units = (long)ntiles * strips * 4;
+    void* flags = nullptr;
+    TOPO_TRY(workspace(10, (size_t)units, &flags));
+    a.flags = (unsigned char*)flags;
     hipLaunchKernelGGL(gauss_axis0_mfma_kernel, grid, dim3(256), lds, c.compute, a, tile_first, ntiles, per);
+    TOPO_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gauss_mfma_repair_kernel<false>, dim3((unsigned)std::min<long>(1024, (units + 63) / 64)), dim3(64), 0, c.compute,
+                       a, ntiles, strips * 4, tile_first, 0);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
@@ -1212,7 +1297,14 @@ int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, 
         }
     }
     const long waves = (long)bands * nseg;
+    const long units = (long)bands * ntile;
+    void* flags = nullptr;
+    TOPO_TRY(workspace(10, (size_t)units, &flags));
+    a.flags = (unsigned char*)flags;
     hipLaunchKernelGGL(gauss_axis1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, c.compute, a, rows, nseg);
+    TOPO_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gauss_mfma_repair_kernel<true>, dim3((unsigned)std::min<long>(1024, (units + 63) / 64)), dim3(64), 0, c.compute,
+                       a, bands, ntile, 0, rows);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }

@@ -68,8 +68,7 @@ def tpi(dem, size, sigma=None):
     diameter ``size`` pixels, centre excluded; optional Gaussian pre-smoothing ``sigma``
     (reference topo.py:145-181).  float32 in, float32 out; DataArray in, DataArray out.
 
-    With ``sigma`` the pre-smoothing is :func:`dem`'s: see there for how far a non-finite sample reaches (further
-    than in the reference's ``ndimage.gaussian_filter``).  Without it a NaN reaches the windows that contain it and
+    With ``sigma`` the pre-smoothing is :func:`dem`'s: see there for how far a non-finite sample reaches.  Without it a NaN reaches the windows that contain it and
     some more pixels of its tile (it travels down the column prefix sums); the reference's FFT convolution makes the
     whole array NaN."""
     values, rewrap = _unwrap(dem)
@@ -149,13 +148,13 @@ def dem(dem, sigma):
     """Gaussian-smoothed DEM, reflect boundary, 4-sigma truncation (reference topo.py:62-80).
     ``sigma`` may be a scalar or an (axis0, axis1) pair.
 
-    Non-finite samples: a NaN / inf in the DEM makes NaN at least every output whose window contains it, as in the
-    reference, and - unlike ``scipy.ndimage.gaussian_filter`` - up to 37 pixels beyond it along each axis when the
-    smoothing runs on the matrix cores (Gaussian radius ``int(4 sigma + 0.5)`` of 4 ... 121 and a DEM width that is a
-    multiple of 4): those kernels evaluate 32 outputs at a time against a zero-padded band of taps, and 0 x NaN is
-    NaN.  Fill or mask nodata before calling (``helpers.fill_na`` / ``fill_na_array``), as the reference's driver
-    does (scripts/compute_topo_descriptors.py:21-22); ``tests/test_gpu_parity.py::test_gaussian_nan_footprint`` pins
-    the bound.
+    Non-finite samples: a NaN / inf in the DEM makes non-finite every output whose window contains it, as in
+    ``scipy.ndimage.gaussian_filter`` - and exactly those when the smoothing runs on the matrix cores (Gaussian radius
+    ``int(4 sigma + 0.5)`` of 4 ... 121 and a DEM width that is a multiple of 4): those kernels mark the tiles a
+    non-finite sample spoiled (they multiply a zero-padded band of taps in, and 0 x NaN is NaN) and a repair pass takes
+    the marked tiles again over each output's own window.  The vector-ALU kernels (shorter or much longer filters,
+    other widths) pad their taps to chunks of 8 or 16 and spoil up to one chunk more towards lower indices.
+    ``tests/test_gpu_parity.py::test_gaussian_nan_footprint`` pins both.
     """
     values, rewrap = _unwrap(dem)
     _check_2d(values, "dem")
