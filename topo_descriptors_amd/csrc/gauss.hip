@@ -44,6 +44,7 @@ struct GaussArgs {
     int radius, nchunks;
     int group0;  // axis 0: first row group (global numbering) that intersects the output rows
     unsigned char* flags;  // matrix-core kernels: one byte per 32 x 32 output tile, 1 = an output is not finite
+    float tap_scale, out_scale;  // f16 matrix-core kernels: taps are multiplied by tap_scale (a power of two), sums by out_scale
 };
 
 // Register tiling shared by both axes: a thread produces TB consecutive outputs along the
@@ -1137,6 +1138,470 @@ __global__ __launch_bounds__(64) void gauss_mfma_repair_kernel(GaussArgs p, int 
     }
 }
 
+// ---- the banded products on the f16 matrix pipe (round 3) ------------------------------------------------
+// v_mfma_f32_32x32x16_f16 does 16 x the multiply-adds of the f32 instruction per cycle.  A float32 difference
+// d = (x - c) / 4 (c: the tile's offset as above; the quarter keeps |d| inside f16 for any |x| <= 1e5) is split
+// on the fly into d = h + l + e, h = d cut to 11 significant bits (exact in f16), l = f16(d - h) rounded to
+// nearest, |e| <= 2^-22 |d|; a tap t 2^k (k: the scale that puts the largest tap in [512, 1024)) into th + tm the
+// same way, once per kernel, in registers.  Three products stand for t d: th h + tm h + th l (the fourth, tm l, is
+// <= 2^-22 t d like e).  The sums are float32 inside the matrix pipe, 3 roundings per 16 taps instead of 16, on
+// values of the size of x - c: the error against the exact filter is that of the f32 chain or smaller
+// (tools/gauss_f16_error.py).  x = c over a lake gives h = l = 0 and the output c, as before.
+// What changes is the order of the additions: 16 taps at a time, on a grid of steps that starts Rp = R rounded up
+// to 16 above (left of) the 32-output tile.  Tiles sit on global multiples of 32 on both axes, so an output still
+// sees the same operands in the same places whatever row block it is computed in.
+// Non-finite and absurd samples (|x| > 1e5) never reach the matrix pipe: the loader stages them as 0, remembers
+// that the window holds one, and the tile is marked; the repair pass then recomputes, tap by tap in float32, the
+// outputs whose OWN window holds such a sample and leaves the others alone (they are what they would be without
+// it: a zero tap times 0 or times a finite sample adds the same nothing).  The mark may be conservative (a block's
+// clamped ghost rows, neighbouring columns): it costs time, never bits.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr float kWild = 1.0e5f;
+__device__ __forceinline__ bool wild(float x) { return !(fabsf(x) <= kWild); }
+
+__device__ __forceinline__ f32x2 pk_fma_pure(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 o;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+__device__ __forceinline__ f32x2 pk_sub_pure(f32x2 a, f32x2 c) {
+    f32x2 o;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(c));
+    return o;
+}
+
+// lane (j = lane & 31, g = lane >> 5) of step s holds the taps T[j][16 s + 8 g + q], q = 0 ... 7: the operand the
+// Toeplitz factor has on either side of the product (A for axis 0, B for axis 1: the band is symmetric)
+template <int S>
+__device__ __forceinline__ void build_tap_blocks(const float* taps, int R, float scale, int lane, f16x8 (&hi)[S], f16x8 (&lo)[S]) {
+    const int j = lane & 31, g = lane >> 5, Rp = 8 * (S - 2);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int n = 16 * s + 8 * g + q - j - (Rp - R);
+            const float t = (n >= 0 && n <= 2 * R) ? taps[n] * scale : 0.0f;
+            const _Float16 th = (_Float16)t;
+            hi[s][q] = th;
+            lo[s][q] = (_Float16)(t - (float)th);
+        }
+    }
+}
+
+// 8 samples -> (x - c) / 4 -> f16 pair of operands
+__device__ __forceinline__ void split8(const float (&x)[8], f32x2 quarter, f32x2 mcq, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const f32x2 d = pk_fma_pure(f32x2{x[2 * u], x[2 * u + 1]}, quarter, mcq);
+        // (as one vector operation: __builtin_bit_cast on the ELEMENT d[1] reads d[0] with this compiler)
+        const f32x2 hf = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, d) & u32x2{0xFFFFE000u, 0xFFFFE000u});
+        const f32x2 r = pk_sub_pure(d, hf);
+        const f16x2 hh = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]));  // exact: hf has 11 bits
+        const f16x2 ll = __builtin_convertvector(r, f16x2);                                     // v_cvt_pk_f16_f32, to nearest
+        hi[2 * u] = hh[0];
+        hi[2 * u + 1] = hh[1];
+        lo[2 * u] = ll[0];
+        lo[2 * u + 1] = ll[1];
+    }
+}
+
+template <bool DATA_IS_A, int NP>
+__device__ __forceinline__ void f16_products(const f16x8& th, const f16x8& tm, const f16x8& dh, const f16x8& dl, f32x16& acc) {
+    if (DATA_IS_A) {
+        if (NP >= 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, tm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, tm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dl, th, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(dh, th, acc, 0, 0, 0);
+    } else {
+        if (NP >= 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tm, dl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tm, dh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, dl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, dh, acc, 0, 0, 0);
+    }
+}
+
+constexpr int kNoWild = -(1 << 28);
+
+// Axis 0.  A wave owns 32 columns and a run of row tiles, top to bottom, and talks to nobody: its window of input
+// rows is a ring in LDS (its 32 columns of the block's [row][128] array), the rows the next tile adds are loaded
+// into registers while this tile is computed and written over the oldest rows afterwards (the wave's own reads come
+// first in program order: no spare rows, no barrier).
+// MT = 2: the wave's tile is 64 rows (two MFMA tiles on top of each other, global multiples of 64) with ONE offset
+// per column, so one split of the samples feeds both: the vector-ALU work per output halves.  The offset row is 32
+// rows into the tile; a row block holds it for every tile it computes when it carries 32 ghost rows, so the
+// launcher takes MT = 2 from radius 32.
+template <int S, int NP, int MT>
+__global__ __launch_bounds__(256) void gauss_axis0_f16_kernel(GaussArgs p, int tile_first, int ntiles, int tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    constexpr int Rp = 8 * (S - 2), NS = S + 2 * (MT - 1), RR = 16 * NS, TILE = 32 * MT;
+    constexpr int kStay = (RR + TILE - 1) / TILE;  // tiles whose window holds a slab of TILE rows, rounded up
+    static_assert(S % 2 == 0, "whole 16-row steps on both sides of the tile");
+    const int R = p.radius;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    const int x0 = blockIdx.x * kMfmaCols;
+    const int tb = blockIdx.y * tiles_per_block, te = min(tb + tiles_per_block, ntiles);
+    if (tb >= te) return;
+    f16x8 twh[S], twl[S];
+    build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
+    float* ring = L + 32 * wave;  // [row][128], this wave's 32 columns
+    // loader: lane -> row (lane >> 3) of a pass of 8 rows, 4 columns (lane & 7) * 4
+    const int lq = lane >> 3, lcol = (lane & 7) * 4;
+    const int lc = min(x0 + 32 * wave + lcol, p.nx - 4);  // (columns past nx: clamped, never stored)
+    auto row_ptr = [&](int gy) {
+        gy = reflect_index(gy, p.gny);
+        gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
+        return p.in + (size_t)(gy - p.in_row0) * p.nx + lc;
+    };
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const unsigned in_lane_off = (unsigned)(lq * p.nx + lc) * 4u;
+    float* const ring_lane = ring + lq * kMfmaCols + lcol;
+    const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
+    int last_wild = kNoWild;  // last tile whose window holds a staged sample that is not a plain finite one
+    {
+        const int y0 = (tile_first + tb) * TILE;
+        bool bad = false;
+        for (int k = 0; k < RR; k += 8) {
+            f4 v = *reinterpret_cast<const f4*>(row_ptr(y0 - Rp + k + lq));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool w = wild(v[e]);
+                bad |= w;
+                v[e] = w ? 0.0f : v[e];
+            }
+            *reinterpret_cast<f4*>(ring_lane + k * kMfmaCols) = v;
+        }
+        if (__builtin_amdgcn_ballot_w64(bad)) last_wild = tb + kStay - 1;
+    }
+    int base = 0;  // ring row of input row y0 - Rp
+    const int xw = 32 * wave + j;
+    const unsigned out_lane_off = (unsigned)(4 * g * p.nx + xw) * 4u;
+    const f32x2 quarter = {0.25f, 0.25f};
+    const float* const bl = L + (8 * g) * kMfmaCols + xw;
+    for (int t = tb; t < te; ++t) {
+        const int y0 = (tile_first + t) * TILE;
+        f4 pre[4 * MT];
+        const bool more = t + 1 < te;
+        if (more) {
+            const int n0 = y0 - Rp + RR;  // the rows the next tile adds
+            if (n0 >= row_lo && n0 + TILE <= row_hi) {
+                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)(n0 - p.in_row0) * p.nx);
+#pragma unroll
+                for (int q = 0; q < 4 * MT; ++q) pre[q] = *reinterpret_cast<const f4*>(rb + (size_t)(8 * q) * p.nx * 4 + in_lane_off);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4 * MT; ++q) pre[q] = *reinterpret_cast<const f4*>(row_ptr(n0 + 8 * q + lq));
+            }
+        }
+        int sc = base + Rp + TILE / 2;
+        sc = sc >= RR ? sc - RR : sc;
+        const float c = L[sc * kMfmaCols + xw];  // the column's sample at the tile's middle row (0 if it was not a plain finite one)
+        const f32x2 mcq = {-0.25f * c, -0.25f * c};
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[m][v] = 0.0f;
+        int slot = base;
+        auto fetch = [&](float (&x)[8]) {
+            const float* bp = bl + slot * kMfmaCols;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = bp[q * kMfmaCols];
+            slot += 16;
+            slot = slot >= RR ? slot - RR : slot;
+        };
+        float xa[8], xb[8];
+        fetch(xa);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            f16x8 dh, dl;
+            // the next step's samples are requested before this step's are split (the compiler otherwise sinks the
+            // reads to their use and the wave, alone on its SIMD, waits out the LDS latency every step)
+            if (s & 1) {
+                if (s + 1 < NS) fetch(xa);
+                __builtin_amdgcn_sched_barrier(0);
+                split8(xb, quarter, mcq, dh, dl);
+            } else {
+                if (s + 1 < NS) fetch(xb);
+                __builtin_amdgcn_sched_barrier(0);
+                split8(xa, quarter, mcq, dh, dl);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (s - 2 * m >= 0 && s - 2 * m < S) f16_products<false, NP>(twh[s - 2 * m], twl[s - 2 * m], dh, dl, acc[m]);
+        }
+        if (more) {
+            bool bad = false;
+#pragma unroll
+            for (int q = 0; q < 4 * MT; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bad |= wild(pre[q][e]);
+            if (__builtin_amdgcn_ballot_w64(bad)) {
+#pragma unroll
+                for (int q = 0; q < 4 * MT; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pre[q][e] = wild(pre[q][e]) ? 0.0f : pre[q][e];
+                last_wild = t + kStay;  // the rows enter with tile t + 1
+            }
+            int s8 = base;  // over the oldest rows
+#pragma unroll
+            for (int q = 0; q < 4 * MT; ++q) {
+                *reinterpret_cast<f4*>(ring_lane + s8 * kMfmaCols) = pre[q];
+                s8 += 8;
+                s8 = s8 >= RR ? s8 - RR : s8;
+            }
+        }
+        const int ox = x0 + xw;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int ym = y0 + 32 * m;
+            if (lane == 0) p.flags[((size_t)(t * MT + m) * gridDim.x + blockIdx.x) * 4 + wave] = last_wild >= t ? 1 : 0;
+            if (ox < p.nx) {
+                if (ym >= p.out_row0 && ym + 32 <= p.out_row0 + p.out_rows) {
+                    char* ub = reinterpret_cast<char*>(p.out + (size_t)(ym - p.out_row0) * p.nx + x0);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + out_lane_off) = fmaf(acc[m][v], p.out_scale, c);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int oy = ym + (v & 3) + 8 * (v >> 2) + 4 * g;
+                        if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = fmaf(acc[m][v], p.out_scale, c);
+                    }
+                }
+            }
+        }
+        base += TILE;
+        base = base >= RR ? base - RR : base;
+    }
+}
+
+// Axis 1.  A wave owns a band of 32 rows and marches along x; its window of input columns is a ring of LDS columns
+// (row pitch = window + 4 floats: the two 16-byte reads of an A operand are aligned and 16 rows fall into 16
+// different bank groups).  `in` holds plane rows [0, rows); a row's result depends on that row alone.  MT = 2: tiles
+// of 64 columns with one offset per row (the sample 32 columns into the tile: always there), one split for two MFMA
+// tiles.  NW waves per block: the widest window (radius 113 ... 121, MT = 2) fits LDS three times, not four.
+template <int S, int NP, int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, int rows, int nseg) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    constexpr int Rp = 8 * (S - 2), NS = S + 2 * (MT - 1), RC = 16 * NS, pitch = RC + 4, TILE = 32 * MT;
+    constexpr int kStay = (RC + TILE - 1) / TILE;
+    static_assert(S % 2 == 0, "whole 16-column steps on both sides of the tile");
+    const int R = p.radius;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* ring = L + wave * (32 * pitch + 32);
+    float* crow = ring + 32 * pitch;
+    const int gw = blockIdx.x * NW + wave;
+    const int band = gw / nseg, seg = gw - band * nseg;
+    const int r0 = band * 32;
+    if (r0 >= rows) return;
+    const int i = lane & 31, g = lane >> 5;
+    f16x8 twh[S], twl[S];
+    build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
+    auto load_cols = [&](int xfirst, int q) {  // rows 2 q + g, columns xfirst + i
+        const int r = min(r0 + 2 * q + g, rows - 1);
+        const int cx = reflect_index(xfirst + i, p.nx);
+        return p.in[(size_t)r * p.nx + cx];
+    };
+    const unsigned in_lane_off = (unsigned)(g * p.nx + i) * 4u;
+    const unsigned out_lane_off = (unsigned)(4 * g * p.nx + i) * 4u;
+    const bool full_band = r0 + 32 <= rows;
+    const int ntile = (p.nx + TILE - 1) / TILE, nunit = (p.nx + 31) / 32;
+    const int tper = (ntile + nseg - 1) / nseg;
+    const int t_first = seg * tper, t_last = min(t_first + tper, ntile);
+    if (t_first >= t_last) return;
+    int last_wild = kNoWild;
+    {
+        bool bad = false;
+        for (int k0 = 0; k0 < RC; k0 += 32) {
+            if (k0 + i < RC) {
+#pragma unroll 4
+                for (int q = 0; q < 16; ++q) {
+                    const float v = load_cols(t_first * TILE - Rp + k0, q);
+                    const bool w = wild(v);
+                    bad |= w;
+                    ring[(2 * q + g) * pitch + k0 + i] = w ? 0.0f : v;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(bad)) last_wild = t_first + kStay - 1;
+    }
+    int base = 0;  // ring column of input column x0 - Rp
+    const f32x2 quarter = {0.25f, 0.25f};
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const float* const al = ring + i * pitch + 8 * g;
+    for (int t = t_first; t < t_last; ++t) {
+        const int x0 = t * TILE;
+        float pre[16 * MT];
+        const bool more = t + 1 < t_last;
+        if (more) {
+            const int n0 = x0 - Rp + RC;  // the columns the next tile adds
+            if (full_band && n0 >= 0 && n0 + TILE <= p.nx) {
+                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)r0 * p.nx + n0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) pre[16 * m + q] = *reinterpret_cast<const float*>(rb + (size_t)(2 * q) * p.nx * 4 + 128 * m + in_lane_off);
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) pre[16 * m + q] = load_cols(n0 + 32 * m, q);
+            }
+        }
+        int sc = base + Rp + TILE / 2;
+        sc = sc >= RC ? sc - RC : sc;
+        const float c = ring[i * pitch + sc];  // the row's sample at the tile's middle column
+        if (g == 0) crow[i] = c;
+        const f32x2 mcq = {-0.25f * c, -0.25f * c};
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[m][v] = 0.0f;
+        int slot = base;
+        auto fetch = [&](float (&x)[8]) {
+            const f4 lo4 = *reinterpret_cast<const f4*>(al + slot), hi4 = *reinterpret_cast<const f4*>(al + slot + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x[q] = lo4[q];
+                x[4 + q] = hi4[q];
+            }
+            slot += 16;
+            slot = slot >= RC ? slot - RC : slot;
+        };
+        float xa[8], xb[8];
+        fetch(xa);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            f16x8 dh, dl;
+            if (s & 1) {
+                if (s + 1 < NS) fetch(xa);
+                __builtin_amdgcn_sched_barrier(0);
+                split8(xb, quarter, mcq, dh, dl);
+            } else {
+                if (s + 1 < NS) fetch(xb);
+                __builtin_amdgcn_sched_barrier(0);
+                split8(xa, quarter, mcq, dh, dl);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (s - 2 * m >= 0 && s - 2 * m < S) f16_products<true, NP>(twh[s - 2 * m], twl[s - 2 * m], dh, dl, acc[m]);
+        }
+        if (more) {
+            bool bad = false;
+#pragma unroll
+            for (int q = 0; q < 16 * MT; ++q) bad |= wild(pre[q]);
+            if (__builtin_amdgcn_ballot_w64(bad)) {
+#pragma unroll
+                for (int q = 0; q < 16 * MT; ++q) pre[q] = wild(pre[q]) ? 0.0f : pre[q];
+                last_wild = t + kStay;
+            }
+            int sl = base;  // over the oldest columns
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) ring[(2 * q + g) * pitch + sl + i] = pre[16 * m + q];
+                sl += 32;
+                sl = sl >= RC ? sl - RC : sl;
+            }
+        }
+        float cr[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) cr[v] = crow[(v & 3) + 8 * (v >> 2) + 4 * g];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int xm = x0 + 32 * m, ox = xm + i;  // D: column = lane & 31
+            if (xm >= p.nx) break;
+            if (lane == 0) p.flags[(size_t)band * nunit + (t * MT + m)] = last_wild >= t ? 1 : 0;
+            if (ox < p.nx) {
+                if (full_band) {
+                    char* ub = reinterpret_cast<char*>(p.out + (size_t)r0 * p.nx + xm);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + out_lane_off) = fmaf(acc[m][v], p.out_scale, cr[v]);
+                } else {
+                    float* o = p.out + (size_t)(r0 + 4 * g) * p.nx + ox;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int ri = (v & 3) + 8 * (v >> 2);
+                        if (r0 + 4 * g + ri < rows) o[(size_t)ri * p.nx] = fmaf(acc[m][v], p.out_scale, cr[v]);
+                    }
+                }
+            }
+        }
+        base += TILE;
+        base = base >= RC ? base - RC : base;
+    }
+}
+
+
+// Repair pass of the f16 route: the outputs of a marked tile whose own window holds a sample that is not a plain
+// finite one (non-finite, or |x| > 1e5) are taken tap by tap in float32 - an ascending chain of fused multiply-adds
+// on x - c, c the tile's offset - so they are NaN / inf exactly where the reference's are; every other output
+// keeps what the matrix cores gave it.
+template <bool AXIS1>
+__global__ __launch_bounds__(64) void gauss_f16_repair_kernel(GaussArgs p, int units_a, int units_b, int first_a, int rows_plane) {
+    const int lane = threadIdx.x;
+    const long units = (long)units_a * units_b;
+    const int R = p.radius;
+    for (long base = (long)blockIdx.x * 64; base < units; base += (long)gridDim.x * 64) {
+        const long mine = base + lane;
+        unsigned long long marked = __builtin_amdgcn_ballot_w64(mine < units && p.flags[mine < units ? mine : 0] != 0);
+        while (marked) {
+            const int bit = __builtin_ctzll(marked);
+            marked &= marked - 1;
+            const long u = base + bit;
+            const int a = (int)(u / units_b), b = (int)(u % units_b);
+            const int j = lane & 31, h = lane >> 5;
+            if (!AXIS1) {
+                const int y0 = (first_a + a) * 32, x = 32 * b + j;
+                if (x >= p.nx) continue;
+                auto in_at = [&](int gy) {
+                    gy = reflect_index(gy, p.gny);
+                    gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
+                    return p.in[(size_t)(gy - p.in_row0) * p.nx + x];
+                };
+                float c = in_at(y0 + 16);
+                c = wild(c) ? 0.0f : c;
+                for (int k = 0; k < 16; ++k) {
+                    const int oy = y0 + 16 * h + k;
+                    if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
+                    float acc = 0.0f;
+                    bool any = false;
+                    for (int q = 0; q <= 2 * R; ++q) {
+                        const float v = in_at(oy - R + q);
+                        any |= wild(v);
+                        acc = fmaf(p.taps[q], v - c, acc);
+                    }
+                    if (any) p.out[(size_t)(oy - p.out_row0) * p.nx + x] = c + acc;
+                }
+            } else {
+                const int r = 32 * a + j, x0 = 32 * b;
+                if (r >= rows_plane) continue;
+                const float* row = p.in + (size_t)r * p.nx;
+                float c = row[reflect_index(x0 + 16, p.nx)];
+                c = wild(c) ? 0.0f : c;
+                for (int k = 0; k < 16; ++k) {
+                    const int ox = x0 + 16 * h + k;
+                    if (ox >= p.nx) continue;
+                    float acc = 0.0f;
+                    bool any = false;
+                    for (int q = 0; q <= 2 * R; ++q) {
+                        const float v = row[reflect_index(ox - R + q, p.nx)];
+                        any |= wild(v);
+                        acc = fmaf(p.taps[q], v - c, acc);
+                    }
+                    if (any) p.out[(size_t)r * p.nx + ox] = c + acc;
+                }
+            }
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------
 int upload_weights(int slot, double sigma, int kb, GaussArgs* a) {
     const int R = gaussian_radius(sigma);
@@ -1212,6 +1677,148 @@ int upload_plain_weights(int slot, double sigma, GaussArgs* a) {
     return upload_weights(slot, sigma, 1, a);  // 2 R + 1 taps, no padding
 }
 
+// ---- f16 route: scales, step count, dispatch over the step count ----
+bool f16_route() {
+    static const bool on = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_F16");
+        return !(e && *e == '0');
+    }();
+    return on;
+}
+#ifndef TOPO_F16_NP
+#define TOPO_F16_NP 3  // products per tap block: th h + tm h + th l (4 adds tm l: 7 % slower, same error; lab builds)
+#endif
+int f16_steps(int R);
+// two MFMA tiles per offset (MT = 2): axis 1 always; axis 0 from radius 32 (the offset row is 32 rows into a
+// 64-row tile).  TOPO_AMD_GAUSS_F16_MT=1 keeps one tile everywhere (A/B).
+int f16_mt(bool axis1, int R) {
+    static const int forced = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_F16_MT");
+        return e && *e ? std::atoi(e) : 0;
+    }();
+    if (forced == 1) return 1;
+    if (axis1) return forced == 2 || f16_steps(R) < 18 ? 2 : 1;  // the widest window fits LDS 3 times with MT = 2: 2.95 ms against 2.66 with MT = 1
+    return R >= 32 ? 2 : 1;
+}
+int f16_steps(int R) { return 2 + (R + 15) / 16 * 2; }  // 16-sample steps of a 32-output tile's window: 32 + 2 Rp, Rp = R rounded up to 16
+void set_f16_scales(double sigma, GaussArgs* a) {
+    const int R = gaussian_radius(sigma);
+    double sum = 0.0;
+    for (int k = -R; k <= R; ++k) sum += std::exp(-0.5 / (sigma * sigma) * (double)k * (double)k);
+    const float peak = (float)(1.0 / sum);  // the largest tap, as upload_weights rounds it
+    const int e = 9 - std::ilogb(peak);     // peak 2^e in [512, 1024)
+    a->tap_scale = std::ldexp(1.0f, e);
+    a->out_scale = std::ldexp(1.0f, 2 - e);  // the data goes in divided by 4
+}
+constexpr int f16_axis1_waves(int S, int MT) { return S == 18 && MT == 2 ? 3 : 4; }  // 4 x 32 rows x 324 floats do not fit 160 KB
+template <int S, int MT>
+int launch_f16_axis0(dim3 grid, const GaussArgs& a, int tile_first, int ntiles, int per) {
+    Context& c = ctx();
+    static bool ready = false;
+    if (!ready) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis0_f16_kernel<S, TOPO_F16_NP, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ready = true;
+    }
+    const size_t lds = (size_t)(16 * (S + 2 * (MT - 1))) * kMfmaCols * sizeof(float);
+    hipLaunchKernelGGL((gauss_axis0_f16_kernel<S, TOPO_F16_NP, MT>), grid, dim3(256), lds, c.compute, a, tile_first, ntiles, per);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+template <int S, int MT>
+int launch_f16_axis1(long waves, const GaussArgs& a, int rows, int nseg) {
+    Context& c = ctx();
+    constexpr int NW = f16_axis1_waves(S, MT);
+    static bool ready = false;
+    if (!ready) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_f16_kernel<S, TOPO_F16_NP, MT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ready = true;
+    }
+    const size_t lds = NW * (size_t)(32 * (16 * (S + 2 * (MT - 1)) + 4) + 32) * sizeof(float);
+    hipLaunchKernelGGL((gauss_axis1_f16_kernel<S, TOPO_F16_NP, MT, NW>), dim3((unsigned)((waves + NW - 1) / NW)), dim3(64 * NW), lds, c.compute, a, rows, nseg);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+#define TOPO_F16_STEPS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
+int launch_f16_axis0_any(int steps, int mt, dim3 grid, const GaussArgs& a, int tile_first, int ntiles, int per) {
+    switch (steps) {
+#define TOPO_F16_CASE(S_) \
+    case S_: return mt == 2 ? launch_f16_axis0<S_, 2>(grid, a, tile_first, ntiles, per) : launch_f16_axis0<S_, 1>(grid, a, tile_first, ntiles, per);
+        TOPO_F16_STEPS(TOPO_F16_CASE)
+#undef TOPO_F16_CASE
+    }
+    set_error("gaussian (f16 matrix-core route): no kernel for this radius");
+    return TOPO_AMD_EUNSUP;
+}
+int launch_f16_axis1_any(int steps, int mt, long waves, const GaussArgs& a, int rows, int nseg) {
+    switch (steps) {
+#define TOPO_F16_CASE(S_) \
+    case S_: return mt == 2 ? launch_f16_axis1<S_, 2>(waves, a, rows, nseg) : launch_f16_axis1<S_, 1>(waves, a, rows, nseg);
+        TOPO_F16_STEPS(TOPO_F16_CASE)
+#undef TOPO_F16_CASE
+    }
+    set_error("gaussian (f16 matrix-core route): no kernel for this radius");
+    return TOPO_AMD_EUNSUP;
+}
+
+// axis 0 on the f16 route: tiles of 32 MT rows on the global grid, one flag byte per 32 x 32 unit
+int run_axis0_f16(const Block& b, GaussArgs a, double sigma) {
+    Context& c = ctx();
+    set_f16_scales(sigma, &a);
+    const int mt = f16_mt(false, a.radius), tile = 32 * mt;
+    const int tile_first = b.out_row0 / tile;
+    const int ntiles = (b.out_row0 + b.out_rows - 1) / tile - tile_first + 1;
+    const int strips = (b.nx + kMfmaCols - 1) / kMfmaCols;
+    int splits = (2 * c.num_cu + strips - 1) / strips;
+    const int min_run = 8 / mt;  // a cut restages 2 Rp rows: runs of 256 rows or more
+    splits = std::max(1, std::min(splits, ntiles / min_run > 0 ? ntiles / min_run : 1));
+    if (strips >= c.num_cu) splits = 1;
+    const int per = (ntiles + splits - 1) / splits;
+    TOPO_TRY(check_grid_rows((ntiles + per - 1) / per, "gaussian (matrix-core axis 0)"));
+    dim3 grid(strips, (ntiles + per - 1) / per);
+    const long units = (long)ntiles * mt * strips * 4;
+    void* flags = nullptr;
+    TOPO_TRY(workspace(10, (size_t)units, &flags));
+    a.flags = (unsigned char*)flags;
+    TOPO_TRY(launch_f16_axis0_any(f16_steps(a.radius), mt, grid, a, tile_first, ntiles, per));
+    hipLaunchKernelGGL(gauss_f16_repair_kernel<false>, dim3((unsigned)std::min<long>(1024, (units + 63) / 64)), dim3(64), 0, c.compute,
+                       a, ntiles * mt, strips * 4, tile_first * mt, 0);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+int run_axis1_f16(GaussArgs a, int rows, int nx, double sigma) {
+    Context& c = ctx();
+    set_f16_scales(sigma, &a);
+    const int steps = f16_steps(a.radius), mt = f16_mt(true, a.radius);
+    const int nw = steps == 18 && mt == 2 ? 3 : 4;
+    const int bands = (rows + 31) / 32;
+    const int ntile = (nx + 32 * mt - 1) / (32 * mt), nunit = (nx + 31) / 32;
+    // one block of nw waves per CU (the rings take the LDS): pick the cut of a band's tiles into runs with the least
+    // rounds x (tiles per run + the halo a run restages), runs no shorter than 512 columns
+    const long slots = (long)nw * c.num_cu;
+    const int halo_tiles = (2 * a.radius + 32 * mt - 1) / (32 * mt);
+    int nseg = 1;
+    long best = -1;
+    for (int n = 1; n <= std::max(1, ntile / (16 / mt)); ++n) {
+        const long rounds = ((long)bands * n + slots - 1) / slots;
+        const long cost = rounds * ((ntile + n - 1) / n + halo_tiles);
+        if (best < 0 || cost < best) {
+            best = cost;
+            nseg = n;
+        }
+    }
+    const long waves = (long)bands * nseg;
+    const long units = (long)bands * nunit;
+    void* flags = nullptr;
+    TOPO_TRY(workspace(10, (size_t)units, &flags));
+    a.flags = (unsigned char*)flags;
+    TOPO_TRY(launch_f16_axis1_any(steps, mt, waves, a, rows, nseg));
+    hipLaunchKernelGGL(gauss_f16_repair_kernel<true>, dim3((unsigned)std::min<long>(1024, (units + 63) / 64)), dim3(64), 0, c.compute,
+                       a, bands, nunit, 0, rows);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
 int run_axis0_mfma(const Block& b, double sigma, float* out, int table_slot) {
     Context& c = ctx();
     GaussArgs a;
@@ -1233,6 +1840,7 @@ int run_axis0_mfma(const Block& b, double sigma, float* out, int table_slot) {
                                      160 * 1024));
         ready = true;
     }
+    if (f16_route()) return run_axis0_f16(b, a, sigma);
     const int tile_first = b.out_row0 / 32;  // row tiles sit on global multiples of 32 (the accumulation offsets)
     const int ntiles = (b.out_row0 + b.out_rows - 1) / 32 - tile_first + 1;
     const int strips = (b.nx + kMfmaCols - 1) / kMfmaCols;
@@ -1270,6 +1878,7 @@ int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, 
     a.out_row0 = 0;
     a.out_rows = rows;
     a.group0 = 0;
+    if (f16_route()) return run_axis1_f16(a, rows, nx, sigma);
     const int K = 32 + 2 * a.radius;
     const size_t lds = ((size_t)(K + kWzPad) + 4 * (size_t)(32 * ((K + 32 + 7) / 8 * 8 + 1) + 32)) * sizeof(float);
     static bool ready = false;
