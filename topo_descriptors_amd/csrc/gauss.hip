@@ -1194,10 +1194,12 @@ __device__ __forceinline__ void build_tap_blocks(const float* taps, int R, float
 __device__ __forceinline__ void split8(const float (&x)[8], f32x2 quarter, f32x2 mcq, f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const f32x2 d = pk_fma_pure(f32x2{x[2 * u], x[2 * u + 1]}, quarter, mcq);
+        // (plain fma / sub: a wave alone on its SIMD takes 53 ns for the 8 samples this way, 64 ns with v_pk_fma_f32 /
+        // v_pk_add_f32: tools/ubench/split_rate.hip)
+        const f32x2 d = {__builtin_fmaf(x[2 * u], quarter[0], mcq[0]), __builtin_fmaf(x[2 * u + 1], quarter[1], mcq[1])};
         // (as one vector operation: __builtin_bit_cast on the ELEMENT d[1] reads d[0] with this compiler)
         const f32x2 hf = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, d) & u32x2{0xFFFFE000u, 0xFFFFE000u});
-        const f32x2 r = pk_sub_pure(d, hf);
+        const f32x2 r = {d[0] - hf[0], d[1] - hf[1]};
         const f16x2 hh = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]));  // exact: hf has 11 bits
         const f16x2 ll = __builtin_convertvector(r, f16x2);                                     // v_cvt_pk_f16_f32, to nearest
         hi[2 * u] = hh[0];
