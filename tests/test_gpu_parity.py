@@ -9,6 +9,8 @@ Tolerance contract (written out here):
   * STD: (i) |gpu - exact| <= 1e-4 * max|ref|; (ii) |gpu - ref| <= |ref - exact|_max + 1e-4 * max|ref|
     (the reference's own float32-FFT noise floor is stored with each fixture).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -208,6 +210,65 @@ def test_gaussian_nan_repair_is_partition_invariant():
     assert np.array_equal(np.isnan(w), np.isnan(ndimage.gaussian_filter(dem, sigma)))
     dev.free()
     whole.free()
+
+
+def test_gaussian_fused_is_the_two_passes():
+    """Radius 4 ... 16 with one sigma runs both passes in one kernel (gauss_fused_f16_kernel): the arithmetic of the
+    two f16 kernels tile for tile, the intermediate in LDS.  Same bits as the two passes (TOPO_AMD_GAUSS_FUSED=0 in
+    a child process), on shapes with partial bands, partial tiles, a width that is not a multiple of 64, a block
+    narrower than one tile, and through row blocks."""
+    import subprocess, sys, tempfile
+    shapes = [(200, 512), (129, 68), (33, 20), (300, 1000), (64, 64)]
+    sigmas = [1.0, 2.25, 3.25, 4.0]
+    with tempfile.TemporaryDirectory() as tmp:
+        code = (
+            "import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "from topo_descriptors_amd import topo\n"
+            "from oracle import topo_oracle as orc\n"
+            "out = {}\n"
+            "for k, (ny, nx) in enumerate(%r):\n"
+            "    dem = orc.synthetic_dem(ny, nx, seed=40 + k)\n"
+            "    for s in %r:\n"
+            "        out['%%d_%%s' %% (k, s)] = topo.dem(dem, s)\n"
+            "np.savez(%r, **out)\n"
+        ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), shapes, sigmas, os.path.join(tmp, "two.npz"))
+        env = dict(os.environ, TOPO_AMD_GAUSS_FUSED="0")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env)
+        two = np.load(os.path.join(tmp, "two.npz"))
+        for k, (ny, nx) in enumerate(shapes):
+            dem = orc.synthetic_dem(ny, nx, seed=40 + k)
+            for s in sigmas:
+                assert np.array_equal(topo.dem(dem, s), two["%d_%s" % (k, s)]), (ny, nx, s)
+    # row blocks of the fused route: the single block's bits (clean DEM, and one with a non-finite sample, where the
+    # two-pass kernels and their repair passes take over inside the library)
+    from topo_descriptors_amd import _lib, device as d, shard
+    gny, nx, sigma = 420, 512, 3.25
+    for poison in (False, True):
+        dem = orc.synthetic_dem(gny, nx, seed=78)
+        if poison:
+            dem[139, 200] = np.nan
+            dem[300, 31:34] = np.inf
+        dev = d.DeviceArray.from_host(dem)
+        whole = d.DeviceArray(gny, nx)
+        d.Block(dev).gaussian(sigma, sigma, whole)
+        d.sync()
+        w = whole.to_host()
+        up, down = shard.halo_rows(_lib.DESC_GAUSS, sigma)
+        for nb in (2, 3):
+            parts = []
+            for row0, rows in shard.split_rows(gny, nb):
+                lo, hi = max(0, row0 - up), min(gny, row0 + rows + down)
+                part = d.DeviceArray.from_host(dem[lo:hi])
+                out = d.DeviceArray(rows, nx)
+                d.Block(part, row0=lo, gny=gny).gaussian(sigma, sigma, out, out_row0=row0, out_rows=rows)
+                d.sync()
+                parts.append(out.to_host())
+                part.free()
+                out.free()
+            assert np.array_equal(np.concatenate(parts), w, equal_nan=True), (poison, nb)
+        dev.free()
+        whole.free()
 
 
 @pytest.mark.parametrize("sigma", [4.0, 4.25, 5.25, 6.25, 9.0, 30.25])

@@ -125,13 +125,13 @@ def test_sx_requires_dataset():
 def test_halo_rows_contract():
     lib = _lib.load()
     up, down = ctypes.c_int32(), ctypes.c_int32()
-    # Gaussian radii 4 ... 15 (gradient: 8 ... 15) run on the matrix cores, whose 32-row tiles take their
-    # accumulation offset 16 rows into the tile: 16 ghost rows (gradient: 17) instead of R (R + 1)
+    # Gaussian radii 4 ... 15 run on the matrix cores, whose 32-row tiles take their accumulation offset 16 rows
+    # into the tile: 16 ghost rows (gradient: 17) instead of R (R + 1)
     cases = [(_lib.DESC_TPI, 67, 0, 33, 33), (_lib.DESC_TPI, 6, 0, 3, 2), (_lib.DESC_STD, 7, 1.75, 3 + 16, 3 + 16),
              (_lib.DESC_STD, 7, 0.75, 3 + 3, 3 + 3), (_lib.DESC_STD, 7, 5.0, 3 + 20, 3 + 20),
              (_lib.DESC_GAUSS, 30.25, 0, 121, 121), (_lib.DESC_GAUSS, 3.25, 0, 16, 16), (_lib.DESC_GAUSS, 0.75, 0, 3, 3),
              (_lib.DESC_GRADIENT, 30.25, 0, 122, 122), (_lib.DESC_GRADIENT, 3.25, 0, 17, 17),
-             (_lib.DESC_GRADIENT, 1.5, 0, 7, 7), (_lib.DESC_GRADIENT, 3.25, 1.0, 17, 17),
+             (_lib.DESC_GRADIENT, 1.5, 0, 17, 17), (_lib.DESC_GRADIENT, 3.25, 1.0, 17, 17),
              (_lib.DESC_GRADIENT, 3.25, 2.0, 27, 27), (_lib.DESC_GRADIENT, 2.25, 0.5, 10, 10),
              (_lib.DESC_GRADIENT, 0.75, 0, 1, 1), (_lib.DESC_SOBEL, 0, 0, 1, 1),
              (_lib.DESC_SX, 17, 0, 17, 0)]

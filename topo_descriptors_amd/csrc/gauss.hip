@@ -45,6 +45,8 @@ struct GaussArgs {
     int group0;  // axis 0: first row group (global numbering) that intersects the output rows
     unsigned char* flags;  // matrix-core kernels: one byte per 32 x 32 output tile, 1 = an output is not finite
     float tap_scale, out_scale;  // f16 matrix-core kernels: taps are multiplied by tap_scale (a power of two), sums by out_scale
+    int* wild_flag;     // fused kernel: set to 1 when it stages a sample that is not a plain finite one
+    const int* run_if;  // two-pass f16 kernels behind a fused launch: return at once unless *run_if != 0 (nullptr: run)
 };
 
 // Register tiling shared by both axes: a thread produces TB consecutive outputs along the
@@ -1246,6 +1248,7 @@ __global__ __launch_bounds__(256) void gauss_axis0_f16_kernel(GaussArgs p, int t
     const int x0 = blockIdx.x * kMfmaCols;
     const int tb = blockIdx.y * tiles_per_block, te = min(tb + tiles_per_block, ntiles);
     if (tb >= te) return;
+    if (p.run_if && *p.run_if == 0) return;
     f16x8 twh[S], twl[S];
     build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
     float* ring = L + 32 * wave;  // [row][128], this wave's 32 columns
@@ -1399,6 +1402,7 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
     const int band = gw / nseg, seg = gw - band * nseg;
     const int r0 = band * 32;
     if (r0 >= rows) return;
+    if (p.run_if && *p.run_if == 0) return;
     const int i = lane & 31, g = lane >> 5;
     f16x8 twh[S], twl[S];
     build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
@@ -1541,12 +1545,205 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
 }
 
 
+// Both passes of a short isotropic filter (radius 4 ... 16: 4 steps of 16 taps per 32-output tile) in ONE kernel:
+// the intermediate plane (4 B written + 4 B read per pixel out of 16) stays in LDS.  A block owns 4 bands of 32
+// rows (global multiples of 32) and marches along x in blocks of 64 columns.  Per step: the block's 160 raw rows
+// (its 128 + 16 above and below) x 64 columns come in through a double buffer; every wave forms the axis-0 product
+// for its band - the arithmetic of gauss_axis0_f16_kernel<4, ., 1>, tile for tile: same rows, same offset (the
+// column's sample 16 rows into the band), same steps - rounds it to float32 like the stored intermediate, and puts
+// the 32 x 64 block into its own ring of 96 columns; then it takes the 64-column output tile whose window the block
+// completes with the arithmetic of gauss_axis1_f16_kernel<4, ., 2, .>.  An output therefore has the bits of the two
+// kernels (tests/test_gpu_parity.py::test_gaussian_fused_is_the_two_passes).  The raw blocks sit 16 columns to the
+// right of the tile grid, so block u completes the window of tile u; columns beyond the DEM are the reflected
+// columns (the axis-0 result of a reflected column is that column's).  Rows are read 160 / 128 times, not twice.
+// A sample that is not a plain finite one is staged as 0 and raises *wild_flag: the launcher has queued the two-pass
+// kernels behind this one with run_if = wild_flag, and they (with their repair passes) redo the whole plane then.
+template <int NP>
+__global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int tile_first, int ntile_rows, int nseg) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    constexpr int S = 4, Rp = 16, RAWR = 160, RAWC = 64, RC = 96, pitch = RC + 4;
+    const int R = p.radius;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    float* const rawbuf = L;  // 2 x [160][64]
+    float* const ring = L + 2 * RAWR * RAWC + wave * (32 * pitch + 32);
+    float* const crow = ring + 32 * pitch;
+    f16x8 twh[S], twl[S];
+    build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
+    const int y_blk = (tile_first + 4 * (int)blockIdx.y) * 32;  // global row of the block's first band
+    const int y_band = y_blk + 32 * wave;
+    const bool band_on = 4 * (int)blockIdx.y + wave < ntile_rows;
+    const int ntile = (p.nx + 63) / 64;
+    const int tper = (ntile + nseg - 1) / nseg;
+    const int t_first = blockIdx.x * tper, t_last = min(t_first + tper, ntile);
+    if (t_first >= t_last) return;
+    const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
+    const bool rows_inside = y_blk - Rp >= row_lo && y_blk + 128 + Rp <= row_hi;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    // loader: 16 threads x 16 bytes per raw row, 16 rows per pass, 10 passes
+    const int lr = threadIdx.x >> 4, lcq = (threadIdx.x & 15) * 4;
+    auto load_raw = [&](int u, f4 (&pre)[10]) {
+        const int xb = 64 * u + Rp;  // first column of raw block u
+        if (rows_inside && xb >= 0 && xb + 64 <= p.nx) {
+            const float* rb = p.in + (size_t)(y_blk - Rp + lr - p.in_row0) * p.nx + xb + lcq;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) pre[q] = *reinterpret_cast<const f4*>(rb + (size_t)(16 * q) * p.nx);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                int gy = reflect_index(y_blk - Rp + 16 * q + lr, p.gny);
+                gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
+                const float* rowp = p.in + (size_t)(gy - p.in_row0) * p.nx;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pre[q][e] = rowp[reflect_index(xb + lcq + e, p.nx)];
+            }
+        }
+    };
+    auto store_raw = [&](f4 (&pre)[10], float* dst) {
+        bool bad = false;
+#pragma unroll
+        for (int q = 0; q < 10; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= wild(pre[q][e]);
+        if (__builtin_amdgcn_ballot_w64(bad)) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pre[q][e] = wild(pre[q][e]) ? 0.0f : pre[q][e];
+            if (lane == 0) *p.wild_flag = 1;
+        }
+#pragma unroll
+        for (int q = 0; q < 10; ++q) *reinterpret_cast<f4*>(dst + (16 * q + lr) * RAWC + lcq) = pre[q];
+    };
+    const f32x2 quarter = {0.25f, 0.25f};
+    const unsigned out_lane_off = (unsigned)(4 * g * p.nx + i) * 4u;
+    const bool full_band = y_band >= p.out_row0 && y_band + 32 <= p.out_row0 + p.out_rows;
+    {
+        f4 pre[10];
+        load_raw(t_first - 1, pre);
+        store_raw(pre, rawbuf);
+    }
+    __syncthreads();
+    int cur = 0;
+    int rb = 0;  // ring column of the window of the next output tile (global column 64 t - 16)
+    for (int u = t_first - 1; u < t_last; ++u) {
+        f4 pre[10];
+        const bool more = u + 1 < t_last;
+        if (more) load_raw(u + 1, pre);
+        if (band_on) {
+            // ---- axis 0: the band's 32 rows of raw block u (its second half only for the run-in block) -> ring ----
+            const float* raw = rawbuf + cur * (RAWR * RAWC);
+            int wpos = rb + (u < t_first ? 64 : 32);  // ring column of the block's first column
+            wpos = wpos >= RC ? wpos - RC : wpos;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (nt == 0 && u < t_first) continue;
+                const int col = 32 * nt + i;
+                const float c0 = raw[(32 * wave + Rp + 16) * RAWC + col];
+                const f32x2 mcq = {-0.25f * c0, -0.25f * c0};
+                f32x16 acc;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+                const float* bl = raw + (32 * wave + 8 * g) * RAWC + col;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    float x[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[q] = bl[(16 * s + q) * RAWC];
+                    f16x8 dh, dl;
+                    split8(x, quarter, mcq, dh, dl);
+                    f16_products<false, NP>(twh[s], twl[s], dh, dl, acc);
+                }
+                int wc = wpos + 32 * nt;
+                wc = wc >= RC ? wc - RC : wc;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) ring[((v & 3) + 8 * (v >> 2) + 4 * g) * pitch + wc + i] = fmaf(acc[v], p.out_scale, c0);
+            }
+            // ---- axis 1: output tile u, columns 64 u ... 64 u + 63 ----
+            if (u >= t_first) {
+                const int x0 = 64 * u;
+                int sc = rb + Rp + 32;
+                sc = sc >= RC ? sc - RC : sc;
+                const float c = ring[i * pitch + sc];
+                if (g == 0) crow[i] = c;
+                const f32x2 mcq = {-0.25f * c, -0.25f * c};
+                f32x16 acc[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[m][v] = 0.0f;
+                const float* const al = ring + i * pitch + 8 * g;
+                int slot = rb;
+                auto fetch = [&](float (&x)[8]) {
+                    const f4 lo4 = *reinterpret_cast<const f4*>(al + slot), hi4 = *reinterpret_cast<const f4*>(al + slot + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        x[q] = lo4[q];
+                        x[4 + q] = hi4[q];
+                    }
+                    slot += 16;
+                    slot = slot >= RC ? slot - RC : slot;
+                };
+                float xa[8], xb[8];
+                fetch(xa);
+#pragma unroll
+                for (int s = 0; s < S + 2; ++s) {
+                    f16x8 dh, dl;
+                    if (s & 1) {
+                        if (s + 1 < S + 2) fetch(xa);
+                        __builtin_amdgcn_sched_barrier(0);
+                        split8(xb, quarter, mcq, dh, dl);
+                    } else {
+                        if (s + 1 < S + 2) fetch(xb);
+                        __builtin_amdgcn_sched_barrier(0);
+                        split8(xa, quarter, mcq, dh, dl);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        if (s - 2 * m >= 0 && s - 2 * m < S) f16_products<true, NP>(twh[s - 2 * m], twl[s - 2 * m], dh, dl, acc[m]);
+                }
+                float cr[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) cr[v] = crow[(v & 3) + 8 * (v >> 2) + 4 * g];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int xm = x0 + 32 * m, ox = xm + i;
+                    if (ox < p.nx) {
+                        if (full_band) {
+                            char* ub = reinterpret_cast<char*>(p.out + (size_t)(y_band - p.out_row0) * p.nx + xm);
+#pragma unroll
+                            for (int v = 0; v < 16; ++v)
+                                *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + out_lane_off) = fmaf(acc[m][v], p.out_scale, cr[v]);
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) {
+                                const int oy = y_band + (v & 3) + 8 * (v >> 2) + 4 * g;
+                                if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = fmaf(acc[m][v], p.out_scale, cr[v]);
+                            }
+                        }
+                    }
+                }
+                rb += 64;
+                rb = rb >= RC ? rb - RC : rb;
+            }
+        } else if (u >= t_first) {
+            rb += 64;
+            rb = rb >= RC ? rb - RC : rb;
+        }
+        if (more) store_raw(pre, rawbuf + (cur ^ 1) * (RAWR * RAWC));
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // Repair pass of the f16 route: the outputs of a marked tile whose own window holds a sample that is not a plain
 // finite one (non-finite, or |x| > 1e5) are taken tap by tap in float32 - an ascending chain of fused multiply-adds
 // on x - c, c the tile's offset - so they are NaN / inf exactly where the reference's are; every other output
 // keeps what the matrix cores gave it.
 template <bool AXIS1>
 __global__ __launch_bounds__(64) void gauss_f16_repair_kernel(GaussArgs p, int units_a, int units_b, int first_a, int rows_plane) {
+    if (p.run_if && *p.run_if == 0) return;
     const int lane = threadIdx.x;
     const long units = (long)units_a * units_b;
     const int R = p.radius;
@@ -1656,7 +1853,9 @@ int mfma_min_radius_impl(bool for_gradient) {
     }();
     static const int from_grad = [] {
         const char* e = std::getenv("TOPO_AMD_GRAD_MFMA_MIN_RADIUS");
-        return std::max(kMfmaSmallFloor, e && *e ? std::atoi(e) : 8);
+        // (round 3: 4, was 8: with both passes in one kernel the route is 6.1 ms at sigma 1.25 on 32768^2, the
+        // vector-ALU kernel with the epilogue fused in 7.4)
+        return std::max(kMfmaSmallFloor, e && *e ? std::atoi(e) : 4);
     }();
     return for_gradient ? from_grad : from_gauss;
 }
@@ -1762,10 +1961,15 @@ int launch_f16_axis1_any(int steps, int mt, long waves, const GaussArgs& a, int 
     return TOPO_AMD_EUNSUP;
 }
 
+// set around the two-pass launches that follow a fused launch: they run only if the fused kernel raised its flag
+thread_local const int* t_run_if = nullptr;
+
 // axis 0 on the f16 route: tiles of 32 MT rows on the global grid, one flag byte per 32 x 32 unit
 int run_axis0_f16(const Block& b, GaussArgs a, double sigma) {
     Context& c = ctx();
     set_f16_scales(sigma, &a);
+    a.run_if = t_run_if;
+    a.wild_flag = nullptr;
     const int mt = f16_mt(false, a.radius), tile = 32 * mt;
     const int tile_first = b.out_row0 / tile;
     const int ntiles = (b.out_row0 + b.out_rows - 1) / tile - tile_first + 1;
@@ -1791,6 +1995,8 @@ int run_axis0_f16(const Block& b, GaussArgs a, double sigma) {
 int run_axis1_f16(GaussArgs a, int rows, int nx, double sigma) {
     Context& c = ctx();
     set_f16_scales(sigma, &a);
+    a.run_if = t_run_if;
+    a.wild_flag = nullptr;
     const int steps = f16_steps(a.radius), mt = f16_mt(true, a.radius);
     const int nw = steps == 18 && mt == 2 ? 3 : 4;
     const int bands = (rows + 31) / 32;
@@ -1918,6 +2124,73 @@ int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, 
                        a, bands, ntile, 0, rows);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
+}
+
+// ---- one kernel for both passes (radius 4 ... 16, one sigma) ----
+bool fused_radius(int R) {
+    static const bool on = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED");
+        return !(e && *e == '0');
+    }();
+    return on && f16_route() && R >= kMfmaSmallFloor && R <= 16;
+}
+int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, const int** flag_out) {
+    Context& c = ctx();
+    GaussArgs a;
+    TOPO_TRY(upload_plain_weights(table_slot, sigma, &a));
+    a.in = b.in;
+    a.out = out;
+    a.in_rows = b.in_rows;
+    a.in_row0 = b.in_row0;
+    a.gny = b.gny;
+    a.nx = b.nx;
+    a.out_row0 = b.out_row0;
+    a.out_rows = b.out_rows;
+    a.group0 = 0;
+    a.flags = nullptr;
+    a.run_if = nullptr;
+    set_f16_scales(sigma, &a);
+    void* flag = nullptr;
+    TOPO_TRY(workspace(11, 64, &flag));
+    TOPO_HIP(hipMemsetAsync(flag, 0, sizeof(int), c.compute));
+    a.wild_flag = (int*)flag;
+    *flag_out = (const int*)flag;
+    static bool ready = false;
+    if (!ready) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_fused_f16_kernel<TOPO_F16_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ready = true;
+    }
+    const int tile_first = b.out_row0 / 32;
+    const int ntile_rows = (b.out_row0 + b.out_rows - 1) / 32 - tile_first + 1;
+    const int row_blocks = (ntile_rows + 3) / 4;
+    const int ntile = (b.nx + 63) / 64;
+    // one block per CU (134 KB of LDS): the cut of the columns into runs with the least rounds x (tiles per run + 1)
+    int nseg = 1;
+    long best = -1;
+    for (int n = 1; n <= std::max(1, ntile / 4); ++n) {
+        const long rounds = ((long)row_blocks * n + c.num_cu - 1) / c.num_cu;
+        const long cost = rounds * ((ntile + n - 1) / n + 1);
+        if (best < 0 || cost < best) {
+            best = cost;
+            nseg = n;
+        }
+    }
+    TOPO_TRY(check_grid_rows(row_blocks, "gaussian (fused matrix-core kernel)"));
+    const size_t lds = (size_t)(2 * 160 * 64 + 4 * (32 * 100 + 32)) * sizeof(float);
+    hipLaunchKernelGGL((gauss_fused_f16_kernel<TOPO_F16_NP>), dim3(nseg, row_blocks), dim3(256), lds, c.compute, a, tile_first, ntile_rows, nseg);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+// both passes with one sigma on the matrix cores: rows `b.out_row0 ...` -> out; tmp: a plane of the same size
+int smooth_both_mfma(const Block& b, double sigma, float* tmp, float* out, int table_slot) {
+    const bool fused = fused_radius(gaussian_radius(sigma));
+    const int* flag = nullptr;
+    if (fused) TOPO_TRY(run_fused_f16(b, sigma, out, table_slot, &flag));
+    t_run_if = flag;
+    int r = run_axis0_mfma(b, sigma, tmp, table_slot);
+    if (r == TOPO_AMD_OK) r = run_axis1_mfma(tmp, b.out_rows, b.nx, sigma, out, table_slot + 1);
+    t_run_if = nullptr;
+    return r;
 }
 
 int run_axis0(const Block& b, double sigma, float* out, int table_slot, bool mfma_ok = true, bool small_ok = true) {
@@ -2173,8 +2446,13 @@ int smooth_rows(const Block& src, double sigma_y, double sigma_x, int row0, int 
     if (do_y && do_x) {
         void* tmp = nullptr;
         TOPO_TRY(workspace(ws_slot, bytes, &tmp));
-        TOPO_TRY(run_axis0(b, sigma_y, (float*)tmp, table_slot, true, small_ok));
-        TOPO_TRY(run_axis1((const float*)tmp, rows, src.nx, sigma_x, out, table_slot + 1, small_ok));
+        const int R = gaussian_radius(sigma_y);
+        if (sigma_y == sigma_x && mfma_radius(R, b.nx, false, small_ok) && mfma_rows_ok(b, R)) {
+            TOPO_TRY(smooth_both_mfma(b, sigma_y, (float*)tmp, out, table_slot));
+        } else {
+            TOPO_TRY(run_axis0(b, sigma_y, (float*)tmp, table_slot, true, small_ok));
+            TOPO_TRY(run_axis1((const float*)tmp, rows, src.nx, sigma_x, out, table_slot + 1, small_ok));
+        }
     } else if (do_y) {
         TOPO_TRY(run_axis0(b, sigma_y, out, table_slot, true, small_ok));
     } else if (do_x) {
@@ -2333,8 +2611,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             rows.out_rows = c1 - c0;
             float* a_k = (float*)pa + (size_t)(c0 - s0) * b.nx;
             float* b_k = (float*)pb + (size_t)(c0 - s0) * b.nx;
-            TOPO_TRY(run_axis0_mfma(rows, sigma, a_k, 1));
-            TOPO_TRY(run_axis1_mfma(a_k, c1 - c0, b.nx, sigma, b_k, 2));
+            TOPO_TRY(smooth_both_mfma(rows, sigma, a_k, b_k, 1));
             if (use_aux) {
                 TOPO_HIP(hipEventRecord(c.aux_ready[k], c.compute));
                 TOPO_HIP(hipStreamWaitEvent(c.aux, c.aux_ready[k], 0));
