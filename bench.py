@@ -258,9 +258,14 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
               disc_kernels("tpi_std", size))
     o3 = d.DeviceArray(ny, nx)
     o4 = d.DeviceArray(ny, nx)
-    mfma_route = ("8 row chunks of gauss_axis0_mfma_kernel + gauss_axis1_mfma_kernel (banded Toeplitz on the fp32 "
-                  "matrix cores), gradient_epilogue4_kernel of chunk k on a second stream beside the smooth of chunk k + 1")
-    grad_kernels = {3.25: mfma_route, 30.25: mfma_route}
+    chunks = "16 row chunks, gradient_epilogue4_kernel of chunk k on a second stream beside the smooth of chunk k + 1"
+    grad_kernels = {
+        3.25: "gauss_fused_f16_kernel (both passes of the radius-13 filter in one kernel on the f16 matrix pipe, the "
+              "intermediate plane in LDS; the two-pass kernels queued behind it return at once on a DEM without "
+              "non-finite samples); " + chunks,
+        30.25: "gauss_axis0_f16_kernel<18, 3, 2> + gauss_axis1_f16_kernel<18, 3, 1, 4> (banded Toeplitz products as three "
+               "v_mfma_f32_32x32x16_f16 per 16 taps, samples split into two f16 parts around the tile offset) + their "
+               "repair passes; " + chunks}
     for sigma in (3.25, 30.25):
         fn = lambda: blk.gradient(sigma, [30.0], [-30.0], dx=o1, dy=o2, slope=o3, aspect=o4)  # noqa: E731
         entry(f"gradient_sigma{sigma}", time_kernel(fn, REPS, d), 20, grad_kernels[sigma])
@@ -299,9 +304,11 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     fblk = block_cls(frac)
     for size in (7, 67):
         entry(f"tpi_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, tpi=o1), REPS, d), 8,
-              "ring / march kernel (sums of trunc x) + fraction pass" if size >= 17 else
-              "ring kernel (marks) + disc_wave_kernel over every tile")
+              "tpi_march_kernel (sums of trunc x) + tpi_fraction_march_kernel" if size > 17 else
+              "tpi_ring_kernel<., kRingMark> (whole-metre tiles, marks) + tpi_ring_kernel<., kRingBoth> (second image: the "
+              "fractional parts in 2^-16 m)")
         entry(f"std_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, std=o2), REPS, d), 8,
+              "std_ring_kernel<., kStdMain> + std_ring_kernel<., kStdBoth> (third image: the fractional parts)" if size <= 41 else
               "disc_wave_kernel (general, three staging passes)")
     frac.free()
     for a in (o1, o2, o3, o4):
