@@ -102,7 +102,7 @@ int topo_amd_disc_mask(int size, float* mask);
  * p1: pre-smoothing sigma (TPI/STD, 0 = none) | sig_ratio (GRADIENT; 0 or 1 = isotropic) | unused
  * GRADIENT answers exactly the depth topo_amd_shard_gradient(sigma, sig_ratio) lays its block out with.
  * For SX pass the extremes of the offset table instead: p0 = -min(dj), p1 = max(dj).
- * For Gaussian radii int(4 sigma + 0.5) of 4 ... 15 (gradient: 8 ... 15; also the pre-smoothing of TPI / STD) the
+ * For Gaussian radii int(4 sigma + 0.5) of 4 ... 15 (the gradient's too; also the pre-smoothing of TPI / STD) the
  * answer is 16 rows (gradient: 17) rather than the radius: the matrix-core kernels used there take a per-tile
  * offset sample 16 rows into their 32-row tiles.  A block with fewer ghost rows (but at least the radius) is still
  * computed correctly, by the vector-ALU kernels; only bit-identity with other partitions is lost.              */
