@@ -1558,15 +1558,21 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
 // columns (the axis-0 result of a reflected column is that column's).  Rows are read 160 / 128 times, not twice.
 // A sample that is not a plain finite one is staged as 0 and raises *wild_flag: the launcher has queued the two-pass
 // kernels behind this one with run_if = wild_flag, and they (with their repair passes) redo the whole plane then.
-template <int NP>
+// (S = 6, radius 17 ... 32: raw blocks of 32 columns - 192 rows of them, twice, plus four rings of 128 columns are
+// 117 KB - two per output tile, two run-in blocks.)
+template <int NP, int S, int CW>
 __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int tile_first, int ntile_rows, int nseg) {
     extern __shared__ __attribute__((aligned(16))) float L[];
-    constexpr int S = 4, Rp = 16, RAWR = 160, RAWC = 64, RC = 96, pitch = RC + 4;
+    constexpr int Rp = 8 * (S - 2), RAWR = 128 + 2 * Rp, NS = S + 2, RC = 16 * NS, pitch = RC + 4;
+    constexpr int BPT = 64 / CW;                  // raw blocks per 64-column output tile
+    constexpr int TPR = CW / 4, RPP = 256 / TPR;  // loader: threads per raw row, rows per pass
+    constexpr int NPASS = RAWR / RPP;
+    static_assert(RAWR % RPP == 0 && (CW == 32 || CW == 64), "loader geometry");
     const int R = p.radius;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, g = lane >> 5;
-    float* const rawbuf = L;  // 2 x [160][64]
-    float* const ring = L + 2 * RAWR * RAWC + wave * (32 * pitch + 32);
+    float* const rawbuf = L;  // 2 x [RAWR][CW]
+    float* const ring = L + 2 * RAWR * CW + wave * (32 * pitch + 32);
     float* const crow = ring + 32 * pitch;
     f16x8 twh[S], twl[S];
     build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
@@ -1580,18 +1586,19 @@ __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int t
     const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
     const bool rows_inside = y_blk - Rp >= row_lo && y_blk + 128 + Rp <= row_hi;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    // loader: 16 threads x 16 bytes per raw row, 16 rows per pass, 10 passes
-    const int lr = threadIdx.x >> 4, lcq = (threadIdx.x & 15) * 4;
-    auto load_raw = [&](int u, f4 (&pre)[10]) {
-        const int xb = 64 * u + Rp;  // first column of raw block u
-        if (rows_inside && xb >= 0 && xb + 64 <= p.nx) {
-            const float* rb = p.in + (size_t)(y_blk - Rp + lr - p.in_row0) * p.nx + xb + lcq;
+    const int lr = threadIdx.x / TPR, lcq = (threadIdx.x % TPR) * 4;
+    // raw block u: columns CW u + Rp ... (the blocks sit Rp columns to the right of the tile grid, so the last block
+    // of a tile completes its window)
+    auto load_raw = [&](int u, f4 (&pre)[NPASS]) {
+        const int xb = CW * u + Rp;
+        if (rows_inside && xb >= 0 && xb + CW <= p.nx) {
+            const float* rbp = p.in + (size_t)(y_blk - Rp + lr - p.in_row0) * p.nx + xb + lcq;
 #pragma unroll
-            for (int q = 0; q < 10; ++q) pre[q] = *reinterpret_cast<const f4*>(rb + (size_t)(16 * q) * p.nx);
+            for (int q = 0; q < NPASS; ++q) pre[q] = *reinterpret_cast<const f4*>(rbp + (size_t)(RPP * q) * p.nx);
         } else {
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
-                int gy = reflect_index(y_blk - Rp + 16 * q + lr, p.gny);
+            for (int q = 0; q < NPASS; ++q) {
+                int gy = reflect_index(y_blk - Rp + RPP * q + lr, p.gny);
                 gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
                 const float* rowp = p.in + (size_t)(gy - p.in_row0) * p.nx;
 #pragma unroll
@@ -1599,69 +1606,71 @@ __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int t
             }
         }
     };
-    auto store_raw = [&](f4 (&pre)[10], float* dst) {
+    auto store_raw = [&](f4 (&pre)[NPASS], float* dst) {
         bool bad = false;
 #pragma unroll
-        for (int q = 0; q < 10; ++q)
+        for (int q = 0; q < NPASS; ++q)
 #pragma unroll
             for (int e = 0; e < 4; ++e) bad |= wild(pre[q][e]);
         if (__builtin_amdgcn_ballot_w64(bad)) {
 #pragma unroll
-            for (int q = 0; q < 10; ++q)
+            for (int q = 0; q < NPASS; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pre[q][e] = wild(pre[q][e]) ? 0.0f : pre[q][e];
             if (lane == 0) *p.wild_flag = 1;
         }
 #pragma unroll
-        for (int q = 0; q < 10; ++q) *reinterpret_cast<f4*>(dst + (16 * q + lr) * RAWC + lcq) = pre[q];
+        for (int q = 0; q < NPASS; ++q) *reinterpret_cast<f4*>(dst + (RPP * q + lr) * CW + lcq) = pre[q];
     };
     const f32x2 quarter = {0.25f, 0.25f};
     const unsigned out_lane_off = (unsigned)(4 * g * p.nx + i) * 4u;
     const bool full_band = y_band >= p.out_row0 && y_band + 32 <= p.out_row0 + p.out_rows;
+    const int u0 = BPT * t_first;                       // first block of the first tile
+    const int u_start = u0 - (2 * Rp + CW - 1) / CW;    // run-in: the 2 Rp columns left of it
+    const int u_last = BPT * t_last - 1;
     {
-        f4 pre[10];
-        load_raw(t_first - 1, pre);
+        f4 pre[NPASS];
+        load_raw(u_start, pre);
         store_raw(pre, rawbuf);
     }
     __syncthreads();
     int cur = 0;
-    int rb = 0;  // ring column of the window of the next output tile (global column 64 t - 16)
-    for (int u = t_first - 1; u < t_last; ++u) {
-        f4 pre[10];
-        const bool more = u + 1 < t_last;
+    int rb = 0;                                   // ring column of the window of the next output tile (global column 64 t - Rp)
+    int rel = CW * (u_start - u0) + 2 * Rp;       // column of block u relative to the first tile's window (may start below 0)
+    for (int u = u_start; u <= u_last; ++u) {
+        f4 pre[NPASS];
+        const bool more = u < u_last;
         if (more) load_raw(u + 1, pre);
+        const bool tile_done = u >= u0 && (u + 1) % BPT == 0;
         if (band_on) {
-            // ---- axis 0: the band's 32 rows of raw block u (its second half only for the run-in block) -> ring ----
-            const float* raw = rawbuf + cur * (RAWR * RAWC);
-            int wpos = rb + (u < t_first ? 64 : 32);  // ring column of the block's first column
-            wpos = wpos >= RC ? wpos - RC : wpos;
+            // ---- axis 0: the band's 32 rows of raw block u -> ring ----
+            const float* raw = rawbuf + cur * (RAWR * CW);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                if (nt == 0 && u < t_first) continue;
+            for (int nt = 0; nt < CW / 32; ++nt) {
+                if (rel + 32 * nt < 0) continue;  // (run-in of S = 4: only the second half of the block is in the window)
                 const int col = 32 * nt + i;
-                const float c0 = raw[(32 * wave + Rp + 16) * RAWC + col];
+                const float c0 = raw[(32 * wave + Rp + 16) * CW + col];
                 const f32x2 mcq = {-0.25f * c0, -0.25f * c0};
                 f32x16 acc;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-                const float* bl = raw + (32 * wave + 8 * g) * RAWC + col;
+                const float* bl = raw + (32 * wave + 8 * g) * CW + col;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     float x[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) x[q] = bl[(16 * s + q) * RAWC];
+                    for (int q = 0; q < 8; ++q) x[q] = bl[(16 * s + q) * CW];
                     f16x8 dh, dl;
                     split8(x, quarter, mcq, dh, dl);
                     f16_products<false, NP>(twh[s], twl[s], dh, dl, acc);
                 }
-                int wc = wpos + 32 * nt;
-                wc = wc >= RC ? wc - RC : wc;
+                int wc = (rel + 32 * nt) % RC;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) ring[((v & 3) + 8 * (v >> 2) + 4 * g) * pitch + wc + i] = fmaf(acc[v], p.out_scale, c0);
             }
-            // ---- axis 1: output tile u, columns 64 u ... 64 u + 63 ----
-            if (u >= t_first) {
-                const int x0 = 64 * u;
+            // ---- axis 1: the output tile this block completes, columns 64 t ... 64 t + 63 ----
+            if (tile_done) {
+                const int x0 = 64 * ((u + 1) / BPT - 1);
                 int sc = rb + Rp + 32;
                 sc = sc >= RC ? sc - RC : sc;
                 const float c = ring[i * pitch + sc];
@@ -1687,14 +1696,14 @@ __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int t
                 float xa[8], xb[8];
                 fetch(xa);
 #pragma unroll
-                for (int s = 0; s < S + 2; ++s) {
+                for (int s = 0; s < NS; ++s) {
                     f16x8 dh, dl;
                     if (s & 1) {
-                        if (s + 1 < S + 2) fetch(xa);
+                        if (s + 1 < NS) fetch(xa);
                         __builtin_amdgcn_sched_barrier(0);
                         split8(xb, quarter, mcq, dh, dl);
                     } else {
-                        if (s + 1 < S + 2) fetch(xb);
+                        if (s + 1 < NS) fetch(xb);
                         __builtin_amdgcn_sched_barrier(0);
                         split8(xa, quarter, mcq, dh, dl);
                     }
@@ -1724,14 +1733,15 @@ __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int t
                         }
                     }
                 }
-                rb += 64;
-                rb = rb >= RC ? rb - RC : rb;
             }
-        } else if (u >= t_first) {
+        }
+        if (tile_done) {
             rb += 64;
             rb = rb >= RC ? rb - RC : rb;
         }
-        if (more) store_raw(pre, rawbuf + (cur ^ 1) * (RAWR * RAWC));
+        rel += CW;
+        if (rel >= 64 * RC) rel -= 63 * RC;  // (kept small; only rel % RC and its sign before the first tile matter)
+        if (more) store_raw(pre, rawbuf + (cur ^ 1) * (RAWR * CW));
         __syncthreads();
         cur ^= 1;
     }
@@ -2132,7 +2142,26 @@ bool fused_radius(int R) {
         const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED");
         return !(e && *e == '0');
     }();
-    return on && f16_route() && R >= kMfmaSmallFloor && R <= 16;
+    static const int max_r = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED_MFMA_MAX_RADIUS");
+        return e && *e ? std::atoi(e) : 31;
+    }();
+    // (radius 32 takes 64-row tiles on axis 0 in the two-pass kernels: the fused kernel's bands are 32-row tiles)
+    return on && f16_route() && R >= kMfmaSmallFloor && R <= std::min(31, max_r);
+}
+template <int S, int CW>
+int launch_fused_f16(dim3 grid, const GaussArgs& a, int tile_first, int ntile_rows, int nseg) {
+    Context& c = ctx();
+    static bool ready = false;
+    if (!ready) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_fused_f16_kernel<TOPO_F16_NP, S, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ready = true;
+    }
+    constexpr int Rp = 8 * (S - 2);
+    const size_t lds = (size_t)(2 * (128 + 2 * Rp) * CW + 4 * (32 * (16 * (S + 2) + 4) + 32)) * sizeof(float);
+    hipLaunchKernelGGL((gauss_fused_f16_kernel<TOPO_F16_NP, S, CW>), grid, dim3(256), lds, c.compute, a, tile_first, ntile_rows, nseg);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
 }
 int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, const int** flag_out) {
     Context& c = ctx();
@@ -2155,16 +2184,11 @@ int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, cons
     TOPO_HIP(hipMemsetAsync(flag, 0, sizeof(int), c.compute));
     a.wild_flag = (int*)flag;
     *flag_out = (const int*)flag;
-    static bool ready = false;
-    if (!ready) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_fused_f16_kernel<TOPO_F16_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ready = true;
-    }
     const int tile_first = b.out_row0 / 32;
     const int ntile_rows = (b.out_row0 + b.out_rows - 1) / 32 - tile_first + 1;
     const int row_blocks = (ntile_rows + 3) / 4;
     const int ntile = (b.nx + 63) / 64;
-    // one block per CU (134 KB of LDS): the cut of the columns into runs with the least rounds x (tiles per run + 1)
+    // one block per CU (the LDS): the cut of the columns into runs with the least rounds x (tiles per run + run-in)
     int nseg = 1;
     long best = -1;
     for (int n = 1; n <= std::max(1, ntile / 4); ++n) {
@@ -2176,10 +2200,9 @@ int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, cons
         }
     }
     TOPO_TRY(check_grid_rows(row_blocks, "gaussian (fused matrix-core kernel)"));
-    const size_t lds = (size_t)(2 * 160 * 64 + 4 * (32 * 100 + 32)) * sizeof(float);
-    hipLaunchKernelGGL((gauss_fused_f16_kernel<TOPO_F16_NP>), dim3(nseg, row_blocks), dim3(256), lds, c.compute, a, tile_first, ntile_rows, nseg);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
+    const dim3 grid(nseg, row_blocks);
+    if (f16_steps(a.radius) == 4) return launch_fused_f16<4, 64>(grid, a, tile_first, ntile_rows, nseg);
+    return launch_fused_f16<6, 32>(grid, a, tile_first, ntile_rows, nseg);
 }
 // both passes with one sigma on the matrix cores: rows `b.out_row0 ...` -> out; tmp: a plane of the same size
 int smooth_both_mfma(const Block& b, double sigma, float* tmp, float* out, int table_slot) {
