@@ -2595,13 +2595,15 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         b.nx % 4 == 0 && aligned16(dx) && aligned16(dy) && aligned16(slope) && aligned16(aspect)) {
         static const int NCH = [] {
             const char* e = std::getenv("TOPO_AMD_GRAD_CHUNKS");
-            return std::max(1, std::min(64, e && *e ? std::atoi(e) : 16));
+            return std::max(1, std::min(64, e && *e ? std::atoi(e) : 8));
         }();
         static const int chunk_rows = [] {  // smallest chunk (rows); a chunk's planes should fit the 256 MB Infinity Cache
             const char* e = std::getenv("TOPO_AMD_GRAD_CHUNK_ROWS");
             // 32768^2, chunks x rows (profiles/r03_gradient_chunks.txt): 8 x 4096 8.04 / 13.70 ms at sigma 3.25 / 30.25,
             // 16 x 2048 7.77 / 13.50, 32 x 1024 8.27 / 14.55, 64 x 512 8.54 / 16.16
-            return std::max(256, e && *e ? std::atoi(e) : 2048);
+            // with the f16 kernels (profiles/r03_gauss_f16.txt, section 7): 4 x 8192 6.15 / 9.01, 8 x 4096 6.08 / 9.12,
+            // 12 x 2752 6.31 / 9.40, 16 x 2048 6.31 / 9.59, 32 x 1024 6.64 / 11.20; one stream: 6.71 / 10.43
+            return std::max(256, e && *e ? std::atoi(e) : 4096);
         }();
         static const bool use_aux = [] {
             const char* e = std::getenv("TOPO_AMD_GRAD_AUX");
