@@ -1,1 +1,1 @@
-for cfg in "4 8192 1" "6 5472 1" "8 4096 1" "12 2752 1"; do set -- $cfg; TOPO_AMD_GRAD_CHUNKS=$1 TOPO_AMD_GRAD_CHUNK_ROWS=$2 TOPO_AMD_GRAD_AUX=$3 python tools/grad_time.py 3.25 30.25 | sed "s/^/chunks $1 rows>=$2 aux=$3: /"; done
+for f in 1 0; do TOPO_AMD_GAUSS_F16_TALL=$f python tools/gauss_axes_time.py 30.25 | sed "s/^/tall=$f: /"; done
