@@ -636,3 +636,45 @@ def test_gradient_row_chunks_bit_identical(tmp_path):
 
 
 
+
+
+def test_requests_taller_than_one_launch():
+    """Several kernels launch one block row per DEM row, and a launch covers 65 535 of them: the launch_* entry points
+    cut taller requests into row blocks themselves (kMaxLaunchRows), and row blocks give the single block's bits.
+    70 016 rows x 64 columns in one call against two calls of 35 008 rows: Sobel, the fused and the two-pass
+    Gaussian, the gradient with and without row chunks, a generic (even) disc size and a ring-kernel size."""
+    ny, nx, half = 70016, 64, 35008
+    dem = d.DeviceArray(ny, nx)
+    d.synth_dem(40000, nx, row0=0, seed=5, out=dem, out_row=0)
+    d.synth_dem(ny - 40000, nx, row0=40000, seed=5, out=dem, out_row=40000)
+    blk = d.Block(dem)
+
+    def both_ways(nplanes, call):
+        whole = [d.DeviceArray(ny, nx) for _ in range(nplanes)]
+        call(whole, None, None)
+        d.sync()
+        w = [a.to_host() for a in whole]
+        for o0, on in ((0, half), (half, ny - half)):
+            part = [d.DeviceArray(on, nx) for _ in range(nplanes)]
+            call(part, o0, on)
+            d.sync()
+            for k in range(nplanes):
+                assert np.array_equal(part[k].to_host(), w[k][o0:o0 + on], equal_nan=True), (k, o0)
+            for a in part:
+                a.free()
+        for a in whole:
+            a.free()
+        return w
+
+    for sigma in (0.75, 2.0, 9.0):
+        both_ways(4, lambda o, o0, on: blk.gradient(sigma, [30.0], [-30.0], dx=o[0], dy=o[1], slope=o[2], aspect=o[3],
+                                                    out_row0=o0, out_rows=on))
+    for sigma in (2.0, 9.0):
+        g = both_ways(1, lambda o, o0, on: blk.gaussian(sigma, sigma, o[0], out_row0=o0, out_rows=on))[0]
+        host = dem.to_host(69000, 1016)
+        from scipy import ndimage
+        ref = ndimage.gaussian_filter(host, sigma, mode="reflect")
+        assert np.max(np.abs(g[69000 + 40:] - ref[40:])) <= 1e-3  # the last rows, beyond the first launch's reach
+    for size in (6, 7):
+        both_ways(2, lambda o, o0, on: blk.tpi_std(size, tpi=o[0], std=o[1], out_row0=o0, out_rows=on))
+    dem.free()

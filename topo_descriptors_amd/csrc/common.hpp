@@ -75,8 +75,10 @@ struct Block {
     int out_row0, out_rows;
 };
 int check_block(const Block& b, int need_above, int need_below, const char* who);
-// Several kernels launch one block row per DEM row (gridDim.y): 65 535 rows per call at most.  Taller
-// requests go through the row-block arguments (out_row0, out_rows) in pieces.
+// Several kernels launch one block row per DEM row (gridDim.y): 65 535 rows per launch at most.  The launch_*
+// entry points therefore cut taller requests into row blocks of kMaxLaunchRows output rows (a multiple of every
+// tile height in use: 32, 60, 64, 192) - row blocks give the single block's bits, so nobody sees the cut.
+constexpr int kMaxLaunchRows = 65280;
 inline int check_grid_rows(long rows, const char* who) {
     TOPO_REQUIRE(rows <= 65535, "%s: %ld rows in one call, the launch covers at most 65535 (gridDim.y): split the "
                  "request with out_row0 / out_rows", who, rows);

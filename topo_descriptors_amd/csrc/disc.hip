@@ -397,6 +397,15 @@ int launch_disc_wave_repitched(const Block& b, int size, float* tpi_out, float* 
 }  // namespace
 
 int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out) {
+    if (b.out_rows > kMaxLaunchRows) {
+        for (int r = 0; r < b.out_rows; r += kMaxLaunchRows) {
+            Block s = b;
+            s.out_row0 = b.out_row0 + r;
+            s.out_rows = std::min(kMaxLaunchRows, b.out_rows - r);
+            TOPO_TRY(launch_tpi_std(s, disc, tpi_out ? tpi_out + (size_t)r * b.nx : nullptr, std_out ? std_out + (size_t)r * b.nx : nullptr));
+        }
+        return TOPO_AMD_OK;
+    }
     TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
     Context& c = ctx();
     {

@@ -2517,10 +2517,23 @@ int gaussian_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
 int mfma_min_radius(bool for_gradient) { return mfma_min_radius_impl(for_gradient); }
 
 int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out, bool small_ok) {
-    return smooth_rows(b, sigma_y, sigma_x, b.out_row0, b.out_rows, out, 0, 1, small_ok);
+    for (int r = 0; r < b.out_rows; r += kMaxLaunchRows) {  // (one pass unless the block is taller than a launch covers)
+        const int n = std::min(kMaxLaunchRows, b.out_rows - r);
+        TOPO_TRY(smooth_rows(b, sigma_y, sigma_x, b.out_row0 + r, n, out + (size_t)r * b.nx, 0, 1, small_ok));
+    }
+    return TOPO_AMD_OK;
 }
 
 int launch_sobel(const Block& b, float* dx_out, float* dy_out) {
+    if (b.out_rows > kMaxLaunchRows) {
+        for (int r = 0; r < b.out_rows; r += kMaxLaunchRows) {
+            Block s = b;
+            s.out_row0 = b.out_row0 + r;
+            s.out_rows = std::min(kMaxLaunchRows, b.out_rows - r);
+            TOPO_TRY(launch_sobel(s, dx_out ? dx_out + (size_t)r * b.nx : nullptr, dy_out ? dy_out + (size_t)r * b.nx : nullptr));
+        }
+        return TOPO_AMD_OK;
+    }
     Context& c = ctx();
     GradArgs g{};
     g.raw = b.in;
@@ -2553,6 +2566,22 @@ Block smoothed_rows_block(const Block& b) {
 int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode,
                     const void* res_x, const void* res_y, float* dx, float* dy, float* slope,
                     float* aspect) {
+    if (b.out_rows > kMaxLaunchRows) {
+        for (int r = 0; r < b.out_rows; r += kMaxLaunchRows) {
+            Block s = b;
+            s.out_row0 = b.out_row0 + r;
+            s.out_rows = std::min(kMaxLaunchRows, b.out_rows - r);
+            const size_t shift = (size_t)r * b.nx;
+            const void *rx = res_x, *ry = res_y;
+            if (res_mode == TOPO_AMD_RES_2D && res_x && res_y) {
+                rx = (const float*)res_x + shift;
+                ry = (const float*)res_y + shift;
+            }
+            TOPO_TRY(launch_gradient(s, sigma, sig_ratio, res_mode, rx, ry, dx ? dx + shift : nullptr, dy ? dy + shift : nullptr,
+                                     slope ? slope + shift : nullptr, aspect ? aspect + shift : nullptr));
+        }
+        return TOPO_AMD_OK;
+    }
     Context& c = ctx();
     TOPO_REQUIRE(res_mode >= 0 && res_mode <= 2, "gradient: bad res_mode %d", res_mode);
     TOPO_REQUIRE(res_x && res_y, "gradient: resolution arrays are NULL");
