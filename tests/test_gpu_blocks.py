@@ -678,3 +678,37 @@ def test_requests_taller_than_one_launch():
     for size in (6, 7):
         both_ways(2, lambda o, o0, on: blk.tpi_std(size, tpi=o[0], std=o[1], out_row0=o0, out_rows=on))
     dem.free()
+
+
+@pytest.mark.parametrize("azimuth", [45.0, 135.0, 225.0, 315.0, 30.0])
+def test_sx_diagonal_chains(azimuth):
+    """Sectors off the axes at a radius where the launcher scans along a diagonal (sx_kernel<.., DIAG = +-1>, from ~100
+    comparisons per pixel): the oracle, the axis-aligned scan of the same sector (TOPO_AMD_SX_DIAG=0 would give the
+    same bits: a maximum does not care about the order; here checked against the fan kernel, which never scans
+    diagonally), row blocks, and a width where the leaning slabs meet both DEM edges."""
+    gny, nx = 330, 300
+    dem = orc.synthetic_dem(gny, nx, seed=23)
+    window, dj, di, dist = d.sx_offsets(azimuth, 1500.0, 30.0, -30.0)
+    up, down = halo(_lib.DESC_SX, max(0, -dj.min()), max(0, dj.max()))
+
+    def call(blk, row0, rows):
+        out = d.DeviceArray(rows, nx)
+        blk.sx(dj, di, dist, window, 10.0, out, out_row0=row0, out_rows=rows)
+        return [out]
+
+    whole = run_blocks(dem, 1, up, down, call)[0]
+    for nb in (2, 3):
+        assert np.array_equal(run_blocks(dem, nb, up, down, call)[0], whole, equal_nan=True), (azimuth, nb)
+    x = 2600000.0 + 30.0 * np.arange(nx)
+    y = 1200000.0 - 30.0 * np.arange(gny)
+    want = orc.sx(dem, x, y, azimuth, 1500.0)
+    assert np.max(np.abs(whole - want)) <= 1e-4 * np.max(np.abs(want))
+    # the fan kernel on the same sector (and a neighbour, so that it is a fan): plane for plane the same bits
+    dev = d.DeviceArray.from_host(dem)
+    outs = [d.DeviceArray(gny, nx) for _ in range(2)]
+    d.Block(dev).sx_multi([(window, dj, di, dist), d.sx_offsets(azimuth + 5.0, 1500.0, 30.0, -30.0)], 10.0, outs)
+    d.sync()
+    assert np.array_equal(outs[0].to_host(), whole, equal_nan=True)
+    for a in outs:
+        a.free()
+    dev.free()

@@ -73,21 +73,29 @@ constexpr int kSxOwn = kSxTile / (kThreads / 64);  // consecutive pixels per lan
 // like nanmax; what such a chain reads past the tile is spare LDS.
 // NW waves: 4 (tile 64 x 64) or, lanes along x only, 8 (tile 64 columns x 128 rows: a third less halo per output and
 // two blocks of 8 waves per CU where the 64-row tile has three of 4).
-template <int STRIDE, bool ALONG_X, int NW>
+// DIAG = +1 / -1 (round 3; lanes along x only): the chains run along a DIAGONAL - the sample for (own pixel k, ray
+// pixel m + 1) is again the one for (own pixel k + 1, ray pixel m) when both the own pixels of a lane and the ray
+// pixels of a chain step (1 row, DIAG columns) - so the runs of a sector that points north-east ... are as long as
+// those of one that points north.  The code is the same with the LDS step STRIDE + DIAG; the 16 pixels of a lane
+// lean over 15 columns (every wave's slab of 16 rows starts upright again, so the staged tile is 15 columns wider
+// and the tile grid one tile longer), and for a fixed k the lanes still store 64 consecutive columns of one row.
+template <int STRIDE, bool ALONG_X, int NW, int DIAG = 0>
 __global__ __launch_bounds__(NW * 64) void sx_kernel(SxArgs p) {
     static_assert(NW == 4 || !ALONG_X, "8 waves: lanes along x only");
+    static_assert(DIAG == 0 || !ALONG_X, "diagonal chains: lanes along x only");
     constexpr int SPAN = kSxOwn * NW;  // tile extent along the chain axis
+    constexpr int XS = DIAG < 0 ? kSxOwn - 1 : 0;  // own pixels lean left: the tile is staged that many columns further left
     extern __shared__ __attribute__((aligned(16))) float L[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int ox0 = blockIdx.x * (ALONG_X ? SPAN : kSxTile);
+    const int ox0 = ((int)blockIdx.x - (DIAG > 0 ? 1 : 0)) * (ALONG_X ? SPAN : kSxTile);
     const int oy0 = p.out_row0 + blockIdx.y * (ALONG_X ? kSxTile : SPAN);
 
     // stage tile + offset bounding box; pixels outside the DEM are never used by interior
     // outputs (the zero frame is exactly as wide as the reach of the rays).  Four rows per wave in flight.
     for (int r0 = 0; r0 < p.rows_l; r0 += 4 * NW) {
         for (int k0 = 0; k0 < p.cols_l; k0 += 64) {
-            const int k = k0 + lane, gx = ox0 + p.di_min + k;
+            const int k = k0 + lane, gx = ox0 + p.di_min - XS + k;
             const bool col_ok = k < p.cols_l && gx >= 0 && gx < p.nx;
             float v[4];
 #pragma unroll
@@ -108,10 +116,10 @@ __global__ __launch_bounds__(NW * 64) void sx_kernel(SxArgs p) {
     }
     __syncthreads();
 
-    constexpr int S = ALONG_X ? 1 : STRIDE;  // LDS step along the chain axis
+    constexpr int S = ALONG_X ? 1 : STRIDE + DIAG;  // LDS step along the chain axis
     float best[kSxOwn], centre[kSxOwn];
     // own pixel k of this lane at LDS index Lw + k S (+ the offset of a ray pixel)
-    const float* Lw = ALONG_X ? L + lane * STRIDE + wave * kSxOwn : L + wave * kSxOwn * STRIDE + lane;
+    const float* Lw = ALONG_X ? L + lane * STRIDE + wave * kSxOwn : L + wave * kSxOwn * STRIDE + lane + XS;
     const int self = -p.dj_min * STRIDE - p.di_min;
 #pragma unroll
     for (int k = 0; k < kSxOwn; ++k) {
@@ -184,10 +192,10 @@ __global__ __launch_bounds__(NW * 64) void sx_kernel(SxArgs p) {
 #pragma unroll
         for (int k = 0; k < kSxOwn; ++k) best[k] = L[(wave * kSxOwn + k) * (kSxTile + 1) + lane];
     }
-    const int ox = ox0 + lane;
-    if (ox >= p.nx) return;
 #pragma unroll
     for (int k = 0; k < kSxOwn; ++k) {
+        const int ox = ox0 + lane + DIAG * k;
+        if (ox < 0 || ox >= p.nx) continue;
         const int oy = oy0 + wave * kSxOwn + k;
         if (oy >= p.out_row0 + p.out_rows) continue;
         const bool inside = oy >= p.window && oy < p.gny - p.window && ox >= p.window &&
@@ -203,7 +211,7 @@ constexpr int kSxStrides[] = {67, 71, 75, 81, 89, 97, 105, 113, 129, 145, 161, 1
 constexpr int kSxStrideCount = sizeof(kSxStrides) / sizeof(kSxStrides[0]);
 
 template <int I = 0>
-int launch_sx_stride(int stride, bool along_x, int waves, dim3 grid, size_t lds, hipStream_t stream, const SxArgs& a) {
+int launch_sx_stride(int stride, bool along_x, int waves, dim3 grid, size_t lds, hipStream_t stream, const SxArgs& a, int diag = 0) {
     if constexpr (I < kSxStrideCount) {
         if (stride == kSxStrides[I]) {
             auto go = [&](auto kernel) -> int {
@@ -213,9 +221,11 @@ int launch_sx_stride(int stride, bool along_x, int waves, dim3 grid, size_t lds,
                 return TOPO_AMD_OK;
             };
             if (along_x) return go(sx_kernel<kSxStrides[I], true, 4>);
+            if (diag > 0) return go(sx_kernel<kSxStrides[I], false, 4, 1>);
+            if (diag < 0) return go(sx_kernel<kSxStrides[I], false, 4, -1>);
             return waves == 8 ? go(sx_kernel<kSxStrides[I], false, 8>) : go(sx_kernel<kSxStrides[I], false, 4>);
         }
-        return launch_sx_stride<I + 1>(stride, along_x, waves, grid, lds, stream, a);
+        return launch_sx_stride<I + 1>(stride, along_x, waves, grid, lds, stream, a, diag);
     } else {
         set_error("sx: no kernel for LDS stride %d", stride);
         return TOPO_AMD_EUNSUP;
@@ -231,10 +241,14 @@ int sx_stride_for(int cols_l) {
 // Cut the unique ray pixels into chains along one axis: runs of neighbours in eights, what is left of a run (or
 // a run shorter than 7) in fours and twos, so that at most one comparison per run is padding.  `along_x`: chains run along di (same dj), else along dj (same di).
 typedef std::vector<std::pair<std::pair<int, int>, double>> SxPoints;
-void sx_chains(SxPoints pts, bool along_x, int stride, int dj_min, int di_min, std::vector<SxChain8>* t8,
+// `mode`: 0 chains along dj (same di), 1 along di (same dj), 2 / 3 along the diagonals (dj + 1, di + 1) / (dj + 1, di - 1).
+void sx_chains(SxPoints pts, int mode, int stride, int dj_min, int di_min, std::vector<SxChain8>* t8,
                std::vector<SxChain4>* t4, std::vector<SxChain2>* t2) {
-    auto line = [&](const SxPoints::value_type& q) { return along_x ? q.first.first : q.first.second; };
-    auto pos = [&](const SxPoints::value_type& q) { return along_x ? q.first.second : q.first.first; };
+    auto line = [&](const SxPoints::value_type& q) {
+        const int dj = q.first.first, di = q.first.second;
+        return mode == 0 ? di : mode == 1 ? dj : mode == 2 ? di - dj : di + dj;
+    };
+    auto pos = [&](const SxPoints::value_type& q) { return mode == 1 ? q.first.second : q.first.first; };
     std::sort(pts.begin(), pts.end(), [&](const auto& x, const auto& y) {
         return std::make_pair(line(x), pos(x)) < std::make_pair(line(y), pos(y));
     });
@@ -595,15 +609,47 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
         TOPO_HIP(hipGetLastError());
         return TOPO_AMD_OK;
     }
-    // chains along the axis that needs fewer comparisons (padding included)
-    std::vector<SxChain8> t8[2];
-    std::vector<SxChain4> t4[2];
-    std::vector<SxChain2> t2[2];
-    for (int ax = 0; ax < 2; ++ax) sx_chains(pts, ax == 1, stride, dj_min, di_min, &t8[ax], &t4[ax], &t2[ax]);
-    const bool along_x = 8 * t8[1].size() + 4 * t4[1].size() + 2 * t2[1].size() < 8 * t8[0].size() + 4 * t4[0].size() + 2 * t2[0].size();
-    const std::vector<SxChain8>& c8 = t8[along_x];
-    const std::vector<SxChain4>& c4 = t4[along_x];
-    std::vector<SxChain2>& c2 = t2[along_x];
+    // chains along the direction that needs the fewest comparisons (padding included): down the columns, along the
+    // rows, or along one of the two diagonals (whose tile is 15 columns wider: its own LDS stride)
+    static const bool diag_on = [] {
+        const char* e = std::getenv("TOPO_AMD_SX_DIAG");
+        return !(e && *e == '0');
+    }();
+    static const int diag_min_saving = [] {
+        const char* e = std::getenv("TOPO_AMD_SX_DIAG_MIN_SAVING");
+        // 32768^2, azimuth 45: radius 2000 m 428 -> 366 comparisons 28.4 -> 25.0 ms; 1000 m 146 -> 132: 8.45 -> 8.10;
+        // 500 m 42 -> 36: 3.90 -> 3.99 (hence the floor below)
+        return e && *e ? std::atoi(e) : 5;
+    }();
+    static const int diag_min_cost = [] {
+        const char* e = std::getenv("TOPO_AMD_SX_DIAG_MIN_COST");
+        return e && *e ? std::atoi(e) : 100;
+    }();
+    const int cols_d = a.cols_l + kSxOwn - 1;
+    const int stride_d = sx_stride_for(cols_d);
+    const size_t lds_d = (size_t)(a.rows_l + 8) * stride_d * sizeof(float);
+    const bool diag_fits = diag_on && stride_d != 0 && lds_d <= 160 * 1024;
+    std::vector<SxChain8> t8[4];
+    std::vector<SxChain4> t4[4];
+    std::vector<SxChain2> t2[4];
+    size_t cost[4];
+    int mode = 0;
+    for (int m = 0; m < 4; ++m) {
+        if (m >= 2 && !diag_fits) break;
+        sx_chains(pts, m, m >= 2 ? stride_d : stride, dj_min, di_min, &t8[m], &t4[m], &t2[m]);
+        cost[m] = 8 * t8[m].size() + 4 * t4[m].size() + 2 * t2[m].size();
+        // a diagonal scan has to save comparisons to be worth its wider tile and its extra column of tiles
+        // (TOPO_AMD_SX_DIAG_MIN_SAVING, percent), and the scan has to be long enough for that to show
+        // (TOPO_AMD_SX_DIAG_MIN_COST comparisons)
+        if (m > 0 && (m < 2 ? cost[m] < cost[mode]
+                            : cost[mode] >= (size_t)diag_min_cost && 100 * cost[m] < (size_t)(100 - diag_min_saving) * cost[mode]))
+            mode = m;
+    }
+    const bool along_x = mode == 1;
+    const int diag = mode == 2 ? 1 : mode == 3 ? -1 : 0;
+    const std::vector<SxChain8>& c8 = t8[mode];
+    const std::vector<SxChain4>& c4 = t4[mode];
+    std::vector<SxChain2>& c2 = t2[mode];
     while (c2.size() % 4) {  // the kernel takes four at a time: entries whose products are all NaN
         SxChain2 e{};
         e.inv[0] = e.inv[1] = std::nanf("");
@@ -636,6 +682,11 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     // 128-row tiles with 8 waves while two such blocks share a CU
     int waves = 4;
     size_t lds_used = lds;
+    if (diag != 0) {
+        a.cols_l = cols_d;
+        dim3 dgrid((b.nx + kSxTile - 1) / kSxTile + 1, (b.out_rows + kSxTile - 1) / kSxTile);  // the slabs lean: one tile more
+        return launch_sx_stride(stride_d, false, 4, dgrid, lds_d, c.compute, a, diag);
+    }
     if (!along_x && b.out_rows >= 2 * kSxTile && 8 * c8.size() + 4 * c4.size() + 2 * c2.size() >= 256) {
         const size_t lds8 = (size_t)(a.rows_l + kSxTile + 8) * stride * sizeof(float);
         if (lds8 <= 80 * 1024) {
