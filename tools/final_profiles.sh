@@ -17,8 +17,12 @@ cp profiles/r03_tpi67_valu_bound.json $F/
 PMC_SCRIPT=tools/std_trace.py tools/pmc_passes.sh final/pmc_std67 32768 67 > /dev/null 2>&1
 python3 tools/traffic_from_pmc.py gpurun_out/final/pmc_std67 std_ring_kernel $F/r03_std67_traffic.json $HEAD > $F/traffic_std67.log 2>&1
 cp gpurun_out/final/pmc_std67/summary.txt $F/r03_std67_pmc_summary.txt
-# (the gradient and Sx kernels did not change in round 3: profiles/r02_grad30_pmc_summary.txt, r02_grad325_pmc_summary.txt
-# and r02_sx_pmc_summary.txt stand; PMC_SCRIPT=tools/grad_trace.py / tools/sx_trace.py re-takes them)
+# the gradient at both sigmas of config 3 (round 3: f16 matrix pipe, fused short filters)
+PMC_SCRIPT=tools/grad_trace.py tools/pmc_passes.sh final/pmc_grad325 32768 3.25 > /dev/null 2>&1
+cp gpurun_out/final/pmc_grad325/summary.txt $F/r03_grad325_pmc_summary.txt
+PMC_SCRIPT=tools/grad_trace.py tools/pmc_passes.sh final/pmc_grad30 32768 30.25 > /dev/null 2>&1
+cp gpurun_out/final/pmc_grad30/summary.txt $F/r03_grad30_pmc_summary.txt
+# (the Sx kernels' counters: profiles/r02_sx_pmc_summary.txt stands for the axis-aligned scans; PMC_SCRIPT=tools/sx_trace.py re-takes them)
 # the sharded step with the real exchange on one GPU: one 4096-row shard of the 8-GPU split, neighbours = itself
 TOPO_AMD_HALO_LOOPBACK=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --ny 4096 > $F/r03_bench_loopback_4096rows.json 2> $F/loopback.err
 python3 bench.py > $F/r03_bench.json 2> $F/r03_bench.err
