@@ -258,7 +258,7 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
               disc_kernels("tpi_std", size))
     o3 = d.DeviceArray(ny, nx)
     o4 = d.DeviceArray(ny, nx)
-    chunks = "16 row chunks, gradient_epilogue4_kernel of chunk k on a second stream beside the smooth of chunk k + 1"
+    chunks = "8 row chunks, gradient_epilogue4_kernel of chunk k on a second stream beside the smooth of chunk k + 1"
     grad_kernels = {
         3.25: "gauss_fused_f16_kernel (both passes of the radius-13 filter in one kernel on the f16 matrix pipe, the "
               "intermediate plane in LDS; the two-pass kernels queued behind it return at once on a DEM without "
@@ -275,7 +275,7 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     for azimuth, radius in ((0.0, 500.0), (0.0, 2000.0), (45.0, 500.0), (45.0, 2000.0)):
         window, dj, di, dist = d.sx_offsets(azimuth, radius, 30.0, -30.0)
         fn = lambda: blk.sx(dj, di, dist, window, 10.0, o1)  # noqa: E731
-        entry(f"sx_az{int(azimuth)}_r{int(radius)}", time_kernel(fn, REPS, d), 8, "sx_kernel<stride> (LDS tile, chains of 8 neighbouring ray pixels along the sector's axis, one atan per pixel)")
+        entry(f"sx_az{int(azimuth)}_r{int(radius)}", time_kernel(fn, REPS, d), 8, "sx_kernel<stride> (LDS tile, chains of 8 / 4 / 2 neighbouring ray pixels down the columns, along the rows or along a diagonal, whichever needs the fewest comparisons; one atan per pixel)")
     # two small discs in one pass over the DEM: ms for the pair, rate and fraction per plane
     st = time_kernel(lambda: blk.tpi_multi([7, 11], [o1, o2]), REPS, d)
     entry("tpi_s7_s11_one_pass_per_plane", st, 6, "tpi_ring_kernel<11, 8, kRingMain, 7> (one staging pass, one ring, two chains; 4 B read + 8 B "
