@@ -65,6 +65,18 @@ struct alignas(16) Vec4 {
 
 #define DPP_WAVE_SHL1 0x130  // lane i takes lane i + 1; lane 63 takes 0 (bound_ctrl)
 
+#ifdef HOP_BPERMUTE
+// lab variant (tools/ubench/tpi_lab.hip -DHOP_BPERMUTE): the lane shift through the LDS crossbar (ds_bpermute_b32, no
+// LDS memory) instead of a DPP operand - takes the hop off the vector ALU (where every DPP form issues at half rate)
+// and puts it on the LDS pipe.  Same bits; TPI 67 px 4.42 -> 7.30 ms, STD 8.85 -> 11.03 ms on 32768^2: the crossbar's
+// latency sits in the 18-hop dependent chain and its issue competes with the 44 ds_read_b128 of a row.
+__device__ __forceinline__ int hop_addr() {
+    return (int)(((__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) + 1u) & 63u) << 2);
+}
+__device__ __forceinline__ float hop(float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(hop_addr(), __float_as_int(x))); }
+__device__ __forceinline__ int hop(int x) { return __builtin_amdgcn_ds_bpermute(hop_addr(), x); }
+__device__ __forceinline__ uint32_t hop(uint32_t x) { return (uint32_t)__builtin_amdgcn_ds_bpermute(hop_addr(), (int)x); }
+#else
 __device__ __forceinline__ float hop(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), DPP_WAVE_SHL1, 0xf, 0xf, true));
 }
@@ -74,6 +86,7 @@ __device__ __forceinline__ int hop(int x) {
 __device__ __forceinline__ uint32_t hop(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_SHL1, 0xf, 0xf, true);
 }
+#endif
 
 // Disc sums of output row jj (tile-relative) for the NC output columns that end up in this
 // lane: lane l receives the sums of staged columns NC * (l - D_LO) + t, valid for l < NVL.
