@@ -1,1 +1,2 @@
-for f in 1 0; do TOPO_AMD_GAUSS_F16_TALL=$f python tools/gauss_axes_time.py 30.25 | sed "s/^/tall=$f: /"; done
+python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "gauss or gradient" 2>&1 | grep -E "passed|failed|Error|assert" | head
+python tools/grad_time.py 1.25 3.25 6.0

@@ -1655,13 +1655,28 @@ __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int t
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
                 const float* bl = raw + (32 * wave + 8 * g) * CW + col;
+                float xa[8], xb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xa[q] = bl[q * CW];
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    float x[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) x[q] = bl[(16 * s + q) * CW];
                     f16x8 dh, dl;
-                    split8(x, quarter, mcq, dh, dl);
+                    // the next step's samples are on their way while this step's are split (as in the two-pass kernels)
+                    if (s & 1) {
+                        if (s + 1 < S) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) xa[q] = bl[(16 * (s + 1) + q) * CW];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        split8(xb, quarter, mcq, dh, dl);
+                    } else {
+                        if (s + 1 < S) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) xb[q] = bl[(16 * (s + 1) + q) * CW];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        split8(xa, quarter, mcq, dh, dl);
+                    }
                     f16_products<false, NP>(twh[s], twl[s], dh, dl, acc);
                 }
                 int wc = (rel + 32 * nt) % RC;
