@@ -2054,7 +2054,7 @@ int run_axis1_f16(GaussArgs a, int rows, int nx, double sigma) {
 
 int run_axis0_mfma(const Block& b, double sigma, float* out, int table_slot) {
     Context& c = ctx();
-    GaussArgs a;
+    GaussArgs a{};
     TOPO_TRY(upload_plain_weights(table_slot, sigma, &a));
     a.in = b.in;
     a.out = out;
@@ -2100,7 +2100,7 @@ int run_axis0_mfma(const Block& b, double sigma, float* out, int table_slot) {
 
 int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, int table_slot) {
     Context& c = ctx();
-    GaussArgs a;
+    GaussArgs a{};
     TOPO_TRY(upload_plain_weights(table_slot, sigma, &a));
     a.in = in;
     a.out = out;
@@ -2180,7 +2180,7 @@ int launch_fused_f16(dim3 grid, const GaussArgs& a, int tile_first, int ntile_ro
 }
 int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, const int** flag_out) {
     Context& c = ctx();
-    GaussArgs a;
+    GaussArgs a{};
     TOPO_TRY(upload_plain_weights(table_slot, sigma, &a));
     a.in = b.in;
     a.out = out;
@@ -2236,7 +2236,7 @@ int run_axis0(const Block& b, double sigma, float* out, int table_slot, bool mfm
     if (mfma_ok && mfma_radius(gaussian_radius(sigma), b.nx, false, small_ok) && mfma_rows_ok(b, gaussian_radius(sigma)))
         return run_axis0_mfma(b, sigma, out, table_slot);
     const bool wide = wide_tiling(gaussian_radius(sigma));
-    GaussArgs a;
+    GaussArgs a{};
     TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
     a.in = b.in;
     a.out = out;
@@ -2284,7 +2284,7 @@ int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, c
 int run_axis1(const float* in, int rows, int nx, double sigma, float* out, int table_slot, bool small_ok = true) {
     if (mfma_radius(gaussian_radius(sigma), nx, false, small_ok)) return run_axis1_mfma(in, rows, nx, sigma, out, table_slot);
     const bool wide = wide_tiling(gaussian_radius(sigma));
-    GaussArgs a;
+    GaussArgs a{};
     TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
     a.in = in;
     a.out = out;
@@ -2380,7 +2380,7 @@ int run_axis1_grad(const float* in, int s_row0, int s_rows, int gny, int nx, dou
         return e && *e ? std::atoi(e) : 60;
     }();
     const bool wide = gaussian_radius(sigma) >= wide_from;
-    GaussArgs a;
+    GaussArgs a{};
     TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
     a.in = in;
     a.out = nullptr;
