@@ -68,7 +68,7 @@ def test_tpi_std_blocks_bit_identical(size, nx, integer):
 
 # radius int(4 sigma + 0.5): 13, 28 and 48 (fused LDS-tiled axis 1, 3 / 3 / 4 samples per lane held for
 # the next tile), 64 and 88 (the same kernel with 16-wide tap chunks, 4 / 5 samples), 104 (wave-shift axis 1)
-@pytest.mark.parametrize("sigma", [0.75, 3.25, 7.0, 12.0, 16.0, 22.0, 26.0])
+@pytest.mark.parametrize("sigma", [0.75, 3.25, 7.0, 10.0, 12.0, 16.0, 22.0, 26.0])
 def test_gradient_blocks_bit_identical(sigma):
     gny, nx = 420, 320
     dem = orc.synthetic_dem(gny, nx, seed=9)
@@ -91,6 +91,31 @@ def test_gradient_blocks_bit_identical(sigma):
     exact = orc.gradient_exact(dem, sigma, res)
     for k in range(3):
         assert np.max(np.abs(whole[k] - exact[k])) <= 1e-4 * np.max(np.abs(exact[k]))
+
+
+@pytest.mark.parametrize("sigma", [3.25, 6.0, 10.0, 16.0])
+def test_gradient_blocks_with_non_finite_samples(sigma):
+    """The smooth of the gradient at radius 4 ... 47 is ONE kernel that raises a flag when it meets a sample that is
+    not a plain finite one; the two-pass kernels queued behind it then redo the block.  A block without such a sample
+    keeps the fused kernel's result: the two routes must give the same bits, and the non-finite footprint must not
+    depend on the cut either (sigma 16: the two-pass kernels alone)."""
+    gny, nx = 420, 320
+    dem = orc.synthetic_dem(gny, nx, seed=19)
+    dem[150, 100] = np.nan
+    dem[333, 31:34] = np.inf
+    up, down = halo(_lib.DESC_GRADIENT, sigma)
+
+    def call(blk, row0, rows):
+        outs = [d.DeviceArray(rows, nx) for _ in range(4)]
+        blk.gradient(sigma, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3], out_row0=row0, out_rows=rows)
+        return outs
+
+    whole = run_blocks(dem, 1, up, down, call)
+    assert np.isnan(whole[0][150, 100]) and np.isfinite(whole[0][10, 10])
+    for nb in (2, 3, 5):
+        parts = run_blocks(dem, nb, up, down, call)
+        for k in range(4):
+            assert np.array_equal(parts[k], whole[k], equal_nan=True), (sigma, nb, k)
 
 
 @pytest.mark.parametrize("azimuth", [0.0, 135.0, 260.0])
@@ -621,7 +646,7 @@ def test_gradient_row_chunks_bit_identical(tmp_path):
         "from oracle import topo_oracle as orc\n"
         "import topo_descriptors_amd.topo as topo\n"
         "dem = orc.synthetic_dem(700, 512, seed=5)\n"
-        "np.save(sys.argv[1], np.stack(topo.gradient(dem, 9.0, {'x': 50.0, 'y': -50.0})))\n"
+        "np.save(sys.argv[1], np.stack(topo.gradient(dem, 9.0, {'x': 50.0, 'y': -50.0}) + topo.gradient(dem, 11.0, {'x': 50.0, 'y': -50.0})))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for name, rows in (("chunked", "64"), ("whole", "100000000")):

@@ -213,13 +213,13 @@ def test_gaussian_nan_repair_is_partition_invariant():
 
 
 def test_gaussian_fused_is_the_two_passes():
-    """Radius 4 ... 31 with one sigma runs both passes in one kernel (gauss_fused_f16_kernel): the arithmetic of the
+    """Radius 4 ... 47 with one sigma runs both passes in one kernel (gauss_fused_f16_kernel): the arithmetic of the
     two f16 kernels tile for tile, the intermediate in LDS.  Same bits as the two passes (TOPO_AMD_GAUSS_FUSED=0 in
     a child process), on shapes with partial bands, partial tiles, a width that is not a multiple of 64, a block
     narrower than one tile, and through row blocks."""
     import subprocess, sys, tempfile
     shapes = [(200, 512), (129, 68), (33, 20), (300, 1000), (64, 64)]
-    sigmas = [1.0, 2.25, 3.25, 4.0, 5.0, 7.75]  # radii 4, 9, 13, 16 (64-column raw blocks) and 20, 31 (32-column ones)
+    sigmas = [1.0, 2.25, 3.25, 4.0, 5.0, 7.75, 8.0, 11.75]  # radii 4, 9, 13, 16 (64-column raw blocks), 20, 31, 32, 47 (32-column ones)
     with tempfile.TemporaryDirectory() as tmp:
         code = (
             "import sys, numpy as np\n"
@@ -244,7 +244,7 @@ def test_gaussian_fused_is_the_two_passes():
     # two-pass kernels and their repair passes take over inside the library)
     from topo_descriptors_amd import _lib, device as d, shard
     gny, nx = 420, 512
-    for poison, sigma in ((False, 3.25), (True, 3.25), (False, 6.0), (True, 6.0)):
+    for poison, sigma in ((False, 3.25), (True, 3.25), (False, 6.0), (True, 6.0), (False, 10.0), (True, 10.0)):
         dem = orc.synthetic_dem(gny, nx, seed=78)
         if poison:
             dem[139, 200] = np.nan

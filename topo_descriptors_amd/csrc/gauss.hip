@@ -1235,7 +1235,7 @@ constexpr int kNoWild = -(1 << 28);
 // MT = 2: the wave's tile is 64 rows (two MFMA tiles on top of each other, global multiples of 64) with ONE offset
 // per column, so one split of the samples feeds both: the vector-ALU work per output halves.  The offset row is 32
 // rows into the tile; a row block holds it for every tile it computes when it carries 32 ghost rows, so the
-// launcher takes MT = 2 from radius 32.
+// launcher takes MT = 2 from radius 32 (except behind a fused launch, whose bands are 32-row tiles).
 template <int S, int NP, int MT>
 __global__ __launch_bounds__(256) void gauss_axis0_f16_kernel(GaussArgs p, int tile_first, int ntiles, int tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) float L[];
@@ -1915,6 +1915,7 @@ bool f16_route() {
 #define TOPO_F16_NP 3  // products per tap block: th h + tm h + th l (4 adds tm l: 7 % slower, same error; lab builds)
 #endif
 int f16_steps(int R);
+thread_local bool t_axis0_one_tile = false;  // set around the two-pass launches queued behind a fused launch
 // two MFMA tiles per offset (MT = 2): axis 1 always; axis 0 from radius 32 (the offset row is 32 rows into a
 // 64-row tile).  TOPO_AMD_GAUSS_F16_MT=1 keeps one tile everywhere (A/B).
 int f16_mt(bool axis1, int R) {
@@ -1924,6 +1925,9 @@ int f16_mt(bool axis1, int R) {
     }();
     if (forced == 1) return 1;
     if (axis1) return forced == 2 || f16_steps(R) < 18 ? 2 : 1;  // the widest window fits LDS 3 times with MT = 2: 2.95 ms against 2.66 with MT = 1
+    // (behind a fused launch - radius 32 ... 47 of the gradient - the two-pass kernels must give the fused kernel's bits,
+    // and its bands are 32-row tiles)
+    if (t_axis0_one_tile) return 1;
     return R >= 32 ? 2 : 1;
 }
 int f16_steps(int R) { return 2 + (R + 15) / 16 * 2; }  // 16-sample steps of a 32-output tile's window: 32 + 2 Rp, Rp = R rounded up to 16
@@ -2152,17 +2156,19 @@ int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, 
 }
 
 // ---- one kernel for both passes (radius 4 ... 16, one sigma) ----
-bool fused_radius(int R) {
+bool fused_radius(int R, bool wide_too) {
     static const bool on = [] {
         const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED");
         return !(e && *e == '0');
     }();
     static const int max_r = [] {
         const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED_MFMA_MAX_RADIUS");
-        return e && *e ? std::atoi(e) : 31;
+        return e && *e ? std::atoi(e) : 47;
     }();
-    // (radius 32 takes 64-row tiles on axis 0 in the two-pass kernels: the fused kernel's bands are 32-row tiles)
-    return on && f16_route() && R >= kMfmaSmallFloor && R <= std::min(31, max_r);
+    // (the raw blocks and rings of 10 steps no longer fit LDS.)  Radius 32 ... 47 only where the caller says so - the
+    // gradient, whose smooth shares HBM with the epilogue (sigma 10: 7.9 -> 6.7 ms); alone the two passes with 64-row
+    // tiles on axis 0 are faster there (Gaussian sigma 10: 3.3 ms against 4.4)
+    return on && f16_route() && R >= kMfmaSmallFloor && R <= std::min(wide_too ? 47 : 31, max_r);
 }
 template <int S, int CW>
 int launch_fused_f16(dim3 grid, const GaussArgs& a, int tile_first, int ntile_rows, int nseg) {
@@ -2217,17 +2223,20 @@ int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, cons
     TOPO_TRY(check_grid_rows(row_blocks, "gaussian (fused matrix-core kernel)"));
     const dim3 grid(nseg, row_blocks);
     if (f16_steps(a.radius) == 4) return launch_fused_f16<4, 64>(grid, a, tile_first, ntile_rows, nseg);
-    return launch_fused_f16<6, 32>(grid, a, tile_first, ntile_rows, nseg);
+    if (f16_steps(a.radius) == 6) return launch_fused_f16<6, 32>(grid, a, tile_first, ntile_rows, nseg);
+    return launch_fused_f16<8, 32>(grid, a, tile_first, ntile_rows, nseg);
 }
 // both passes with one sigma on the matrix cores: rows `b.out_row0 ...` -> out; tmp: a plane of the same size
-int smooth_both_mfma(const Block& b, double sigma, float* tmp, float* out, int table_slot) {
-    const bool fused = fused_radius(gaussian_radius(sigma));
+int smooth_both_mfma(const Block& b, double sigma, float* tmp, float* out, int table_slot, bool for_gradient) {
+    const bool fused = fused_radius(gaussian_radius(sigma), for_gradient);
     const int* flag = nullptr;
     if (fused) TOPO_TRY(run_fused_f16(b, sigma, out, table_slot, &flag));
     t_run_if = flag;
+    t_axis0_one_tile = fused;
     int r = run_axis0_mfma(b, sigma, tmp, table_slot);
     if (r == TOPO_AMD_OK) r = run_axis1_mfma(tmp, b.out_rows, b.nx, sigma, out, table_slot + 1);
     t_run_if = nullptr;
+    t_axis0_one_tile = false;
     return r;
 }
 
@@ -2486,7 +2495,7 @@ int smooth_rows(const Block& src, double sigma_y, double sigma_x, int row0, int 
         TOPO_TRY(workspace(ws_slot, bytes, &tmp));
         const int R = gaussian_radius(sigma_y);
         if (sigma_y == sigma_x && mfma_radius(R, b.nx, false, small_ok) && mfma_rows_ok(b, R)) {
-            TOPO_TRY(smooth_both_mfma(b, sigma_y, (float*)tmp, out, table_slot));
+            TOPO_TRY(smooth_both_mfma(b, sigma_y, (float*)tmp, out, table_slot, false));
         } else {
             TOPO_TRY(run_axis0(b, sigma_y, (float*)tmp, table_slot, true, small_ok));
             TOPO_TRY(run_axis1((const float*)tmp, rows, src.nx, sigma_x, out, table_slot + 1, small_ok));
@@ -2680,7 +2689,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             rows.out_rows = c1 - c0;
             float* a_k = (float*)pa + (size_t)(c0 - s0) * b.nx;
             float* b_k = (float*)pb + (size_t)(c0 - s0) * b.nx;
-            TOPO_TRY(smooth_both_mfma(rows, sigma, a_k, b_k, 1));
+            TOPO_TRY(smooth_both_mfma(rows, sigma, a_k, b_k, 1, true));
             if (use_aux) {
                 TOPO_HIP(hipEventRecord(c.aux_ready[k], c.compute));
                 TOPO_HIP(hipStreamWaitEvent(c.aux, c.aux_ready[k], 0));
@@ -2729,8 +2738,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         rows.out_row0 = s0;
         rows.out_rows = s_rows;
         const bool mfma = mfma_radius(gaussian_radius(sigma), b.nx, true) && mfma_rows_ok(rows, gaussian_radius(sigma));
-        if (mfma) TOPO_TRY(run_axis0_mfma(rows, sigma, (float*)plane_a, 1));
-        else TOPO_TRY(run_axis0(rows, sigma, (float*)plane_a, 1, false));
+        if (!mfma) TOPO_TRY(run_axis0(rows, sigma, (float*)plane_a, 1, false));
         // short and medium filters: LDS-tiled axis 1 (9.8 vs 13.6 ms at sigma 3.25 on 32768^2); long
         // filters: wave-shift axis 1 (26.7 vs 27.8 ms at sigma 30.25) while enough lanes produce output
         static const int fused_max = [] {
@@ -2747,10 +2755,12 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             const int r = run_axis1_wave_grad((const float*)plane_a, s0, s_rows, sigma, g, nullptr);
             if (r != TOPO_AMD_EUNSUP) return r;
         }
-        // matrix-core range (or a filter wider than a wavefront can chain): finish the smooth unfused, then the
-        // stand-alone epilogue (beyond radius 121 axis 1 goes through the wave-shift or the transpose path)
+        // matrix-core range: the smooth of the chunked route above (same kernels, same bits), then the stand-alone
+        // epilogue; a filter wider than a wavefront can chain: finish the smooth unfused (beyond radius 121 axis 1 goes
+        // through the wave-shift or the transpose path)
         TOPO_TRY(workspace(2, bytes, &plane_b));
-        TOPO_TRY(run_axis1((const float*)plane_a, s_rows, b.nx, sigma, (float*)plane_b, 2));
+        if (mfma) TOPO_TRY(smooth_both_mfma(rows, sigma, (float*)plane_a, (float*)plane_b, 1, true));
+        else TOPO_TRY(run_axis1((const float*)plane_a, s_rows, b.nx, sigma, (float*)plane_b, 2));
         plane_a = plane_b;
     } else {  // topo.py:633-635
         const double perp = sigma * sig_ratio;
