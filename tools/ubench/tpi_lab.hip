@@ -20,6 +20,10 @@
 #include LAB_EXTRA
 #endif
 
+#ifndef LAB_TH
+#define LAB_TH 60  // rows a marching tile adds (12 waves: a multiple of 12)
+#endif
+
 #define CK(x)                                                                         \
     do {                                                                              \
         int rc_ = (x);                                                                \
@@ -65,11 +69,13 @@ int main(int argc, char** argv) {
     if (out2) CK(topo_amd_memset(out2, 0xFF, bytes));
     auto run = [&]() -> int {
         if (!strcmp(variant, "march")) {
-            int rc = topo::launch_march<SIZE, 60, 12, true, true, true>(b, (float*)out);
+            int rc = topo::launch_march<SIZE, LAB_TH, 12, true, true, true>(b, (float*)out);
             if (rc != TOPO_AMD_OK) return rc;
-            rc = topo::launch_fraction_march<SIZE, 60, 12>(b, (float*)out);
+            rc = topo::launch_fraction_march<SIZE, LAB_TH, 12>(b, (float*)out);
             if (rc != TOPO_AMD_OK) return rc;
-            return topo::launch_wave<SIZE, 60, 12, true, false>(b, (float*)out, nullptr, true);
+            // (the general kernel's tile of LAB_TH > 60 rows does not fit LDS; on the bench DEM nothing is deferred to it)
+            if constexpr (LAB_TH <= 60) return topo::launch_wave<SIZE, LAB_TH, 12, true, false>(b, (float*)out, nullptr, true);
+            return TOPO_AMD_OK;
         }
         if (!strcmp(variant, "ring")) return topo::launch_ring<SIZE, 8, topo::kRingMain>(b, (float*)out);
         // the product's dispatch (launch_wave_any) with this build's -D flags
