@@ -309,10 +309,12 @@ __global__ __launch_bounds__(kThreads) void gradient_epilogue4_kernel(GradArgs p
         oas[t] = aspect;
     }
     const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
-    if (p.dx) *reinterpret_cast<f4*>(p.dx + o) = odx;
-    if (p.dy) *reinterpret_cast<f4*>(p.dy + o) = ody;
-    if (p.slope) *reinterpret_cast<f4*>(p.slope + o) = osl;
-    if (p.aspect) *reinterpret_cast<f4*>(p.aspect + o) = oas;
+    // streaming stores (nobody reads the four planes back from the caches; the smoothed rows above and below are what
+    // L2 should keep): gradient sigma 3.25 / 30.25 on 32768^2 5.95-6.38 / 9.12-9.30 -> 5.87-5.90 / 8.96-9.00 ms
+    if (p.dx) __builtin_nontemporal_store(odx, reinterpret_cast<f4*>(p.dx + o));
+    if (p.dy) __builtin_nontemporal_store(ody, reinterpret_cast<f4*>(p.dy + o));
+    if (p.slope) __builtin_nontemporal_store(osl, reinterpret_cast<f4*>(p.slope + o));
+    if (p.aspect) __builtin_nontemporal_store(oas, reinterpret_cast<f4*>(p.aspect + o));
 }
 
 __device__ __forceinline__ double raw_reflect(const GradArgs& p, int gy, int gx) {
