@@ -153,16 +153,17 @@ def test_gaussian_anisotropic_and_identity(golden):
 
 
 @pytest.mark.parametrize("sigma", [0.75, 2.25, 3.25, 6.0, 12.0])
-def test_gaussian_nan_footprint(sigma):
+@pytest.mark.parametrize("nx", [300, 299, 301])  # (any width takes the matrix cores since round 3)
+def test_gaussian_nan_footprint(sigma, nx):
     """A non-finite sample makes non-finite every output ndimage.gaussian_filter (topo.py:80) makes non-finite.  On
-    the matrix cores (radius int(4 sigma + 0.5) from 4, width a multiple of 4) EXACTLY those: the kernels evaluate 32
+    the matrix cores (radius int(4 sigma + 0.5) from 4) EXACTLY those: the kernels evaluate 32
     outputs against a zero-padded band of taps (0 x NaN = NaN), mark the tiles that came out non-finite, and a repair
     pass takes them again over each output's own window (round 3; before, up to 37 more outputs along each axis).
     The vector-ALU kernels (radius below 4) pad their taps to a chunk of 8: up to 7 more outputs towards lower
     indices.  The accumulation offsets must not spread it further (a non-finite offset falls back to 0), and the
     finite outputs keep their accuracy."""
     from scipy import ndimage
-    dem = orc.synthetic_dem(200, 300, seed=21)
+    dem = orc.synthetic_dem(200, nx, seed=21)
     dem[100, 151] = np.nan
     dem[7, 290] = np.inf
     dem[150:153, 40] = -np.inf

@@ -253,10 +253,14 @@ __device__ __forceinline__ void finish_gradient(const GradArgs& p, int oy, int o
     if (p.aspect) p.aspect[o] = aspect;
 }
 
+__device__ __forceinline__ void epilogue_pixel(const GradArgs& p, int oy, int ox);
 __global__ __launch_bounds__(kThreads) void gradient_epilogue_kernel(GradArgs p) {
     const int ox = blockIdx.x * kThreads + threadIdx.x;
     const int oy = p.out_row0 + blockIdx.y;
     if (ox >= p.nx) return;
+    epilogue_pixel(p, oy, ox);
+}
+__device__ __forceinline__ void epilogue_pixel(const GradArgs& p, int oy, int ox) {
     // numpy.gradient: central difference / 2 inside, first-order one-sided at the edges
     const float* rowx = p.gx_src + (size_t)(oy - p.s_row0) * p.nx;
     float dx;
@@ -272,13 +276,18 @@ __global__ __launch_bounds__(kThreads) void gradient_epilogue_kernel(GradArgs p)
 }
 
 // The same, four adjacent pixels per thread: 16-byte loads of the three smoothed rows and 16-byte stores of
-// the four outputs (the one-pixel kernel moves the 20 B/pixel as dwords and ran at 3.2 TB/s).  Needs
-// nx % 4 == 0 and 16-byte aligned planes; identical arithmetic per pixel, hence identical bits.
+// the four outputs (the one-pixel kernel moves the 20 B/pixel as dwords and ran at 3.2 TB/s).  Identical arithmetic
+// per pixel, hence identical bits.  Any width from 8 columns (round 3: the 16-byte accesses only need dword alignment;
+// the last 1 ... 3 pixels of a row whose length is not a multiple of 4 go one by one).
 __global__ __launch_bounds__(kThreads) void gradient_epilogue4_kernel(GradArgs p) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int ox = (blockIdx.x * kThreads + threadIdx.x) * 4;
     const int oy = p.out_row0 + blockIdx.y;
     if (ox >= p.nx) return;
+    if (ox + 4 > p.nx) {
+        for (int x = ox; x < p.nx; ++x) epilogue_pixel(p, oy, x);
+        return;
+    }
     const float* rowx = p.gx_src + (size_t)(oy - p.s_row0) * p.nx;
     const f4 mid = *reinterpret_cast<const f4*>(rowx + ox);
     const float left = ox > 0 ? rowx[ox - 1] : 0.0f, right = ox + 4 < p.nx ? rowx[ox + 4] : 0.0f;
@@ -1256,14 +1265,24 @@ __global__ __launch_bounds__(256) void gauss_axis0_f16_kernel(GaussArgs p, int t
     float* ring = L + 32 * wave;  // [row][128], this wave's 32 columns
     // loader: lane -> row (lane >> 3) of a pass of 8 rows, 4 columns (lane & 7) * 4
     const int lq = lane >> 3, lcol = (lane & 7) * 4;
-    const int lc = min(x0 + 32 * wave + lcol, p.nx - 4);  // (columns past nx: clamped, never stored)
-    auto row_ptr = [&](int gy) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    // the lane's 4 columns of a row: one 16-byte load (dword alignment is all it needs, so any row length will do); the
+    // group that straddles the DEM's right edge (widths that are not multiples of 4) and the groups beyond it go
+    // column by column, clamped (what lies past the edge is never stored)
+    const int lx = x0 + 32 * wave + lcol;
+    const bool lane_full = lx + 4 <= p.nx;
+    auto load4 = [&](const float* rowbase) {
+        if (lane_full) return *reinterpret_cast<const f4*>(rowbase + lx);
+        f4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rowbase[min(lx + e, p.nx - 1)];
+        return v;
+    };
+    auto row_base = [&](int gy) {
         gy = reflect_index(gy, p.gny);
         gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
-        return p.in + (size_t)(gy - p.in_row0) * p.nx + lc;
+        return p.in + (size_t)(gy - p.in_row0) * p.nx;
     };
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const unsigned in_lane_off = (unsigned)(lq * p.nx + lc) * 4u;
     float* const ring_lane = ring + lq * kMfmaCols + lcol;
     const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
     int last_wild = kNoWild;  // last tile whose window holds a staged sample that is not a plain finite one
@@ -1271,7 +1290,7 @@ __global__ __launch_bounds__(256) void gauss_axis0_f16_kernel(GaussArgs p, int t
         const int y0 = (tile_first + tb) * TILE;
         bool bad = false;
         for (int k = 0; k < RR; k += 8) {
-            f4 v = *reinterpret_cast<const f4*>(row_ptr(y0 - Rp + k + lq));
+            f4 v = load4(row_base(y0 - Rp + k + lq));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool w = wild(v[e]);
@@ -1294,12 +1313,12 @@ __global__ __launch_bounds__(256) void gauss_axis0_f16_kernel(GaussArgs p, int t
         if (more) {
             const int n0 = y0 - Rp + RR;  // the rows the next tile adds
             if (n0 >= row_lo && n0 + TILE <= row_hi) {
-                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)(n0 - p.in_row0) * p.nx);
+                const float* rb = p.in + (size_t)(n0 + lq - p.in_row0) * p.nx;
 #pragma unroll
-                for (int q = 0; q < 4 * MT; ++q) pre[q] = *reinterpret_cast<const f4*>(rb + (size_t)(8 * q) * p.nx * 4 + in_lane_off);
+                for (int q = 0; q < 4 * MT; ++q) pre[q] = load4(rb + (size_t)(8 * q) * p.nx);
             } else {
 #pragma unroll
-                for (int q = 0; q < 4 * MT; ++q) pre[q] = *reinterpret_cast<const f4*>(row_ptr(n0 + 8 * q + lq));
+                for (int q = 0; q < 4 * MT; ++q) pre[q] = load4(row_base(n0 + 8 * q + lq));
             }
         }
         int sc = base + Rp + TILE / 2;
@@ -1931,7 +1950,13 @@ int mfma_min_radius_impl(bool for_gradient) {
 }
 
 bool mfma_radius(int R, int nx, bool for_gradient = false, bool small_ok = true) {
-    return R >= std::max(small_ok ? kMfmaSmallFloor : 16, mfma_min_radius_impl(for_gradient)) && R <= 121 && nx % 4 == 0 && nx >= 4;
+    // (any width from 4 columns: the loaders' 16-byte loads only need dword alignment, which a row of any length has;
+    // TOPO_AMD_GAUSS_MFMA_ANY_WIDTH=0: multiples of 4 only, as before round 3)
+    static const bool any_width = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_MFMA_ANY_WIDTH");
+        return !(e && *e == '0');
+    }();
+    return R >= std::max(small_ok ? kMfmaSmallFloor : 16, mfma_min_radius_impl(for_gradient)) && R <= 121 && (any_width || nx % 4 == 0) && nx >= 4;
 }
 
 // the accumulation-offset row of every axis-0 tile that holds one of the block's output rows is inside the block
@@ -2678,7 +2703,6 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     TOPO_REQUIRE(b.gny >= 2 && b.nx >= 2,
                  "gradient: numpy.gradient needs at least 2 samples per axis (got %d x %d)",
                  b.gny, b.nx);
-    auto aligned16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     // Matrix-core route on a large block: the smooth is MFMA-bound and leaves HBM idle, the epilogue is
     // HBM-bound and needs no LDS, so the rows go in chunks and the epilogue of chunk k runs on a second stream
     // next to the smooth of chunk k + 1 (15.7 -> 14.5 ms at sigma 30.25 on 32768^2 with 4 -> 8 chunks; one chunk:
@@ -2689,8 +2713,9 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         return e && *e ? std::atoi(e) : 2048;  // (the interior of a 4096-row shard of the 8-GPU split goes in two chunks)
     }();
     if (sigma > 1.0 && sig_ratio == 1.0 && mfma_radius(gaussian_radius(sigma), b.nx, true) &&
-        mfma_rows_ok(smoothed_rows_block(b), gaussian_radius(sigma)) && b.out_rows >= chunk_min &&
-        b.nx % 4 == 0 && aligned16(dx) && aligned16(dy) && aligned16(slope) && aligned16(aspect)) {
+        mfma_rows_ok(smoothed_rows_block(b), gaussian_radius(sigma)) && b.out_rows >= chunk_min) {
+        // (widths that are not multiples of 4, or planes that are not 16-byte aligned: the one-pixel-per-thread epilogue)
+        const bool wide_epilogue = b.nx >= 8;
         static const int NCH = [] {
             const char* e = std::getenv("TOPO_AMD_GRAD_CHUNKS");
             return std::max(1, std::min(64, e && *e ? std::atoi(e) : 8));
@@ -2758,8 +2783,13 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
                 gk.s_row0 = s0;
                 gk.s_rows = s1 - s0;
                 TOPO_TRY(check_grid_rows(o1 - o0, "gradient epilogue"));
-                dim3 grid4((b.nx / 4 + kThreads - 1) / kThreads, o1 - o0);
-                hipLaunchKernelGGL(gradient_epilogue4_kernel, grid4, dim3(kThreads), 0, use_aux ? c.aux : c.compute, gk);
+                if (wide_epilogue) {
+                    dim3 grid4(((b.nx + 3) / 4 + kThreads - 1) / kThreads, o1 - o0);
+                    hipLaunchKernelGGL(gradient_epilogue4_kernel, grid4, dim3(kThreads), 0, use_aux ? c.aux : c.compute, gk);
+                } else {
+                    dim3 grid1((b.nx + kThreads - 1) / kThreads, o1 - o0);
+                    hipLaunchKernelGGL(gradient_epilogue_kernel, grid1, dim3(kThreads), 0, use_aux ? c.aux : c.compute, gk);
+                }
                 TOPO_HIP(hipGetLastError());
                 o0 = o1;
             }
@@ -2819,9 +2849,8 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     g.gy_src = (const float*)plane_b;
     g.s_row0 = s0;
     g.s_rows = s_rows;
-    if (b.nx % 4 == 0 && b.nx >= 8 && aligned16(g.gx_src) && aligned16(g.gy_src) && aligned16(dx) && aligned16(dy) &&
-        aligned16(slope) && aligned16(aspect)) {
-        dim3 grid4((b.nx / 4 + kThreads - 1) / kThreads, b.out_rows);
+    if (b.nx >= 8) {
+        dim3 grid4(((b.nx + 3) / 4 + kThreads - 1) / kThreads, b.out_rows);
         hipLaunchKernelGGL(gradient_epilogue4_kernel, grid4, dim3(kThreads), 0, c.compute, g);
     } else {
         hipLaunchKernelGGL(gradient_epilogue_kernel, grid, dim3(kThreads), 0, c.compute, g);
