@@ -275,7 +275,7 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     for azimuth, radius in ((0.0, 500.0), (0.0, 2000.0), (45.0, 500.0), (45.0, 2000.0)):
         window, dj, di, dist = d.sx_offsets(azimuth, radius, 30.0, -30.0)
         fn = lambda: blk.sx(dj, di, dist, window, 10.0, o1)  # noqa: E731
-        entry(f"sx_az{int(azimuth)}_r{int(radius)}", time_kernel(fn, REPS, d), 8, "sx_kernel<stride> (LDS tile, chains of 8 / 4 / 2 neighbouring ray pixels down the columns, along the rows or along a diagonal, whichever needs the fewest comparisons; one atan per pixel)")
+        entry(f"sx_az{int(azimuth)}_r{int(radius)}", time_kernel(fn, REPS, d), 8, "sx_kernel<stride> (LDS tile, chains of 8 / 4 / 2 neighbouring ray pixels down the columns, along the rows or along a diagonal, whichever needs the fewest comparisons; chains with equal weights - the two sides of a sector - scanned as one; one atan per pixel)")
     # two small discs in one pass over the DEM: ms for the pair, rate and fraction per plane
     st = time_kernel(lambda: blk.tpi_multi([7, 11], [o1, o2]), REPS, d)
     entry("tpi_s7_s11_one_pass_per_plane", st, 6, "tpi_ring_kernel<11, 8, kRingMain, 7> (one staging pass, one ring, two chains; 4 B read + 8 B "

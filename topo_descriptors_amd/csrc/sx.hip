@@ -16,7 +16,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
+#include <vector>
 
 namespace topo {
 
@@ -50,6 +52,11 @@ struct SxArgs {
     const SxChain4* tab4;
     const SxChain2* tab2;
     int n8, n4, n2;
+    // pairs of chains with the same weights (pad[0] / pad of the entry: the LDS index of the second chain)
+    const SxChain8* tab8p;
+    const SxChain4* tab4p;
+    const SxChain2* tab2p;
+    int n8p, n4p, n2p;
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
     int window;
@@ -180,6 +187,64 @@ __global__ __launch_bounds__(NW * 64) void sx_kernel(SxArgs p) {
                 const float z1 = (w[1 + k] - centre[k]) * g.e[u].inv[1];
                 asm("v_max3_f32 %0, %0, %1, %2" : "+v"(best[k]) : "v"(z0), "v"(z1));
             }
+        }
+    }
+    // Pairs (round 3).  A sector that points along an axis is symmetric about it: the ray pixels (dj, di) and (dj, -di)
+    // are equally far, so their chains carry the same weights, and since (w - c) inv grows with w the larger of the two
+    // SAMPLES decides - one v_max per sample (8 + 15 of them) instead of a second set of 8 x 16 products and their
+    // maxima.  The launcher pairs any two chains of one length whose weights are equal bit for bit.  NaN: v_max
+    // returns the other operand, as the two separate products would have been dropped one by one.
+    auto larger = [](float a, float b) {
+        float m;
+        asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+        return m;
+    };
+    for (int c = 0; c < p.n8p; ++c) {
+        const SxChain8 e = p.tab8p[c];
+        const float* qa = Lw + e.off;
+        const float* qb = Lw + e.pad[0];
+        float w[kSxOwn + 7];
+#pragma unroll
+        for (int j = 0; j < kSxOwn + 7; ++j) w[j] = larger(qa[j * S], qb[j * S]);
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) {
+#pragma unroll
+            for (int k = 0; k < kSxOwn; ++k) {
+                const float z0 = (w[m + k] - centre[k]) * e.inv[m];
+                const float z1 = (w[m + 1 + k] - centre[k]) * e.inv[m + 1];
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(best[k]) : "v"(z0), "v"(z1));
+            }
+        }
+    }
+    for (int c = 0; c < p.n4p; ++c) {
+        const SxChain4 e = p.tab4p[c];
+        const float* qa = Lw + e.off;
+        const float* qb = Lw + e.pad[0];
+        float w[kSxOwn + 3];
+#pragma unroll
+        for (int j = 0; j < kSxOwn + 3; ++j) w[j] = larger(qa[j * S], qb[j * S]);
+#pragma unroll
+        for (int m = 0; m < 4; m += 2) {
+#pragma unroll
+            for (int k = 0; k < kSxOwn; ++k) {
+                const float z0 = (w[m + k] - centre[k]) * e.inv[m];
+                const float z1 = (w[m + 1 + k] - centre[k]) * e.inv[m + 1];
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(best[k]) : "v"(z0), "v"(z1));
+            }
+        }
+    }
+    for (int c = 0; c < p.n2p; ++c) {
+        const SxChain2 e = p.tab2p[c];
+        const float* qa = Lw + e.off;
+        const float* qb = Lw + e.pad;
+        float w[kSxOwn + 1];
+#pragma unroll
+        for (int j = 0; j < kSxOwn + 1; ++j) w[j] = larger(qa[j * S], qb[j * S]);
+#pragma unroll
+        for (int k = 0; k < kSxOwn; ++k) {
+            const float z0 = (w[k] - centre[k]) * e.inv[0];
+            const float z1 = (w[1 + k] - centre[k]) * e.inv[1];
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(best[k]) : "v"(z0), "v"(z1));
         }
     }
     const float rad2deg = 57.29577951308232f;
@@ -629,15 +694,44 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     const int stride_d = sx_stride_for(cols_d);
     const size_t lds_d = (size_t)(a.rows_l + 8) * stride_d * sizeof(float);
     const bool diag_fits = diag_on && stride_d != 0 && lds_d <= 160 * 1024;
-    std::vector<SxChain8> t8[4];
-    std::vector<SxChain4> t4[4];
-    std::vector<SxChain2> t2[4];
+    // pairs: any two chains of one length with the same weights, bit for bit (TOPO_AMD_SX_PAIRS=0: none)
+    static const bool pairs_on = [] {
+        const char* e = std::getenv("TOPO_AMD_SX_PAIRS");
+        return !(e && *e == '0');
+    }();
+    auto pair_up = [&](const auto& all, auto& singles, auto& pairs, auto second) {
+        std::vector<char> used(all.size(), 0);
+        for (size_t i = 0; i < all.size(); ++i) {
+            if (used[i]) continue;
+            size_t partner = all.size();
+            for (size_t k = i + 1; pairs_on && k < all.size(); ++k)
+                if (!used[k] && std::memcmp(all[i].inv, all[k].inv, sizeof(all[i].inv)) == 0) {
+                    partner = k;
+                    break;
+                }
+            if (partner == all.size()) {
+                singles.push_back(all[i]);
+            } else {
+                auto e = all[i];
+                second(e) = all[partner].off;
+                pairs.push_back(e);
+                used[partner] = 1;
+            }
+        }
+    };
+    std::vector<SxChain8> t8, s8m[4], p8m[4];
+    std::vector<SxChain4> t4, s4m[4], p4m[4];
+    std::vector<SxChain2> t2, s2m[4], p2m[4];
     size_t cost[4];
     int mode = 0;
     for (int m = 0; m < 4; ++m) {
         if (m >= 2 && !diag_fits) break;
-        sx_chains(pts, m, m >= 2 ? stride_d : stride, dj_min, di_min, &t8[m], &t4[m], &t2[m]);
-        cost[m] = 8 * t8[m].size() + 4 * t4[m].size() + 2 * t2[m].size();
+        sx_chains(pts, m, m >= 2 ? stride_d : stride, dj_min, di_min, &t8, &t4, &t2);
+        pair_up(t8, s8m[m], p8m[m], [](SxChain8& e) -> int& { return e.pad[0]; });
+        pair_up(t4, s4m[m], p4m[m], [](SxChain4& e) -> int& { return e.pad[0]; });
+        pair_up(t2, s2m[m], p2m[m], [](SxChain2& e) -> int& { return e.pad; });
+        // comparisons per pixel, padding included; a pair costs its 8 (4, 2) and a sample maximum per own pixel and chain
+        cost[m] = 8 * s8m[m].size() + 4 * s4m[m].size() + 2 * s2m[m].size() + 10 * p8m[m].size() + 5 * p4m[m].size() + 3 * p2m[m].size();
         // a diagonal scan has to save comparisons to be worth its wider tile and its extra column of tiles
         // (TOPO_AMD_SX_DIAG_MIN_SAVING, percent), and the scan has to be long enough for that to show
         // (TOPO_AMD_SX_DIAG_MIN_COST comparisons)
@@ -647,29 +741,41 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     }
     const bool along_x = mode == 1;
     const int diag = mode == 2 ? 1 : mode == 3 ? -1 : 0;
-    const std::vector<SxChain8>& c8 = t8[mode];
-    const std::vector<SxChain4>& c4 = t4[mode];
-    std::vector<SxChain2>& c2 = t2[mode];
-    while (c2.size() % 4) {  // the kernel takes four at a time: entries whose products are all NaN
+    const std::vector<SxChain8>&s8 = s8m[mode], &p8 = p8m[mode];
+    const std::vector<SxChain4>&s4 = s4m[mode], &p4 = p4m[mode];
+    std::vector<SxChain2>& s2 = s2m[mode];
+    const std::vector<SxChain2>& p2 = p2m[mode];
+    while (s2.size() % 4) {  // the kernel takes four at a time: entries whose products are all NaN
         SxChain2 e{};
         e.inv[0] = e.inv[1] = std::nanf("");
-        c2.push_back(e);
+        s2.push_back(e);
     }
+    const size_t scan_cost = cost[mode];
     const SxChain8 none8{};
     const SxChain4 none4{};
     const SxChain2 none2{};
     void *d_t8 = nullptr, *d_t4 = nullptr, *d_t2 = nullptr;  // (an empty table still uploads one entry; its count stays 0)
-    TOPO_TRY(upload_table(0, c8.empty() ? &none8 : c8.data(), std::max<size_t>(1, c8.size()) * sizeof(SxChain8), &d_t8));
-    TOPO_TRY(upload_table(1, c2.empty() ? &none2 : c2.data(), std::max<size_t>(1, c2.size()) * sizeof(SxChain2), &d_t2));
-    TOPO_TRY(upload_table(2, c4.empty() ? &none4 : c4.data(), std::max<size_t>(1, c4.size()) * sizeof(SxChain4), &d_t4));
+    void *d_p8 = nullptr, *d_p4 = nullptr, *d_p2 = nullptr;
+    TOPO_TRY(upload_table(0, s8.empty() ? &none8 : s8.data(), std::max<size_t>(1, s8.size()) * sizeof(SxChain8), &d_t8));
+    TOPO_TRY(upload_table(1, s2.empty() ? &none2 : s2.data(), std::max<size_t>(1, s2.size()) * sizeof(SxChain2), &d_t2));
+    TOPO_TRY(upload_table(2, s4.empty() ? &none4 : s4.data(), std::max<size_t>(1, s4.size()) * sizeof(SxChain4), &d_t4));
+    TOPO_TRY(upload_table(3, p8.empty() ? &none8 : p8.data(), std::max<size_t>(1, p8.size()) * sizeof(SxChain8), &d_p8));
+    TOPO_TRY(upload_table(4, p2.empty() ? &none2 : p2.data(), std::max<size_t>(1, p2.size()) * sizeof(SxChain2), &d_p2));
+    TOPO_TRY(upload_table(5, p4.empty() ? &none4 : p4.data(), std::max<size_t>(1, p4.size()) * sizeof(SxChain4), &d_p4));
     a.in = b.in;
     a.out = out;
     a.tab8 = (const SxChain8*)d_t8;
     a.tab4 = (const SxChain4*)d_t4;
     a.tab2 = (const SxChain2*)d_t2;
-    a.n8 = (int)c8.size();
-    a.n4 = (int)c4.size();
-    a.n2 = (int)c2.size();
+    a.n8 = (int)s8.size();
+    a.n4 = (int)s4.size();
+    a.n2 = (int)s2.size();
+    a.tab8p = (const SxChain8*)d_p8;
+    a.tab4p = (const SxChain4*)d_p4;
+    a.tab2p = (const SxChain2*)d_p2;
+    a.n8p = (int)p8.size();
+    a.n4p = (int)p4.size();
+    a.n2p = (int)p2.size();
     a.in_rows = b.in_rows;
     a.in_row0 = b.in_row0;
     a.gny = b.gny;
@@ -687,7 +793,7 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
         dim3 dgrid((b.nx + kSxTile - 1) / kSxTile + 1, (b.out_rows + kSxTile - 1) / kSxTile);  // the slabs lean: one tile more
         return launch_sx_stride(stride_d, false, 4, dgrid, lds_d, c.compute, a, diag);
     }
-    if (!along_x && b.out_rows >= 2 * kSxTile && 8 * c8.size() + 4 * c4.size() + 2 * c2.size() >= 256) {
+    if (!along_x && b.out_rows >= 2 * kSxTile && scan_cost >= 256) {
         const size_t lds8 = (size_t)(a.rows_l + kSxTile + 8) * stride * sizeof(float);
         if (lds8 <= 80 * 1024) {
             waves = 8;
