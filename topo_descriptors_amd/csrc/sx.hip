@@ -421,23 +421,46 @@ __global__ __launch_bounds__(kThreads) void sx_multi_kernel(SxMultiArgs p) {
     const int ox0 = blockIdx.x * TW;
     const int oy0 = p.out_row0 + blockIdx.y * TH;
 
-    for (int r0 = 0; r0 < p.rows_l; r0 += 16) {
-        for (int k0 = 0; k0 < p.cols_l; k0 += 64) {
-            const int k = k0 + lane, gx = ox0 + p.di_min + k;
-            const bool col_ok = k < p.cols_l && gx >= 0 && gx < p.nx;
-            float v[4];
+    // (as in sx_kernel: no test per sample for a tile that lies inside the block)
+    const int gx_first = ox0 + p.di_min, gy_first = oy0 + p.dj_min;
+    const bool tile_inside = gx_first >= 0 && gx_first + p.cols_l <= p.nx && gy_first >= max(0, p.in_row0) &&
+                             gy_first + p.rows_l <= min(p.gny, p.in_row0 + p.in_rows);
+    if (tile_inside) {
+        const float* src = p.in + (size_t)(gy_first - p.in_row0) * p.nx + gx_first;
+        for (int r0 = 0; r0 < p.rows_l; r0 += 16) {
+            for (int k0 = 0; k0 < p.cols_l; k0 += 64) {
+                const int k = k0 + lane;
+                if (k < p.cols_l) {
+                    float v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + wave + 4 * u;
-                const int gy = oy0 + p.dj_min + r, by = gy - p.in_row0;
-                const bool ok = col_ok && r < p.rows_l && gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
-                v[u] = ok ? p.in[(size_t)by * p.nx + gx] : 0.0f;
+                    for (int u = 0; u < 4; ++u) v[u] = src[(size_t)min(r0 + wave + 4 * u, p.rows_l - 1) * p.nx + k];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = r0 + wave + 4 * u;
+                        if (r < p.rows_l) L[r * STRIDE + k] = v[u];
+                    }
+                }
             }
-            if (k < p.cols_l) {
+        }
+    } else {
+        for (int r0 = 0; r0 < p.rows_l; r0 += 16) {
+            for (int k0 = 0; k0 < p.cols_l; k0 += 64) {
+                const int k = k0 + lane, gx = gx_first + k;
+                const bool col_ok = k < p.cols_l && gx >= 0 && gx < p.nx;
+                float v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int r = r0 + wave + 4 * u;
-                    if (r < p.rows_l) L[r * STRIDE + k] = v[u];
+                    const int gy = gy_first + r, by = gy - p.in_row0;
+                    const bool ok = col_ok && r < p.rows_l && gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
+                    v[u] = ok ? p.in[(size_t)by * p.nx + gx] : 0.0f;
+                }
+                if (k < p.cols_l) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = r0 + wave + 4 * u;
+                        if (r < p.rows_l) L[r * STRIDE + k] = v[u];
+                    }
                 }
             }
         }
