@@ -705,9 +705,11 @@ def test_requests_taller_than_one_launch():
     dem.free()
 
 
-@pytest.mark.parametrize("azimuth", [45.0, 135.0, 225.0, 315.0, 30.0])
+@pytest.mark.parametrize("azimuth", [45.0, 135.0, 225.0, 315.0, 30.0, 0.0, 90.0, 180.0])
 def test_sx_diagonal_chains(azimuth):
-    """Sectors off the axes at a radius where the launcher scans along a diagonal (sx_kernel<.., DIAG = +-1>, from ~100
+    """(Azimuths 0, 90, 180: the paired chains of a sector that points along an axis - the larger of two samples at
+    equal distance decides - against the same three references.)
+    Sectors off the axes at a radius where the launcher scans along a diagonal (sx_kernel<.., DIAG = +-1>, from ~100
     comparisons per pixel): the oracle, the axis-aligned scan of the same sector (TOPO_AMD_SX_DIAG=0 would give the
     same bits: a maximum does not care about the order; here checked against the fan kernel, which never scans
     diagonally), row blocks, and a width where the leaning slabs meet both DEM edges."""
