@@ -321,11 +321,11 @@ SHARD_BYTES = {"tpi_s67": 8, "std_s67": 8, "tpi_std_s67": 12, "gradient_sigma3.2
                "sx_az0_r500": 8}
 
 
-def sharded_steps(sd, d, rows_local, nx):
+def sharded_steps(sd, d, rows_local, nx, outs=None):
     """One collective step per descriptor of BASELINE configs[4] on this rank's shard: {key: (callable, outputs)}.
-    Every call refreshes the descriptor's own ghost rows over RCCL (overlapped with the interior rows) and then
-    computes the seam strips."""
-    outs = [d.DeviceArray(rows_local, nx) for _ in range(4)]
+    Every call refreshes the descriptor's own ghost rows over RCCL (overlapped with the interior rows) and computes
+    the seam rows behind the ghost-row gate.  (`sd` may also be a device.Block: the same calls on one block.)"""
+    outs = outs or [d.DeviceArray(rows_local, nx) for _ in range(4)]
     window, dj, di, dist = d.sx_offsets(0.0, 500.0, 30.0, -30.0)
     return outs, {
         "tpi_s67": lambda: sd.tpi_std(67, tpi=outs[0]),
@@ -543,8 +543,27 @@ def main():
         d.sync()
         for a in outs:
             a.free()
+        gave_up = ctypes.c_uint()
+        _lib.check(lib.topo_amd_gate_giveups(ctypes.byref(gave_up)), "gate_giveups")
+        gave_up_max = int(rdv.max(float(gave_up.value)))
+        if loopback and rank == 0:
+            # shard_efficiency = (single-GPU time of the DEM this shard is one eighth of) / (8 x the shard's step): what
+            # 8-way strong scaling could reach at best, before any link cost (both ends of the exchange are this GPU)
+            parts = 8
+            full = d.synth_dem(parts * ny, nx, seed=0)
+            fouts = [d.DeviceArray(parts * ny, nx) for _ in range(4)]
+            fblk = d.Block(full)
+            _, full_steps = sharded_steps(fblk, d, parts * ny, nx, outs=fouts)
+            for key in SHARD_KEYS:
+                full_ms = stats(d.time_launches(full_steps[key], 6, 2))["median"]
+                table[key]["single_gpu_ms_whole_dem"] = round(full_ms, 4)
+                table[key]["shard_efficiency"] = round(full_ms / (parts * table[key]["ms"]), 4)
+            d.sync()
+            for a in fouts + [full]:
+                a.free()
         if rank == 0:
             result["descriptors"] = table
+            result["gate_giveups"] = gave_up_max  # blocks that found the ghost-row gate closed (0: the exchange hid behind the interior rows)
             result["descriptors_note"] = (
                 "row-sharded entry points (topo_amd_shard_*), one ghost-row exchange per step and descriptor; ms = "
                 "median of 10 launches on the slowest rank; Mpixels_per_s = the whole DEM over that time; hbm_frac "

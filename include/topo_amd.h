@@ -239,6 +239,11 @@ int topo_amd_comm_destroy(void);
 int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_above,
                                  int halo_below);
 int topo_amd_halo_wait(void);
+/* Round 4: a sharded call is ONE launch per kernel - the interior rows, then, behind a device-side gate the
+ * communication stream opens when the ghost rows have landed, the seam rows - with a clean-up launch behind the
+ * exchange's event for blocks that found the gate closed for longer than TOPO_AMD_GATE_WAIT_US (100).  Reads and
+ * resets the number of such blocks since the last call: 0 when the exchange hid behind the interior rows.      */
+int topo_amd_gate_giveups(unsigned* count);
 /* Declares the ghost depth the shard buffers handed to topo_amd_shard_* are laid out with:
  * [halo_above | rows_local | halo_below] rows.  A descriptor that needs fewer ghost rows uses
  * the ones next to the owned rows; one that needs more is refused (TOPO_AMD_EINVAL) instead of

@@ -290,3 +290,87 @@ def test_shard_tpi_std_fractional_dem_under_the_live_exchange(loopback_comm):
     assert np.array_equal(s.to_host(), ws.to_host())
     for a in (t, s, wt, ws, whole, sd.block):
         a.free()
+
+
+# ---- round 4: one launch per kernel behind the ghost-row gate, in every mode (task 1) ---------------
+_GATE_CHILD = r"""
+import os, sys, zlib, json
+import numpy as np
+sys.path.insert(0, %r)
+os.environ["TOPO_AMD_HALO_LOOPBACK"] = "1"
+from oracle import topo_oracle as orc
+from topo_descriptors_amd import _lib, device as d, shard
+import ctypes as C
+lib = _lib.lib()
+shard.ShardedDEM.init_comm(0, 1, lambda payload: payload)
+rows, nx = 2112, 16384           # 90 strips x 36 tile rows of the 67-px kernels: more tiles than blocks, every block has a run
+local = orc.synthetic_dem(rows, nx, seed=21)
+local[700:760, 3000:3300] += 0.25   # a patch of fractional elevations: the second kernels of the chains have work
+deep = max(shard.halo_rows(_lib.DESC_GRADIENT, 30.25, 1.0))
+plan = shard.RowShardPlan(3 * rows, nx, 3, 1, deep, deep)
+sd = shard.ShardedDEM(plan)
+outs = [d.DeviceArray(rows, nx) for _ in range(4)]
+window, dj, di, dist = d.sx_offsets(0.0, 500.0, 30.0, -30.0)
+w2, dj2, di2, dist2 = d.sx_offsets(135.0, 300.0, 30.0, -30.0)
+crc = {}
+def poison():
+    p = sd.plan
+    _lib.check(lib.topo_amd_memset(sd.block.ptr, 0xFF, p.halo_above * p.nx * 4), "memset")
+    _lib.check(lib.topo_amd_memset(sd.block.row_ptr(p.halo_above + p.rows_local), 0xFF, p.halo_below * p.nx * 4), "memset")
+def take(name, planes):
+    d.sync()
+    crc[name] = [zlib.crc32(outs[k].to_host().tobytes()) for k in range(planes)]
+sd.block.upload_rows(local, plan.halo_above)
+for rep in range(5):             # (auto mode: careful calls first, lean ones after three clean careful calls)
+    poison(); sd.tpi_std(67, tpi=outs[0], std=outs[1]); take("tpi_std67_%%d" %% rep, 2)
+poison(); sd.tpi_std(67, tpi=outs[0]); take("tpi67", 1)
+poison(); sd.tpi_std(7, tpi=outs[0], std=outs[1]); take("tpi_std7", 2)
+poison(); sd.gradient(3.25, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3]); take("grad3", 4)
+poison(); sd.gradient(30.25, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3]); take("grad30", 4)
+poison(); sd.sx(dj, di, dist, window, 10.0, outs[0]); take("sx0", 1)
+poison(); sd.sx(dj2, di2, dist2, w2, 10.0, outs[0]); take("sx135", 1)
+gave_up = C.c_uint()
+_lib.check(lib.topo_amd_gate_giveups(C.byref(gave_up)), "gate_giveups")
+print(json.dumps({"crc": crc, "gave_up": gave_up.value}))
+"""
+
+
+def test_gate_modes_give_the_single_block_bits(tmp_path):
+    """Sharded TPI / STD, gradient and Sx through (a) the three launches of rounds 1-3, (b) one launch behind the gate
+    with the clean-up launch (careful), (c) without it (lean), (d) the default (careful, then lean): every plane has
+    the same CRC-32 in all four, and those of the single block."""
+    import json
+    import subprocess
+    import sys
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    results = {}
+    for name, env in (("three_launches", {"TOPO_AMD_SHARD_FUSED": "0"}), ("careful", {"TOPO_AMD_GATE_MODE": "careful"}),
+                      ("lean", {"TOPO_AMD_GATE_MODE": "lean"}), ("auto", {})):
+        out = subprocess.run([sys.executable, "-c", _GATE_CHILD % root], cwd=root, env=dict(os.environ, **env),
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (name, out.stderr[-3000:])
+        results[name] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    base = results["three_launches"]["crc"]
+    for name in ("careful", "lean", "auto"):
+        assert results[name]["crc"] == base, name
+    assert results["lean"]["gave_up"] == 0  # (lean blocks wait; a wait that runs out is an error, not a statistic)
+    # and against the single block, in this process
+    rows, nx = 2112, 16384
+    local = orc.synthetic_dem(rows, nx, seed=21)
+    local[700:760, 3000:3300] += 0.25
+    whole = d.DeviceArray.from_host(np.concatenate([local, local, local], axis=0))
+    outs = [d.DeviceArray(rows, nx) for _ in range(4)]
+    blk = d.Block(whole)
+    blk.tpi_std(67, tpi=outs[0], std=outs[1], out_row0=rows, out_rows=rows)
+    d.sync()
+    assert [zlib.crc32(outs[k].to_host().tobytes()) for k in range(2)] == base["tpi_std67_0"]
+    blk.gradient(3.25, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3], out_row0=rows, out_rows=rows)
+    d.sync()
+    assert [zlib.crc32(outs[k].to_host().tobytes()) for k in range(4)] == base["grad3"]
+    window, dj, di, dist = d.sx_offsets(0.0, 500.0, 30.0, -30.0)
+    blk.sx(dj, di, dist, window, 10.0, outs[0], out_row0=rows, out_rows=rows)
+    d.sync()
+    assert zlib.crc32(outs[0].to_host().tobytes()) == base["sx0"][0]
+    for a in outs + [whole]:
+        a.free()

@@ -81,6 +81,7 @@ SIGNATURES = {
     "topo_amd_comm_destroy": (C.c_int, []),
     "topo_amd_halo_exchange_start": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "topo_amd_halo_wait": (C.c_int, []),
+    "topo_amd_gate_giveups": (C.c_int, [C.POINTER(C.c_uint)]),
     "topo_amd_shard_layout": (C.c_int, [C.c_int, C.c_int]),
     "topo_amd_shard_layout_get": (C.c_int, [_i32p, _i32p]),
     "topo_amd_shard_tpi_std": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),

@@ -30,8 +30,8 @@ def _newer(target, deps):
 
 def build_library(force=False, verbose=True):
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
-    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "atan.hpp"), os.path.join(CSRC, "disc_runs.hpp"), os.path.join(CSRC, "disc_wave_impl.hpp"), os.path.join(CSRC, "disc_ring_impl.hpp"),
-               os.path.join(os.path.dirname(HERE), "include", "topo_amd.h")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "topo_amd.h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if not force and _newer(LIB, srcs + headers):
         return LIB

@@ -254,6 +254,11 @@ int download(void* host, const void* dev, size_t bytes) {
 
 using namespace topo;
 
+namespace {
+int check_gate_errors();
+constexpr size_t kGateBytes = 16384;  // the gate word, then (from byte 256) one "gave up" byte per block of a launch
+}
+
 extern "C" {
 
 const char* topo_amd_version(void) { return "topo_amd 0.1.0 (gfx950)"; }
@@ -289,11 +294,32 @@ int topo_amd_init(int device) {
         if (n >= 8 && n < c.num_cu) c.num_cu = n;
     }
     TOPO_HIP(hipStreamCreateWithFlags(&c.compute, hipStreamNonBlocking));
-    TOPO_HIP(hipStreamCreateWithFlags(&c.comm, hipStreamNonBlocking));
+    {
+        // the ghost-row exchange goes on a high-priority stream: RCCL's few workgroups are dispatched ahead of the
+        // pending workgroups of a grid kernel on the compute stream (which otherwise refill every slot that frees up
+        // and leave the exchange for the end of the launch: Sx, kernel trace in profiles/r04_shard_fused.txt)
+        int least = 0, greatest = 0;
+        TOPO_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const char* e = std::getenv("TOPO_AMD_COMM_PRIORITY");
+        if (e && *e == '0') TOPO_HIP(hipStreamCreateWithFlags(&c.comm, hipStreamNonBlocking));
+        else TOPO_HIP(hipStreamCreateWithPriority(&c.comm, hipStreamNonBlocking, greatest));
+    }
     TOPO_HIP(hipEventCreateWithFlags(&c.halo_done, hipEventDisableTiming));
     TOPO_HIP(hipEventCreateWithFlags(&c.input_ready, hipEventDisableTiming));
     TOPO_HIP(hipEventCreate(&c.t0));
     TOPO_HIP(hipEventCreate(&c.t1));
+    // the ghost-row gate (common.hpp): a device word the communication stream stamps with the exchange epoch, and a
+    // pinned host word in which blocks that gave up waiting count themselves
+    TOPO_HIP(hipMalloc((void**)&c.gate_word, kGateBytes));
+    TOPO_HIP(hipMemset(c.gate_word, 0, kGateBytes));
+    TOPO_HIP(hipHostMalloc((void**)&c.gate_timeouts, 64, hipHostMallocMapped));
+    c.gate_timeouts[0] = 0;  // blocks that gave up at a closed gate (careful mode)
+    c.gate_timeouts[4] = 0;  // blocks whose wait ran out (lean mode): an error
+    c.gate_epoch = 0;
+    c.gate_mode = 0;
+    c.gate_clean_calls = 0;
+    c.gate_probe_pending = false;
+    TOPO_HIP(hipEventCreateWithFlags(&c.gate_probe, hipEventDisableTiming));
     c.device = device;
     c.ready = true;
     return TOPO_AMD_OK;
@@ -326,6 +352,9 @@ int topo_amd_shutdown(void) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
     }
+    if (c.gate_word) (void)hipFree(c.gate_word);
+    if (c.gate_timeouts) (void)hipHostFree(c.gate_timeouts);
+    if (c.gate_probe) (void)hipEventDestroy(c.gate_probe);
     (void)hipEventDestroy(c.halo_done);
     (void)hipEventDestroy(c.input_ready);
     (void)hipEventDestroy(c.t0);
@@ -387,7 +416,7 @@ int topo_amd_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     }
     TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().compute));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
-    return TOPO_AMD_OK;
+    return check_gate_errors();
 }
 
 int topo_amd_memcpy_d2d(void* dst, const void* src, size_t bytes) {
@@ -402,11 +431,52 @@ int topo_amd_memset(void* dst, int value, size_t bytes) {
     return TOPO_AMD_OK;
 }
 
+namespace topo {
+namespace {
+void gate_probe_poll();
+}
+}  // namespace topo
+
+namespace {
+uint32_t g_giveups_reported = 0;  // value of the give-up counter at the last topo_amd_gate_giveups
+uint32_t g_giveups_probed = 0;    //                              ... at the last look of the mode logic
+// lean mode: a block's wait at the gate ran out (gate.hpp) - the seam rows of that call were computed from ghost rows
+// that had not arrived.  Reported once, by the next call that synchronises; the library is careful from then on.
+int check_gate_errors() {
+    Context& c = ctx();
+    gate_probe_poll();  // (a synchronising call: whatever careful calls were in flight are over)
+    volatile uint32_t* err = c.gate_timeouts ? c.gate_timeouts + 4 : nullptr;
+    if (err && *err != 0) {
+        const unsigned n = *err;
+        *err = 0;
+        c.gate_mode = 2;
+        set_error("ghost-row gate: %u blocks waited longer than TOPO_AMD_GATE_TIMEOUT_MS for the halo exchange; the seam "
+                  "rows of the sharded calls since the last synchronisation are invalid (is a neighbour rank missing?).  "
+                  "Later calls run with the clean-up launch again", n);
+        return TOPO_AMD_ERCCL;
+    }
+    return TOPO_AMD_OK;
+}
+}  // namespace
+
+// Blocks of sharded launches that gave up waiting at the ghost-row gate since the last call (gate.hpp): their seam
+// tiles were done by the clean-up launch behind the exchange, i.e. the exchange was NOT hidden behind the interior
+// rows for them.  0 in a healthy run (after the first calls, in which RCCL sets its connections up); a statistic
+// for bench.py and the tests, never an error.
+int topo_amd_gate_giveups(unsigned* count) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(count != nullptr, "gate_giveups: NULL output");
+    const uint32_t now = *(volatile uint32_t*)ctx().gate_timeouts;
+    *count = now - g_giveups_reported;
+    g_giveups_reported = now;
+    return TOPO_AMD_OK;
+}
+
 int topo_amd_sync(void) {
     TOPO_TRY(require_ready());
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     TOPO_HIP(hipStreamSynchronize(ctx().comm));
-    return TOPO_AMD_OK;
+    return check_gate_errors();
 }
 
 int topo_amd_timer_start(void) {
@@ -420,7 +490,7 @@ int topo_amd_timer_stop(float* elapsed_ms) {
     TOPO_HIP(hipEventRecord(ctx().t1, ctx().compute));
     TOPO_HIP(hipEventSynchronize(ctx().t1));
     TOPO_HIP(hipEventElapsedTime(elapsed_ms, ctx().t0, ctx().t1));
-    return TOPO_AMD_OK;
+    return check_gate_errors();
 }
 
 
@@ -438,7 +508,7 @@ int topo_amd_mark_elapsed(int from, int to, float* elapsed_ms) {
                  "mark_elapsed: marks %d and %d must have been recorded", from, to);
     TOPO_HIP(hipEventSynchronize(g_marks[to]));
     TOPO_HIP(hipEventElapsedTime(elapsed_ms, g_marks[from], g_marks[to]));
-    return TOPO_AMD_OK;
+    return check_gate_errors();
 }
 
 int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed, int integer_valued) {
@@ -872,8 +942,32 @@ int topo_amd_valley_ridge_f32(const float* dem, int ny, int nx, const float* tap
 }
 
 // ---- RCCL row sharding ------------------------------------------------------------------------
+namespace {
+// CUs the persistent kernels of a sharded call leave to RCCL's send / receive kernel (TOPO_AMD_RESERVE_CUS, 0 ... 64;
+// effective in steps of 8: one CU on every XCD, see march_grid)
+int reserve_cus_setting() {
+    static const int v = [] {
+        const char* e = std::getenv("TOPO_AMD_RESERVE_CUS");
+        return e && *e ? std::max(0, std::min(64, std::atoi(e))) : 8;
+    }();
+    return v;
+}
+// The ghost-row exchange is two point-to-point messages of a few MB over one xGMI link each (50 GB/s): it needs a
+// few channels, not the 64 workgroups RCCL launches by default - which do not fit next to a persistent kernel
+// that fills the chip, so that the "overlapped" exchange of rounds 1-3 really ran when the interior launch ended
+// (kernel trace: profiles/r04_shard_fused.txt).  8 channels = 8 workgroups (256 threads, 37 KB of LDS, 124 VGPRs),
+// one per XCD, each on the CU the shorter grid leaves free there; in loop-back they move the 2 x 4.3 MB of the TPI
+// halo in 46 us (4 channels: 79 us, 2: 163 us).  Whatever the user has set stays.
+void cap_rccl_channels() {
+    setenv("NCCL_MAX_NCHANNELS", "8", 0);
+    setenv("NCCL_MAX_P2P_NCHANNELS", "8", 0);
+    setenv("NCCL_MIN_P2P_NCHANNELS", "1", 0);
+}
+}  // namespace
+
 int topo_amd_comm_unique_id(char id[TOPO_AMD_UNIQUE_ID_BYTES]) {
     static_assert(sizeof(ncclUniqueId) <= TOPO_AMD_UNIQUE_ID_BYTES, "unique id size");
+    cap_rccl_channels();
     ncclUniqueId uid;
     TOPO_NCCL(ncclGetUniqueId(&uid));
     std::memset(id, 0, TOPO_AMD_UNIQUE_ID_BYTES);
@@ -885,6 +979,7 @@ int topo_amd_comm_init(int rank, int nranks, const char id[TOPO_AMD_UNIQUE_ID_BY
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_init: rank %d of %d", rank, nranks);
     TOPO_REQUIRE(g_comm.comm == nullptr, "comm_init: communicator already exists");
+    cap_rccl_channels();
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof(uid));
     TOPO_NCCL(ncclCommInitRank(&g_comm.comm, nranks, uid, rank));
@@ -904,6 +999,28 @@ int topo_amd_comm_destroy(void) {
     g_comm = Comm();
     return TOPO_AMD_OK;
 }
+
+namespace {
+__global__ void stamp_kernel(uint32_t* word, uint32_t value) {
+    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// writes the current epoch into the gate word, in stream order on the communication stream: a stream memory
+// operation where the runtime has one (no kernel, no CU), a one-thread kernel otherwise (TOPO_AMD_GATE_STAMP=kernel)
+int stamp_gate(Context& c) {
+    static int mode = [] {
+        const char* e = std::getenv("TOPO_AMD_GATE_STAMP");
+        return e && e[0] == 'k' ? 1 : 0;
+    }();
+    if (mode == 0) {
+        if (hipStreamWriteValue32(c.comm, c.gate_word, c.gate_epoch, 0) == hipSuccess) return TOPO_AMD_OK;
+        (void)hipGetLastError();
+        mode = 1;
+    }
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, c.comm, c.gate_word, c.gate_epoch);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+}  // namespace
 
 int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_above,
                                  int halo_below) {
@@ -954,6 +1071,9 @@ int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_
         }
         TOPO_NCCL(ncclGroupEnd());
     }
+    // the gate of the fused seam parts: the epoch of this exchange, written behind the receives
+    ++c.gate_epoch;
+    TOPO_TRY(stamp_gate(c));
     TOPO_HIP(hipEventRecord(c.halo_done, c.comm));
     g_comm.halo_pending = true;
     return TOPO_AMD_OK;
@@ -1036,19 +1156,14 @@ Shard make_shard(float* block, int rows_local, int row0, int gny, int nx, int ab
 // seam strips: the exchange overlaps the interior compute.  The interior launch gets the OWNED rows as
 // its block: the ghost rows are being written by the exchange meanwhile, and a tile-based kernel stages
 // (and classifies) every row of its block that a tile touches, not only the rows its outputs need.
+// The three-launch route of rounds 1-3: interior rows first (on the owned rows: the ghost rows are being written
+// meanwhile, and a tile-based kernel stages - and classifies - every row of its block that a tile touches), then, behind
+// the exchange's event, the two seam strips.  `started`: the exchange is already in flight.
 template <class Fn>
-int run_overlapped(float* block, const Shard& s, int above, int below, Fn fn) {
-    TOPO_TRY(topo_amd_halo_exchange_start(block, s.rows_local, s.whole.nx, above, below));
-    // the interior launch is persistent (it would otherwise hold every CU until it ends): leave
-    // a few CUs to the send/recv kernels so that the exchange really runs next to it
-    static const int kReserve = [] {
-        const char* e = std::getenv("TOPO_AMD_RESERVE_CUS");  // tuning knob (0 ... 64)
-        // one 4096 x 32768 shard in loop-back, ms per TPI / STD step (profiles/r03_reserve_cus.txt): 32 CUs 0.724 / 1.579,
-        // 16 0.688 / 1.447, 8 0.681 / 1.430, 4 0.680 / 1.428, 0 0.654 / 1.386 (in loop-back the copy needs no link;
-        // with real neighbours an exchange that finds no free CU starts when the interior launch ends)
-        return e && *e ? std::max(0, std::min(64, std::atoi(e))) : 8;
-    }();
-    ctx().reserve_cus = (g_comm.size > 1 || halo_loopback()) ? kReserve : 0;
+int run_three(float* block, const Shard& s, int above, int below, Fn fn, bool started) {
+    if (!started) TOPO_TRY(topo_amd_halo_exchange_start(block, s.rows_local, s.whole.nx, above, below));
+    // persistent launches leave a round of CUs to RCCL's kernel (march_grid)
+    ctx().reserve_cus = (g_comm.size > 1 || halo_loopback()) ? reserve_cus_setting() : 0;
     int rc = TOPO_AMD_OK;
     if (s.interior1 > s.interior0) rc = fn(s.owned, s.interior0, s.interior1 - s.interior0);
     ctx().reserve_cus = 0;
@@ -1058,6 +1173,152 @@ int run_overlapped(float* block, const Shard& s, int above, int below, Fn fn) {
     const int end = s.row0 + s.rows_local;
     if (end > s.interior1) TOPO_TRY(fn(s.whole, s.interior1, end - s.interior1));
     return TOPO_AMD_OK;
+}
+template <class Fn>
+int run_overlapped(float* block, const Shard& s, int above, int below, Fn fn) {
+    return run_three(block, s, above, below, fn, false);
+}
+
+// ---- round 4: ONE launch per kernel of the descriptor for the whole shard -------------------------------------------
+// Two forms, both behind the ghost-row gate (gate.hpp) that the communication stream opens when the ghost rows have
+// landed, both with the block views, output rows and kernels of run_three, hence its bits:
+//  * run_fused (marching kernels: TPI / STD): the seam strips travel with the interior launch as "parts"
+//    (Context::seams; disc_wave_impl.hpp, make_parts): every persistent block does its share of the interior, finds the
+//    gate open - the exchange ran next to the interior - and does its share of the seams;
+//  * run_gated (kernels of independent tiles: Sx): one launch over all owned rows on the block with its ghost rows; the
+//    tile rows that read ghost rows are dispatched last and wait at the gate (Context::ghost).
+// No relaunch tail, no under-filled seam launches, a third of the launches.  A launcher that cannot do it says so
+// (leaves the gate armed / answers TOPO_AMD_EUNSUP before launching) and the call takes run_three.
+// TOPO_AMD_SHARD_FUSED=0: always run_three (A/B).
+bool shard_fused_on() {
+    static const bool on = [] {
+        const char* e = std::getenv("TOPO_AMD_SHARD_FUSED");
+        return !(e && *e == '0');
+    }();
+    return on;
+}
+// how long a block waits at a closed gate before it leaves its seam tiles to the clean-up launch (TOPO_AMD_GATE_WAIT_US)
+uint32_t gate_limit_ticks() {
+    static const uint32_t v = [] {
+        const char* e = std::getenv("TOPO_AMD_GATE_WAIT_US");
+        const double us = e && *e ? std::atof(e) : 100.0;
+        return (uint32_t)std::min(4.0e9, std::max(0.0, us) * 100.0);  // s_memtime: 100 MHz
+    }();
+    return v;
+}
+// lean mode: how long a block waits before it reports an error (TOPO_AMD_GATE_TIMEOUT_MS)
+uint32_t gate_timeout_ticks() {
+    static const uint32_t v = [] {
+        const char* e = std::getenv("TOPO_AMD_GATE_TIMEOUT_MS");
+        const double ms = e && *e ? std::atof(e) : 1000.0;
+        return (uint32_t)std::min(4.0e9, std::max(1.0, ms) * 1.0e5);
+    }();
+    return v;
+}
+// careful calls whose completion nobody has looked at yet (the probe event stands behind the last of them)
+int g_probe_calls = 0;
+void gate_probe_poll() {
+    Context& c = ctx();
+    if (c.gate_mode != 0 || !c.gate_probe_pending || hipEventQuery(c.gate_probe) != hipSuccess) return;
+    // every careful call up to the probe is over: did all of their blocks find the gate open?
+    c.gate_probe_pending = false;
+    const uint32_t now = *(volatile uint32_t*)c.gate_timeouts;
+    c.gate_clean_calls = now == g_giveups_probed ? c.gate_clean_calls + g_probe_calls : 0;
+    g_giveups_probed = now;
+    g_probe_calls = 0;
+    if (c.gate_clean_calls >= 3) c.gate_mode = 1;
+    if (std::getenv("TOPO_AMD_DEBUG_GATE"))
+        std::fprintf(stderr, "gate probe: give-ups so far %u, clean careful calls %d -> mode %d\n", now, c.gate_clean_calls, c.gate_mode);
+}
+// The gate of the exchange just started, careful or lean (Context::gate_mode; TOPO_AMD_GATE_MODE=careful / lean pins it).
+Gate make_gate(bool* lean) {
+    Context& c = ctx();
+    static const int pinned = [] {
+        const char* e = std::getenv("TOPO_AMD_GATE_MODE");
+        return e && e[0] == 'l' ? 1 : e && e[0] == 'c' ? 2 : 0;
+    }();
+    if (pinned) c.gate_mode = c.gate_mode == 2 ? 2 : pinned;  // (an error always ends lean mode)
+    gate_probe_poll();
+    *lean = c.gate_mode == 1;
+    return Gate{c.gate_word, c.gate_epoch, c.gate_timeouts, *lean ? gate_timeout_ticks() : gate_limit_ticks(),
+                (uint8_t*)c.gate_word + 256, *lean ? c.gate_timeouts + 4 : nullptr};
+}
+// behind a call whose launcher took the gate
+int finish_gated(bool lean, bool probe) {
+    Context& c = ctx();
+    // every later launch on the compute stream is ordered behind a kernel all of whose blocks passed the gate
+    if (lean) {
+        g_comm.halo_pending = false;  // (no event wait on the compute stream: nothing is left to wait for)
+        return TOPO_AMD_OK;
+    }
+    if (c.gate_mode == 0 && probe) {
+        TOPO_HIP(hipEventRecord(c.gate_probe, c.compute));
+        c.gate_probe_pending = true;
+        ++g_probe_calls;
+    }
+    return topo_amd_halo_wait();  // (the clean-up launch waited already: keeps topo_amd_halo_wait's contract)
+}
+
+template <class Fn>
+int run_fused(float* block, const Shard& s, int above, int below, Fn fn) {
+    const int end = s.row0 + s.rows_local;
+    const bool top = s.interior0 > s.row0, bottom = end > s.interior1;
+    if (!shard_fused_on() || s.interior1 <= s.interior0 || (!top && !bottom)) return run_three(block, s, above, below, fn, false);
+    Context& c = ctx();
+    TOPO_TRY(topo_amd_halo_exchange_start(block, s.rows_local, s.whole.nx, above, below));
+    const bool live = g_comm.size > 1 || halo_loopback();
+    c.reserve_cus = live ? reserve_cus_setting() : 0;
+    c.seams = Seams();
+    auto add = [&](int r0, int rows) {
+        Block b = s.whole;
+        b.out_row0 = r0;
+        b.out_rows = rows;
+        c.seams.b[c.seams.n++] = b;
+    };
+    if (top) add(s.row0, s.interior0 - s.row0);
+    if (bottom) add(s.interior1, end - s.interior1);
+    bool lean = false;
+    c.seams.gate = make_gate(&lean);
+    c.seams.gate_armed = true;
+    const int rc = fn(s.owned, s.interior0, s.interior1 - s.interior0);
+    const bool taken = !c.seams.gate_armed;
+    c.seams = Seams();
+    c.reserve_cus = 0;
+    if (rc != TOPO_AMD_OK) return rc;
+    if (taken) return finish_gated(lean, true);
+    TOPO_TRY(topo_amd_halo_wait());
+    if (top) TOPO_TRY(fn(s.whole, s.row0, s.interior0 - s.row0));
+    if (bottom) TOPO_TRY(fn(s.whole, s.interior1, end - s.interior1));
+    return TOPO_AMD_OK;
+}
+
+// device_gate: the launcher's kernel waits at the gate itself (Sx) - in lean mode only: a grid kernel keeps every CU
+// slot filled with its own pending workgroups, so RCCL's kernel gets to run when the grid drains, i.e. when the
+// blocks of the ghost tile rows are already waiting; with the careful mode's short wait they would all give up.
+// Otherwise (gradient) the launcher orders its row chunks around the exchange's event and needs no mode.
+template <class Fn>
+int run_gated(float* block, const Shard& s, int above, int below, bool device_gate, Fn fn) {
+    const int end = s.row0 + s.rows_local;
+    const bool top = s.interior0 > s.row0, bottom = end > s.interior1;
+    if (!shard_fused_on() || (!top && !bottom)) return run_three(block, s, above, below, fn, false);
+    Context& c = ctx();
+    bool lean = false;
+    const Gate gate = make_gate(&lean);  // (the epoch is patched in below, once the exchange has its number)
+    if (device_gate && !lean) return run_three(block, s, above, below, fn, false);
+    TOPO_TRY(topo_amd_halo_exchange_start(block, s.rows_local, s.whole.nx, above, below));
+    c.ghost = GhostGate();
+    c.ghost.gate = gate;
+    c.ghost.gate.epoch = c.gate_epoch;
+    c.ghost.ghost_lo = s.whole.in_row0 < s.row0 ? s.row0 : -(1 << 30);  // rows above the owned ones that exist: ghost rows
+    c.ghost.ghost_hi = s.whole.in_row0 + s.whole.in_rows > end ? end : (1 << 30);
+    c.ghost.slots = kGateBytes - 256;
+    c.ghost.armed = true;
+    const int rc = fn(s.whole, s.row0, s.rows_local);
+    const bool taken = !c.ghost.armed;
+    c.ghost = GhostGate();
+    if (taken) return rc == TOPO_AMD_OK ? finish_gated(lean && device_gate, false) : rc;
+    if (rc != TOPO_AMD_EUNSUP) return rc;  // (an error before anything was launched)
+    return run_three(block, s, above, below, fn, true);
 }
 
 float* shift(float* p, int rows, int nx) { return p ? p + (size_t)rows * nx : nullptr; }
@@ -1076,7 +1337,7 @@ int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int 
     TOPO_TRY(shard_view(&block, above, below, "shard_tpi_std"));
     block += shard_view_offset(above, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, above, below);
-    return run_overlapped(block, s, above, below, [&](const Block& view, int o0, int on) {
+    return run_fused(block, s, above, below, [&](const Block& view, int o0, int on) {
         Block b = view;
         b.out_row0 = o0;
         b.out_rows = on;
@@ -1093,7 +1354,7 @@ int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int
     TOPO_TRY(shard_view(&block, h, h, "shard_gradient"));
     block += shard_view_offset(h, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, h, h);
-    return run_overlapped(block, s, h, h, [&](const Block& view, int o0, int on) {
+    return run_gated(block, s, h, h, false, [&](const Block& view, int o0, int on) {
         Block b = view;
         b.out_row0 = o0;
         b.out_rows = on;
@@ -1122,7 +1383,7 @@ int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx, c
     TOPO_TRY(shard_view(&block, up, down, "shard_sx"));
     block += shard_view_offset(up, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, up, down);
-    return run_overlapped(block, s, up, down, [&](const Block& view, int o0, int on) {
+    return run_gated(block, s, up, down, true, [&](const Block& view, int o0, int on) {
         Block b = view;
         b.out_row0 = o0;
         b.out_rows = on;

@@ -40,12 +40,70 @@ void set_error(const char* fmt, ...);
         if (r_ != TOPO_AMD_OK) return r_;                                                  \
     } while (0)
 
+// Geometry of a row block inside the global DEM (see include/topo_amd.h).
+struct Block {
+    const float* in;
+    int in_rows, in_row0, gny, nx;
+    int out_row0, out_rows;
+};
+
+// ---- ghost-row gate (row shards) ----------------------------------------------------------------
+// A sharded call runs ONE launch over the rows a shard owns: the interior rows first, then - behind this gate -
+// the seam rows whose stencils read ghost rows.  The communication stream writes `epoch` into `*word` once the
+// ghost rows of the exchange have landed (topo_amd_halo_exchange_start); the blocks that reach a seam part
+// before that wait for it.  word == nullptr: no gate (the ghost rows are already final).
+struct Gate {
+    const uint32_t* word;
+    uint32_t epoch;
+    uint32_t* timeouts;  // pinned host word: blocks that gave up waiting (a statistic: topo_amd_gate_giveups)
+    uint32_t limit_ticks;  // s_memtime ticks (100 MHz) a block waits at most
+    uint8_t* skipped;    // one byte per block of the launch: set by a block that gave up, cleared by the clean-up launch
+    uint32_t* errors;    // pinned host word, lean mode (no clean-up launch): blocks whose wait ran out - an error
+};
+
+// The seam parts of a sharded call, taken up by the first launcher that supports parts (common.hpp: launchers
+// that read `Context::seams` build one kernel argument per part; output pointers of a part are the main block's
+// shifted by the difference of the first output rows).
+struct Seams {
+    int n = 0;          // seam parts behind the main block (0: an ordinary call)
+    Block b[2];
+    Gate gate{nullptr, 0, nullptr, 0, nullptr, nullptr};
+    bool gate_armed = false;  // the first launch of the call waits at the gate; later ones are ordered behind it
+};
+
+// The other form of a sharded call, for kernels whose tiles are independent (Sx, the Gaussian passes): ONE launch over
+// all the rows the shard owns, on the block with its ghost rows.  The launcher puts the tile rows that read ghost
+// rows (global rows < ghost_lo or >= ghost_hi) at the end of the dispatch order, and their blocks wait at the gate.
+// A launcher that cannot do that answers TOPO_AMD_EUNSUP BEFORE it launches anything (capi.hip then runs the
+// interior and the seam strips as separate launches); one that can clears `armed`.
+struct GhostGate {
+    bool armed = false;
+    Gate gate{nullptr, 0, nullptr, 0, nullptr, nullptr};
+    int ghost_lo = 0, ghost_hi = 0;
+    size_t slots = 0;  // bytes behind gate.skipped
+};
+
 // ---- per-process context (one process drives one GPU) -------------------------------------
 struct Context {
     bool ready = false;
     int device = -1;
     int num_cu = 256;
     int reserve_cus = 0;  // CUs persistent kernels leave free while a ghost-row exchange is in flight
+    Seams seams;          // set by run_fused (capi.hip) around the launchers of one sharded call
+    GhostGate ghost;      // set by run_gated (capi.hip) around the launcher of one sharded call
+    uint32_t* gate_word = nullptr;      // device word the communication stream writes the exchange epoch into
+    uint32_t* gate_timeouts = nullptr;  // pinned host word (see Gate)
+    uint32_t gate_epoch = 0;            // epoch of the last exchange started
+    // How the seam parts wait (capi.hip, run_fused).  The library starts CAREFUL: a block waits a short while at a
+    // closed gate, then leaves its seam tiles to a clean-up launch behind the exchange's event - correct whatever
+    // RCCL's kernel needs to make progress.  After a few careful calls in which no block gave up (the exchange does
+    // run next to the interior launch on this machine) it goes LEAN: no clean-up launch and no event wait on the
+    // compute stream (20 us of a 600 us step), blocks wait up to TOPO_AMD_GATE_TIMEOUT_MS and a wait that runs out
+    // is an error reported by the next synchronising call - after which the library is careful again for good.
+    int gate_mode = 0;          // 0 careful (probing), 1 lean, 2 careful for good
+    int gate_clean_calls = 0;   // consecutive careful calls that have completed without a block giving up
+    hipEvent_t gate_probe = nullptr;  // recorded behind the last careful call
+    bool gate_probe_pending = false;
     size_t lds_per_block = 65536;
     hipStream_t compute = nullptr;   // every kernel goes here
     hipStream_t comm = nullptr;      // RCCL ghost-row traffic
@@ -68,12 +126,6 @@ int require_ready();
 int workspace(int slot, size_t bytes, void** out);       // device scratch, grow-only
 int upload_table(int slot, const void* host, size_t bytes, void** out);  // async on compute
 
-// Geometry of a row block inside the global DEM (see include/topo_amd.h).
-struct Block {
-    const float* in;
-    int in_rows, in_row0, gny, nx;
-    int out_row0, out_rows;
-};
 int check_block(const Block& b, int need_above, int need_below, const char* who);
 // Several kernels launch one block row per DEM row (gridDim.y): 65 535 rows per launch at most.  The launch_*
 // entry points therefore cut taller requests into row blocks of kMaxLaunchRows output rows (a multiple of every

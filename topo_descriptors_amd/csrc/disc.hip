@@ -416,6 +416,7 @@ int launch_disc_wave_repitched(const Block& b, int size, float* tpi_out, float* 
 
 int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* std_out) {
     if (b.out_rows > kMaxLaunchRows) {
+        ctx().seams.n = 0;  // (a sharded call this tall keeps its seams as launches of their own)
         for (int r = 0; r < b.out_rows; r += kMaxLaunchRows) {
             Block s = b;
             s.out_row0 = b.out_row0 + r;
@@ -426,6 +427,11 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
     }
     TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
     Context& c = ctx();
+    // the seam parts of a sharded call ride along only in the launchers of disc_wave_impl.hpp, on the block as it is
+    // (not on a re-pitched copy); otherwise they stay with the caller, who sees the gate still armed
+    if (c.seams.n > 0 && !(disc_wave_covers(disc.size) && b.nx % 4 == 0 && (reinterpret_cast<uintptr_t>(b.in) & 15) == 0 &&
+                           (reinterpret_cast<uintptr_t>(std_out) & 15) == 0 && (reinterpret_cast<uintptr_t>(tpi_out) & 15) == 0))
+        c.seams.n = 0;
     {
         int r = launch_disc_wave(b, disc.size, tpi_out, std_out);
         if (r == TOPO_AMD_EUNSUP && disc_wave_covers(disc.size) && b.nx >= 4)

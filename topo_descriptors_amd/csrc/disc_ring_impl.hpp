@@ -286,7 +286,7 @@ constexpr bool ring_both_fits(int size) {
 // own first row, and TPI of SIZE2 goes to p.tpi2 with the expression of the single call, hence with its bits.  A tile
 // the pass leaves to the general kernel is left for both sizes (kRingMain only: discs below 17 px).
 template <int SIZE, int NCR, int MODE, int SIZE2 = 0>
-__global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+__device__ __forceinline__ void tpi_ring_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     static_assert(SIZE2 == 0 || (SIZE2 < SIZE && SIZE2 >= 5 && SIZE2 % 2 == 1 && MODE == kRingMain), "pair: a smaller odd disc, main pass");
     using G = RGeo<SIZE, NCR>;
     using C = RingCfg<SIZE, NCR>;
@@ -304,12 +304,10 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ntiles = tiles_x * tiles_y;
-    const int nb = gridDim.x;
-    const int per_xcd = nb >> 3;
-    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    const int per = (ntiles + nb - 1) / nb;  // a contiguous run of the strip-major tile list; neighbouring runs in one XCD
-    const int first = vb * per;
-    const int last = min(first + per, ntiles);
+    const int vb = (vb0 + deal.shift) % nb;
+    // the block's contiguous run of the strip-major tile list (deal_parts)
+    const int first = deal.first(vb);
+    const int last = min(first + deal.count(vb), ntiles);
     const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
 
     if (SECOND) {
@@ -615,6 +613,15 @@ __global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, 
 }
 
 template <int SIZE, int NCR, int MODE, int SIZE2 = 0>
+__global__ __launch_bounds__(512) void tpi_ring_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((tpi_ring_kernel_body<SIZE, NCR, MODE, SIZE2>));
+}
+template <int SIZE, int NCR, int MODE, int SIZE2 = 0>
+__global__ __launch_bounds__(512) void tpi_ring_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((tpi_ring_kernel_body<SIZE, NCR, MODE, SIZE2>));
+}
+
+template <int SIZE, int NCR, int MODE, int SIZE2 = 0>
 int launch_ring(const Block& b, float* tpi_out, float* tpi2_out = nullptr) {
     using G = RGeo<SIZE, NCR>;
     using C = RingCfg<SIZE, NCR>;
@@ -632,22 +639,13 @@ int launch_ring(const Block& b, float* tpi_out, float* tpi2_out = nullptr) {
                                                               C::NW * 64, kLds));
         blocks_per_cu = nblk < 1 ? 1 : (nblk > 4 ? 4 : nblk);  // small discs: several rings per CU
     }
-    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
-    const int tiles_y = (b.out_row0 + b.out_rows - 1) / C::TH - b.out_row0 / C::TH + 1;
-    const long ntiles = (long)tiles_x * tiles_y;
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, MODE == kRingMainFrac || MODE == kRingFraction, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
-    void* defer = nullptr;
-    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
-    a.defer = (uint8_t*)defer;
-    if (MODE == kRingMainFrac || MODE == kRingFraction) {
-        void* sums = nullptr;
-        TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
-        a.sums = (int32_t*)sums;
-    }
-    hipLaunchKernelGGL((tpi_ring_kernel<SIZE, NCR, MODE, SIZE2>), dim3((unsigned)grid), dim3(C::NW * 64), kLds, c.compute, a,
-                       tiles_x, tiles_y);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
+    deal_parts(&ps, tiles_x, grid, blocks_per_cu);
+    return launch_parts(tpi_ring_kernel<SIZE, NCR, MODE, SIZE2>, tpi_ring_kernel_parts<SIZE, NCR, MODE, SIZE2>, grid, C::NW * 64, kLds, ps, tiles_x);
 }
 
 
@@ -714,7 +712,7 @@ constexpr bool std_ring_both_fits(int size) {
 enum StdRingMode { kStdMain = 0, kStdBoth = 2 };
 
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
-__global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+__device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = RGeo<SIZE, 4>;
     using C = StdRingCfg<SIZE>;
     constexpr bool BOTH = MODE == kStdBoth;
@@ -731,12 +729,10 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ntiles = tiles_x * tiles_y;
-    const int nb = gridDim.x;
-    const int per_xcd = nb >> 3;
-    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    const int per = (ntiles + nb - 1) / nb;
-    const int first = vb * per;
-    const int last = min(first + per, ntiles);
+    const int vb = (vb0 + deal.shift) % nb;
+    // the block's contiguous run of the strip-major tile list (deal_parts)
+    const int first = deal.first(vb);
+    const int last = min(first + deal.count(vb), ntiles);
     const double n = (double)G::T.taps;
     const double inv_n = 1.0 / n;
     const double inv_nm1 = 1.0 / (n - 1.0);
@@ -1049,6 +1045,15 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
 }
 
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
+__global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((std_ring_kernel_body<SIZE, WANT_TPI, MODE>));
+}
+template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
+__global__ __launch_bounds__(768) void std_ring_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((std_ring_kernel_body<SIZE, WANT_TPI, MODE>));
+}
+
+template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
 int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
     using G = RGeo<SIZE, 4>;
     using C = StdRingCfg<SIZE>;
@@ -1066,16 +1071,14 @@ int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
                                                               kLds));
         blocks_per_cu = nblk < 1 ? 1 : (nblk > 2 ? 2 : nblk);  // small discs: two rings per CU
     }
-    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
-    const int tiles_y = (b.out_row0 + b.out_rows - 1) / C::TH - b.out_row0 / C::TH + 1;
-    const long ntiles = (long)tiles_x * tiles_y;
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
-    void* defer = nullptr;
-    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
-    a.defer = (uint8_t*)defer;
-    hipLaunchKernelGGL((std_ring_kernel<SIZE, WANT_TPI, MODE>), dim3((unsigned)grid), dim3(C::NW * 64), kLds, c.compute, a,
-                       tiles_x, tiles_y);
-    TOPO_HIP(hipGetLastError());
+    deal_parts(&ps, tiles_x, grid, blocks_per_cu);
+    void* defer = ps.a[0].defer;
+    TOPO_TRY(launch_parts(std_ring_kernel<SIZE, WANT_TPI, MODE>, std_ring_kernel_parts<SIZE, WANT_TPI, MODE>, grid, C::NW * 64, kLds, ps, tiles_x));
     if (std::getenv("TOPO_AMD_DEBUG_MAP")) {  // diagnostic: how many tiles were left to the general kernel
         std::vector<uint8_t> h((size_t)ntiles);
         TOPO_HIP(hipMemcpyAsync(h.data(), defer, (size_t)ntiles, hipMemcpyDeviceToHost, c.compute));

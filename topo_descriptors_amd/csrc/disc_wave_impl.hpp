@@ -21,6 +21,7 @@
 
 #include "common.hpp"
 #include "disc_runs.hpp"
+#include "gate.hpp"
 
 namespace topo {
 
@@ -57,6 +58,170 @@ struct WaveArgs {
     int map_tw;         //                 and its strip width when that differs too (0 = its own)
     float* tpi2;        // ring kernel for a pair of disc sizes: TPI of the smaller disc
 };
+
+// One launch, several row blocks ("parts").  An ordinary call has one part.  A sharded call (capi.hip, run_fused)
+// has the rows whose stencils stay inside the shard as part 0 and the seam strips - the rows that read ghost rows -
+// as parts 1 and 2, each with the block view, the output rows and the slices of the workspaces that the separate
+// launches of rounds 1-3 gave it (so the bits cannot differ).  Every persistent block walks its share of part 0,
+// waits at the gate (gate.hpp) and walks its share of the seam parts: the seams ride in the tail of the interior
+// launch instead of two under-filled launches behind an event.  `shift` rotates the block numbering of a part,
+// so that the few tiles of a seam part go to the blocks at the end of the grid, whose interior runs are the
+// shortest ones.
+constexpr int kMaxParts = 3;
+// How a part's tile list is dealt to the blocks: block vb (after the XCD-aware renumbering) acts as block
+// (vb + shift) % nb and takes a contiguous run of the strip-major tile list; the runs differ by at most one tile
+// (deal_parts), none is empty while there are as many tiles as blocks.
+struct PartRun {
+    int shift;  // block vb acts as block (vb + shift) % nb
+    int base;   // tiles of a run ...
+    int b1, b2, mid;  // ... plus `mid` (+1 or -1) for the blocks b1 <= vb < b2
+    __host__ __device__ int first(int vb) const { return vb * base + mid * (vb <= b1 ? 0 : (vb < b2 ? vb - b1 : b2 - b1)); }
+    __host__ __device__ int count(int vb) const { return base + (vb >= b1 && vb < b2 ? mid : 0); }
+};
+struct WaveParts {
+    WaveArgs a[kMaxParts];
+    int tiles_y[kMaxParts];
+    PartRun run[kMaxParts];
+    int n;
+    int cleanup;               // the clean-up launch behind the exchange's event: seam parts of the blocks that gave up
+    Gate gate;
+};
+
+// The kernels' common frame.  (1) Which block am I: workgroups go to the XCDs round-robin, so numbering the blocks
+// of a grid of whole rounds XCD by XCD (vb) puts neighbouring runs of the tile list behind one L2.  (2) The parts:
+// part 0, then - behind the gate - the seam parts; a block that gives up at the gate marks itself, and the clean-up
+// launch (same grid, same dealing) does the seam parts of the marked blocks.
+// body: `void body(const WaveArgs&, int tiles_x, int tiles_y, PartRun deal, int vb0, int nb)`.  (One copy of the
+// body in a loop, the parts indexed in the kernel arguments: scalar loads, no scratch.)
+// An ordinary call is one part: the kernel with the arguments of rounds 1-3 (the frame's loop state costs the ring
+// kernels at the register limit dear: std_ring_kernel<65, true> spilt 109 VGPRs through it).
+#define TOPO_RUN_ONE(body)                                                                              \
+    const int nb_ = (int)gridDim.x;                                                                     \
+    const int vb_ = (nb_ & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nb_ >> 3) + (int)(blockIdx.x >> 3); \
+    body(p, tiles_x, tiles_y, deal, vb_, nb_);
+#define TOPO_RUN_PARTS(body)                                                                            \
+    const int nb_ = (int)gridDim.x;                                                                     \
+    const int vb_ = (nb_ & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nb_ >> 3) + (int)(blockIdx.x >> 3); \
+    if (ps.cleanup) {                                                                                   \
+        if (ps.gate.skipped[blockIdx.x] == 0) return;                                                   \
+        __syncthreads();                                                                                \
+        if (threadIdx.x == 0) ps.gate.skipped[blockIdx.x] = 0;                                          \
+    } else {                                                                                            \
+        /* part 0 - nearly all of the work - is a copy of the body with its arguments at fixed offsets, like the */ \
+        /* ordinary kernel's; the seam parts share a second copy in a loop (what that loop keeps alive cost the */ \
+        /* ring kernels at the register limit 8 % when part 0 went through it too) */               \
+        body(ps.a[0], tiles_x, ps.tiles_y[0], ps.run[0], vb_, nb_);                                     \
+        if (!gate_wait(ps.gate, blockIdx.x) && ps.gate.errors == nullptr) return;                       \
+    }                                                                                                   \
+    _Pragma("unroll 1") for (int part_ = 1; part_ < ps.n; ++part_) {                                    \
+        __syncthreads();                                                                                \
+        body(ps.a[part_], tiles_x, ps.tiles_y[part_], ps.run[part_], vb_, nb_);                         \
+    }
+
+// Fills `ps` for the block `b` (arguments `a0`: the launcher's, with the output pointers of `b`) and for the seam
+// parts of the sharded call in flight, if any.  tile_h x strip_w: the kernel's tile geometry; want_defer /
+// want_sums: slices of workspaces 8 (one byte per tile) and 9 (an int32 per output pixel).  map_th / map_tw: the
+// general kernel reading the tile map of a marching launch with another geometry (rows of map_th, strips of
+// map_tw; 0 = its own).  Returns the number of strips and the tiles of part 0 (what the grid is sized by).
+inline int make_parts(const Block& b, const WaveArgs& a0, int tile_h, int strip_w, bool want_defer, bool want_sums,
+                      WaveParts* ps, int* tiles_x_out, long* ntiles0, int map_th = 0, int map_tw = 0) {
+    Context& c = ctx();
+    const int n = 1 + c.seams.n;
+    const int tiles_x = (b.nx + strip_w - 1) / strip_w;
+    const bool other_map = map_th != 0 && (map_th != tile_h || map_tw != 0);
+    const int mtw = (other_map && map_tw != strip_w) ? map_tw : 0;
+    const int map_tiles_x = mtw ? (b.nx + mtw - 1) / mtw : tiles_x;
+    size_t defer_off[kMaxParts + 1] = {0}, sums_off[kMaxParts + 1] = {0};
+    for (int k = 0; k < n; ++k) {
+        const Block& bk = k == 0 ? b : c.seams.b[k - 1];
+        WaveArgs& a = ps->a[k];
+        a = a0;
+        a.in = bk.in;
+        a.in_rows = bk.in_rows;
+        a.in_row0 = bk.in_row0;
+        a.out_row0 = bk.out_row0;
+        a.out_rows = bk.out_rows;
+        const ptrdiff_t moved = (ptrdiff_t)(bk.out_row0 - b.out_row0) * b.nx;
+        if (a.tpi) a.tpi += moved;
+        if (a.sd) a.sd += moved;
+        if (a.tpi2) a.tpi2 += moved;
+        ps->tiles_y[k] = (bk.out_row0 + bk.out_rows - 1) / tile_h - bk.out_row0 / tile_h + 1;
+        long map_tiles = (long)tiles_x * ps->tiles_y[k];
+        if (other_map) {
+            a.map_th = map_th;
+            a.map_tiles_y = (bk.out_row0 + bk.out_rows - 1) / map_th - bk.out_row0 / map_th + 1;
+            a.map_tw = mtw;
+            map_tiles = (long)map_tiles_x * a.map_tiles_y;
+        }
+        defer_off[k + 1] = defer_off[k] + (size_t)map_tiles;
+        sums_off[k + 1] = sums_off[k] + (size_t)bk.out_rows * b.nx;
+        ps->run[k] = PartRun{0, 0, 0};
+    }
+    for (int k = n; k < kMaxParts; ++k) {
+        ps->a[k] = ps->a[0];
+        ps->tiles_y[k] = 0;
+        ps->run[k] = PartRun{0, 0, 0};
+    }
+    if (want_defer) {
+        void* defer = nullptr;  // the same sizes in every launch of a group, so the same slices of one allocation
+        TOPO_TRY(workspace(8, defer_off[n], &defer));
+        for (int k = 0; k < n; ++k) ps->a[k].defer = (uint8_t*)defer + defer_off[k];
+    }
+    if (want_sums) {
+        void* sums = nullptr;
+        TOPO_TRY(workspace(9, sums_off[n] * sizeof(int32_t), &sums));
+        for (int k = 0; k < n; ++k) ps->a[k].sums = (int32_t*)sums + sums_off[k];
+    }
+    ps->n = n;
+    ps->gate = Gate{nullptr, 0, nullptr, 0, nullptr, nullptr};
+    ps->cleanup = 0;
+    if (n > 1 && c.seams.gate_armed) {
+        ps->gate = c.seams.gate;
+        c.seams.gate_armed = false;
+    }
+    *tiles_x_out = tiles_x;
+    *ntiles0 = (long)tiles_x * ps->tiles_y[0];
+    return TOPO_AMD_OK;
+}
+
+// Deals the tiles of every part to the `grid` blocks of the launch (PartRun).  An ordinary call: runs of
+// ceil(ntiles / grid) tiles.  With seam parts: the seam tiles go round the ring of blocks one each, starting at block
+// 0 - part 1 to blocks 0 ... n1 - 1, part 2 to the blocks behind them, wrapping - so the first (n1 + n2) % grid blocks
+// hold one seam tile more than the others, and exactly those blocks get an interior run one tile shorter: every
+// block ends up with the same number of tiles (a seam tile - a full staging for half a tile of rows - costs about
+// what a marched interior tile costs).  The launches of one group use the same grid, hence the same runs.
+inline void deal_parts(WaveParts* ps, int tiles_x, long grid, int blocks_per_cu) {
+    (void)blocks_per_cu;
+    const int nb = (int)grid;
+    long seam = 0;
+    bool ring = true;  // every seam part fits once round the blocks
+    for (int k = 1; k < ps->n; ++k) {
+        const long nk = (long)tiles_x * ps->tiles_y[k];
+        ring = ring && nk <= nb;
+        seam += nk;
+    }
+    const long n0 = (long)tiles_x * ps->tiles_y[0];
+    // Every block should end up with floor or ceil of (n0 + seam) / nb tiles in all.  The seam tiles go round the ring of
+    // blocks one each, starting at block 0 (below), so the first `light` = seam % nb blocks hold one seam tile more than
+    // the others; with `rem` = (n0 + seam) % nb blocks owed the extra tile of the division, the interior run of block b
+    // has base + [b < rem] - [b < light] tiles: base everywhere except between the two marks.
+    const int light = (ps->n > 1 && ring) ? (int)(seam % nb) : 0;
+    const long total = n0 + (light ? seam : 0);
+    const int rem = (int)(total % nb);
+    int base = (int)(total / nb - (light ? seam / nb : 0));
+    if (base < 1 || (base == 1 && light > rem)) {  // fewer tiles than blocks (or nearly): the plain split of part 0
+        ps->run[0] = PartRun{0, (int)(n0 / nb), 0, (int)(n0 % nb), 1};
+    } else {
+        ps->run[0] = PartRun{0, base, std::min(light, rem), std::max(light, rem), rem >= light ? 1 : -1};
+    }
+    long before = 0;
+    for (int k = 1; k < ps->n; ++k) {
+        const long nk = (long)tiles_x * ps->tiles_y[k];
+        // block vb acts as block (vb - before) mod nb: tile t of this part lands on block (before + t) mod nb
+        ps->run[k] = PartRun{(int)((nb - before % nb) % nb), (int)(nk / nb), 0, (int)(nk % nb), 1};
+        before += nk;
+    }
+}
 
 template <typename T>
 struct alignas(16) Vec4 {
@@ -347,7 +512,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
 // With p.defer set (TPI alone) the kernel processes only the tiles the marching build
 // (tpi_march_kernel, below) marked for it.
 template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
-__global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+__device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = Geo<SIZE>;
     constexpr bool ABS_CLASS = !WANT_STD;
     // pinned, software-pipelined order of the chain's LDS reads: 3-5 % faster from 45 px (STD 67 px
@@ -365,9 +530,7 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ntiles = tiles_x * tiles_y;
-    const int nb = gridDim.x;
-    const int per_xcd = nb >> 3;
-    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int vb = (vb0 + deal.shift) % nb;
     const double n = (double)G::T.taps;
     const double inv_n = 1.0 / n;
     const double inv_nm1 = 1.0 / (n - 1.0);
@@ -604,6 +767,15 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int 
     }
 }
 
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
+__global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((disc_wave_kernel_body<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>));
+}
+template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
+__global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((disc_wave_kernel_body<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>));
+}
+
 // ---- TPI alone on tiles of whole metres: the marching build --------------------------------------
 // The general kernel stages TH + SIZE - 1 rows to produce TH of them; for 67 px that is 126 rows for
 // 60, and the 66 extra rows are the ones the tile above staged a moment ago.  This build gives each
@@ -739,7 +911,7 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
 enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2 };
 
 template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
-__global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+__device__ __forceinline__ void tpi_march_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = Geo<SIZE>;
     static_assert(OUT_TPI || OUT_SUM, "nothing to write");
     static_assert(G::T.centre == 0, "odd disc sizes only: the zeroed tap is the pixel itself");
@@ -755,13 +927,11 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ntiles = tiles_x * tiles_y;
-    const int nb = gridDim.x;
-    const int per_xcd = nb >> 3;
-    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int vb = (vb0 + deal.shift) % nb;
     // a contiguous run of the strip-major tile list per block; neighbouring runs sit in one XCD
-    const int per = (ntiles + nb - 1) / nb;
-    const int first = vb * per;
-    const int last = min(first + per, ntiles);
+    // the block's contiguous run of the strip-major tile list (deal_parts)
+    const int first = deal.first(vb);
+    const int last = min(first + deal.count(vb), ntiles);
     const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
 
     bool carry = false;  // the LDS image holds the window of the tile right above
@@ -840,10 +1010,13 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
             while (next_row < TH) {
                 const int jj = next_row;
                 next_row = MARCH_DYN_ROWS ? draw() : jj + NWAVES;
+                const int oy = oy0 + jj;
+                // (a row outside the output rows - the first and last tile of a row block, and most of a seam tile of a
+                // row shard - costs no chain; the test is on scalars)
+                if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
                 uint32_t acc[NC];  // sum of trunc(x) over the disc modulo 2^32; the true value fits int32
                 wave_disc_sum<SIZE, uint32_t, 0, (SIZE >= 41)>(Q, jj, lane, acc);
-                const int oy = oy0 + jj;
-                if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
+                if (!lane_ok) continue;
                 const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
                 if (OUT_SUM && (!ALLOW_FRAC || SUMS_ONLY)) {
                     const Vec4<int> sv{{(int)acc[0], (int)acc[1], (int)acc[2], (int)acc[3]}};
@@ -882,12 +1055,50 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
 #endif
 }
 
+template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
+__global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((tpi_march_kernel_body<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>));
+}
+template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
+__global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((tpi_march_kernel_body<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>));
+}
+
 // Grid of the marching launches: persistent blocks, whole XCD rounds, never more blocks than tiles.
+// While a ghost-row exchange is in flight the grid is one round of 8 shorter per reserved CU-round: a kernel's
+// workgroups go to the 8 XCDs round-robin, so a grid of whole rounds leaves the same number of CUs free on EVERY XCD,
+// which is where RCCL's 8 workgroups (one per XCD, cap_rccl_channels) land.  Measured with tools/ubench/xcd_map.hip:
+// next to 248 resident blocks a second kernel's 8 workgroups start at once; next to 252 only the one whose XCD has the
+// free CU does; and a CU whose workgroup has left early is NOT handed to another kernel while the launch is resident.
 inline long march_grid(Context& c, int blocks_per_cu, long ntiles) {
-    long grid = (long)(c.num_cu - c.reserve_cus) * blocks_per_cu;
+    const int rounds_off = (c.reserve_cus + 7) / 8;
+    long grid = (long)(c.num_cu - 8 * rounds_off) * blocks_per_cu;
     if (grid < 8) grid = 8;
     grid -= grid % 8;
     return grid > ntiles ? ntiles : grid;
+}
+
+// Launches `kernel` over the parts and, when this launch took the gate of a sharded call, the clean-up launch
+// behind the exchange's event: an empty launch (one byte read per block) unless blocks gave up at the gate.
+template <class K1, class K>
+int launch_parts(K1 kernel_one, K kernel, long grid, int threads, size_t lds, WaveParts& ps, int tiles_x) {
+    Context& c = ctx();
+    if (ps.n == 1) {  // an ordinary call
+        hipLaunchKernelGGL(kernel_one, dim3((unsigned)grid), dim3(threads), lds, c.compute, ps.a[0], tiles_x, ps.tiles_y[0], ps.run[0]);
+        TOPO_HIP(hipGetLastError());
+        return TOPO_AMD_OK;
+    }
+    TOPO_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, c.compute, ps, tiles_x);
+    TOPO_HIP(hipGetLastError());
+    if (ps.gate.word != nullptr && ps.gate.errors == nullptr) {  // (lean mode: no clean-up, see Context::gate_mode)
+        TOPO_TRY(topo_amd_halo_wait());
+        ps.gate.word = nullptr;
+        ps.cleanup = 1;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, c.compute, ps, tiles_x);
+        TOPO_HIP(hipGetLastError());
+    }
+    return TOPO_AMD_OK;
 }
 
 template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
@@ -907,22 +1118,13 @@ int launch_march(const Block& b, float* tpi_out) {
             &nblk, (const void*)tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>, NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
-    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
-    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
-    const long ntiles = (long)tiles_x * tiles_y;
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, OUT_SUM, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
-    void* defer = nullptr;  // same size in every launch of a group, so the same allocation
-    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
-    a.defer = (uint8_t*)defer;
-    if (OUT_SUM) {
-        void* sums = nullptr;
-        TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
-        a.sums = (int32_t*)sums;
-    }
-    hipLaunchKernelGGL((tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>), dim3((unsigned)grid), dim3(NWAVES * 64),
-                       lds, c.compute, a, tiles_x, tiles_y);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
+    deal_parts(&ps, tiles_x, grid, blocks_per_cu);
+    return launch_parts(tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>, tpi_march_kernel_parts<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 // ---- TPI on tiles with fractional elevations: the fraction pass ---------------------------------
@@ -936,7 +1138,7 @@ int launch_march(const Block& b, float* tpi_out) {
 // Each row's sum of trunc(x) arrives by an LDS-DMA load into the wave's idle slot of the segment
 // totals, in flight during the chain; the pixel's own x is an ordinary load issued before the chain.
 template <int SIZE, int TH, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+__device__ __forceinline__ void tpi_fraction_march_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = Geo<SIZE>;
     static_assert(G::T.centre == 0, "odd disc sizes only: the zeroed tap is the pixel itself");
     static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
@@ -952,12 +1154,10 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveArg
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ntiles = tiles_x * tiles_y;
-    const int nb = gridDim.x;
-    const int per_xcd = nb >> 3;
-    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    const int per = (ntiles + nb - 1) / nb;  // the same runs as tpi_march_kernel
-    const int first = vb * per;
-    const int last = min(first + per, ntiles);
+    const int vb = (vb0 + deal.shift) % nb;
+    // the block's contiguous run of the strip-major tile list (deal_parts)
+    const int first = deal.first(vb);
+    const int last = min(first + deal.count(vb), ntiles);
     const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
 
     // Nothing to do on a DEM of whole metres: find that out with one flag per lane (64 tiles per
@@ -1026,6 +1226,15 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveArg
 }
 
 template <int SIZE, int TH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((tpi_fraction_march_kernel_body<SIZE, TH, NWAVES>));
+}
+template <int SIZE, int TH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((tpi_fraction_march_kernel_body<SIZE, TH, NWAVES>));
+}
+
+template <int SIZE, int TH, int NWAVES>
 int launch_fraction_march(const Block& b, float* tpi_out) {
     using G = Geo<SIZE>;
     Context& c = ctx();
@@ -1042,20 +1251,13 @@ int launch_fraction_march(const Block& b, float* tpi_out) {
             &nblk, (const void*)tpi_fraction_march_kernel<SIZE, TH, NWAVES>, NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
-    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
-    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
-    const long ntiles = (long)tiles_x * tiles_y;
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, true, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
-    void* defer = nullptr;
-    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
-    a.defer = (uint8_t*)defer;
-    void* sums = nullptr;
-    TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
-    a.sums = (int32_t*)sums;
-    hipLaunchKernelGGL((tpi_fraction_march_kernel<SIZE, TH, NWAVES>), dim3((unsigned)grid), dim3(NWAVES * 64), lds,
-                       c.compute, a, tiles_x, tiles_y);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
+    deal_parts(&ps, tiles_x, grid, blocks_per_cu);
+    return launch_parts(tpi_fraction_march_kernel<SIZE, TH, NWAVES>, tpi_fraction_march_kernel_parts<SIZE, TH, NWAVES>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 // ---- STD on tiles of whole metres: the second marching kernel ------------------------------------
@@ -1158,7 +1360,7 @@ __device__ __forceinline__ int stage_u2(const WaveArgs& p, uint32_t* Q, int* fla
 }
 
 template <int SIZE, int TH, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void std_march_kernel(WaveArgs p, int tiles_x, int tiles_y) {
+__device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = Geo<SIZE>;
     static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
     constexpr int NROWS = TH + SIZE - 1;
@@ -1175,12 +1377,10 @@ __global__ __launch_bounds__(NWAVES * 64) void std_march_kernel(WaveArgs p, int 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ntiles = tiles_x * tiles_y;
-    const int nb = gridDim.x;
-    const int per_xcd = nb >> 3;
-    const int vb = (nb & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    const int per = (ntiles + nb - 1) / nb;  // the same runs as tpi_march_kernel
-    const int first = vb * per;
-    const int last = min(first + per, ntiles);
+    const int vb = (vb0 + deal.shift) % nb;
+    // the block's contiguous run of the strip-major tile list (deal_parts)
+    const int first = deal.first(vb);
+    const int last = min(first + deal.count(vb), ntiles);
     const double n = (double)G::T.taps;
     const double inv_n = 1.0 / n;
     const double inv_nm1 = 1.0 / (n - 1.0);
@@ -1321,6 +1521,15 @@ __global__ __launch_bounds__(NWAVES * 64) void std_march_kernel(WaveArgs p, int 
 }
 
 template <int SIZE, int TH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void std_march_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((std_march_kernel_body<SIZE, TH, NWAVES>));
+}
+template <int SIZE, int TH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void std_march_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((std_march_kernel_body<SIZE, TH, NWAVES>));
+}
+
+template <int SIZE, int TH, int NWAVES>
 int launch_std_march(const Block& b, float* std_out) {
     using G = Geo<SIZE>;
     Context& c = ctx();
@@ -1338,20 +1547,13 @@ int launch_std_march(const Block& b, float* std_out) {
                                                               NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
-    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
-    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
-    const long ntiles = (long)tiles_x * tiles_y;
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, true, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
-    void* defer = nullptr;
-    TOPO_TRY(workspace(8, (size_t)ntiles, &defer));
-    a.defer = (uint8_t*)defer;
-    void* sums = nullptr;
-    TOPO_TRY(workspace(9, (size_t)b.out_rows * b.nx * sizeof(int32_t), &sums));
-    a.sums = (int32_t*)sums;
-    hipLaunchKernelGGL((std_march_kernel<SIZE, TH, NWAVES>), dim3((unsigned)grid), dim3(NWAVES * 64), lds, c.compute, a,
-                       tiles_x, tiles_y);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
+    deal_parts(&ps, tiles_x, grid, blocks_per_cu);
+    return launch_parts(std_march_kernel<SIZE, TH, NWAVES>, std_march_kernel_parts<SIZE, TH, NWAVES>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 // only_deferred: process the tiles a preceding launch_march of the same geometry marked.
@@ -1376,35 +1578,18 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferr
             &nblk, (const void*)disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
-    const int tiles_x = (b.nx + G::TILE_W - 1) / G::TILE_W;
-    const int tiles_y = (b.out_row0 + b.out_rows - 1) / TH - b.out_row0 / TH + 1;
-    const long ntiles = (long)tiles_x * tiles_y;
-    // persistent blocks fill the chip, minus the CUs kept free for the RCCL send/recv kernels of
-    // a ghost-row exchange that runs next to this launch
-    long grid = (long)(c.num_cu - c.reserve_cus) * blocks_per_cu;
-    if (grid < 8) grid = 8;
-    grid -= grid % 8;  // whole XCD rounds: the tile list is cut into XCD-contiguous runs
-    if (grid > ntiles) grid = ntiles;
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    TOPO_TRY(make_parts(b, a, TH, G::TILE_W, only_deferred, false, &ps, &tiles_x, &ntiles, only_deferred ? map_th : 0,
+                        only_deferred ? map_tw : 0));
+    // persistent blocks fill the chip (whole XCD rounds: the tile list is cut into XCD-contiguous runs)
+    const long grid = march_grid(c, blocks_per_cu, ntiles);
     void* scratch = nullptr;
     TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
-    a.scratch = (uint32_t*)scratch;
-    if (only_deferred) {
-        long map_tiles = ntiles;
-        if (map_th != 0 && (map_th != TH || map_tw != 0)) {
-            a.map_th = map_th;
-            a.map_tiles_y = (b.out_row0 + b.out_rows - 1) / map_th - b.out_row0 / map_th + 1;
-            a.map_tw = map_tw == G::TILE_W ? 0 : map_tw;
-            const int map_tiles_x = a.map_tw ? (b.nx + a.map_tw - 1) / a.map_tw : tiles_x;
-            map_tiles = (long)map_tiles_x * a.map_tiles_y;
-        }
-        void* defer = nullptr;  // same size as in the marching launches, so the same allocation
-        TOPO_TRY(workspace(8, (size_t)map_tiles, &defer));
-        a.defer = (uint8_t*)defer;
-    }
-    hipLaunchKernelGGL((disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>), dim3((unsigned)grid),
-                       dim3(NWAVES * 64), lds, c.compute, a, tiles_x, tiles_y);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
+    for (int k = 0; k < kMaxParts; ++k) ps.a[k].scratch = (uint32_t*)scratch;
+    deal_parts(&ps, tiles_x, grid, blocks_per_cu);  // (this kernel deals its tiles round-robin: only the shifts matter)
+    return launch_parts(disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, disc_wave_kernel_parts<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 }  // namespace

@@ -187,6 +187,7 @@ struct GradArgs {
     const float* res_x;   // device: 1 value, nx values, or out_rows*nx values
     const float* res_y;   // device: 1 value, gny values, or out_rows*nx values
     float *dx, *dy, *slope, *aspect;
+    const int* run_if;  // nullptr, or: return at once unless *run_if != 0 (the epilogue behind a deferred two-pass smooth)
 };
 
 // ---- slope / aspect arithmetic -----------------------------------------------------------------
@@ -260,6 +261,14 @@ __global__ __launch_bounds__(kThreads) void gradient_epilogue_kernel(GradArgs p)
     if (ox >= p.nx) return;
     epilogue_pixel(p, oy, ox);
 }
+// the epilogue behind a deferred two-pass smooth: nothing unless *p.run_if != 0; a grid of a few hundred rows that
+// strides over the output rows (a million blocks that only read the flag would take a few hundred microseconds)
+__global__ __launch_bounds__(kThreads) void gradient_epilogue_if_kernel(GradArgs p) {
+    if (*p.run_if == 0) return;
+    const int ox = blockIdx.x * kThreads + threadIdx.x;
+    if (ox >= p.nx) return;
+    for (int oy = p.out_row0 + blockIdx.y; oy < p.out_row0 + p.out_rows; oy += gridDim.y) epilogue_pixel(p, oy, ox);
+}
 __device__ __forceinline__ void epilogue_pixel(const GradArgs& p, int oy, int ox) {
     // numpy.gradient: central difference / 2 inside, first-order one-sided at the edges
     const float* rowx = p.gx_src + (size_t)(oy - p.s_row0) * p.nx;
@@ -279,11 +288,21 @@ __device__ __forceinline__ void epilogue_pixel(const GradArgs& p, int oy, int ox
 // the four outputs (the one-pixel kernel moves the 20 B/pixel as dwords and ran at 3.2 TB/s).  Identical arithmetic
 // per pixel, hence identical bits.  Any width from 8 columns (round 3: the 16-byte accesses only need dword alignment;
 // the last 1 ... 3 pixels of a row whose length is not a multiple of 4 go one by one).
+__device__ __forceinline__ void epilogue_row4(const GradArgs& p, int oy, int ox);
 __global__ __launch_bounds__(kThreads) void gradient_epilogue4_kernel(GradArgs p) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
     const int ox = (blockIdx.x * kThreads + threadIdx.x) * 4;
     const int oy = p.out_row0 + blockIdx.y;
     if (ox >= p.nx) return;
+    epilogue_row4(p, oy, ox);
+}
+__global__ __launch_bounds__(kThreads) void gradient_epilogue4_if_kernel(GradArgs p) {  // (see gradient_epilogue_if_kernel)
+    if (*p.run_if == 0) return;
+    const int ox = (blockIdx.x * kThreads + threadIdx.x) * 4;
+    if (ox >= p.nx) return;
+    for (int oy = p.out_row0 + blockIdx.y; oy < p.out_row0 + p.out_rows; oy += gridDim.y) epilogue_row4(p, oy, ox);
+}
+__device__ __forceinline__ void epilogue_row4(const GradArgs& p, int oy, int ox) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
     if (ox + 4 > p.nx) {
         for (int x = ox; x < p.nx; ++x) epilogue_pixel(p, oy, x);
         return;
@@ -2254,6 +2273,8 @@ int launch_fused_f16(dim3 grid, const GaussArgs& a, int tile_first, int ntile_ro
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
+// *flag_out == nullptr on entry: the launch gets a flag of its own, cleared here.  Otherwise it raises the caller's flag
+// (the chunked gradient clears one flag per call and queues the two-pass route behind all of its chunks).
 int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, const int** flag_out) {
     Context& c = ctx();
     GaussArgs a{};
@@ -2270,11 +2291,13 @@ int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, cons
     a.flags = nullptr;
     a.run_if = nullptr;
     set_f16_scales(sigma, &a);
-    void* flag = nullptr;
-    TOPO_TRY(workspace(11, 64, &flag));
-    TOPO_HIP(hipMemsetAsync(flag, 0, sizeof(int), c.compute));
-    a.wild_flag = (int*)flag;
-    *flag_out = (const int*)flag;
+    if (*flag_out == nullptr) {
+        void* flag = nullptr;
+        TOPO_TRY(workspace(11, 64, &flag));
+        TOPO_HIP(hipMemsetAsync(flag, 0, sizeof(int), c.compute));
+        *flag_out = (const int*)flag;
+    }
+    a.wild_flag = const_cast<int*>(*flag_out);
     const int tile_first = b.out_row0 / 32;
     const int ntile_rows = (b.out_row0 + b.out_rows - 1) / 32 - tile_first + 1;
     const int row_blocks = (ntile_rows + 3) / 4;
@@ -2297,12 +2320,28 @@ int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, cons
     return launch_fused_f16<8, 32>(grid, a, tile_first, ntile_rows, nseg);
 }
 // both passes with one sigma on the matrix cores: rows `b.out_row0 ...` -> out; tmp: a plane of the same size
-int smooth_both_mfma(const Block& b, double sigma, float* tmp, float* out, int table_slot, bool for_gradient) {
+// deferred != nullptr (chunked gradient): on the fused route only the fused kernel is launched, raising *deferred (a flag
+// the caller cleared) when it meets a sample that is not a plain finite one; the caller queues smooth_two_pass_if behind
+// its last chunk.  Returns whether the two passes are still owed in *owed.
+int smooth_both_mfma(const Block& b, double sigma, float* tmp, float* out, int table_slot, bool for_gradient,
+                     const int* deferred = nullptr, bool* owed = nullptr) {
     const bool fused = fused_radius(gaussian_radius(sigma), for_gradient);
-    const int* flag = nullptr;
+    const int* flag = fused ? deferred : nullptr;
     if (fused) TOPO_TRY(run_fused_f16(b, sigma, out, table_slot, &flag));
+    if (owed) *owed = fused && deferred != nullptr;
+    if (fused && deferred != nullptr) return TOPO_AMD_OK;
     t_run_if = flag;
     t_axis0_one_tile = fused;
+    int r = run_axis0_mfma(b, sigma, tmp, table_slot);
+    if (r == TOPO_AMD_OK) r = run_axis1_mfma(tmp, b.out_rows, b.nx, sigma, out, table_slot + 1);
+    t_run_if = nullptr;
+    t_axis0_one_tile = false;
+    return r;
+}
+// the two passes over rows `b.out_row0 ...`, run only if *flag != 0 (queued behind fused launches that share the flag)
+int smooth_two_pass_if(const Block& b, double sigma, float* tmp, float* out, int table_slot, const int* flag) {
+    t_run_if = flag;
+    t_axis0_one_tile = true;
     int r = run_axis0_mfma(b, sigma, tmp, table_slot);
     if (r == TOPO_AMD_OK) r = run_axis1_mfma(tmp, b.out_rows, b.nx, sigma, out, table_slot + 1);
     t_run_if = nullptr;
@@ -2661,6 +2700,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
                     const void* res_x, const void* res_y, float* dx, float* dy, float* slope,
                     float* aspect) {
     if (b.out_rows > kMaxLaunchRows) {
+        if (ctx().ghost.armed) return TOPO_AMD_EUNSUP;
         for (int r = 0; r < b.out_rows; r += kMaxLaunchRows) {
             Block s = b;
             s.out_row0 = b.out_row0 + r;
@@ -2679,6 +2719,16 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     Context& c = ctx();
     TOPO_REQUIRE(res_mode >= 0 && res_mode <= 2, "gradient: bad res_mode %d", res_mode);
     TOPO_REQUIRE(res_x && res_y, "gradient: resolution arrays are NULL");
+    // a row shard whose exchange is in flight (common.hpp, GhostGate): only the chunked matrix-core route below knows
+    // what to do with it; every other route says so before it launches anything
+    static const int chunk_min = [] {
+        const char* e = std::getenv("TOPO_AMD_GRAD_CHUNK_MIN_ROWS");
+        return e && *e ? std::atoi(e) : 2048;  // (the interior of a 4096-row shard of the 8-GPU split goes in two chunks)
+    }();
+    const bool gated = c.ghost.armed;
+    if (gated && !(sigma > 1.0 && sig_ratio == 1.0 && mfma_radius(gaussian_radius(sigma), b.nx, true) &&
+                   mfma_rows_ok(smoothed_rows_block(b), gaussian_radius(sigma)) && b.out_rows >= chunk_min))
+        return TOPO_AMD_EUNSUP;
     GradArgs g{};
     TOPO_TRY(upload_resolution(res_mode, res_x, res_y, b.nx, b.gny, &g.res_x, &g.res_y));
     g.res_mode = res_mode;
@@ -2708,10 +2758,6 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
     // next to the smooth of chunk k + 1 (15.7 -> 14.5 ms at sigma 30.25 on 32768^2 with 4 -> 8 chunks; one chunk:
     // 18.5).  Row chunks are row blocks:
     // same bits.
-    static const int chunk_min = [] {
-        const char* e = std::getenv("TOPO_AMD_GRAD_CHUNK_MIN_ROWS");
-        return e && *e ? std::atoi(e) : 2048;  // (the interior of a 4096-row shard of the 8-GPU split goes in two chunks)
-    }();
     if (sigma > 1.0 && sig_ratio == 1.0 && mfma_radius(gaussian_radius(sigma), b.nx, true) &&
         mfma_rows_ok(smoothed_rows_block(b), gaussian_radius(sigma)) && b.out_rows >= chunk_min) {
         // (widths that are not multiples of 4, or planes that are not 16-byte aligned: the one-pixel-per-thread epilogue)
@@ -2732,6 +2778,17 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             const char* e = std::getenv("TOPO_AMD_GRAD_AUX");
             return !(e && *e == '0');
         }();
+        // A short block (a row shard: 4096 rows) in few chunks leaves the smooth of its first chunk and the epilogue of its
+        // last one uncovered: the fused route (one kernel per chunk, nothing restaged across a cut but Rp rows) goes in at
+        // least 6 chunks of 512 rows or more, the two-pass route (every chunk restages 2 R rows on axis 0: 24 % at
+        // radius 121 and 1024 rows) in at least 3.  One 4096-row shard in loop-back, sigma 3.25 / 30.25, ms per step
+        // (profiles/r04_shard_fused.txt): 2 chunks 0.98 / 1.56, 3: 0.95 / 1.55, 4: 0.83 / 1.60, 6: 0.81 / 1.73, 8: 0.85 / 1.91.
+        static const int kMinChunksEnv = [] {
+            const char* e = std::getenv("TOPO_AMD_GRAD_MIN_CHUNKS");
+            return std::max(0, std::min(64, e && *e ? std::atoi(e) : 0));
+        }();
+        const int kMinChunks = kMinChunksEnv ? kMinChunksEnv
+                                             : std::max(2, std::min(fused_radius(gaussian_radius(sigma), true) ? 6 : 3, b.out_rows / 512));
         if (!c.aux) {
             TOPO_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
             for (auto& e : c.aux_ready) TOPO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2739,7 +2796,9 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         }
         // smoothed rows [s0, s1) = the output rows plus one neighbour row inside the DEM, cut at global multiples
         // of 32 rows (the row tiles of the axis-0 kernel; a chunk of 32 k rows is also a whole number of axis-1
-        // bands); the epilogue of chunk j emits the output rows whose lower neighbour is already smoothed
+        // bands).  Behind the smooth of a chunk, the epilogue emits the output rows whose two neighbour rows are smoothed
+        // by then: the chunk's own rows, short of the first / last one where the chunk next to it is still to come,
+        // plus the row that chunk left behind where it is done.
         const int s0 = b.out_row0 > 0 ? b.out_row0 - 1 : 0;
         const int s1 = (b.out_row0 + b.out_rows + 1 < b.gny) ? b.out_row0 + b.out_rows + 1 : b.gny;
         const int out_end = b.out_row0 + b.out_rows;
@@ -2747,24 +2806,70 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         void *pa = nullptr, *pb = nullptr;
         TOPO_TRY(workspace(1, bytes, &pa));
         TOPO_TRY(workspace(2, bytes, &pb));
-        // chunks of >= 2048 rows (every chunk restages the 2 R halo rows of the axis-0 ring: 12 % at radius 121)
-        const int nch = std::max(2, std::min(NCH, (s1 - s0) / chunk_rows));
+        // chunks of >= 2048 rows (every chunk restages the 2 R halo rows of the axis-0 ring: 12 % at radius 121); a
+        // short block (a row shard) goes in at least kMinChunks, because the epilogue of its LAST chunk runs alone
+        const int nch = std::max(kMinChunks, std::min(NCH, (s1 - s0) / chunk_rows));
         const int per = std::max(32, ((s1 - s0 + nch - 1) / nch + 31) / 32 * 32);
-        int o0 = b.out_row0;
-        for (int k = 0, c0 = s0; c0 < s1; ++k) {
+        struct Chunk {
+            int c0, c1;
+            bool ghost, done;
+        };
+        std::vector<Chunk> chunks;
+        const int R = gaussian_radius(sigma);
+        for (int c0 = s0; c0 < s1;) {
             int c1 = (c0 + per) / 32 * 32;
             if (c1 + 32 > s1) c1 = s1;  // no sliver at the end
-            Block rows = b;
-            rows.out_row0 = c0;
-            rows.out_rows = c1 - c0;
-            float* a_k = (float*)pa + (size_t)(c0 - s0) * b.nx;
-            float* b_k = (float*)pb + (size_t)(c0 - s0) * b.nx;
-            TOPO_TRY(smooth_both_mfma(rows, sigma, a_k, b_k, 1, true));
+            // row shard with its exchange in flight: does the filter of these rows reach into the ghost rows?
+            chunks.push_back({c0, c1, gated && (c0 - R < c.ghost.ghost_lo || c1 + R > c.ghost.ghost_hi), false});
+            c0 = c1;
+        }
+        TOPO_REQUIRE(chunks.size() <= 64, "gradient: %zu row chunks (at most 64)", chunks.size());
+        // Row shard: the chunks that stay clear of the ghost rows go first, on the rows the shard owns (the ghost rows are
+        // being written meanwhile; staging clamps to the view), then the compute stream waits for the exchange and the
+        // chunks at the two seams follow on the whole block - ordinary chunks of the ordinary pipeline, no seam strips
+        // of their own, and the exchange hides behind the first chunks.  Row chunks are row blocks: same bits.
+        std::vector<int> order;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int k = 0; k < (int)chunks.size(); ++k)
+                if (chunks[k].ghost == (pass == 1)) order.push_back(k);
+        Block owned = b;
+        if (gated) {
+            const int lo = std::max(b.in_row0, c.ghost.ghost_lo), hi = std::min(b.in_row0 + b.in_rows, c.ghost.ghost_hi);
+            owned.in = b.in + (size_t)(lo - b.in_row0) * b.nx;
+            owned.in_row0 = lo;
+            owned.in_rows = hi - lo;
+            c.ghost.armed = false;  // taken
+        }
+        // one "met a sample that is not a plain finite one" flag for the call: the fused kernels of all chunks raise it, and
+        // the two-pass route (five launches that return at once on an ordinary DEM) is queued ONCE, behind the last
+        // chunk, over all rows - not behind every chunk, where its launches sat in front of the next chunk's smooth
+        void* wild = nullptr;
+        TOPO_TRY(workspace(11, 64, &wild));
+        TOPO_HIP(hipMemsetAsync(wild, 0, sizeof(int), c.compute));
+        bool owed = false;
+        bool waited = !gated;
+        for (int k : order) {
+            Chunk& ck = chunks[k];
+            if (ck.ghost && !waited) {
+                TOPO_TRY(topo_amd_halo_wait());
+                waited = true;
+            }
+            Block rows = ck.ghost || !gated ? b : owned;
+            rows.out_row0 = ck.c0;
+            rows.out_rows = ck.c1 - ck.c0;
+            float* a_k = (float*)pa + (size_t)(ck.c0 - s0) * b.nx;
+            float* b_k = (float*)pb + (size_t)(ck.c0 - s0) * b.nx;
+            bool owes = false;
+            TOPO_TRY(smooth_both_mfma(rows, sigma, a_k, b_k, 1, true, (const int*)wild, &owes));
+            owed = owed || owes;
+            ck.done = true;
             if (use_aux) {
                 TOPO_HIP(hipEventRecord(c.aux_ready[k], c.compute));
                 TOPO_HIP(hipStreamWaitEvent(c.aux, c.aux_ready[k], 0));
             }
-            const int o1 = c1 == s1 ? out_end : c1 - 1;
+            const bool first = k == 0, last = k + 1 == (int)chunks.size();
+            const int o0 = std::max(b.out_row0, first ? b.out_row0 : (chunks[k - 1].done ? ck.c0 - 1 : ck.c0 + 1));
+            const int o1 = std::min(out_end, last ? out_end : (chunks[k + 1].done ? ck.c1 + 1 : ck.c1 - 1));
             if (o1 > o0) {
                 GradArgs gk = g;
                 const size_t shift = (size_t)(o0 - b.out_row0) * b.nx;
@@ -2791,9 +2896,35 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
                     hipLaunchKernelGGL(gradient_epilogue_kernel, grid1, dim3(kThreads), 0, use_aux ? c.aux : c.compute, gk);
                 }
                 TOPO_HIP(hipGetLastError());
-                o0 = o1;
             }
-            c0 = c1;
+        }
+        if (!waited) TOPO_TRY(topo_amd_halo_wait());
+        if (owed) {
+            // behind every chunk and its epilogue: smooth [s0, s1) again by the two passes and redo the epilogue, if the flag is up
+            if (use_aux) {
+                TOPO_HIP(hipEventRecord(c.aux_done, c.aux));
+                TOPO_HIP(hipStreamWaitEvent(c.compute, c.aux_done, 0));
+            }
+            Block rows = b;
+            rows.out_row0 = s0;
+            rows.out_rows = s1 - s0;
+            TOPO_TRY(smooth_two_pass_if(rows, sigma, (float*)pa, (float*)pb, 1, (const int*)wild));
+            GradArgs gk = g;
+            gk.gx_src = (const float*)pb;
+            gk.gy_src = (const float*)pb;
+            gk.s_row0 = s0;
+            gk.s_rows = s1 - s0;
+            gk.run_if = (const int*)wild;
+            const int if_rows = std::min(b.out_rows, 512);
+            if (wide_epilogue) {
+                dim3 grid4(((b.nx + 3) / 4 + kThreads - 1) / kThreads, if_rows);
+                hipLaunchKernelGGL(gradient_epilogue4_if_kernel, grid4, dim3(kThreads), 0, c.compute, gk);
+            } else {
+                dim3 grid1((b.nx + kThreads - 1) / kThreads, if_rows);
+                hipLaunchKernelGGL(gradient_epilogue_if_kernel, grid1, dim3(kThreads), 0, c.compute, gk);
+            }
+            TOPO_HIP(hipGetLastError());
+            return TOPO_AMD_OK;
         }
         if (use_aux) {
             TOPO_HIP(hipEventRecord(c.aux_done, c.aux));

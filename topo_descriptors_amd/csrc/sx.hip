@@ -11,6 +11,7 @@
 // along x, the offset table is wave-uniform (scalar loads), so every step is one conflict-
 // free ds_read_b32 + v_sub + v_mul + v_max per lane.
 #include "common.hpp"
+#include "gate.hpp"
 #include "atan.hpp"
 
 #include <algorithm>
@@ -62,6 +63,11 @@ struct SxArgs {
     int window;
     int dj_min, di_min, rows_l, cols_l;
     float height;
+    // row shards (common.hpp, GhostGate): tile rows 0 ... n_top - 1 read ghost rows above the shard, the last n_bot
+    // ones ghost rows below it; they are dispatched last and wait at the gate.  tiles_y: tile rows of the launch
+    // (gridDim.y, except in the clean-up launch, whose grid holds the n_bot + n_top ghost tile rows only).
+    int tiles_y, n_top, n_bot, cleanup;
+    Gate gate;
 };
 
 constexpr int kSxTile = 64;                     // output tile: 64 x 64 pixels
@@ -86,7 +92,9 @@ constexpr int kSxOwn = kSxTile / (kThreads / 64);  // consecutive pixels per lan
 // those of one that points north.  The code is the same with the LDS step STRIDE + DIAG; the 16 pixels of a lane
 // lean over 15 columns (every wave's slab of 16 rows starts upright again, so the staged tile is 15 columns wider
 // and the tile grid one tile longer), and for a fixed k the lanes still store 64 consecutive columns of one row.
-template <int STRIDE, bool ALONG_X, int NW, int DIAG = 0>
+// GATED (row shards): the tile rows that read ghost rows come last in the dispatch order and wait at the ghost-row gate
+// (a second instantiation: the few scalars it keeps alive cost the ordinary kernel 4 ... 19 % at radius 500 ... 2000 m).
+template <int STRIDE, bool ALONG_X, int NW, int DIAG = 0, bool GATED = false>
 __global__ __launch_bounds__(NW * 64) void sx_kernel(SxArgs p) {
     static_assert(NW == 4 || !ALONG_X, "8 waves: lanes along x only");
     static_assert(DIAG == 0 || !ALONG_X, "diagonal chains: lanes along x only");
@@ -96,7 +104,25 @@ __global__ __launch_bounds__(NW * 64) void sx_kernel(SxArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ox0 = ((int)blockIdx.x - (DIAG > 0 ? 1 : 0)) * (ALONG_X ? SPAN : kSxTile);
-    const int oy0 = p.out_row0 + blockIdx.y * (ALONG_X ? kSxTile : SPAN);
+    // tile row: the rows that read ghost rows come last in the dispatch order (top ones after the bottom ones)
+    int ty = (int)blockIdx.y;
+    if (GATED) {
+        ty += p.n_top;
+        ty = ty >= p.tiles_y ? ty - p.tiles_y : ty;
+        if (p.cleanup) ty = (int)blockIdx.y < p.n_bot ? p.tiles_y - p.n_bot + (int)blockIdx.y : (int)blockIdx.y - p.n_bot;
+    }
+    const int oy0 = p.out_row0 + ty * (ALONG_X ? kSxTile : SPAN);
+    if (GATED && p.gate.word != nullptr && (ty < p.n_top || ty >= p.tiles_y - p.n_bot)) {
+        const int rank = ty >= p.tiles_y - p.n_bot ? ty - (p.tiles_y - p.n_bot) : p.n_bot + ty;
+        const unsigned slot = (unsigned)rank * gridDim.x + blockIdx.x;
+        if (p.cleanup) {
+            if (p.gate.skipped[slot] == 0) return;
+            __syncthreads();
+            if (threadIdx.x == 0) p.gate.skipped[slot] = 0;
+        } else if (!gate_wait(p.gate, slot) && p.gate.errors == nullptr) {
+            return;  // left to the clean-up launch behind the exchange's event
+        }
+    }
 
     // stage tile + offset bounding box; pixels outside the DEM are never used by interior
     // outputs (the zero frame is exactly as wide as the reach of the rays).  Four rows per wave in flight.
@@ -301,22 +327,34 @@ __global__ __launch_bounds__(NW * 64) void sx_kernel(SxArgs p) {
 constexpr int kSxStrides[] = {67, 71, 75, 81, 89, 97, 105, 113, 129, 145, 161, 177, 193, 209, 225, 257};
 constexpr int kSxStrideCount = sizeof(kSxStrides) / sizeof(kSxStrides[0]);
 
+// blocks_per_cu != nullptr: no launch, only how many blocks of this kernel a CU holds
 template <int I = 0>
-int launch_sx_stride(int stride, bool along_x, int waves, dim3 grid, size_t lds, hipStream_t stream, const SxArgs& a, int diag = 0) {
+int launch_sx_stride(int stride, bool along_x, int waves, dim3 grid, size_t lds, hipStream_t stream, const SxArgs& a, int diag = 0,
+                     int* blocks_per_cu = nullptr) {
     if constexpr (I < kSxStrideCount) {
         if (stride == kSxStrides[I]) {
             auto go = [&](auto kernel) -> int {
                 TOPO_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (blocks_per_cu) {
+                    TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)kernel, waves * 64, lds));
+                    return TOPO_AMD_OK;
+                }
                 hipLaunchKernelGGL(kernel, grid, dim3(waves * 64), lds, stream, a);
                 TOPO_HIP(hipGetLastError());
                 return TOPO_AMD_OK;
             };
+            if (a.gate.word != nullptr) {
+                if (along_x) return go(sx_kernel<kSxStrides[I], true, 4, 0, true>);
+                if (diag > 0) return go(sx_kernel<kSxStrides[I], false, 4, 1, true>);
+                if (diag < 0) return go(sx_kernel<kSxStrides[I], false, 4, -1, true>);
+                return waves == 8 ? go(sx_kernel<kSxStrides[I], false, 8, 0, true>) : go(sx_kernel<kSxStrides[I], false, 4, 0, true>);
+            }
             if (along_x) return go(sx_kernel<kSxStrides[I], true, 4>);
             if (diag > 0) return go(sx_kernel<kSxStrides[I], false, 4, 1>);
             if (diag < 0) return go(sx_kernel<kSxStrides[I], false, 4, -1>);
             return waves == 8 ? go(sx_kernel<kSxStrides[I], false, 8>) : go(sx_kernel<kSxStrides[I], false, 4>);
         }
-        return launch_sx_stride<I + 1>(stride, along_x, waves, grid, lds, stream, a, diag);
+        return launch_sx_stride<I + 1>(stride, along_x, waves, grid, lds, stream, a, diag, blocks_per_cu);
     } else {
         set_error("sx: no kernel for LDS stride %d", stride);
         return TOPO_AMD_EUNSUP;
@@ -680,6 +718,7 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
                           [](const auto& a, const auto& b2) { return a.first == b2.first; }),
               pts.end());
     const size_t total = (size_t)b.out_rows * b.nx;
+    if (c.ghost.armed && (pts.empty() || b.out_rows > kMaxLaunchRows)) return TOPO_AMD_EUNSUP;  // (not as one gated launch)
     if (pts.empty()) {
         // nanmax over nothing: NaN inside the frame (numpy warns and returns NaN)
         int blocks = (int)std::min<size_t>((total + kThreads - 1) / kThreads, 4096);
@@ -705,6 +744,7 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     // when the chains run along y)
     const size_t lds = (size_t)(a.rows_l + 8) * stride * sizeof(float);
     if (stride == 0 || lds > 160 * 1024) {
+        if (c.ghost.armed) return TOPO_AMD_EUNSUP;  // the kernel without tiles knows no gate
         std::vector<int> vdj(pts.size()), vdi(pts.size());
         std::vector<float> vinv(pts.size());
         for (size_t n = 0; n < pts.size(); ++n) {
@@ -837,10 +877,46 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     // 128-row tiles with 8 waves while two such blocks share a CU
     int waves = 4;
     size_t lds_used = lds;
+    a.tiles_y = a.n_top = a.n_bot = a.cleanup = 0;
+    a.gate = Gate{nullptr, 0, nullptr, 0, nullptr, nullptr};
+    // One launch, and for a row shard whose exchange is in flight (c.ghost.armed) its clean-up launch: the tile rows that
+    // read ghost rows go last and wait at the gate (sx_kernel).  tile_h: rows per tile row; rows_l: rows a tile stages.
+    auto go = [&](int use_stride, bool use_along_x, int use_waves, dim3 grid, size_t use_lds, int use_diag, int tile_h) -> int {
+        a.tiles_y = (int)grid.y;
+        if (!c.ghost.armed) return launch_sx_stride(use_stride, use_along_x, use_waves, grid, use_lds, c.compute, a, use_diag);
+        const int T = (int)grid.y;
+        int n_top = 0, n_bot = 0;
+        for (int t = 0; t < T; ++t) {
+            const int gy_first = b.out_row0 + t * tile_h + a.dj_min;
+            const bool top = gy_first < c.ghost.ghost_lo, bot = gy_first + a.rows_l > c.ghost.ghost_hi;
+            if (top && t != n_top) return TOPO_AMD_EUNSUP;  // (cannot happen: the tile rows go down the block)
+            n_top += top ? 1 : 0;
+            n_bot += bot ? 1 : 0;
+        }
+        if (n_top + n_bot > T || (size_t)(n_top + n_bot) * grid.x > c.ghost.slots) return TOPO_AMD_EUNSUP;
+        // the blocks that wait at the gate hold their CU slots; RCCL's workgroups need room next to them, or nobody moves:
+        // at most as many waiting blocks as leave one block slot per CU free (else: separate launches)
+        int per_cu = 0;
+        a.gate = c.ghost.gate;  // (from here on `a` names the gated instantiation of the kernel)
+        TOPO_TRY(launch_sx_stride(use_stride, use_along_x, use_waves, grid, use_lds, c.compute, a, use_diag, &per_cu));
+        if ((long)(n_top + n_bot) * grid.x > (long)(per_cu - 1) * c.num_cu) return TOPO_AMD_EUNSUP;
+        a.n_top = n_top;
+        a.n_bot = n_bot;
+        c.ghost.armed = false;
+        TOPO_TRY(launch_sx_stride(use_stride, use_along_x, use_waves, grid, use_lds, c.compute, a, use_diag));
+        if (a.gate.errors == nullptr && n_top + n_bot > 0) {  // careful mode: the blocks that gave up at the gate
+            TOPO_TRY(topo_amd_halo_wait());
+            a.cleanup = 1;
+            a.gate.word = c.ghost.gate.word;  // (non-null: the kernel's "this is a gated launch" switch)
+            TOPO_TRY(launch_sx_stride(use_stride, use_along_x, use_waves, dim3(grid.x, (unsigned)(n_top + n_bot)), use_lds, c.compute, a,
+                                      use_diag));
+        }
+        return TOPO_AMD_OK;
+    };
     if (diag != 0) {
         a.cols_l = cols_d;
         dim3 dgrid((b.nx + kSxTile - 1) / kSxTile + 1, (b.out_rows + kSxTile - 1) / kSxTile);  // the slabs lean: one tile more
-        return launch_sx_stride(stride_d, false, 4, dgrid, lds_d, c.compute, a, diag);
+        return go(stride_d, false, 4, dgrid, lds_d, diag, kSxTile);
     }
     if (!along_x && b.out_rows >= 2 * kSxTile && scan_cost >= 256) {
         const size_t lds8 = (size_t)(a.rows_l + kSxTile + 8) * stride * sizeof(float);
@@ -852,7 +928,7 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     }
     const int span = kSxOwn * waves;
     dim3 grid((b.nx + kSxTile - 1) / kSxTile, (b.out_rows + span - 1) / span);
-    return launch_sx_stride(stride, along_x, waves, grid, lds_used, c.compute, a);
+    return go(stride, along_x, waves, grid, lds_used, 0, along_x ? kSxTile : span);
 }
 
 namespace {
