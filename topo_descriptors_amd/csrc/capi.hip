@@ -59,6 +59,51 @@ int workspace(int slot, size_t bytes, void** out) {
     return TOPO_AMD_OK;
 }
 
+// ---- dem_memo (common.hpp) ---------------------------------------------------------------------------------------------
+namespace {
+struct DemMemo {
+    const void* in = nullptr;
+    int rows = 0, nx = 0;
+    unsigned long used = 0;
+};
+constexpr int kMemos = 8;
+DemMemo g_memo[kMemos];
+uint32_t* g_memo_words = nullptr;  // pinned: two words per entry
+unsigned long g_memo_clock = 0;
+
+int memo_slot(const Block& b, bool create) {
+    if (!g_memo_words) {
+        if (hipHostMalloc((void**)&g_memo_words, kMemos * 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return -1;
+        std::memset(g_memo_words, 0, kMemos * 2 * sizeof(uint32_t));
+    }
+    int oldest = 0;
+    for (int k = 0; k < kMemos; ++k) {
+        if (g_memo[k].in == b.in && g_memo[k].rows == b.in_rows && g_memo[k].nx == b.nx) {
+            g_memo[k].used = ++g_memo_clock;
+            return k;
+        }
+        if (g_memo[k].used < g_memo[oldest].used) oldest = k;
+    }
+    if (!create) return -1;
+    g_memo[oldest] = DemMemo{b.in, b.in_rows, b.nx, ++g_memo_clock};
+    // (a launch in flight may still write the evicted entry's words: they are cleared here, and a late report for
+    // another DEM can at worst pick the wrong first kernel once - the results do not depend on that choice)
+    g_memo_words[2 * oldest] = g_memo_words[2 * oldest + 1] = 0;
+    return oldest;
+}
+}  // namespace
+
+uint32_t* dem_memo_report(const Block& b) {
+    const int k = memo_slot(b, true);
+    return k < 0 ? nullptr : g_memo_words + 2 * k;
+}
+bool dem_memo_mostly_fractional(const Block& b) {
+    const int k = memo_slot(b, false);
+    if (k < 0) return false;
+    const uint32_t tiles = *(volatile uint32_t*)(g_memo_words + 2 * k), frac = *(volatile uint32_t*)(g_memo_words + 2 * k + 1);
+    return tiles > 0 && 2 * frac > tiles;
+}
+
 // Small parameter tables: pinned staging + async copy on the compute stream.  The previous
 // content is remembered so a loop over the same parameters uploads nothing.
 namespace {
@@ -351,6 +396,11 @@ int topo_amd_shutdown(void) {
     for (auto& e : g_marks) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
+    }
+    if (g_memo_words) {
+        (void)hipHostFree(g_memo_words);
+        g_memo_words = nullptr;
+        for (auto& m : g_memo) m = DemMemo();
     }
     if (c.gate_word) (void)hipFree(c.gate_word);
     if (c.gate_timeouts) (void)hipHostFree(c.gate_timeouts);

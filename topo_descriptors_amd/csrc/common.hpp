@@ -185,4 +185,11 @@ int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize,
 
 int gaussian_radius(double sigma);
 
+// What the library remembers about the DEMs it has seen (keyed by block pointer, rows and width; a few entries): the share
+// of tiles with fractional elevations in one block's run of the last TPI call, written by that block into pinned host
+// memory (no stream operation, no synchronisation; a call reads what the last finished call left).  A DEM remembered
+// as mostly fractional starts with the kernel that suits it (tpi_scaled_march_kernel<TAKE_ALL>).
+uint32_t* dem_memo_report(const Block& b);           // the pinned words {tiles, fractional tiles} of this DEM's entry
+bool dem_memo_mostly_fractional(const Block& b);
+
 }  // namespace topo

@@ -57,6 +57,8 @@ struct WaveArgs {
     int map_tiles_y;    //                 and its number of tile rows
     int map_tw;         //                 and its strip width when that differs too (0 = its own)
     float* tpi2;        // ring kernel for a pair of disc sizes: TPI of the smaller disc
+    int scaled;         // TPI alone, tiles with fractional elevations: 1 = the scaled one-chain route (tpi_scaled_march_kernel)
+    uint32_t* report;   // pinned host words {tiles, tiles with fractional samples} of ONE block's run (dem_memo), or nullptr
 };
 
 // One launch, several row blocks ("parts").  An ordinary call has one part.  A sharded call (capi.hip, run_fused)
@@ -373,7 +375,10 @@ __device__ __forceinline__ Vec4<float> load_row4(const WaveArgs& p, int gy, int 
 // fractional parts in integer units of 2^-16 m (exact as well) and exists only on fractional DEMs.  Tiles holding non-finite or absurd samples (|u| so
 // large that one 67-row column sum of u^2 passes 2^32, e.g. -9999 nodata next to real terrain)
 // run float chains on a = x - c and (trunc(x) - c)^2 instead, so NaN propagates and nothing wraps.
-enum Stage { kStU = 0, kStU2 = 1, kStF = 2, kStA = 3, kStT2 = 4 };
+enum Stage { kStU = 0, kStU2 = 1, kStF = 2, kStA = 3, kStT2 = 4, kStS = 5 };
+// kStS: x in units of 2^-8 m, rounded to the nearest integer - an ABSOLUTE quantisation (no offset), so the value does not
+// depend on which tile, run or row block stages the sample (tpi_scaled_march_kernel).
+constexpr float kScaledUnit = 256.0f;
 
 // sqrt(max(0, (s2 - s1^2/n) / (n-1))) from the float64 sums.  The variance stays in float64 (the
 // difference cancels a few hundred-fold), but 1/n and 1/(n-1) are multiplied in and the root is
@@ -403,6 +408,7 @@ enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4 };
 template <int WHAT>
 __device__ __forceinline__ uint32_t stage_value(float x, float c, int ci) {
     if (WHAT == kStA) return __float_as_uint(x - c);
+    if (WHAT == kStS) return (uint32_t)(int)rintf(x * kScaledUnit);
     const float t = truncf(x);
     // the fractional part in units of 2^-16 m, as an integer: |x - t| < 1, so 3409 of them stay far
     // inside int32, the sums are exact (hence the same for every row block and every kernel that
@@ -426,9 +432,24 @@ __device__ __forceinline__ uint32_t stage_value(float x, float c, int ci) {
 // the rows it adds to a carried window.
 constexpr float kAbsLim = 262144.0f;
 
+// Block-wide minimum / maximum of per-lane values through two LDS words (flag_word[2], flag_word[3]; the caller keeps
+// them at INT_MAX / INT_MIN between tiles): one butterfly per wave, one atomic pair per wave.
+__device__ __forceinline__ void block_range(int* flag_word, int lo, int hi) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        lo = min(lo, __shfl_xor(lo, m));
+        hi = max(hi, __shfl_xor(hi, m));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&flag_word[2], lo);
+        atomicMax(&flag_word[3], hi);
+    }
+}
+
+// range (kStS only): smallest and largest staged value of the window, padded samples (0) included.
 template <int SIZE, int TH, int NWAVES, int WHAT, typename T, bool ABS_CLASS = false>
 __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, int* flag_word, int gy0,
-                                            int gx, float c, int ci, float lim32, float limcv) {
+                                            int gx, float c, int ci, float lim32, float limcv, int* range = nullptr) {
     constexpr int NROWS = TH + SIZE - 1;
     constexpr int SL = (NROWS + NWAVES - 1) / NWAVES;
     T* Q = reinterpret_cast<T*>(lds);
@@ -441,6 +462,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     int flags = 0;
     uint32_t umax = 0;  // largest |trunc(x) - c| seen, as float bits (NaN / inf sort above all)
     bool frac = false;
+    int smin = 0x7fffffff, smax = -0x7fffffff - 1;
     Vec4<T> run{{(T)0, (T)0, (T)0, (T)0}};
     if (wave == 0) *reinterpret_cast<Vec4<T>*>(Q + lane * NC) = run;
 #pragma unroll
@@ -448,6 +470,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
         const int r = wave * SL + k;
         if (r < NROWS) {
             const bool ok = row4_inside(p, gy0 + r, gx);
+            const bool padded = gy0 + r < 0 || gy0 + r >= p.gny || gx < 0 || gx >= p.nx;  // a tap outside the DEM: the zero padding
 #pragma unroll
             for (int s = 0; s < NC; ++s) {
                 const float x = v[k].v[s];
@@ -461,6 +484,15 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
                     bits = ok ? (uint32_t)(int)d : 0u;
                 } else {
                     bits = ok ? stage_value<WHAT>(x, c, ci) : 0u;
+                    if (WHAT == kStS && ABS_CLASS) {  // the take-all scaled build classifies the window itself
+                        const float t = truncf(x);
+                        frac |= ok && (x != t);
+                        umax = max(umax, ok ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
+                    }
+                    if (WHAT == kStS && (ok || padded)) {  // (rows of the DEM outside the block view feed no requested output)
+                        smin = min(smin, (int)bits);
+                        smax = max(smax, (int)bits);
+                    }
                 }
                 T val;
                 __builtin_memcpy(&val, &bits, sizeof(T));
@@ -469,7 +501,8 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
             *reinterpret_cast<Vec4<T>*>(Q + (r + 1) * ROWW + lane * NC) = run;
         }
     }
-    if (WHAT == kStU) {
+    constexpr bool kClassify = WHAT == kStU || (WHAT == kStS && ABS_CLASS);
+    if (kClassify) {
         if (frac) flags |= kTileFrac;
         if (!ABS_CLASS && umax > __float_as_uint(lim32)) flags |= kTileWide;
         if (umax > __float_as_uint(ABS_CLASS ? kAbsLim : limcv)) flags |= kTileFloat;  // also NaN / inf
@@ -477,15 +510,20 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     *reinterpret_cast<Vec4<T>*>(TOT + wave * ROWW + lane * NC) = run;
     // tile flags: one ballot per bit inside the wave, one LDS atomic per wave, and the barrier the
     // fix-up pass needs anyway (the flag word is cleared again at the end of the tile)
-    if (WHAT == kStU) {
+    if (kClassify) {
         int wf = 0;
         if (__builtin_amdgcn_ballot_w64(flags & kTileFrac)) wf |= kTileFrac;
         if (__builtin_amdgcn_ballot_w64(flags & kTileWide)) wf |= kTileWide;
         if (__builtin_amdgcn_ballot_w64(flags & kTileFloat)) wf |= kTileFloat;
         if (lane == 0 && wf) atomicOr(flag_word, wf);
     }
+    if (WHAT == kStS) block_range(flag_word, smin, smax);
     __syncthreads();
-    const int all = WHAT == kStU ? *flag_word : 0;
+    const int all = kClassify ? *flag_word : 0;
+    if (WHAT == kStS && range != nullptr) {
+        range[0] = flag_word[2];
+        range[1] = flag_word[3];
+    }
     if (wave > 0) {
         Vec4<T> off{{(T)0, (T)0, (T)0, (T)0}};
         for (int w = 0; w < wave; ++w) {
@@ -815,8 +853,13 @@ __global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel_parts(WaveParts 
 #define MARCH_DYN_ROWS 1
 #endif
 
-template <int SIZE, int TH, int NWAVES, bool FRACTION = false>
-__device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* flag_word, int gy0, int gx MARCH_STAMP_ARGS) {
+// MODE 0: trunc(x), classified; 1 (the former FRACTION): kStF; 2: kStS, with the range of the NEW rows in range[0 .. 1];
+// 3: kStS, range and classification (the take-all scaled build)
+template <int SIZE, int TH, int NWAVES, int MODE = 0>
+__device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* flag_word, int gy0, int gx MARCH_STAMP_ARGS,
+                                           int* range = nullptr) {
+    constexpr bool FRACTION = MODE == 1 || MODE == 2;  // (no classification)
+    constexpr bool SCALED = MODE == 2 || MODE == 3;
     constexpr int NROWS = TH + SIZE - 1;
     constexpr int KEEP = NROWS + 1 - TH;  // prefix rows carried over: those of window rows TH-1 .. NROWS-1
     constexpr int RW = TH / NWAVES;       // new rows per wave
@@ -853,14 +896,28 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
     }
     uint32_t amax = 0;
     bool frac = false;
+    int smin = 0x7fffffff, smax = -0x7fffffff - 1;
     Vec4<uint32_t> run{{0u, 0u, 0u, 0u}};  // unsigned: the running prefix is allowed to wrap
 #pragma unroll
     for (int k = 0; k < RW; ++k) {
         const bool ok = row4_inside(p, gy0 + r0 + k, gx);
+        const bool padded = gy0 + r0 + k < 0 || gy0 + r0 + k >= p.gny || gx < 0 || gx >= p.nx;
 #pragma unroll
         for (int s = 0; s < NC; ++s) {
             const float x = v[k].v[s];
-            if (FRACTION) {
+            if (SCALED) {
+                const uint32_t q = ok ? stage_value<kStS>(x, 0.0f, 0) : 0u;
+                if (ok || padded) {
+                    smin = min(smin, (int)q);
+                    smax = max(smax, (int)q);
+                }
+                if (MODE == 3) {
+                    const float t = truncf(x);
+                    frac |= ok && (x != t);
+                    amax = max(amax, ok ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
+                }
+                run.v[s] += q;
+            } else if (MODE == 1) {
                 run.v[s] += ok ? stage_value<kStF>(x, 0.0f, 0) : 0u;
             } else {
                 const float t = truncf(x);
@@ -878,10 +935,15 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
         if (__builtin_amdgcn_ballot_w64(amax > __float_as_uint(kAbsLim))) wf |= kTileFloat;
         if (lane == 0 && wf) atomicOr(flag_word, wf);
     }
+    if (SCALED) block_range(flag_word, smin, smax);
     MARCH_STAMP(2)
     __syncthreads();
     MARCH_STAMP(3)
     const int all = FRACTION ? 0 : *flag_word;
+    if (SCALED && range != nullptr) {
+        range[0] = flag_word[2];
+        range[1] = flag_word[3];
+    }
     // every wave adds the carried prefix (row KEEP-1) and the totals of the waves above it
     Vec4<uint32_t> off = *reinterpret_cast<const Vec4<uint32_t>*>(Q + (KEEP - 1) * ROWW + lane * NC);
     for (int w = 0; w < wave; ++w) {
@@ -945,6 +1007,7 @@ __device__ __forceinline__ void tpi_march_kernel_body(const WaveArgs& p, int til
     constexpr int kHist = (SIZE - 1 + TH - 1) / TH;
     unsigned frac_hist = 0;
     int deferred_in_a_row = 0;
+    int seen_frac = 0;  // tiles of the run with fractional samples in their window (the report to dem_memo)
 #ifdef MARCH_STAMPS
     long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = __builtin_amdgcn_s_memtime();
@@ -1041,11 +1104,16 @@ __device__ __forceinline__ void tpi_march_kernel_body(const WaveArgs& p, int til
             }
         };
         if (ALLOW_FRAC && fraction) {
-            rows(std::true_type{});
+            ++seen_frac;
+            if (p.scaled == 0) rows(std::true_type{});  // (scaled route: tpi_scaled_march_kernel needs no sums)
         } else {
             rows(std::false_type{});
         }
         MARCH_STAMP(6)
+    }
+    if (ALLOW_FRAC && p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
+        __hip_atomic_store(p.report + 1, (uint32_t)seen_frac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.report, (uint32_t)(last > first ? last - first : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #ifdef MARCH_STAMPS
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && (wave == 0 || wave == 5 || wave == 11))
@@ -1102,7 +1170,7 @@ int launch_parts(K1 kernel_one, K kernel, long grid, int threads, size_t lds, Wa
 }
 
 template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
-int launch_march(const Block& b, float* tpi_out) {
+int launch_march(const Block& b, float* tpi_out, bool scaled = false) {
     using G = Geo<SIZE>;
     Context& c = ctx();
     WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
@@ -1121,7 +1189,9 @@ int launch_march(const Block& b, float* tpi_out) {
     WaveParts ps;
     int tiles_x = 0;
     long ntiles = 0;
-    TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, OUT_SUM, &ps, &tiles_x, &ntiles));
+    a.scaled = ALLOW_FRAC && scaled ? 1 : 0;
+    a.report = ALLOW_FRAC && scaled ? dem_memo_report(b) : nullptr;
+    TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, OUT_SUM && a.scaled == 0, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
     return launch_parts(tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>, tpi_march_kernel_parts<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>, grid, NWAVES * 64, lds, ps, tiles_x);
@@ -1186,7 +1256,7 @@ __device__ __forceinline__ void tpi_fraction_march_kernel_body(const WaveArgs& p
 #ifdef MARCH_STAMPS
             long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #endif
-            (void)stage_march<SIZE, TH, NWAVES, true>(p, Q, flag_word, gy0, gx MARCH_STAMP_PASS);
+            (void)stage_march<SIZE, TH, NWAVES, 1>(p, Q, flag_word, gy0, gx MARCH_STAMP_PASS);
         } else {
             __syncthreads();  // the previous tile's image is done with
             (void)stage_prefix<SIZE, TH, NWAVES, kStF, uint32_t>(p, lds_u, flag_word, gy0, gx, 0.0f, 0, 0.0f, 0.0f);
@@ -1258,6 +1328,198 @@ int launch_fraction_march(const Block& b, float* tpi_out) {
     const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
     return launch_parts(tpi_fraction_march_kernel<SIZE, TH, NWAVES>, tpi_fraction_march_kernel_parts<SIZE, TH, NWAVES>, grid, NWAVES * 64, lds, ps, tiles_x);
+}
+
+// ---- TPI on tiles with fractional elevations: the scaled one-chain route (round 4) -----------------------------------
+// The exact route above costs a fractional DEM two stagings and two chains per tile (9.6 ms at 67 px on 32768^2 against
+// 4.4 ms on whole metres).  The reference squares trunc(x) (topo.py:300) but TPI only needs s1 = sum x (topo.py:175-181),
+// and ONE integer chain carries it when x is taken in units of 2^-8 m:  q = rint(256 x), absolute - no offset, so a
+// sample's q does not depend on the tile, run or row block that stages it, sums of q are exact integers, and row blocks
+// keep their bit-identity.  The prefix image and the chain work modulo 2^32 like the whole-metre kernel's; the true
+// sum S over the disc's n taps lies within n 256 (relief of the window) of n q_centre, so
+//     S = n q_ctr + int32(S mod 2^32 - n q_ctr mod 2^32)
+// is exact whenever n (max q - min q over the staged window) < 2^31: 2457 m of relief at 67 px.  The block forms that
+// range per tile (block_range; for a marched window from the ranges of the tiles whose rows it holds) and leaves a tile
+// that fails the test - nodata next to terrain - to the general kernel, which is exact, like every tile whose window
+// reaches over the DEM's edge (zeros are no terrain).  Only such a failing window can make a row block differ from the
+// whole DEM (the block sees less of it); everywhere else row blocks give the single block's bits.  TPI = x - (S / 256 - x) / (n - 1) with the pixel's own x read from the DEM.
+// Error: |rint(256 x) / 256 - x| <= 2^-9 m = 1.95 mm per sample, hence <= 1.95 mm on the mean and on TPI (about 0.03 mm rms
+// at 67 px when the fractional parts are spread evenly; the bound is reached by a DEM whose samples all carry one
+// fractional part off the 2^-8 m grid), against the 1.4 - 1.7 mm the reference's own float32 FFT is off by
+// and the 1e-4 x range of the contract.  A pixel whose disc holds whole metres only gets the whole-metre kernel's bits.
+// TOPO_AMD_TPI_FRACTION_EXACT=1: the exact two-pass route above instead.
+// TAKE_ALL: every tile, classified here (non-finite or absurd samples: the general kernel) - the first and only marching
+// launch on a DEM the library remembers as mostly fractional (dem_memo): the whole-metre launch in front of it would
+// stage every tile only to find it fractional (7.1 ms against 5 ms at 67 px on 32768^2).  A window of whole metres gets the
+// whole-metre kernel's bits here too (S = 256 sum trunc(x) exactly).
+template <int SIZE, int TH, int NWAVES, bool TAKE_ALL = false>
+__device__ __forceinline__ void tpi_scaled_march_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
+    using G = Geo<SIZE>;
+    static_assert(G::T.centre == 0, "odd disc sizes only: the zeroed tap is the pixel itself");
+    static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
+    constexpr int NROWS = TH + SIZE - 1;
+    constexpr int RW = TH / NWAVES;
+    constexpr int kHist = (SIZE - 1 + TH - 1) / TH;  // tiles above whose rows a marched window still holds
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    uint32_t* Q = lds_u;
+    int* flag_word = reinterpret_cast<int*>(Q + (NROWS + 1 + NWAVES) * ROWW);
+    if (threadIdx.x == 0) {
+        flag_word[0] = 0;
+        flag_word[2] = 0x7fffffff;
+        flag_word[3] = -0x7fffffff - 1;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = tiles_x * tiles_y;
+    const int vb = (vb0 + deal.shift) % nb;
+    const int first = deal.first(vb);
+    const int last = min(first + deal.count(vb), ntiles);
+    const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
+
+    if (!TAKE_ALL) {
+        // nothing to do on a DEM of whole metres: one flag per lane, 64 tiles per load
+        bool any = false;
+        for (int base = first; base < last; base += 64) {
+            const int mine = base + lane;
+            any = any || __builtin_amdgcn_ballot_w64(mine < last && p.defer[mine < last ? mine : first] == kNeedsFraction) != 0;
+        }
+        if (!any) return;  // the same for every thread of the block
+    }
+
+    bool carry = false;
+    int hlo[kHist + 1], hhi[kHist + 1];  // range of the new rows of this tile ([0]) and of the tiles above it
+#pragma unroll
+    for (int k = 0; k <= kHist; ++k) hlo[k] = 0x7fffffff, hhi[k] = -0x7fffffff - 1;
+    int seen_frac = 0;  // TAKE_ALL: tiles of the run whose new rows hold a fractional sample (the report)
+#pragma unroll 1
+    for (int tile = first; tile < last; ++tile) {
+        if (!TAKE_ALL && p.defer[tile] != kNeedsFraction) {
+            carry = false;
+            continue;
+        }
+        const int ty = tile % tiles_y;
+        const int ox0 = (tile / tiles_y) * G::TILE_W;
+        const int oy0 = (p.out_row0 / TH + ty) * TH;
+        const int gx = ox0 - G::X0 + lane * NC;
+        const int gy0 = oy0 + G::T.off_min;
+        if (ty == 0) carry = false;
+        // A tile whose window reaches over the DEM's edge goes to the general kernel unstaged: its padded taps are
+        // zeros, n q_ctr is no estimate of such a sum, and the test on the range would depend on how much of the window a
+        // row block has in view.  (Geometry of the whole DEM only: every row block takes the same decision.  The two outer
+        // strips and the first and last tile row: 1.5 % of the tiles of a 32768^2 DEM.)
+        if (gy0 < 0 || gy0 + NROWS > p.gny || ox0 - G::X0 < 0 || ox0 - G::X0 + ROWW > p.nx) {
+            if (threadIdx.x == 0) p.defer[tile] = kTileGeneral;
+            carry = false;
+            continue;
+        }
+        int range[2];
+        int flags = 0;
+        if (carry) {
+#ifdef MARCH_STAMPS
+            long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#endif
+            flags = stage_march<SIZE, TH, NWAVES, TAKE_ALL ? 3 : 2>(p, Q, flag_word, gy0, gx MARCH_STAMP_PASS, range);
+#pragma unroll
+            for (int k = kHist; k >= 1; --k) hlo[k] = hlo[k - 1], hhi[k] = hhi[k - 1];
+            hlo[0] = __builtin_amdgcn_readfirstlane(range[0]);
+            hhi[0] = __builtin_amdgcn_readfirstlane(range[1]);
+        } else {
+            __syncthreads();  // the previous tile's image is done with
+            flags = stage_prefix<SIZE, TH, NWAVES, kStS, uint32_t, TAKE_ALL>(p, lds_u, flag_word, gy0, gx, 0.0f, 0, 0.0f, 0.0f, range);
+#pragma unroll
+            for (int k = 0; k <= kHist; ++k) {  // the whole window was staged: its range stands for every tile in it
+                hlo[k] = __builtin_amdgcn_readfirstlane(range[0]);
+                hhi[k] = __builtin_amdgcn_readfirstlane(range[1]);
+            }
+        }
+        int wlo = hlo[0], whi = hhi[0];
+#pragma unroll
+        for (int k = 1; k <= kHist; ++k) wlo = min(wlo, hlo[k]), whi = max(whi, hhi[k]);
+        // the unwrapping below is exact for every pixel of the tile when n x (range of the window) < 2^31
+        const bool fits = (long long)G::T.taps * ((long long)whi - (long long)wlo) < (1ll << 31);
+        const bool leave = TAKE_ALL && (flags & kTileFloat) != 0;  // a non-finite or absurd sample: the general kernel
+        if (TAKE_ALL && (flags & kTileFrac)) ++seen_frac;
+        if (threadIdx.x == 0) {
+            p.defer[tile] = fits && !leave ? kTileDone : kTileGeneral;
+            flag_word[0] = 0;
+            flag_word[2] = 0x7fffffff;  // (every thread has read flags and range; the next atomics are behind a barrier)
+            flag_word[3] = -0x7fffffff - 1;
+        }
+        carry = !leave;  // (a window with such a sample is not carried on: the next tile is staged and classified in full)
+        if (!fits || leave) continue;  // the general kernel takes the tile (exact)
+
+#pragma unroll 1
+        for (int k = 0; k < RW; ++k) {
+            const int jj = wave + k * NWAVES;
+            const int oy = oy0 + jj;
+            if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
+            const int ocol = ox0 + lane * NC;
+            const bool live = lane < G::NVL && ocol < p.nx;
+            const size_t xi = live ? (size_t)(oy - p.in_row0) * p.nx + ocol : 0;
+            const Vec4<float> xs = *reinterpret_cast<const Vec4<float>*>(p.in + xi);
+            uint32_t acc[NC];  // sum of q over the disc modulo 2^32
+            wave_disc_sum<SIZE, uint32_t, 0, (SIZE >= 41)>(Q, jj, lane, acc);
+            if (!live) continue;
+            // the pixel's own q: prefix through its row minus prefix above it
+            const uint32_t* own = Q + (jj - G::T.off_min) * ROWW + lane * NC + G::X0;
+            const Vec4<uint32_t> hi = *reinterpret_cast<const Vec4<uint32_t>*>(own + ROWW);
+            const Vec4<uint32_t> lo = *reinterpret_cast<const Vec4<uint32_t>*>(own);
+            Vec4<float> out_t;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const uint32_t qc = hi.v[t] - lo.v[t];
+                const int off = (int)(acc[t] - (uint32_t)G::T.taps * qc);  // S - n q_ctr, exact (see above)
+                const double s1 = ((double)G::T.taps * (double)(int)qc + (double)off) * (1.0 / (double)kScaledUnit);
+                const double x = (double)xs.v[t];
+                out_t.v[t] = (float)(x - (s1 - x) * inv_nm1);
+            }
+            *reinterpret_cast<Vec4<float>*>(p.tpi + (size_t)(oy - p.out_row0) * p.nx + ocol) = out_t;
+        }
+    }
+    if (TAKE_ALL && p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
+        __hip_atomic_store(p.report + 1, (uint32_t)seen_frac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.report, (uint32_t)(last > first ? last - first : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int SIZE, int TH, int NWAVES, bool TAKE_ALL = false>
+__global__ __launch_bounds__(NWAVES * 64) void tpi_scaled_march_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((tpi_scaled_march_kernel_body<SIZE, TH, NWAVES, TAKE_ALL>));
+}
+template <int SIZE, int TH, int NWAVES, bool TAKE_ALL = false>
+__global__ __launch_bounds__(NWAVES * 64) void tpi_scaled_march_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((tpi_scaled_march_kernel_body<SIZE, TH, NWAVES, TAKE_ALL>));
+}
+
+template <int SIZE, int TH, int NWAVES, bool TAKE_ALL = false>
+int launch_scaled_march(const Block& b, float* tpi_out) {
+    using G = Geo<SIZE>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0};
+    a.scaled = 1;
+    a.report = TAKE_ALL ? dem_memo_report(b) : nullptr;
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16;
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_scaled_march_kernel<SIZE, TH, NWAVES, TAKE_ALL>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nblk, (const void*)tpi_scaled_march_kernel<SIZE, TH, NWAVES, TAKE_ALL>, NWAVES * 64, lds));
+        blocks_per_cu = nblk < 1 ? 1 : nblk;
+    }
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
+    const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
+    deal_parts(&ps, tiles_x, grid, blocks_per_cu);
+    return launch_parts(tpi_scaled_march_kernel<SIZE, TH, NWAVES, TAKE_ALL>, tpi_scaled_march_kernel_parts<SIZE, TH, NWAVES, TAKE_ALL>, grid,
+                        NWAVES * 64, lds, ps, tiles_x);
 }
 
 // ---- STD on tiles of whole metres: the second marching kernel ------------------------------------
@@ -1663,6 +1925,12 @@ inline bool tpi_ring_both() {
     static const int v = env_int("TOPO_AMD_TPI_RING_BOTH", 1);
     return v != 0;
 }
+// TOPO_AMD_TPI_FRACTION_EXACT=1: tiles with fractional elevations take the exact two-pass route (2^-16 m) instead of the
+// scaled one-chain route (2^-8 m, tpi_scaled_march_kernel)
+inline bool tpi_fraction_scaled() {
+    static const int v = env_int("TOPO_AMD_TPI_FRACTION_EXACT", 0);
+    return v == 0;
+}
 inline int tpi_fraction_min_size() {
     static const int v = env_int("TOPO_AMD_TPI_FRACTION_MIN", 17);
     return v;
@@ -1743,6 +2011,16 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
     if (SIZE < tpi_fraction_min_size()) {
         // small discs: the general kernel's two passes over one tile beat two marching kernels
         TOPO_TRY((launch_march<SIZE, TH12, 12, true, false, false>(b, tpi_out)));
+        return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true);
+    }
+    if (tpi_fraction_scaled()) {
+        // fractional tiles: one chain on x in units of 2^-8 m (tpi_scaled_march_kernel: <= 1.95 mm, see there)
+        if (dem_memo_mostly_fractional(b)) {  // what the last call on this DEM reported: the scaled build takes every tile
+            TOPO_TRY((launch_scaled_march<SIZE, TH12, 12, true>(b, tpi_out)));
+            return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true);
+        }
+        TOPO_TRY((launch_march<SIZE, TH12, 12, true, true, true>(b, tpi_out, true)));
+        TOPO_TRY((launch_scaled_march<SIZE, TH12, 12>(b, tpi_out)));
         return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true);
     }
     TOPO_TRY((launch_march<SIZE, TH12, 12, true, true, true>(b, tpi_out)));
