@@ -316,6 +316,149 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     return out
 
 
+def config_rows(d):
+    """BASELINE.json configs[1..3] at their OWN sizes (the `descriptors` table above times everything at the headline's
+    32768^2): 8192^2 TPI / STD at 7 and 65 px, 16384^2 gradient at sigma 3.25 and 30.25, 16384^2 Sx azimuth 0 radius
+    500 m.  Median of 10 launches, HIP events, DEM resident."""
+    out = {}
+
+    def entry(key, n, st, bpp):
+        ms = st["median"]
+        out[key] = {"dem": [n, n], "ms": round(ms, 4), "ms_min": round(st["min"], 4), "ms_max": round(st["max"], 4),
+                    "launches": st["n"], "Mpixels_per_s": round(n * n / ms / 1e3, 1),
+                    "hbm_frac": round(n * n * bpp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    n = 8192
+    dem = d.synth_dem(n, n, seed=0)
+    outs = [d.DeviceArray(n, n) for _ in range(2)]
+    blk = d.Block(dem)
+    for size in (7, 65):
+        entry(f"config2_8192_tpi_s{size}", n, time_kernel(lambda: blk.tpi_std(size, tpi=outs[0]), 10, d), 8)
+        entry(f"config2_8192_std_s{size}", n, time_kernel(lambda: blk.tpi_std(size, std=outs[1]), 10, d), 8)
+        entry(f"config2_8192_tpi_std_s{size}", n, time_kernel(lambda: blk.tpi_std(size, tpi=outs[0], std=outs[1]), 10, d), 12)
+    for a in outs + [dem]:
+        a.free()
+    n = 16384
+    dem = d.synth_dem(n, n, seed=0)
+    outs = [d.DeviceArray(n, n) for _ in range(4)]
+    blk = d.Block(dem)
+    for sigma in (3.25, 30.25):
+        fn = lambda: blk.gradient(sigma, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3])  # noqa: E731
+        entry(f"config3_16384_gradient_sigma{sigma}", n, time_kernel(fn, 10, d), 20)
+        fn = lambda: blk.gradient(sigma, [30.0], [-30.0], slope=outs[2], aspect=outs[3])  # noqa: E731
+        entry(f"config3_16384_slope_aspect_sigma{sigma}", n, time_kernel(fn, 10, d), 12)
+    window, dj, di, dist = d.sx_offsets(0.0, 500.0, 30.0, -30.0)
+    entry("config4_16384_sx_az0_r500", n, time_kernel(lambda: blk.sx(dj, di, dist, window, 10.0, outs[0]), 10, d), 8)
+    for a in outs + [dem]:
+        a.free()
+    return out
+
+
+def end_to_end(d, lib_mod, size, n=16384):
+    """topo.tpi through the HOST-buffer entry point (upload + kernels + download, what `topo.tpi(numpy array)` costs) on an
+    n x n DEM: pageable numpy arrays (second call: the result array's pages are recycled) and page-locked ones
+    (topo_amd_host_alloc), next to the three phases timed one by one on device-resident buffers.  Never the bench
+    `value` (reported separately)."""
+    import ctypes as C
+
+    from topo_descriptors_amd import topo
+    lib = lib_mod.lib()
+    dem = np.rint(1900.0 + 300.0 * np.random.default_rng(0).standard_normal((n, n))).astype(np.float32)
+    out = {"dem": [n, n], "disc_px": size, "bytes_moved": 2 * dem.nbytes}
+    warm = topo.tpi(dem, size)
+    t0 = time.perf_counter()
+    res = topo.tpi(dem, size)
+    dt = time.perf_counter() - t0
+    del warm
+    out["pageable_ms"] = round(dt * 1e3, 2)
+    out["pageable_Mpixels_per_s"] = round(n * n / dt / 1e6, 1)
+    # page-locked arrays
+    hin, hout = C.c_void_p(), C.c_void_p()
+    lib_mod.check(lib.topo_amd_host_alloc(C.byref(hin), dem.nbytes), "host_alloc")
+    lib_mod.check(lib.topo_amd_host_alloc(C.byref(hout), dem.nbytes), "host_alloc")
+    pin_in = np.frombuffer((C.c_char * dem.nbytes).from_address(hin.value), dtype=np.float32).reshape(n, n)
+    pin_out = np.frombuffer((C.c_char * dem.nbytes).from_address(hout.value), dtype=np.float32).reshape(n, n)
+    pin_in[:] = dem
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        lib_mod.check(lib.topo_amd_tpi_f32(hin, n, n, int(size), 0.0, hout), "topo_amd_tpi_f32")
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["pinned_ms"] = round(best * 1e3, 2)
+    out["pinned_Mpixels_per_s"] = round(n * n / best / 1e6, 1)
+    out["pinned_equals_pageable"] = bool(np.array_equal(pin_out, res))
+    del res
+    # the phases, device-resident: H2D, kernels (HIP events), D2H
+    dev, o = d.DeviceArray(n, n), d.DeviceArray(n, n)
+    t0 = time.perf_counter()
+    lib_mod.check(lib.topo_amd_memcpy_h2d(dev.ptr, hin, dem.nbytes), "h2d")
+    d.sync()
+    out["h2d_pinned_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    blk = d.Block(dev)
+    out["kernel_ms"] = round(time_kernel(lambda: blk.tpi_std(size, tpi=o), 5, d)["median"], 4)
+    t0 = time.perf_counter()
+    lib_mod.check(lib.topo_amd_memcpy_d2h(hout, o.ptr, dem.nbytes), "d2h")
+    out["d2h_pinned_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    dev.free()
+    o.free()
+    del pin_in, pin_out
+    lib_mod.check(lib.topo_amd_host_free(hin), "host_free")
+    lib_mod.check(lib.topo_amd_host_free(hout), "host_free")
+    return out
+
+
+def parity_spots(d, block, first_row, nx):
+    """Spot parity at full size, beyond TPI: STD, slope / aspect and Sx of windows of the bench DEM against the oracle's
+    restatement of the reference's scipy / numba calls (interiors only: the windows are cut out of a larger DEM)."""
+    from oracle import c_twin, topo_oracle as orc
+
+    out = {}
+    n = 4096
+    sample = block.to_host(first_row, n)[:, :n].copy()
+    dev = d.DeviceArray.from_host(sample)
+    blk = d.Block(dev)
+    o = [d.DeviceArray(n, n) for _ in range(4)]
+    for size in (7, 67):
+        blk.tpi_std(size, std=o[0])
+        d.sync()
+        got = o[0].to_host().astype(np.float64)
+        want = c_twin.tpi_std(sample, size, want_tpi=False, want_std=True)[1]  # exact float64 evaluation (oracle/topo_oracle.c)
+        ref = orc.std_scipy(sample, size)                                       # the reference's two FFT convolutions
+        r = size
+        inner = (slice(r, n - r), slice(r, n - r))
+        out[f"std_s{size}"] = {"max_abs_err_vs_exact": float(np.max(np.abs(got[inner] - want[inner]))),
+                               "reference_floor_vs_exact": float(np.max(np.abs(ref[inner] - want[inner]))),
+                               "max_std": float(np.max(want[inner])), "window": [n - 2 * r, n - 2 * r]}
+    res = {"x": 30.0, "y": -30.0}
+    for sigma in (3.25, 30.25):
+        blk.gradient(sigma, [30.0], [-30.0], dx=o[0], dy=o[1], slope=o[2], aspect=o[3])
+        d.sync()
+        got = [a.to_host() for a in o]
+        want = orc.gradient_scipy(sample, sigma, res)
+        r = int(4 * sigma + 0.5) + 2
+        inner = (slice(r, n - r), slice(r, n - r))
+        steep = want[2][inner] > 0.1
+        out[f"gradient_sigma{sigma}"] = {
+            "slope_max_abs_err_deg": float(np.max(np.abs(got[2][inner] - want[2][inner]))),
+            "slope_rel_range": float(np.max(np.abs(got[2][inner] - want[2][inner])) / np.max(np.abs(want[2][inner]))),
+            "aspect_max_wrapped_err_deg_where_slope_gt_0.1": float(np.max(orc.wrapped_angle_diff(got[3][inner], want[3][inner])[steep])),
+            "dx_rel_range": float(np.max(np.abs(got[0][inner] - want[0][inner])) / np.max(np.abs(want[0][inner]))),
+            "window": [n - 2 * r, n - 2 * r]}
+    window, dj, di, dist = d.sx_offsets(0.0, 500.0, 30.0, -30.0)
+    blk.sx(dj, di, dist, window, 10.0, o[0])
+    d.sync()
+    got = o[0].to_host()
+    w2, offs, dist2 = orc.sx_geometry(0.0, 500.0, 30.0, -30.0)
+    want = c_twin.sx(sample, offs[:, 0], offs[:, 1], dist2, w2, 10.0)
+    inner = (slice(window, n - window), slice(window, n - window))
+    out["sx_az0_r500"] = {"max_abs_err_deg": float(np.max(np.abs(got[inner] - want[inner]))),
+                          "checker": "oracle/topo_oracle.c (float64 twin of _sx_rolling)", "window": [n - 2 * window, n - 2 * window]}
+    for a in o + [dev]:
+        a.free()
+    return out
+
+
 SHARD_KEYS = ("tpi_s67", "std_s67", "tpi_std_s67", "gradient_sigma3.25", "gradient_sigma30.25", "sx_az0_r500")
 SHARD_BYTES = {"tpi_s67": 8, "std_s67": 8, "tpi_std_s67": 12, "gradient_sigma3.25": 20, "gradient_sigma30.25": 20,
                "sx_az0_r500": 8}
@@ -534,9 +677,13 @@ def main():
                 "max_abs_err_m": float(np.max(np.abs(got[: rows_s - r, : cols_s - r] -
                                                       want[: rows_s - r, : cols_s - r]))),
                 "window": [rows_s - r, cols_s - r],
+                "checker": "oracle.tpi_scipy (the reference's scipy.signal.convolve call)",
             }
+            result["parity_spot"].update(parity_spots(d, block, first_row, nx))
         if not args.no_extras and not sharded:
             result["descriptors"] = extras(d, _lib, args, d.Block, block, ny, nx)
+            result["descriptors_at_config_sizes"] = config_rows(d)
+            result["end_to_end"] = end_to_end(d, _lib, size)
     if not args.no_extras and sharded:  # collective: every rank takes part, rank 0 reports
         outs, steps_by_key = sharded_steps(sd, d, rows_local, nx)
         table = sharded_descriptors(rdv, steps_by_key, d.time_launches, px_total, world)

@@ -71,6 +71,9 @@ int topo_amd_cu_count(void);
 
 int topo_amd_malloc(void** dptr, size_t bytes);
 int topo_amd_free(void* dptr);
+/* Page-locked host memory for arrays handed to the host-buffer entry points (copies at the link's rate). */
+int topo_amd_host_alloc(void** hptr, size_t bytes);
+int topo_amd_host_free(void* hptr);
 int topo_amd_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int topo_amd_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int topo_amd_memcpy_d2d(void* dst, const void* src, size_t bytes);

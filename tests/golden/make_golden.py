@@ -155,7 +155,7 @@ def main():
     # ---- TPI / STD -----------------------------------------------------------------
     out = {"dem_int": dem_int, "dem_frac": dem_frac}
     for tag, dem in (("int", dem_int), ("frac", dem_frac)):
-        for size in (3, 5, 6, 7, 17, 65):
+        for size in (3, 5, 6, 7, 17, 65, 67):  # 67 px = 2000 m at 30 m: the headline size
             out[f"tpi_{tag}_s{size}"] = ref_topo.tpi(dem, size)
             out[f"tpi_{tag}_s{size}_exact"] = orc.tpi_exact(dem, size)
             out[f"std_{tag}_s{size}"] = ref_topo.std(dem, size)

@@ -46,7 +46,7 @@ class FakeDataset:
         return iter(["dem"])
 
 
-SIZES = (3, 5, 6, 7, 17, 65)
+SIZES = (3, 5, 6, 7, 17, 65, 67)
 
 
 @pytest.mark.parametrize("tag", ["int", "frac"])

@@ -76,7 +76,7 @@ def test_circular_kernel_golden(golden):
 
 
 # ---- TPI / STD --------------------------------------------------------------------------
-SIZES = (3, 5, 6, 7, 17, 65)
+SIZES = (3, 5, 6, 7, 17, 65, 67)
 
 
 @pytest.mark.parametrize("tag", ["int", "frac"])

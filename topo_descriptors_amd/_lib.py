@@ -24,6 +24,8 @@ SIGNATURES = {
     "topo_amd_device_name": (C.c_int, [C.c_char_p, C.c_int]),
     "topo_amd_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "topo_amd_free": (C.c_int, [_vp]),
+    "topo_amd_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "topo_amd_host_free": (C.c_int, [C.c_void_p]),
     "topo_amd_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "topo_amd_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "topo_amd_memcpy_d2d": (C.c_int, [_vp, _vp, C.c_size_t]),

@@ -65,6 +65,7 @@ struct DemMemo {
     const void* in = nullptr;
     int rows = 0, nx = 0;
     unsigned long used = 0;
+    unsigned asked = 0;  // calls that asked "mostly fractional?" (every 32nd one is told no: the reporting kernels run again)
 };
 constexpr int kMemos = 8;
 DemMemo g_memo[kMemos];
@@ -85,7 +86,7 @@ int memo_slot(const Block& b, bool create) {
         if (g_memo[k].used < g_memo[oldest].used) oldest = k;
     }
     if (!create) return -1;
-    g_memo[oldest] = DemMemo{b.in, b.in_rows, b.nx, ++g_memo_clock};
+    g_memo[oldest] = DemMemo{b.in, b.in_rows, b.nx, ++g_memo_clock, 0};
     // (a launch in flight may still write the evicted entry's words: they are cleared here, and a late report for
     // another DEM can at worst pick the wrong first kernel once - the results do not depend on that choice)
     g_memo_words[2 * oldest] = g_memo_words[2 * oldest + 1] = 0;
@@ -100,6 +101,8 @@ uint32_t* dem_memo_report(const Block& b) {
 bool dem_memo_mostly_fractional(const Block& b) {
     const int k = memo_slot(b, false);
     if (k < 0) return false;
+    // (a buffer may be refilled with other data: every 32nd call takes the default order, whose kernels report afresh)
+    if (++g_memo[k].asked % 32 == 0) return false;
     const uint32_t tiles = *(volatile uint32_t*)(g_memo_words + 2 * k), frac = *(volatile uint32_t*)(g_memo_words + 2 * k + 1);
     return tiles > 0 && 2 * frac > tiles;
 }
@@ -446,6 +449,20 @@ int topo_amd_free(void* dptr) {
         TOPO_HIP(hipStreamSynchronize(ctx().compute));
         TOPO_HIP(hipFree(dptr));
     }
+    return TOPO_AMD_OK;
+}
+
+// Page-locked host memory for the arrays handed to the host-buffer entry points (topo_amd_*_f32): the copies then run
+// at the link's rate without the driver staging them (bench.py, end_to_end: pinned against pageable).
+int topo_amd_host_alloc(void** hptr, size_t bytes) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(hptr != nullptr && bytes > 0, "host_alloc: bad arguments");
+    TOPO_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return TOPO_AMD_OK;
+}
+int topo_amd_host_free(void* hptr) {
+    TOPO_TRY(require_ready());
+    if (hptr) TOPO_HIP(hipHostFree(hptr));
     return TOPO_AMD_OK;
 }
 

@@ -758,6 +758,7 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
         if (!any) return;  // the same for every thread of the block
     }
     const int scol = 64 * wave + lane;  // staged column of a staging lane
+    int seen_general = 0;
 
 #pragma unroll 1
     for (int tile0 = first; tile0 < last;) {
@@ -1030,6 +1031,7 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                 }
             }
             if (BOTH && ph % PPT == PPT - 1 && tmode == kNeedsFraction && threadIdx.x == 0) p.defer[tile] = kTileDone;
+            if (!BOTH && ph % PPT == PPT - 1 && tmode == kTileGeneral) ++seen_general;
             const Seen seen = convert_batch(C::PRO + ph * B, va, nq, nq2, nqf);
             s0 += B;
             s0 = s0 >= R ? s0 - R : s0;
@@ -1041,6 +1043,12 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
             fold((ph + 1) & 1);
         }
         tile0 += run_tiles;
+    }
+    // what this block's run looked like, for the next call on this DEM (dem_memo, common.hpp): tiles, and tiles it left to
+    // the general kernel (fractional elevations, mostly)
+    if (!BOTH && p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
+        __hip_atomic_store(p.report + 1, (uint32_t)seen_general, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.report, (uint32_t)(last > first ? last - first : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1074,6 +1082,7 @@ int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
     WaveParts ps;
     int tiles_x = 0;
     long ntiles = 0;
+    a.report = MODE == kStdMain ? dem_memo_report(b) : nullptr;
     TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
