@@ -115,11 +115,11 @@ def kernel_sources_sha256():
 
 def measured_traffic(ny, nx, size, world):
     """HBM bytes per launch of the TPI kernel from the committed rocprofv3 PMC passes
-    (profiles/r03_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this exact
+    (profiles/r04_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this exact
     workload), with the git head and the kernel-source hash the profile was taken at.  The number is nulled
     when the workload or the sources differ from the profiled ones."""
-    info = {"traffic": None, "traffic_profile_head": None, "traffic_profile": "profiles/r03_tpi67_traffic.json"}
-    path = os.path.join(REPO, "profiles", "r03_tpi67_traffic.json")
+    info = {"traffic": None, "traffic_profile_head": None, "traffic_profile": "profiles/r04_tpi67_traffic.json"}
+    path = os.path.join(REPO, "profiles", "r04_tpi67_traffic.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -137,13 +137,13 @@ def measured_traffic(ny, nx, size, world):
 
 
 def valu_bound(ny, nx, size, world, kernel_ms):
-    """What bounds the kernel in practice: vector-ALU issue.  profiles/r03_tpi67_valu_bound.json (tools/valu_bound.py)
+    """What bounds the kernel in practice: vector-ALU issue.  profiles/r04_tpi67_valu_bound.json (tools/valu_bound.py)
     prices the kernel's own instruction stream - the row loop's instructions by issue class from the ISA, the rest
     from the launch's SQ_INSTS_VALU counter - with the issue costs measured on the GPU; the fraction is that time
     over the measured one.  Nulled when the workload or the kernel sources differ from the profiled ones."""
-    info = {"valu_bound_ms": None, "frac_of_valu_bound": None, "valu_bound_profile": "profiles/r03_tpi67_valu_bound.json"}
+    info = {"valu_bound_ms": None, "frac_of_valu_bound": None, "valu_bound_profile": "profiles/r04_tpi67_valu_bound.json"}
     try:
-        with open(os.path.join(REPO, "profiles", "r03_tpi67_valu_bound.json")) as fh:
+        with open(os.path.join(REPO, "profiles", "r04_tpi67_valu_bound.json")) as fh:
             prof = json.load(fh)
     except (OSError, ValueError):
         info["valu_bound_note"] = "no committed profile"
@@ -254,6 +254,20 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     for size in (7, 65, 67):
         entry(f"tpi_s{size}", time_kernel(lambda: blk.tpi_std(size, tpi=o1), REPS, d), 8, disc_kernels("tpi", size))
         entry(f"std_s{size}", time_kernel(lambda: blk.tpi_std(size, std=o2), REPS, d), 8, disc_kernels("std", size))
+        if size == 67 and (ny, nx) == (32768, 32768):
+            # what bounds STD in practice: vector-ALU issue too (tools/valu_bound.py std: the launch's SQ_INSTS_VALU priced at
+            # the phase loop's mix of issue classes)
+            try:
+                with open(os.path.join(REPO, "profiles", "r04_std67_valu_bound.json")) as fh:
+                    prof = json.load(fh)
+                if prof.get("kernel_sources_sha256") == kernel_sources_sha256() and prof.get("valu_bound_ms"):
+                    out["std_s67"]["valu_bound_ms"] = prof["valu_bound_ms"]
+                    out["std_s67"]["frac_of_valu_bound"] = round(prof["valu_bound_ms"] / out["std_s67"]["ms"], 4)
+                    out["std_s67"]["valu_bound_profile"] = "profiles/r04_std67_valu_bound.json"
+                else:
+                    out["std_s67"]["valu_bound_note"] = "kernel sources changed since tools/valu_bound.py std ran"
+            except (OSError, ValueError):
+                out["std_s67"]["valu_bound_note"] = "no committed profile"
         entry(f"tpi_std_s{size}", time_kernel(lambda: blk.tpi_std(size, tpi=o1, std=o2), REPS, d), 12,
               disc_kernels("tpi_std", size))
     o3 = d.DeviceArray(ny, nx)
@@ -657,6 +671,9 @@ def main():
                 # 171 of them at half rate (every DPP form, v_add3_u32, converts, float64) - i.e. ~3.1 ms per launch at
                 # 100 % VALU utilisation; valu_bound_ms / frac_of_valu_bound below
                 "bound_in_practice": "valu",
+                # the >= 60 % of north_star is out of reach of an exact disc sum - the kernel's own instruction
+                # stream, priced at measured issue rates, takes 3.0 ms of vector-ALU time per launch (frac 0.35)
+                "target_60pct": "not reachable with an exact disc: VALU bound 0.35",
                 **valu_bound(ny, nx, size, 0 if loopback else world, kernel_ms),
                 "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL["tpi"],
             },

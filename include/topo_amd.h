@@ -115,6 +115,10 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
 /* TPI and/or STD over the reference's disc (replaces topo.tpi topo.py:144-181 and topo.std
  * topo.py:272-307, called from topo.py:138 and :266).  Either output may be NULL.  STD is
  * float32 on the device (the Python wrapper widens to float64 like the reference).       */
+/* TPI alone (std_out == NULL), discs of 19 ... 101 px, tiles with fractional elevations: the neighbourhood sum is taken
+ * on x in units of 2^-8 m (one integer chain; csrc/disc_wave_impl.hpp, tpi_scaled_march_kernel), at most 2^-9 m = 1.95 mm
+ * off per sample and therefore on TPI; whole-metre DEMs, smaller discs and the fused TPI + STD call are exact to float32
+ * rounding.  Environment TOPO_AMD_TPI_FRACTION_EXACT=1: the exact two-pass route (2^-16 m) for those tiles as well.     */
 int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int size,
                          int out_row0, int out_rows, float* tpi_out, float* std_out);
 
@@ -128,6 +132,12 @@ int topo_amd_tpi_multi_dev(const float* in, int in_rows, int in_row0, int gny, i
 /* ndimage.gaussian_filter(dem, (sigma_y, sigma_x)), reflect boundary, truncate 4 sigma
  * (replaces topo.dem topo.py:62-80 and the pre-smoothing at topo.py:173, :298).  A sigma of
  * 0 skips that axis.  The intermediate plane lives in the library's own workspace.       */
+/* Gaussian / gradient, matrix-core routes (filter radius 4 ... 121): a sample that is not finite, or larger than 1e5 in
+ * magnitude (a raster in centimetres or millimetres, a sentinel like 1e20), is "wild": its outputs are recomputed by
+ * slower repair passes with exactly ndimage.gaussian_filter's footprint, and a DEM on which the fused short-filter
+ * kernel met one is remembered (by block pointer) and takes the two-pass kernels on later calls.  Results are the same
+ * either way; rasters whose legitimate values exceed 1e5 everywhere are served correctly but far below the usual rate -
+ * rescale them (the filter is linear) or use sigma below 1 / above 30.4.                                              */
 int topo_amd_gaussian_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
                           double sigma_y, double sigma_x, int out_row0, int out_rows,
                           float* out);
@@ -253,8 +263,10 @@ int topo_amd_gate_giveups(unsigned* count);
  * reading the owned rows from the wrong offset and receiving past the end of the buffer.
  * -1 / -1 (the default): the buffer has exactly the depth topo_amd_halo_rows gives for the
  * descriptor of each call.  The declaration belongs to the CALLING THREAD (thread-local), so
- * concurrent drivers of differently laid-out shards do not disturb each other;
- * topo_amd_shard_layout_get reads it back (to save and restore around a call).              */
+ * concurrent drivers of differently laid-out shards do not disturb each other; a thread that
+ * has never declared one uses the last layout any thread declared (set up once, drive from
+ * worker threads).  topo_amd_shard_layout_get reads back what applies to the calling thread
+ * (to save and restore around a call).                                                      */
 int topo_amd_shard_layout(int halo_above, int halo_below);
 int topo_amd_shard_layout_get(int* halo_above, int* halo_below);
 

@@ -16,12 +16,19 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+MATCHED = set()
+
+
 def mean_counter(pmc_dir, kernel, counter):
+    """Mean of `counter` over the launches whose kernel name contains `kernel` - the name as far as given, template
+    arguments included ("std_ring_kernel<67, false" and "std_ring_kernel<67, true" are different kernels: round 3's
+    r03_std67_traffic.json averaged the two).  The distinct names matched are recorded; more than one is an error."""
     vals = []
     for f in glob.glob(pmc_dir + "/pass*/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
                 vals.append(float(row["Counter_Value"]))
+                MATCHED.add(row["Kernel_Name"].split("(")[0])
     return sum(vals) / len(vals) if vals else None
 
 
@@ -32,8 +39,11 @@ def main():
     write = mean_counter(pmc_dir, kernel, "WRITE_SIZE")
     hit = mean_counter(pmc_dir, kernel, "TCC_HIT_sum")
     miss = mean_counter(pmc_dir, kernel, "TCC_MISS_sum")
+    if len(MATCHED) > 1:
+        sys.exit("traffic_from_pmc: '%s' matches %d kernels, name one of them in full: %s" % (kernel, len(MATCHED), sorted(MATCHED)))
     result = {
         "kernel": kernel,
+        "kernel_matched": sorted(MATCHED),
         "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
         "fetch_bytes_corrected": None if fetch is None else fetch * 1024 * 2,
         "write_bytes": None if write is None else write * 1024,

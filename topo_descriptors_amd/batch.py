@@ -127,27 +127,33 @@ def _tpi_std(dem_ds, scales, smth_factors, ind_nans, crop, outdir, want):
     res = _ResidentDem(hlp.get_da(dem_ds).values)
     out, smooth, results = res.plane(), None, {}
     try:
-        # un-smoothed TPI at two small scales shares one pass over the DEM (Block.tpi_multi): the
-        # planes of such pairs are made ahead of the loop, which then only names and writes them
-        ahead = {}
+        # un-smoothed TPI at two small scales shares one pass over the DEM (Block.tpi_multi).  A pair is
+        # computed when the loop reaches its first member: that plane is finished (NaN re-insertion, output) at once,
+        # the partner's waits on the host for its turn - one extra host plane at most, and nothing computed is lost if a
+        # later scale fails.
+        partner, ahead, second = {}, {}, None
         if want == "tpi":
             small = {}
             for k, (px, sigma) in enumerate(zip(scales_pxl, sigmas)):
                 if not sigma and int(px) in (5, 7, 9, 11):
                     small.setdefault(int(px), k)
             sizes = sorted(small)
-            if len(sizes) >= 2:
-                second = res.plane()
-                try:
-                    for a, b in zip(sizes[0::2], sizes[1::2]):
-                        res.block.tpi_multi([a, b], [out, second])
-                        ahead[small[a]], ahead[small[b]] = out.to_host(), second.to_host()
-                finally:
-                    second.free()
+            for a, b in zip(sizes[0::2], sizes[1::2]):
+                ka, kb = sorted((small[a], small[b]))
+                partner[ka] = kb
+            if len(sizes) % 2:
+                logger.info("TPI at %s px has no partner for a shared pass: computed alone", sizes[-1])
         for k, (scale, px, fact, sigma) in enumerate(zip(scales, scales_pxl, smth_factors, sigmas)):
             logger.info("Computing scale %s meters with smoothing factor %s ...", scale, fact)
             if k in ahead:
                 _finish(ahead.pop(k), ind_nans, dem_ds, _tpi_name(scale, fact), crop, outdir, "m", results)
+                continue
+            if k in partner:
+                kb = partner[k]
+                second = second or res.plane()
+                res.block.tpi_multi([int(px), int(scales_pxl[kb])], [out, second])
+                ahead[kb] = second.to_host()
+                _finish(out.to_host(), ind_nans, dem_ds, _tpi_name(scale, fact), crop, outdir, "m", results)
                 continue
             block = res.block
             if sigma:  # pre-smoothing (reference topo.py:172-173, :297-298)
@@ -163,8 +169,9 @@ def _tpi_std(dem_ds, scales, smth_factors, ind_nans, crop, outdir, want):
             _finish(array, ind_nans, dem_ds, name, crop, outdir, "m", results)
     finally:
         out.free()
-        if smooth is not None:
-            smooth.free()
+        for plane in (smooth, second):
+            if plane is not None:
+                plane.free()
         res.close()
     return results
 

@@ -3,6 +3,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -68,14 +69,15 @@ struct DemMemo {
     unsigned asked = 0;  // calls that asked "mostly fractional?" (every 32nd one is told no: the reporting kernels run again)
 };
 constexpr int kMemos = 8;
+constexpr int kMemoWords = 4;
 DemMemo g_memo[kMemos];
-uint32_t* g_memo_words = nullptr;  // pinned: two words per entry
+uint32_t* g_memo_words = nullptr;  // pinned: kMemoWords words per entry: tiles, fractional tiles, wild sample seen
 unsigned long g_memo_clock = 0;
 
 int memo_slot(const Block& b, bool create) {
     if (!g_memo_words) {
-        if (hipHostMalloc((void**)&g_memo_words, kMemos * 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return -1;
-        std::memset(g_memo_words, 0, kMemos * 2 * sizeof(uint32_t));
+        if (hipHostMalloc((void**)&g_memo_words, kMemos * kMemoWords * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return -1;
+        std::memset(g_memo_words, 0, kMemos * kMemoWords * sizeof(uint32_t));
     }
     int oldest = 0;
     for (int k = 0; k < kMemos; ++k) {
@@ -89,22 +91,36 @@ int memo_slot(const Block& b, bool create) {
     g_memo[oldest] = DemMemo{b.in, b.in_rows, b.nx, ++g_memo_clock, 0};
     // (a launch in flight may still write the evicted entry's words: they are cleared here, and a late report for
     // another DEM can at worst pick the wrong first kernel once - the results do not depend on that choice)
-    g_memo_words[2 * oldest] = g_memo_words[2 * oldest + 1] = 0;
+    for (int w = 0; w < kMemoWords; ++w) g_memo_words[kMemoWords * oldest + w] = 0;
     return oldest;
 }
 }  // namespace
 
 uint32_t* dem_memo_report(const Block& b) {
     const int k = memo_slot(b, true);
-    return k < 0 ? nullptr : g_memo_words + 2 * k;
+    return k < 0 ? nullptr : g_memo_words + kMemoWords * k;
 }
 bool dem_memo_mostly_fractional(const Block& b) {
     const int k = memo_slot(b, false);
     if (k < 0) return false;
     // (a buffer may be refilled with other data: every 32nd call takes the default order, whose kernels report afresh)
     if (++g_memo[k].asked % 32 == 0) return false;
-    const uint32_t tiles = *(volatile uint32_t*)(g_memo_words + 2 * k), frac = *(volatile uint32_t*)(g_memo_words + 2 * k + 1);
+    const uint32_t tiles = *(volatile uint32_t*)(g_memo_words + kMemoWords * k), frac = *(volatile uint32_t*)(g_memo_words + kMemoWords * k + 1);
     return tiles > 0 && 2 * frac > tiles;
+}
+
+uint32_t* dem_memo_wild_word(const Block& b) {
+    const int k = memo_slot(b, true);
+    return k < 0 ? nullptr : g_memo_words + kMemoWords * k + 2;
+}
+bool dem_memo_wild(const Block& b) {
+    const int k = memo_slot(b, false);
+    if (k < 0) return false;
+    if (++g_memo[k].asked % 32 == 0) {  // the buffer may hold other data by now: let the fused kernel look again
+        *(volatile uint32_t*)(g_memo_words + kMemoWords * k + 2) = 0;
+        return false;
+    }
+    return *(volatile uint32_t*)(g_memo_words + kMemoWords * k + 2) != 0;
 }
 
 // Small parameter tables: pinned staging + async copy on the compute stream.  The previous
@@ -173,7 +189,13 @@ struct Comm {
 } g_comm;
 // declared ghost depth of the shard buffers (topo_amd_shard_layout): per calling thread, so that two threads (or an
 // application and a ShardedDEM inside it) that drive shards with different buffer layouts do not see each other's
+// shards.  A thread that has never declared a layout sees the process-wide one - the last one any thread declared (an
+// application that declares it once at set-up and drives the shards from worker threads: ADVICE r03).
 thread_local int t_layout_above = -1, t_layout_below = -1;
+thread_local bool t_layout_set = false;
+std::atomic<int> g_layout_above{-1}, g_layout_below{-1};
+int layout_above() { return t_layout_set ? t_layout_above : g_layout_above.load(); }
+int layout_below() { return t_layout_set ? t_layout_below : g_layout_below.load(); }
 
 // TOPO_AMD_HALO_LOOPBACK=1 with a communicator of one rank: the exchange talks to itself
 bool halo_loopback() {
@@ -1152,13 +1174,16 @@ int topo_amd_shard_layout(int halo_above, int halo_below) {
                  halo_below);
     t_layout_above = halo_above;
     t_layout_below = halo_below;
+    t_layout_set = true;
+    g_layout_above.store(halo_above);
+    g_layout_below.store(halo_below);
     return TOPO_AMD_OK;
 }
 
 int topo_amd_shard_layout_get(int* halo_above, int* halo_below) {
     TOPO_REQUIRE(halo_above && halo_below, "shard_layout_get: NULL output");
-    *halo_above = t_layout_above;
-    *halo_below = t_layout_below;
+    *halo_above = layout_above();
+    *halo_below = layout_below();
     return TOPO_AMD_OK;
 }
 
@@ -1189,14 +1214,14 @@ struct Shard {
 // starts.
 int shard_view(float** block, int above, int below, const char* who) {
     TOPO_REQUIRE(*block != nullptr, "%s: NULL block", who);
-    if (t_layout_above < 0) return TOPO_AMD_OK;
-    TOPO_REQUIRE(above <= t_layout_above && below <= t_layout_below,
+    if (layout_above() < 0) return TOPO_AMD_OK;
+    TOPO_REQUIRE(above <= layout_above() && below <= layout_below(),
                  "%s needs %d / %d ghost rows but the shard buffers were declared with %d / %d (topo_amd_shard_layout)",
-                 who, above, below, t_layout_above, t_layout_below);
+                 who, above, below, layout_above(), layout_below());
     return TOPO_AMD_OK;
 }
 size_t shard_view_offset(int above, int nx) {
-    return t_layout_above < 0 ? 0 : (size_t)(t_layout_above - above) * nx;
+    return layout_above() < 0 ? 0 : (size_t)(layout_above() - above) * nx;
 }
 
 Shard make_shard(float* block, int rows_local, int row0, int gny, int nx, int above, int below) {

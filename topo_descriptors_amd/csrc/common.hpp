@@ -191,5 +191,9 @@ int gaussian_radius(double sigma);
 // as mostly fractional starts with the kernel that suits it (tpi_scaled_march_kernel<TAKE_ALL>).
 uint32_t* dem_memo_report(const Block& b);           // the pinned words {tiles, fractional tiles} of this DEM's entry
 bool dem_memo_mostly_fractional(const Block& b);
+// The same memory for the Gaussian's fused matrix-core kernel: the word it sets when it stages a sample that is not a
+// plain finite one (non-finite, or beyond 1e5 in magnitude), and what that word said after the last finished call.
+uint32_t* dem_memo_wild_word(const Block& b);
+bool dem_memo_wild(const Block& b);
 
 }  // namespace topo

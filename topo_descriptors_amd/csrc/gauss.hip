@@ -46,6 +46,7 @@ struct GaussArgs {
     unsigned char* flags;  // matrix-core kernels: one byte per 32 x 32 output tile, 1 = an output is not finite
     float tap_scale, out_scale;  // f16 matrix-core kernels: taps are multiplied by tap_scale (a power of two), sums by out_scale
     int* wild_flag;     // fused kernel: set to 1 when it stages a sample that is not a plain finite one
+    uint32_t* wild_host;  // ... and this pinned host word of the DEM's memo entry (dem_memo_wild), or nullptr
     const int* run_if;  // two-pass f16 kernels behind a fused launch: return at once unless *run_if != 0 (nullptr: run)
 };
 
@@ -1657,7 +1658,10 @@ __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int t
             for (int q = 0; q < NPASS; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pre[q][e] = wild(pre[q][e]) ? 0.0f : pre[q][e];
-            if (lane == 0) *p.wild_flag = 1;
+            if (lane == 0) {
+                *p.wild_flag = 1;
+                if (p.wild_host) __hip_atomic_store(p.wild_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) *reinterpret_cast<f4*>(dst + (RPP * q + lr) * CW + lcq) = pre[q];
@@ -2298,6 +2302,7 @@ int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, cons
         *flag_out = (const int*)flag;
     }
     a.wild_flag = const_cast<int*>(*flag_out);
+    a.wild_host = dem_memo_wild_word(b);
     const int tile_first = b.out_row0 / 32;
     const int ntile_rows = (b.out_row0 + b.out_rows - 1) / 32 - tile_first + 1;
     const int row_blocks = (ntile_rows + 3) / 4;
@@ -2325,7 +2330,9 @@ int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, cons
 // its last chunk.  Returns whether the two passes are still owed in *owed.
 int smooth_both_mfma(const Block& b, double sigma, float* tmp, float* out, int table_slot, bool for_gradient,
                      const int* deferred = nullptr, bool* owed = nullptr) {
-    const bool fused = fused_radius(gaussian_radius(sigma), for_gradient);
+    // (a DEM the fused kernel has met a non-finite or huge sample on - dem_memo, common.hpp - goes straight to the two
+    // passes: the fused attempt would only be thrown away again)
+    const bool fused = fused_radius(gaussian_radius(sigma), for_gradient) && !dem_memo_wild(b);
     const int* flag = fused ? deferred : nullptr;
     if (fused) TOPO_TRY(run_fused_f16(b, sigma, out, table_slot, &flag));
     if (owed) *owed = fused && deferred != nullptr;

@@ -70,7 +70,15 @@ def tpi(dem, size, sigma=None):
 
     With ``sigma`` the pre-smoothing is :func:`dem`'s: see there for how far a non-finite sample reaches.  Without it a NaN reaches the windows that contain it and
     some more pixels of its tile (it travels down the column prefix sums); the reference's FFT convolution makes the
-    whole array NaN."""
+    whole array NaN.
+
+    Accuracy.  On a DEM of whole metres the result is the float64 evaluation of the reference's formula, rounded to
+    float32.  Where a disc of 19 pixels or more holds fractional elevations, the neighbourhood sum is taken on ``x``
+    in units of 2**-8 m (one integer chain instead of two): each sample is off by at most 2**-9 m = 1.95 mm, hence so are
+    the mean and TPI (about 0.02 mm rms at 67 pixels when the fractional parts are spread evenly) - the order of the
+    1.4 - 1.7 mm the reference's own float32 FFT is off by, and far inside 1e-4 of the range.  Smaller discs, and
+    :func:`tpi_std`, are exact to 2**-16 m; ``TOPO_AMD_TPI_FRACTION_EXACT=1`` makes this function so as well, at about
+    twice the time on such a DEM."""
     values, rewrap = _unwrap(dem)
     _check_2d(values, "tpi")
     src = _lib.as_f32(values)
