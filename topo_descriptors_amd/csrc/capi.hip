@@ -1351,11 +1351,25 @@ int finish_gated(bool lean, bool probe) {
     return topo_amd_halo_wait();  // (the clean-up launch waited already: keeps topo_amd_halo_wait's contract)
 }
 
+// tile_rows: the tile height of the descriptor's first kernel (a hint, 0 = unknown).  The kernels' tile rows sit on global
+// multiples of it, so an interior that starts or ends inside a tile makes that tile be staged twice - once by the
+// interior part for its lower rows, once by the seam part for its upper ones: the interior is shrunk to whole tiles and
+// the two edge tiles belong to the seam parts entirely (any interior inside [interior0, interior1) is valid: the seam
+// parts see the ghost rows).  68 + 2 tile slots per strip become 66 + 2 at 67 px on a 4096-row shard.
 template <class Fn>
-int run_fused(float* block, const Shard& s, int above, int below, Fn fn) {
+int run_fused(float* block, const Shard& s0, int above, int below, int tile_rows, Fn fn) {
+    Shard s = s0;
     const int end = s.row0 + s.rows_local;
+    if (tile_rows > 0) {
+        const int a = s.interior0 > s.row0 ? (s.interior0 + tile_rows - 1) / tile_rows * tile_rows : s.interior0;
+        const int b = end > s.interior1 ? s.interior1 / tile_rows * tile_rows : s.interior1;
+        if (b > a) {
+            s.interior0 = a;
+            s.interior1 = b;
+        }
+    }
     const bool top = s.interior0 > s.row0, bottom = end > s.interior1;
-    if (!shard_fused_on() || s.interior1 <= s.interior0 || (!top && !bottom)) return run_three(block, s, above, below, fn, false);
+    if (!shard_fused_on() || s.interior1 <= s.interior0 || (!top && !bottom)) return run_three(block, s0, above, below, fn, false);
     Context& c = ctx();
     TOPO_TRY(topo_amd_halo_exchange_start(block, s.rows_local, s.whole.nx, above, below));
     const bool live = g_comm.size > 1 || halo_loopback();
@@ -1429,7 +1443,9 @@ int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int 
     TOPO_TRY(shard_view(&block, above, below, "shard_tpi_std"));
     block += shard_view_offset(above, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, above, below);
-    return run_fused(block, s, above, below, [&](const Block& view, int o0, int on) {
+    // (tile rows of the first kernel: 60 for the ring kernels of STD and the marching TPI kernels, 64 for the TPI rings)
+    const int tile_rows = std_out ? 60 : (size <= 17 ? 64 : 60);
+    return run_fused(block, s, above, below, tile_rows, [&](const Block& view, int o0, int on) {
         Block b = view;
         b.out_row0 = o0;
         b.out_rows = on;

@@ -393,9 +393,11 @@ __device__ __forceinline__ float std_from_sums(double s1, double s2, double inv_
 // The same for a pixel whose n taps are all inside the DEM, on a tile of the integer path:
 // n s2 - s1^2 = n Su2 - Su^2 whatever offset c the sums were taken with, a non-negative integer below 2^62 that
 // 64-bit integer arithmetic forms exactly (one v_mad_u64_u32 and one v_mad_i64_i32 when Su2 fits 32 bits), hence
-// identical bits from kernels that used different offsets.  It is rounded to float32 once (high word x 2^32 + low
-// word in one fma: within 1.2e-7 relative), scaled by 1 / (n (n - 1)) and rooted with the hardware's v_sqrt_f32
-// (1 ulp): 3e-7 relative in all, against the 1e-4 of the contract, in 8 instructions where the float64 form with a
+// identical bits from kernels that used different offsets.  It goes to float32 as high word x 2^32 + low word in one
+// fma (the two words are each rounded to float32 when they exceed 2^24, then the fma rounds: <= 1.8e-7 relative), is
+// scaled by the float32 value of 1 / (n (n - 1)) (two more roundings: <= 1.2e-7) and rooted with the hardware's
+// v_sqrt_f32 (the root halves the relative error of its argument and adds 1 ulp): 3e-7 relative in all on STD, against
+// the 1e-4 of the contract (tests: test_std_vs_reference), in 8 instructions where the float64 form with a
 // correctly rounded sqrtf took about 20 per pixel (a tenth of std_ring_kernel's vector instructions).  Every
 // wave-shift and ring kernel uses this one function for such pixels, so they agree bit for bit.
 __device__ __forceinline__ float std_from_int_sums(int su, uint64_t su2, uint32_t n, float inv_nn1) {

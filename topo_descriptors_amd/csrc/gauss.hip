@@ -2332,13 +2332,15 @@ int smooth_both_mfma(const Block& b, double sigma, float* tmp, float* out, int t
                      const int* deferred = nullptr, bool* owed = nullptr) {
     // (a DEM the fused kernel has met a non-finite or huge sample on - dem_memo, common.hpp - goes straight to the two
     // passes: the fused attempt would only be thrown away again)
-    const bool fused = fused_radius(gaussian_radius(sigma), for_gradient) && !dem_memo_wild(b);
+    // (the two passes behind - or instead of - a fused launch keep its tiling of axis 0, hence its bits)
+    const bool fused_class = fused_radius(gaussian_radius(sigma), for_gradient);
+    const bool fused = fused_class && !dem_memo_wild(b);
     const int* flag = fused ? deferred : nullptr;
     if (fused) TOPO_TRY(run_fused_f16(b, sigma, out, table_slot, &flag));
     if (owed) *owed = fused && deferred != nullptr;
     if (fused && deferred != nullptr) return TOPO_AMD_OK;
     t_run_if = flag;
-    t_axis0_one_tile = fused;
+    t_axis0_one_tile = fused_class;
     int r = run_axis0_mfma(b, sigma, tmp, table_slot);
     if (r == TOPO_AMD_OK) r = run_axis1_mfma(tmp, b.out_rows, b.nx, sigma, out, table_slot + 1);
     t_run_if = nullptr;
