@@ -7,13 +7,16 @@ HEAD=${1:-unknown}
 F=$R/gpurun_out/final
 mkdir -p $F
 cd $R
-PMC_SCRIPT=tools/tpi_trace.py tools/pmc_passes.sh final/pmc_tpi67 32768 67 > /dev/null 2>&1
+PMC_SCRIPT=tools/tpi_trace.py tools/pmc_passes.sh final/pmc_tpi67 32768 67 int > /dev/null 2>&1
 python3 tools/traffic_from_pmc.py gpurun_out/final/pmc_tpi67 tpi_march_kernel profiles/r04_tpi67_traffic.json $HEAD > $F/traffic_tpi67.log 2>&1
 cp profiles/r04_tpi67_traffic.json $F/
 cp gpurun_out/final/pmc_tpi67/summary.txt $F/r04_tpi67_pmc_summary.txt
 cp gpurun_out/final/pmc_tpi67/summary.txt profiles/r04_tpi67_pmc_summary.txt
 python3 tools/valu_bound.py > profiles/r04_tpi67_valu_bound.json 2> $F/valu_bound.err
 cp profiles/r04_tpi67_valu_bound.json $F/
+# the scaled one-chain route on fractional elevations (tpi_scaled_march_kernel<67, 60, 12, true> from the second call on)
+PMC_SCRIPT=tools/tpi_trace.py tools/pmc_passes.sh final/pmc_tpi67_frac 32768 67 frac > /dev/null 2>&1
+cp gpurun_out/final/pmc_tpi67_frac/summary.txt $F/r04_tpi67_fractional_pmc_summary.txt
 PMC_SCRIPT=tools/std_trace.py tools/pmc_passes.sh final/pmc_std67 32768 67 > /dev/null 2>&1
 # one traffic file per kernel variant (STD alone, TPI + STD): round 3's file averaged the two
 python3 tools/traffic_from_pmc.py gpurun_out/final/pmc_std67 "std_ring_kernel<67, false" $F/r04_std67_traffic.json $HEAD > $F/traffic_std67.log 2>&1

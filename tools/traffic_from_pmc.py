@@ -28,7 +28,7 @@ def mean_counter(pmc_dir, kernel, counter):
         for row in csv.DictReader(open(f)):
             if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
                 vals.append(float(row["Counter_Value"]))
-                MATCHED.add(row["Kernel_Name"].split("(")[0])
+                MATCHED.add(row["Kernel_Name"].replace("(anonymous namespace)", "").split("(")[0])
     return sum(vals) / len(vals) if vals else None
 
 
