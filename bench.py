@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--size", type=int, default=67, help="disc diameter in pixels (2000 m / 30 m)")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-descriptor side table")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the host-buffer end_to_end section (it launches the headline kernel on a 16384^2 DEM: under "
+                         "rocprofv3 --stats those launches would enter the kernel's average duration)")
     return ap.parse_args()
 
 
@@ -700,7 +703,8 @@ def main():
         if not args.no_extras and not sharded:
             result["descriptors"] = extras(d, _lib, args, d.Block, block, ny, nx)
             result["descriptors_at_config_sizes"] = config_rows(d)
-            result["end_to_end"] = end_to_end(d, _lib, size)
+            if not args.no_end_to_end:
+                result["end_to_end"] = end_to_end(d, _lib, size)
     if not args.no_extras and sharded:  # collective: every rank takes part, rank 0 reports
         outs, steps_by_key = sharded_steps(sd, d, rows_local, nx)
         table = sharded_descriptors(rdv, steps_by_key, d.time_launches, px_total, world)
