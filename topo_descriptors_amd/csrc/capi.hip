@@ -1302,7 +1302,7 @@ uint32_t gate_limit_ticks() {
 uint32_t gate_timeout_ticks() {
     static const uint32_t v = [] {
         const char* e = std::getenv("TOPO_AMD_GATE_TIMEOUT_MS");
-        const double ms = e && *e ? std::atof(e) : 1000.0;
+        const double ms = e && *e ? std::atof(e) : 5000.0;  // (ranks drift apart by milliseconds, a first allocation by tens)
         return (uint32_t)std::min(4.0e9, std::max(1.0, ms) * 1.0e5);
     }();
     return v;
