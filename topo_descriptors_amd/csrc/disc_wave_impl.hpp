@@ -143,6 +143,7 @@ inline int make_parts(const Block& b, const WaveArgs& a0, int tile_h, int strip_
         a.in_row0 = bk.in_row0;
         a.out_row0 = bk.out_row0;
         a.out_rows = bk.out_rows;
+        if (k > 0) a.report = nullptr;  // (the DEM memo hears from a block of part 0, not from a run of one seam tile)
         const ptrdiff_t moved = (ptrdiff_t)(bk.out_row0 - b.out_row0) * b.nx;
         if (a.tpi) a.tpi += moved;
         if (a.sd) a.sd += moved;
