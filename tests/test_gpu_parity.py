@@ -432,3 +432,33 @@ def test_sx_window_beyond_the_lds_tile():
     want = orc.sx(dem, x, y, 45.0, 6000.0)
     assert np.array_equal(got == 0, want == 0)
     assert np.max(np.abs(got - want)) <= REL * np.max(np.abs(want))
+
+
+def test_page_locked_host_arrays_and_gate_statistic():
+    """Round 4 additions to the C ABI: topo_amd_host_alloc hands out page-locked memory the host-buffer entry points take
+    like any other array (same bits as with a pageable one), and topo_amd_gate_giveups answers 0 in a process that has
+    not run a sharded call."""
+    import ctypes as C
+
+    from topo_descriptors_amd import _lib
+
+    lib = _lib.lib()
+    ny, nx, size = 300, 512, 17
+    dem = orc.synthetic_dem(ny, nx, seed=12)
+    want = topo.tpi(dem, size)
+    hin, hout = C.c_void_p(), C.c_void_p()
+    _lib.check(lib.topo_amd_host_alloc(C.byref(hin), dem.nbytes), "host_alloc")
+    _lib.check(lib.topo_amd_host_alloc(C.byref(hout), dem.nbytes), "host_alloc")
+    try:
+        pin_in = np.frombuffer((C.c_char * dem.nbytes).from_address(hin.value), dtype=np.float32).reshape(ny, nx)
+        pin_out = np.frombuffer((C.c_char * dem.nbytes).from_address(hout.value), dtype=np.float32).reshape(ny, nx)
+        pin_in[:] = dem
+        _lib.check(lib.topo_amd_tpi_f32(hin, ny, nx, size, 0.0, hout), "topo_amd_tpi_f32")
+        assert np.array_equal(pin_out, want)
+        del pin_in, pin_out
+    finally:
+        _lib.check(lib.topo_amd_host_free(hin), "host_free")
+        _lib.check(lib.topo_amd_host_free(hout), "host_free")
+    n = C.c_uint(123)
+    _lib.check(lib.topo_amd_gate_giveups(C.byref(n)), "gate_giveups")
+    assert n.value == 0
