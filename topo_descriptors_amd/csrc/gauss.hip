@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "atan.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 
 #include <cmath>
@@ -48,6 +49,7 @@ struct GaussArgs {
     int* wild_flag;     // fused kernel: set to 1 when it stages a sample that is not a plain finite one
     uint32_t* wild_host;  // ... and this pinned host word of the DEM's memo entry (dem_memo_wild), or nullptr
     const int* run_if;  // two-pass f16 kernels behind a fused launch: return at once unless *run_if != 0 (nullptr: run)
+    const float* wtab;  // split-once kernels: W[5][64], the taps an output lays over each slab of 64 (behind the plain taps)
 };
 
 // Register tiling shared by both axes: a thread produces TB consecutive outputs along the
@@ -1586,6 +1588,251 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
 }
 
 
+// ---- split once (radius 49 ... 121) ------------------------------------------------------------------------------
+// The kernels above split every sample of a tile's window into its f16 pair again for every tile: 24 vector
+// instructions per 8 samples and step, ~2/3 of a step's time with one wave per SIMD (profiles/r03_gauss_f16.txt,
+// section 5).  Here a sample is split ONCE, when it is staged: the ring in LDS holds the two f16 planes and a step is
+// two 16-byte LDS reads and its MFMAs.  For that the offset a sample is taken against cannot belong to the tile: the
+// filter axis is cut into slabs of 64 (global multiples of 64) and every sample of a slab is taken against the
+// slab's reference sample c_s of the same row (axis 1: the slab's first column) or column (axis 0).  A tile's window
+// holds up to five slabs; with W_s[o] the sum of the taps that output o lays over slab s (a table of the host,
+// float64 sums rounded once) and b the tile's own slab
+//     out = c_b + [ scale * sum_k t_k (x_k - c_s(k)) / 4  +  sum_{s != b} (c_s - c_b) W_s ]
+// - the taps sum to 1 as far as the existing kernels' "+ c" assumes it.  |x - c_s| is the relief inside 64 samples
+// (the tile kernels: inside the 288 ... 320 of a window), so the products lose less; the correction costs 2 vector
+// instructions per output and slab.  Results depend on the global slab grid only, not on how the march is cut.
+// Samples that are not plain finite ones go in as 0 and mark the tiles whose windows hold them (or hold samples taken
+// against a reference that was one), as above: the repair pass recomputes those.
+__device__ __forceinline__ int floor_div64(int a) { return a >> 6; }  // arithmetic shift: floor for negative a
+
+// W_s[o] of the lane's output position o = 0 ... 63 inside its own slab, s - b = -2, -1, +1, +2
+struct SlabWeights {
+    float w[4];
+};
+__device__ __forceinline__ SlabWeights slab_weights(const float* wtab, int o) {
+    SlabWeights r;
+    r.w[0] = wtab[0 * 64 + o];
+    r.w[1] = wtab[1 * 64 + o];
+    r.w[2] = wtab[3 * 64 + o];
+    r.w[3] = wtab[4 * 64 + o];
+    return r;
+}
+
+#ifdef TOPO_S1_STAMPS
+#define S1_STAMP(k) if (stamping) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); phase[k] += now_ - last_; last_ = now_; }
+#else
+#define S1_STAMP(k)
+#endif
+
+// Axis 1, one MFMA tile of 32 columns per step of the march, four waves (bands of 32 rows) per block.  LDS per wave:
+// hi[32][PITCH], lo[32][PITCH] (f16, PITCH = window + 8: the 16-byte reads of 16 rows fall into different bank groups)
+// and the references of 8 slabs x 32 rows.
+template <int S, int NP, int NW>
+__global__ __launch_bounds__(64 * NW) void gauss_axis1_s1_kernel(GaussArgs p, int rows, int nseg) {
+    extern __shared__ __attribute__((aligned(16))) float L[];
+    constexpr int Rp = 8 * (S - 2), RC = 16 * S, PITCH = RC + 8, NSIDE = (Rp + 63) / 64;
+    constexpr int kStay = RC / 32;
+    constexpr int kWaveFloats = 32 * PITCH + 8 * 32;  // two f16 planes = 32 x PITCH floats, then the references
+    static_assert(S % 2 == 0 && NSIDE <= 2, "whole 16-column steps on both sides of the tile, at most 5 slabs");
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int R = p.radius;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    _Float16* const hi = reinterpret_cast<_Float16*>(L + wave * kWaveFloats);
+    _Float16* const lo = hi + 32 * PITCH;
+    float* const ctab = L + wave * kWaveFloats + 32 * PITCH;
+    const int gw = blockIdx.x * NW + wave;
+    const int band = gw / nseg, seg = gw - band * nseg;
+    const int r0 = band * 32;
+    if (r0 >= rows) return;
+    if (p.run_if && *p.run_if == 0) return;
+    const int i = lane & 31, g = lane >> 5;
+    const int ntile = (p.nx + 31) / 32;
+    const int tper = (ntile + nseg - 1) / nseg;
+    const int t_first = seg * tper, t_last = min(t_first + tper, ntile);
+    if (t_first >= t_last) return;
+#ifdef TOPO_S1_STAMPS
+    const bool stamping = p.wild_flag != nullptr && gw == 517;
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
+    f16x8 twh[S], twl[S];
+    build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
+    const SlabWeights w_even = slab_weights(p.wtab, i), w_odd = slab_weights(p.wtab, 32 + i);
+    const bool full_band = r0 + 32 <= rows;
+    const float* const lrow = p.in + (size_t)min(r0 + i, rows - 1) * p.nx;  // the loader's row: lane & 31
+    // 8 consecutive columns from `col` of the loader's row (reflected at the DEM's edges)
+    auto load8 = [&](int col, float (&x)[8]) {
+        if (col >= 0 && col + 8 <= p.nx) {
+            const f4 a = *reinterpret_cast<const f4*>(lrow + col), b = *reinterpret_cast<const f4*>(lrow + col + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = a[e];
+                x[4 + e] = b[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = lrow[reflect_index(col + e, p.nx)];
+        }
+    };
+    const f32x2 quarter = {0.25f, 0.25f};
+    // split the 8 samples against the reference of their slab and put the pair into the ring at `slot`
+    auto stage8 = [&](float (&x)[8], int col, int slot, bool& bad, bool& ref_bad) {
+        const bool first = (col & 63) == 0;
+        ref_bad |= first && wild(x[0]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool w = wild(x[e]);
+            bad |= w;
+            x[e] = w ? 0.0f : x[e];
+        }
+        const int sl = floor_div64(col) & 7;
+        if (first) ctab[sl * 32 + i] = x[0];  // the slab's first column: its reference from here on
+        __builtin_amdgcn_wave_barrier();
+        const float c = ctab[sl * 32 + i];
+        const f32x2 mcq = {-0.25f * c, -0.25f * c};
+        f16x8 dh, dl;
+        split8(x, quarter, mcq, dh, dl);
+        *reinterpret_cast<f16x8*>(hi + i * PITCH + slot) = dh;
+        *reinterpret_cast<f16x8*>(lo + i * PITCH + slot) = dl;
+    };
+    unsigned ref_wild = 0;  // slabs (slot bits) whose reference column holds a sample that is not a plain finite one
+    int last_wild = kNoWild;
+    {
+        const int x_start = t_first * 32 - Rp;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ctab[lane * 4 + k] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        // the references of the slabs the first window holds: the first one starts left of the window (the others are
+        // written again, with the same value, when their first column is staged)
+        unsigned used = 0;
+        for (int s = floor_div64(x_start); s <= floor_div64(x_start + RC - 1); ++s) {
+            const float v = lrow[reflect_index(64 * s, p.nx)];
+            const bool w = wild(v);
+            if (g == 0) ctab[(s & 7) * 32 + i] = w ? 0.0f : v;
+            if (__builtin_amdgcn_ballot_w64(w)) ref_wild |= 1u << (s & 7);
+            used |= 1u << (s & 7);
+        }
+        __builtin_amdgcn_wave_barrier();
+        bool bad = false, ref_bad = false;  // (ref_bad: covered by the loop above)
+        for (int k0 = 0; k0 < RC; k0 += 16) {
+            float x[8];
+            const int col = x_start + k0 + 8 * g;
+            load8(col, x);
+            stage8(x, col, k0 + 8 * g, bad, ref_bad);
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & used)) last_wild = t_first + kStay - 1;
+    }
+    int base = 0;  // ring column of input column x0 - Rp
+    const unsigned out_lane_off = (unsigned)(4 * g * p.nx + i) * 4u;
+    const _Float16* const ah = hi + i * PITCH + 8 * g;
+    const _Float16* const al = lo + i * PITCH + 8 * g;
+    S1_STAMP(0)
+    for (int t = t_first; t < t_last; ++t) {
+        const int x0 = t * 32;
+        const bool more = t + 1 < t_last;
+        const int n0 = x0 + 32 + Rp;  // the columns the next tile adds; this lane: n0 + 16 g + 8 u, u = 0, 1
+        float pre[2][8];
+        if (more) {
+            load8(n0 + 16 * g, pre[0]);
+            load8(n0 + 16 * g + 8, pre[1]);
+        }
+        S1_STAMP(1)
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        // the operands of a step are requested two steps ahead (three buffers; the scheduling barrier keeps the compiler
+        // from sinking the reads to their use: the wave, alone on its SIMD, would wait out the LDS latency every step)
+        int slot = base;
+        f16x8 bh[3], bl[3];
+        auto fetch = [&](int k) {
+            bh[k] = *reinterpret_cast<const f16x8*>(ah + slot);
+            bl[k] = *reinterpret_cast<const f16x8*>(al + slot);
+            slot += 16;
+            slot = slot >= RC ? slot - RC : slot;
+        };
+        fetch(0);
+        fetch(1);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s + 2 < S) fetch((s + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            f16_products<true, NP>(twh[s], twl[s], bh[s % 3], bl[s % 3], acc);
+        }
+#ifdef TOPO_S1_STAMPS
+        if (stamping) {
+            asm volatile("s_nop 0" ::"v"(acc[0]));
+            S1_STAMP(2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            S1_STAMP(3)
+        }
+#endif
+        if (more) {
+            bool bad = false, ref_bad = false;
+            int sl = base + 16 * g;  // over the oldest columns
+            sl = sl >= RC ? sl - RC : sl;
+            stage8(pre[0], n0 + 16 * g, sl, bad, ref_bad);
+            stage8(pre[1], n0 + 16 * g + 8, sl + 8, bad, ref_bad);
+            // a slab that starts inside these 32 columns takes over the slot of the slab 8 before it
+            const int cfirst = (n0 + 63) & ~63;  // the first multiple of 64 at or after n0
+            if (cfirst < n0 + 32) {
+                if (__builtin_amdgcn_ballot_w64(ref_bad)) ref_wild |= 1u << (floor_div64(cfirst) & 7);
+                else ref_wild &= ~(1u << (floor_div64(cfirst) & 7));
+            }
+            const unsigned used = (1u << (floor_div64(n0) & 7)) | (1u << (floor_div64(n0 + 31) & 7));
+            if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & used)) last_wild = t + kStay;
+        }
+        S1_STAMP(4)
+        // the correction: the other slabs' references against the tile's own
+        const int b = x0 >> 6;
+        const SlabWeights& W = (x0 & 32) ? w_odd : w_even;
+        float cb[16], corr[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f4 v4 = *reinterpret_cast<const f4*>(ctab + (b & 7) * 32 + 8 * q + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cb[4 * q + e] = v4[e];
+                corr[4 * q + e] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int d = -NSIDE; d <= NSIDE; ++d) {
+            if (d == 0) continue;
+            const float wd = W.w[d < 0 ? d + 2 : d + 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 v4 = *reinterpret_cast<const f4*>(ctab + ((b + d) & 7) * 32 + 8 * q + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) corr[4 * q + e] = fmaf(v4[e] - cb[4 * q + e], wd, corr[4 * q + e]);
+            }
+        }
+        if (lane == 0) p.flags[(size_t)band * ntile + t] = last_wild >= t ? 1 : 0;
+        const int ox = x0 + i;  // D: column = lane & 31, rows (v & 3) + 8 (v >> 2) + 4 g
+        if (ox < p.nx) {
+            if (full_band) {
+                char* ub = reinterpret_cast<char*>(p.out + (size_t)r0 * p.nx + x0);
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + out_lane_off) = fmaf(acc[v], p.out_scale, corr[v]) + cb[v];
+            } else {
+                float* o = p.out + (size_t)(r0 + 4 * g) * p.nx + ox;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int ri = (v & 3) + 8 * (v >> 2);
+                    if (r0 + 4 * g + ri < rows) o[(size_t)ri * p.nx] = fmaf(acc[v], p.out_scale, corr[v]) + cb[v];
+                }
+            }
+        }
+        S1_STAMP(5)
+        base += 32;
+        base = base >= RC ? base - RC : base;
+    }
+#ifdef TOPO_S1_STAMPS
+    if (stamping && lane == 0)
+        for (int k = 0; k < 8; ++k) reinterpret_cast<unsigned long long*>(p.wild_flag)[k] = phase[k];
+#endif
+}
+
+
 // Both passes of a short isotropic filter (radius 4 ... 16: 4 steps of 16 taps per 32-output tile) in ONE kernel:
 // the intermediate plane (4 B written + 4 B read per pixel out of 16) stays in LDS.  A block owns 4 bands of 32
 // rows (global multiples of 32) and marches along x in blocks of 64 columns.  Per step: the block's 160 raw rows
@@ -1925,9 +2172,25 @@ int upload_weights(int slot, double sigma, int kb, GaussArgs* a) {
     const int nchunks = (2 * R + 1 + kb - 1) / kb;
     std::vector<float> padded((size_t)nchunks * kb, 0.0f);
     for (int k = 0; k <= 2 * R; ++k) padded[k] = (float)(w[k] / sum);
+    // behind the plain taps (kb == 1): the slab table of the split-once kernels, W[d + 2][o] = the sum of the (float32)
+    // taps that the output at position o = 0 ... 63 of its slab lays over the slab d slabs further on
+    const size_t ntaps = padded.size();
+    if (kb == 1) {
+        padded.resize(ntaps + 5 * 64, 0.0f);
+        for (int d = -2; d <= 2; ++d)
+            for (int o = 0; o < 64; ++o) {
+                double acc = 0.0;
+                for (int k = 64 * d; k < 64 * d + 64; ++k) {
+                    const int q = k - o + R;
+                    if (q >= 0 && q <= 2 * R) acc += (double)padded[q];
+                }
+                padded[ntaps + (size_t)(d + 2) * 64 + o] = (float)acc;
+            }
+    }
     void* d = nullptr;
     TOPO_TRY(upload_table(slot, padded.data(), padded.size() * sizeof(float), &d));
     a->taps = (const float*)d;
+    a->wtab = kb == 1 ? (const float*)d + ntaps : nullptr;
     a->radius = R;
     a->nchunks = nchunks;
     return TOPO_AMD_OK;
@@ -2061,6 +2324,39 @@ int launch_f16_axis1(long waves, const GaussArgs& a, int rows, int nseg) {
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
+// split once (gauss_axis*_s1_kernel): radius 49 ... 121.  TOPO_AMD_GAUSS_SPLIT_ONCE=0: the tile kernels everywhere (A/B)
+bool split_once(int steps) {
+    static const bool on = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_SPLIT_ONCE");
+        return !(e && *e == '0');
+    }();
+    return on && steps >= 10;
+}
+template <int S>
+int launch_s1_axis1(long waves, const GaussArgs& a, int rows, int nseg) {
+    Context& c = ctx();
+    constexpr int NW = 4;
+    static bool ready = false;
+    if (!ready) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_s1_kernel<S, TOPO_F16_NP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ready = true;
+    }
+    const size_t lds = NW * (size_t)(32 * (16 * S + 8) + 8 * 32) * sizeof(float);
+    hipLaunchKernelGGL((gauss_axis1_s1_kernel<S, TOPO_F16_NP, NW>), dim3((unsigned)((waves + NW - 1) / NW)), dim3(64 * NW), lds, c.compute, a, rows, nseg);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+int launch_s1_axis1_any(int steps, long waves, const GaussArgs& a, int rows, int nseg) {
+    switch (steps) {
+        case 10: return launch_s1_axis1<10>(waves, a, rows, nseg);
+        case 12: return launch_s1_axis1<12>(waves, a, rows, nseg);
+        case 14: return launch_s1_axis1<14>(waves, a, rows, nseg);
+        case 16: return launch_s1_axis1<16>(waves, a, rows, nseg);
+        case 18: return launch_s1_axis1<18>(waves, a, rows, nseg);
+    }
+    set_error("gaussian (split-once matrix-core route): no kernel for this radius");
+    return TOPO_AMD_EUNSUP;
+}
 #define TOPO_F16_STEPS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
 int launch_f16_axis0_any(int steps, int mt, dim3 grid, const GaussArgs& a, int tile_first, int ntiles, int per) {
     switch (steps) {
@@ -2119,7 +2415,9 @@ int run_axis1_f16(GaussArgs a, int rows, int nx, double sigma) {
     set_f16_scales(sigma, &a);
     a.run_if = t_run_if;
     a.wild_flag = nullptr;
-    const int steps = f16_steps(a.radius), mt = f16_mt(true, a.radius);
+    const int steps = f16_steps(a.radius);
+    const bool s1 = split_once(steps);
+    const int mt = s1 ? 1 : f16_mt(true, a.radius);
     const int nw = steps == 18 && mt == 2 ? 3 : 4;
     const int bands = (rows + 31) / 32;
     const int ntile = (nx + 32 * mt - 1) / (32 * mt), nunit = (nx + 31) / 32;
@@ -2142,7 +2440,22 @@ int run_axis1_f16(GaussArgs a, int rows, int nx, double sigma) {
     void* flags = nullptr;
     TOPO_TRY(workspace(10, (size_t)units, &flags));
     a.flags = (unsigned char*)flags;
-    TOPO_TRY(launch_f16_axis1_any(steps, mt, waves, a, rows, nseg));
+#ifdef TOPO_S1_STAMPS
+    if (s1 && std::getenv("TOPO_AMD_S1_STAMPS")) {
+        void* st = nullptr;
+        TOPO_TRY(workspace(11, 64, &st));
+        TOPO_HIP(hipMemsetAsync(st, 0, 64, c.compute));
+        a.wild_flag = (int*)st;
+        TOPO_TRY(launch_s1_axis1_any(steps, waves, a, rows, nseg));
+        unsigned long long ph[8];
+        TOPO_HIP(hipMemcpyAsync(ph, st, 64, hipMemcpyDeviceToHost, c.compute));
+        TOPO_HIP(hipStreamSynchronize(c.compute));
+        std::fprintf(stderr, "s1 axis1 stamps (s_memtime ticks): runin %llu loads %llu steps %llu wait %llu stage %llu store %llu\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+        a.wild_flag = nullptr;
+    } else
+#endif
+    if (s1) TOPO_TRY(launch_s1_axis1_any(steps, waves, a, rows, nseg));
+    else TOPO_TRY(launch_f16_axis1_any(steps, mt, waves, a, rows, nseg));
     hipLaunchKernelGGL(gauss_f16_repair_kernel<true>, dim3((unsigned)std::min<long>(kRepairBlocks, (units + 63) / 64)), dim3(64), 0, c.compute,
                        a, bands, nunit, 0, rows);
     TOPO_HIP(hipGetLastError());
