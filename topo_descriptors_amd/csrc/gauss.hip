@@ -50,6 +50,7 @@ struct GaussArgs {
     uint32_t* wild_host;  // ... and this pinned host word of the DEM's memo entry (dem_memo_wild), or nullptr
     const int* run_if;  // two-pass f16 kernels behind a fused launch: return at once unless *run_if != 0 (nullptr: run)
     const float* wtab;  // split-once kernels: W[5][64], the taps an output lays over each slab of 64 (behind the plain taps)
+    int fine_rows, fine_cols;  // split-once kernels: flags is [fine_rows][fine_cols], one byte per 16 x 16 tile (0: one per 32 x 32)
 };
 
 // Register tiling shared by both axes: a thread produces TB consecutive outputs along the
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
         if (more) {
             const int n0 = x0 - R + K8;  // the 32 columns the next tile adds
             if (full_band && n0 >= 0 && n0 + 32 <= p.nx) {  // scalar base + the per-lane byte offset: see axis 0
-                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)r0 * p.nx + n0);
+                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)min(r0, rows - 32) * p.nx + max(0, min(n0, p.nx - 32)));
 #pragma unroll
                 for (int q = 0; q < 16; ++q) pre[q] = *reinterpret_cast<const float*>(rb + (size_t)(2 * q) * p.nx * 4 + in_lane_off);
             } else {
@@ -1488,7 +1489,7 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
         if (more) {
             const int n0 = x0 - Rp + RC;  // the columns the next tile adds
             if (full_band && n0 >= 0 && n0 + TILE <= p.nx) {
-                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)r0 * p.nx + n0);
+                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)min(r0, rows - 32) * p.nx + max(0, min(n0, p.nx - 32)));
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1624,29 +1625,83 @@ __device__ __forceinline__ SlabWeights slab_weights(const float* wtab, int o) {
 #define S1_STAMP(k)
 #endif
 
-// Axis 1, one MFMA tile of 32 columns per step of the march, four waves (bands of 32 rows) per block.  LDS per wave:
-// hi[32][PITCH], lo[32][PITCH] (f16, PITCH = window + 8: the 16-byte reads of 16 rows fall into different bank groups)
-// and the references of 8 slabs x 32 rows.
-template <int S, int NP, int NW>
-__global__ __launch_bounds__(64 * NW) void gauss_axis1_s1_kernel(GaussArgs p, int rows, int nseg) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// 4 samples -> (x - c) / 4 -> f16 pairs (split8's arithmetic)
+__device__ __forceinline__ void split4(const float (&x)[4], float mcq, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const f32x2 d = {__builtin_fmaf(x[2 * u], 0.25f, mcq), __builtin_fmaf(x[2 * u + 1], 0.25f, mcq)};
+        const f32x2 hf = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, d) & u32x2{0xFFFFE000u, 0xFFFFE000u});
+        const f32x2 r = {d[0] - hf[0], d[1] - hf[1]};
+        const f16x2 hh = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(hf[0], hf[1]));  // exact: hf has 11 bits
+        const f16x2 ll = __builtin_convertvector(r, f16x2);                                     // to nearest
+        hi[2 * u] = hh[0];
+        hi[2 * u + 1] = hh[1];
+        lo[2 * u] = ll[0];
+        lo[2 * u + 1] = ll[1];
+    }
+}
+
+// the Toeplitz factor of a 16-output tile for v_mfma_f32_16x16x32_f16: lane (n = lane & 15, kg = lane >> 4) of step s
+// holds the taps that window position m = 32 s + 8 kg + q, q = 0 ... 7, has for output n: tap index m - n - (Rp - R)
+template <int NK>
+__device__ __forceinline__ void build_tap_blocks16(const float* taps, int R, float scale, int lane, f16x8 (&hi)[NK], f16x8 (&lo)[NK]) {
+    const int n = lane & 15, kg = lane >> 4, Rp = 16 * (NK - 1);
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = 32 * s + 8 * kg + q - n - (Rp - R);
+            const float t = (k >= 0 && k <= 2 * R) ? taps[k] * scale : 0.0f;
+            const _Float16 th = (_Float16)t;
+            hi[s][q] = th;
+            lo[s][q] = (_Float16)(t - (float)th);
+        }
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void f16_products16(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4& acc) {
+    // (a = the A operand's pair, b = the B operand's; the cross product with the taps' low part first, like f16_products)
+    if (NP >= 4) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+}
+
+// Axis 1.  A wave owns a band of 16 rows and marches along x in tiles of 16 columns (v_mfma_f32_16x16x32_f16: the
+// rate of the 32 x 32 x 16 form per multiply-add); its ring - hi[16][PITCH], lo[16][PITCH] in f16, PITCH = window + 8 -
+// is half the size of a 32-row band's, so EIGHT waves fit a CU: two per SIMD, one wave's staging, correction and
+// stores under the other's MFMAs (what a wave alone on its SIMD does not do for itself: r03_gauss_f16.txt, section 5).
+// Window of the tile at x0: [x0 - Rp, x0 - Rp + 32 NK), Rp = 16 (NK - 1) >= R, NK steps of 32 (the last 16 columns carry
+// zero taps).  The loader takes the 16 new columns of the next tile as one 16-byte load per lane (lane -> row lane >> 2,
+// columns 4 (lane & 3) ...: 16 rows x 64 B), a tile ahead.  The 16 columns lie in one slab; a slab starts with them when
+// they start on a multiple of 64.  LDS: 8 x (ring + references of 8 slabs x 16 rows) + the slab table W.
+// Flags: one byte per 16 x 16 tile, [band][tile]; the repair pass takes the four of a 32 x 32 unit together.
+template <int NK, int NP>
+__global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int rows, int nseg) {
     extern __shared__ __attribute__((aligned(16))) float L[];
-    constexpr int Rp = 8 * (S - 2), RC = 16 * S, PITCH = RC + 8, NSIDE = (Rp + 63) / 64;
-    constexpr int kStay = RC / 32;
-    constexpr int kWaveFloats = 32 * PITCH + 8 * 32;  // two f16 planes = 32 x PITCH floats, then the references
-    static_assert(S % 2 == 0 && NSIDE <= 2, "whole 16-column steps on both sides of the tile, at most 5 slabs");
+    constexpr int Rp = 16 * (NK - 1), RC = 32 * NK, PITCH = RC + 8, NSIDE = (Rp + 63) / 64;
+    constexpr int kStay = RC / 16;                    // tiles whose window holds a group of 16 columns
+    constexpr int kWaveFloats = 16 * PITCH + 8 * 16;  // two f16 planes = 16 x PITCH floats, then the references
+    static_assert(NSIDE <= 2, "at most 5 slabs per window");
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int R = p.radius;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const wlds = L + 8 * kWaveFloats;  // W[5][64]
+    for (int k = threadIdx.x; k < 5 * 64; k += 512) wlds[k] = p.wtab[k];
+    __syncthreads();
     _Float16* const hi = reinterpret_cast<_Float16*>(L + wave * kWaveFloats);
-    _Float16* const lo = hi + 32 * PITCH;
-    float* const ctab = L + wave * kWaveFloats + 32 * PITCH;
-    const int gw = blockIdx.x * NW + wave;
+    _Float16* const lo = hi + 16 * PITCH;
+    float* const ctab = L + wave * kWaveFloats + 16 * PITCH;  // [8 slabs][16 rows]
+    const int gw = blockIdx.x * 8 + wave;
     const int band = gw / nseg, seg = gw - band * nseg;
-    const int r0 = band * 32;
+    const int r0 = band * 16;
     if (r0 >= rows) return;
     if (p.run_if && *p.run_if == 0) return;
-    const int i = lane & 31, g = lane >> 5;
-    const int ntile = (p.nx + 31) / 32;
+    const int ntile = (p.nx + 15) / 16;
     const int tper = (ntile + nseg - 1) / nseg;
     const int t_first = seg * tper, t_last = min(t_first + tper, ntile);
     if (t_first >= t_last) return;
@@ -1654,108 +1709,104 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_s1_kernel(GaussArgs p, in
     const bool stamping = p.wild_flag != nullptr && gw == 517;
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
-    f16x8 twh[S], twl[S];
-    build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
-    const SlabWeights w_even = slab_weights(p.wtab, i), w_odd = slab_weights(p.wtab, 32 + i);
-    const bool full_band = r0 + 32 <= rows;
-    const float* const lrow = p.in + (size_t)min(r0 + i, rows - 1) * p.nx;  // the loader's row: lane & 31
-    // 8 consecutive columns from `col` of the loader's row (reflected at the DEM's edges)
-    auto load8 = [&](int col, float (&x)[8]) {
-        if (col >= 0 && col + 8 <= p.nx) {
-            const f4 a = *reinterpret_cast<const f4*>(lrow + col), b = *reinterpret_cast<const f4*>(lrow + col + 4);
+    f16x8 twh[NK], twl[NK];
+    build_tap_blocks16<NK>(p.taps, R, p.tap_scale, lane, twh, twl);
+    const bool full_band = r0 + 16 <= rows;
+    const int lr = lane >> 2, lc = 4 * (lane & 3);  // loader: row of the band, first of its 4 columns in the group
+    const float* const lrow = p.in + (size_t)min(r0 + lr, rows - 1) * p.nx;
+    auto load4 = [&](int col) {
+        if (col >= 0 && col + 4 <= p.nx) return *reinterpret_cast<const f4*>(lrow + col);
+        f4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                x[e] = a[e];
-                x[4 + e] = b[e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = lrow[reflect_index(col + e, p.nx)];
-        }
+        for (int e = 0; e < 4; ++e) v[e] = lrow[reflect_index(col + e, p.nx)];
+        return v;
     };
-    const f32x2 quarter = {0.25f, 0.25f};
-    // split the 8 samples against the reference of their slab and put the pair into the ring at `slot`
-    auto stage8 = [&](float (&x)[8], int col, int slot, bool& bad, bool& ref_bad) {
-        const bool first = (col & 63) == 0;
-        ref_bad |= first && wild(x[0]);
+    // the 16 columns from `col0` (a multiple of 16), this lane's four in v, into the ring at `slot`; c_old: the reference
+    // of their slab as the table has it (read ahead of time; not used when the slab starts here)
+    auto stage = [&](f4 v, int col0, int slot, float c_old, bool& bad, bool& ref_bad) {
+        float x[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool w = wild(x[e]);
+        for (int e = 0; e < 4; ++e) {
+            const bool w = wild(v[e]);
             bad |= w;
-            x[e] = w ? 0.0f : x[e];
+            x[e] = w ? 0.0f : v[e];
         }
-        const int sl = floor_div64(col) & 7;
-        if (first) ctab[sl * 32 + i] = x[0];  // the slab's first column: its reference from here on
-        __builtin_amdgcn_wave_barrier();
-        const float c = ctab[sl * 32 + i];
-        const f32x2 mcq = {-0.25f * c, -0.25f * c};
-        f16x8 dh, dl;
-        split8(x, quarter, mcq, dh, dl);
-        *reinterpret_cast<f16x8*>(hi + i * PITCH + slot) = dh;
-        *reinterpret_cast<f16x8*>(lo + i * PITCH + slot) = dl;
+        float c = c_old;
+        if ((col0 & 63) == 0) {  // (wave-uniform) the slab's first column: lane & 3 == 0 of every row holds its reference
+            ref_bad |= (lane & 3) == 0 && wild(v[0]);
+            c = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[0]), 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, false));
+            if ((lane & 3) == 0) ctab[(floor_div64(col0) & 7) * 16 + lr] = c;
+        }
+        f16x4 dh, dl;
+        split4(x, -0.25f * c, dh, dl);
+        *reinterpret_cast<f16x4*>(hi + lr * PITCH + slot + lc) = dh;
+        *reinterpret_cast<f16x4*>(lo + lr * PITCH + slot + lc) = dl;
     };
     unsigned ref_wild = 0;  // slabs (slot bits) whose reference column holds a sample that is not a plain finite one
     int last_wild = kNoWild;
     {
-        const int x_start = t_first * 32 - Rp;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ctab[lane * 4 + k] = 0.0f;
+        const int x_start = t_first * 16 - Rp;
+        ctab[lane] = 0.0f;
+        ctab[64 + lane] = 0.0f;
         __builtin_amdgcn_wave_barrier();
-        // the references of the slabs the first window holds: the first one starts left of the window (the others are
+        // the references of the slabs the first window holds: the first one may start left of the window (the others are
         // written again, with the same value, when their first column is staged)
         unsigned used = 0;
         for (int s = floor_div64(x_start); s <= floor_div64(x_start + RC - 1); ++s) {
             const float v = lrow[reflect_index(64 * s, p.nx)];
             const bool w = wild(v);
-            if (g == 0) ctab[(s & 7) * 32 + i] = w ? 0.0f : v;
+            if ((lane & 3) == 0) ctab[(s & 7) * 16 + lr] = w ? 0.0f : v;
             if (__builtin_amdgcn_ballot_w64(w)) ref_wild |= 1u << (s & 7);
             used |= 1u << (s & 7);
         }
         __builtin_amdgcn_wave_barrier();
         bool bad = false, ref_bad = false;  // (ref_bad: covered by the loop above)
-        for (int k0 = 0; k0 < RC; k0 += 16) {
-            float x[8];
-            const int col = x_start + k0 + 8 * g;
-            load8(col, x);
-            stage8(x, col, k0 + 8 * g, bad, ref_bad);
+        for (int k0 = 0; k0 < RC; k0 += 64) {  // four groups in flight
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + 16 * u < RC) v[u] = load4(x_start + k0 + 16 * u + lc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + 16 * u < RC) {
+                    const int col0 = x_start + k0 + 16 * u;
+                    stage(v[u], col0, k0 + 16 * u, ctab[(floor_div64(col0) & 7) * 16 + lr], bad, ref_bad);
+                }
         }
         if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & used)) last_wild = t_first + kStay - 1;
     }
     int base = 0;  // ring column of input column x0 - Rp
-    const unsigned out_lane_off = (unsigned)(4 * g * p.nx + i) * 4u;
-    const _Float16* const ah = hi + i * PITCH + 8 * g;
-    const _Float16* const al = lo + i * PITCH + 8 * g;
+    const int n = lane & 15, kg = lane >> 4;
+    const _Float16* const ah = hi + n * PITCH + 8 * kg;  // A: row n of the band, 8 window positions from 8 kg
+    const _Float16* const al = lo + n * PITCH + 8 * kg;
     S1_STAMP(0)
     for (int t = t_first; t < t_last; ++t) {
-        const int x0 = t * 32;
+        const int x0 = t * 16;
         const bool more = t + 1 < t_last;
-        const int n0 = x0 + 32 + Rp;  // the columns the next tile adds; this lane: n0 + 16 g + 8 u, u = 0, 1
-        float pre[2][8];
+        const int n0 = x0 - Rp + RC;  // the 16 columns the next tile adds
+        f4 pre;
+        float c_next = 0.0f;
         if (more) {
-            load8(n0 + 16 * g, pre[0]);
-            load8(n0 + 16 * g + 8, pre[1]);
+            pre = load4(n0 + lc);
+            c_next = ctab[(floor_div64(n0) & 7) * 16 + lr];
         }
         S1_STAMP(1)
-        f32x16 acc;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-        // the operands of a step are requested two steps ahead (three buffers; the scheduling barrier keeps the compiler
-        // from sinking the reads to their use: the wave, alone on its SIMD, would wait out the LDS latency every step)
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         int slot = base;
         f16x8 bh[3], bl[3];
         auto fetch = [&](int k) {
             bh[k] = *reinterpret_cast<const f16x8*>(ah + slot);
             bl[k] = *reinterpret_cast<const f16x8*>(al + slot);
-            slot += 16;
+            slot += 32;
             slot = slot >= RC ? slot - RC : slot;
         };
         fetch(0);
-        fetch(1);
+        if (NK > 1) fetch(1);
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (s + 2 < S) fetch((s + 2) % 3);
+        for (int s = 0; s < NK; ++s) {
+            if (s + 2 < NK) fetch((s + 2) % 3);
             __builtin_amdgcn_sched_barrier(0);
-            f16_products<true, NP>(twh[s], twl[s], bh[s % 3], bl[s % 3], acc);
+            f16_products16<NP>(bh[s % 3], bl[s % 3], twh[s], twl[s], acc);
         }
 #ifdef TOPO_S1_STAMPS
         if (stamping) {
@@ -1767,63 +1818,36 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_s1_kernel(GaussArgs p, in
 #endif
         if (more) {
             bool bad = false, ref_bad = false;
-            int sl = base + 16 * g;  // over the oldest columns
-            sl = sl >= RC ? sl - RC : sl;
-            stage8(pre[0], n0 + 16 * g, sl, bad, ref_bad);
-            stage8(pre[1], n0 + 16 * g + 8, sl + 8, bad, ref_bad);
-            // a slab that starts inside these 32 columns takes over the slot of the slab 8 before it
-            const int cfirst = (n0 + 63) & ~63;  // the first multiple of 64 at or after n0
-            if (cfirst < n0 + 32) {
-                if (__builtin_amdgcn_ballot_w64(ref_bad)) ref_wild |= 1u << (floor_div64(cfirst) & 7);
-                else ref_wild &= ~(1u << (floor_div64(cfirst) & 7));
+            stage(pre, n0, base, c_next, bad, ref_bad);  // over the oldest 16 columns
+            if ((n0 & 63) == 0) {  // the slab that starts here takes over the slot of the slab 8 before it
+                if (__builtin_amdgcn_ballot_w64(ref_bad)) ref_wild |= 1u << (floor_div64(n0) & 7);
+                else ref_wild &= ~(1u << (floor_div64(n0) & 7));
             }
-            const unsigned used = (1u << (floor_div64(n0) & 7)) | (1u << (floor_div64(n0 + 31) & 7));
-            if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & used)) last_wild = t + kStay;
+            if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & (1u << (floor_div64(n0) & 7)))) last_wild = t + kStay;
         }
         S1_STAMP(4)
-        // the correction: the other slabs' references against the tile's own
-        const int b = x0 >> 6;
-        const SlabWeights& W = (x0 & 32) ? w_odd : w_even;
-        float cb[16], corr[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f4 v4 = *reinterpret_cast<const f4*>(ctab + (b & 7) * 32 + 8 * q + 4 * g);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                cb[4 * q + e] = v4[e];
-                corr[4 * q + e] = 0.0f;
-            }
-        }
+        // the correction: the other slabs' references against the tile's own.  D: column n, rows 4 kg + v
+        const int b = x0 >> 6, o = (x0 & 63) + n;
+        const f4 cb = *reinterpret_cast<const f4*>(ctab + (b & 7) * 16 + 4 * kg);
+        f4 corr = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int d = -NSIDE; d <= NSIDE; ++d) {
             if (d == 0) continue;
-            const float wd = W.w[d < 0 ? d + 2 : d + 1];
+            const float wd = wlds[(d + 2) * 64 + o];
+            const f4 cs = *reinterpret_cast<const f4*>(ctab + ((b + d) & 7) * 16 + 4 * kg);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4 v4 = *reinterpret_cast<const f4*>(ctab + ((b + d) & 7) * 32 + 8 * q + 4 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) corr[4 * q + e] = fmaf(v4[e] - cb[4 * q + e], wd, corr[4 * q + e]);
-            }
+            for (int e = 0; e < 4; ++e) corr[e] = fmaf(cs[e] - cb[e], wd, corr[e]);
         }
         if (lane == 0) p.flags[(size_t)band * ntile + t] = last_wild >= t ? 1 : 0;
-        const int ox = x0 + i;  // D: column = lane & 31, rows (v & 3) + 8 (v >> 2) + 4 g
+        const int ox = x0 + n;
         if (ox < p.nx) {
-            if (full_band) {
-                char* ub = reinterpret_cast<char*>(p.out + (size_t)r0 * p.nx + x0);
+            float* o0 = p.out + (size_t)(r0 + 4 * kg) * p.nx + ox;
 #pragma unroll
-                for (int v = 0; v < 16; ++v)
-                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + out_lane_off) = fmaf(acc[v], p.out_scale, corr[v]) + cb[v];
-            } else {
-                float* o = p.out + (size_t)(r0 + 4 * g) * p.nx + ox;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int ri = (v & 3) + 8 * (v >> 2);
-                    if (r0 + 4 * g + ri < rows) o[(size_t)ri * p.nx] = fmaf(acc[v], p.out_scale, corr[v]) + cb[v];
-                }
-            }
+            for (int v = 0; v < 4; ++v)
+                if (full_band || r0 + 4 * kg + v < rows) o0[(size_t)v * p.nx] = fmaf(acc[v], p.out_scale, corr[v]) + cb[v];
         }
         S1_STAMP(5)
-        base += 32;
+        base += 16;
         base = base >= RC ? base - RC : base;
     }
 #ifdef TOPO_S1_STAMPS
@@ -2110,7 +2134,18 @@ __global__ __launch_bounds__(64) void gauss_f16_repair_kernel(GaussArgs p, int u
     };
     for (long base = (long)blockIdx.x * 64; base < units; base += (long)gridDim.x * 64) {
         const long mine = base + lane;
-        unsigned long long marked = __builtin_amdgcn_ballot_w64(mine < units && p.flags[mine < units ? mine : 0] != 0);
+        bool mark = false;
+        if (mine < units) {
+            if (p.fine_cols == 0) {
+                mark = p.flags[mine] != 0;
+            } else {  // the four 16 x 16 tiles of the unit
+                const int fa = (int)(mine / units_b) * 2, fb = (int)(mine % units_b) * 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (fa + (e >> 1) < p.fine_rows && fb + (e & 1) < p.fine_cols) mark |= p.flags[(size_t)(fa + (e >> 1)) * p.fine_cols + fb + (e & 1)] != 0;
+            }
+        }
+        unsigned long long marked = __builtin_amdgcn_ballot_w64(mark);
         while (marked) {
             const int bit = __builtin_ctzll(marked);
             marked &= marked - 1;
@@ -2332,27 +2367,28 @@ bool split_once(int steps) {
     }();
     return on && steps >= 10;
 }
-template <int S>
+// NK steps of 32 window positions per 16-output tile: Rp = 16 (NK - 1) >= R
+int s1_steps(int R) { return (R + 15) / 16 + 1; }
+template <int NK>
 int launch_s1_axis1(long waves, const GaussArgs& a, int rows, int nseg) {
     Context& c = ctx();
-    constexpr int NW = 4;
     static bool ready = false;
     if (!ready) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_s1_kernel<S, TOPO_F16_NP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_s1_kernel<NK, TOPO_F16_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ready = true;
     }
-    const size_t lds = NW * (size_t)(32 * (16 * S + 8) + 8 * 32) * sizeof(float);
-    hipLaunchKernelGGL((gauss_axis1_s1_kernel<S, TOPO_F16_NP, NW>), dim3((unsigned)((waves + NW - 1) / NW)), dim3(64 * NW), lds, c.compute, a, rows, nseg);
+    const size_t lds = (8 * (size_t)(16 * (32 * NK + 8) + 8 * 16) + 5 * 64) * sizeof(float);
+    hipLaunchKernelGGL((gauss_axis1_s1_kernel<NK, TOPO_F16_NP>), dim3((unsigned)((waves + 7) / 8)), dim3(512), lds, c.compute, a, rows, nseg);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
-int launch_s1_axis1_any(int steps, long waves, const GaussArgs& a, int rows, int nseg) {
-    switch (steps) {
-        case 10: return launch_s1_axis1<10>(waves, a, rows, nseg);
-        case 12: return launch_s1_axis1<12>(waves, a, rows, nseg);
-        case 14: return launch_s1_axis1<14>(waves, a, rows, nseg);
-        case 16: return launch_s1_axis1<16>(waves, a, rows, nseg);
-        case 18: return launch_s1_axis1<18>(waves, a, rows, nseg);
+int launch_s1_axis1_any(int nk, long waves, const GaussArgs& a, int rows, int nseg) {
+    switch (nk) {
+        case 5: return launch_s1_axis1<5>(waves, a, rows, nseg);
+        case 6: return launch_s1_axis1<6>(waves, a, rows, nseg);
+        case 7: return launch_s1_axis1<7>(waves, a, rows, nseg);
+        case 8: return launch_s1_axis1<8>(waves, a, rows, nseg);
+        case 9: return launch_s1_axis1<9>(waves, a, rows, nseg);
     }
     set_error("gaussian (split-once matrix-core route): no kernel for this radius");
     return TOPO_AMD_EUNSUP;
@@ -2410,14 +2446,62 @@ int run_axis0_f16(const Block& b, GaussArgs a, double sigma) {
     return TOPO_AMD_OK;
 }
 
+// axis 1 on the split-once route: bands of 16 rows, tiles of 16 columns, one flag byte per tile
+int run_axis1_s1(GaussArgs a, int rows, int nx) {
+    Context& c = ctx();
+    const int nk = s1_steps(a.radius);
+    const int bands = (rows + 15) / 16, ntile = (nx + 15) / 16;
+    // one block of 8 waves per CU: the cut of a band's tiles into runs with the least rounds x (tiles per run + run-in),
+    // runs no shorter than 512 columns
+    const long slots = 8L * c.num_cu;
+    const int halo_tiles = 2 * nk;
+    int nseg = 1;
+    long best = -1;
+    for (int n = 1; n <= std::max(1, ntile / 32); ++n) {
+        const long rounds = ((long)bands * n + slots - 1) / slots;
+        const long cost = rounds * ((ntile + n - 1) / n + halo_tiles);
+        if (best < 0 || cost < best) {
+            best = cost;
+            nseg = n;
+        }
+    }
+    const long waves = (long)bands * nseg;
+    void* flags = nullptr;
+    TOPO_TRY(workspace(10, (size_t)bands * ntile, &flags));
+    a.flags = (unsigned char*)flags;
+    a.fine_rows = bands;
+    a.fine_cols = ntile;
+#ifdef TOPO_S1_STAMPS
+    if (std::getenv("TOPO_AMD_S1_STAMPS")) {
+        void* st = nullptr;
+        TOPO_TRY(workspace(11, 64, &st));
+        TOPO_HIP(hipMemsetAsync(st, 0, 64, c.compute));
+        a.wild_flag = (int*)st;
+        TOPO_TRY(launch_s1_axis1_any(nk, waves, a, rows, nseg));
+        unsigned long long ph[8];
+        TOPO_HIP(hipMemcpyAsync(ph, st, 64, hipMemcpyDeviceToHost, c.compute));
+        TOPO_HIP(hipStreamSynchronize(c.compute));
+        std::fprintf(stderr, "s1 axis1 stamps (cycles): runin %llu loads %llu steps %llu wait %llu stage %llu store %llu\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+        a.wild_flag = nullptr;
+    } else
+#endif
+    TOPO_TRY(launch_s1_axis1_any(nk, waves, a, rows, nseg));
+    const int units_a = (rows + 31) / 32, units_b = (nx + 31) / 32;
+    const long units = (long)units_a * units_b;
+    hipLaunchKernelGGL(gauss_f16_repair_kernel<true>, dim3((unsigned)std::min<long>(kRepairBlocks, (units + 63) / 64)), dim3(64), 0, c.compute,
+                       a, units_a, units_b, 0, rows);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
 int run_axis1_f16(GaussArgs a, int rows, int nx, double sigma) {
     Context& c = ctx();
     set_f16_scales(sigma, &a);
     a.run_if = t_run_if;
     a.wild_flag = nullptr;
     const int steps = f16_steps(a.radius);
-    const bool s1 = split_once(steps);
-    const int mt = s1 ? 1 : f16_mt(true, a.radius);
+    if (split_once(steps)) return run_axis1_s1(a, rows, nx);
+    const int mt = f16_mt(true, a.radius);
     const int nw = steps == 18 && mt == 2 ? 3 : 4;
     const int bands = (rows + 31) / 32;
     const int ntile = (nx + 32 * mt - 1) / (32 * mt), nunit = (nx + 31) / 32;
@@ -2440,22 +2524,7 @@ int run_axis1_f16(GaussArgs a, int rows, int nx, double sigma) {
     void* flags = nullptr;
     TOPO_TRY(workspace(10, (size_t)units, &flags));
     a.flags = (unsigned char*)flags;
-#ifdef TOPO_S1_STAMPS
-    if (s1 && std::getenv("TOPO_AMD_S1_STAMPS")) {
-        void* st = nullptr;
-        TOPO_TRY(workspace(11, 64, &st));
-        TOPO_HIP(hipMemsetAsync(st, 0, 64, c.compute));
-        a.wild_flag = (int*)st;
-        TOPO_TRY(launch_s1_axis1_any(steps, waves, a, rows, nseg));
-        unsigned long long ph[8];
-        TOPO_HIP(hipMemcpyAsync(ph, st, 64, hipMemcpyDeviceToHost, c.compute));
-        TOPO_HIP(hipStreamSynchronize(c.compute));
-        std::fprintf(stderr, "s1 axis1 stamps (s_memtime ticks): runin %llu loads %llu steps %llu wait %llu stage %llu store %llu\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
-        a.wild_flag = nullptr;
-    } else
-#endif
-    if (s1) TOPO_TRY(launch_s1_axis1_any(steps, waves, a, rows, nseg));
-    else TOPO_TRY(launch_f16_axis1_any(steps, mt, waves, a, rows, nseg));
+    TOPO_TRY(launch_f16_axis1_any(steps, mt, waves, a, rows, nseg));
     hipLaunchKernelGGL(gauss_f16_repair_kernel<true>, dim3((unsigned)std::min<long>(kRepairBlocks, (units + 63) / 64)), dim3(64), 0, c.compute,
                        a, bands, nunit, 0, rows);
     TOPO_HIP(hipGetLastError());
