@@ -50,7 +50,7 @@ struct GaussArgs {
     uint32_t* wild_host;  // ... and this pinned host word of the DEM's memo entry (dem_memo_wild), or nullptr
     const int* run_if;  // two-pass f16 kernels behind a fused launch: return at once unless *run_if != 0 (nullptr: run)
     const float* wtab;  // split-once kernels: W[5][64], the taps an output lays over each slab of 64 (behind the plain taps)
-    int fine_rows, fine_cols;  // split-once kernels: flags is [fine_rows][fine_cols], one byte per 16 x 16 tile (0: one per 32 x 32)
+    int fine_rows, fine_cols, fine_rpu, fine_cpu;  // split-once kernels: flags is [fine_rows][fine_cols], fine_rpu x fine_cpu bytes per 32 x 32 unit (fine_cols 0: one)
 };
 
 // Register tiling shared by both axes: a thread produces TB consecutive outputs along the
@@ -1644,16 +1644,17 @@ __device__ __forceinline__ void split4(const float (&x)[4], float mcq, f16x4& hi
     }
 }
 
-// the Toeplitz factor of a 16-output tile for v_mfma_f32_16x16x32_f16: lane (n = lane & 15, kg = lane >> 4) of step s
-// holds the taps that window position m = 32 s + 8 kg + q, q = 0 ... 7, has for output n: tap index m - n - (Rp - R)
+// the Toeplitz factor of 16 outputs for v_mfma_f32_16x16x32_f16: lane (n = lane & 15, kg = lane >> 4) of step s holds
+// the taps that window position j = 32 s + 8 kg + q, q = 0 ... 7, has for output n of sub-tile m (outputs 16 m + n of a
+// 32-output tile whose window starts Rp before it): tap index j - n - 16 m - (Rp - R)
 template <int NK>
-__device__ __forceinline__ void build_tap_blocks16(const float* taps, int R, float scale, int lane, f16x8 (&hi)[NK], f16x8 (&lo)[NK]) {
+__device__ __forceinline__ void build_tap_blocks16(const float* taps, int R, float scale, int lane, int m, f16x8 (&hi)[NK], f16x8 (&lo)[NK]) {
     const int n = lane & 15, kg = lane >> 4, Rp = 16 * (NK - 1);
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int k = 32 * s + 8 * kg + q - n - (Rp - R);
+            const int k = 32 * s + 8 * kg + q - n - 16 * m - (Rp - R);
             const float t = (k >= 0 && k <= 2 * R) ? taps[k] * scale : 0.0f;
             const _Float16 th = (_Float16)t;
             hi[s][q] = th;
@@ -1662,29 +1663,44 @@ __device__ __forceinline__ void build_tap_blocks16(const float* taps, int R, flo
     }
 }
 
-template <int NP>
-__device__ __forceinline__ void f16_products16(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4& acc) {
-    // (a = the A operand's pair, b = the B operand's; the cross product with the taps' low part first, like f16_products)
-    if (NP >= 4) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+// data pair (dh, dl) x tap pair (th, tl), the cross product with the taps' low part first (f16_products' order)
+template <bool DATA_IS_A, int NP>
+__device__ __forceinline__ void f16_products16(const f16x8& th, const f16x8& tl, const f16x8& dh, const f16x8& dl, f32x4& acc) {
+    if (DATA_IS_A) {
+        if (NP >= 4) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(dl, tl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, tl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(dl, th, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, th, acc, 0, 0, 0);
+    } else {
+        if (NP >= 4) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, dl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, dh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, dl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, dh, acc, 0, 0, 0);
+    }
 }
 
-// Axis 1.  A wave owns a band of 16 rows and marches along x in tiles of 16 columns (v_mfma_f32_16x16x32_f16: the
-// rate of the 32 x 32 x 16 form per multiply-add); its ring - hi[16][PITCH], lo[16][PITCH] in f16, PITCH = window + 8 -
-// is half the size of a 32-row band's, so EIGHT waves fit a CU: two per SIMD, one wave's staging, correction and
-// stores under the other's MFMAs (what a wave alone on its SIMD does not do for itself: r03_gauss_f16.txt, section 5).
-// Window of the tile at x0: [x0 - Rp, x0 - Rp + 32 NK), Rp = 16 (NK - 1) >= R, NK steps of 32 (the last 16 columns carry
-// zero taps).  The loader takes the 16 new columns of the next tile as one 16-byte load per lane (lane -> row lane >> 2,
-// columns 4 (lane & 3) ...: 16 rows x 64 B), a tile ahead.  The 16 columns lie in one slab; a slab starts with them when
-// they start on a multiple of 64.  LDS: 8 x (ring + references of 8 slabs x 16 rows) + the slab table W.
-// Flags: one byte per 16 x 16 tile, [band][tile]; the repair pass takes the four of a 32 x 32 unit together.
+// a value of lane 8 r (the first of the 8 lanes that load row r) to all 8 of them
+__device__ __forceinline__ float octet_first(float v, int lane) {
+    const int q = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, false);
+    const int up = __builtin_amdgcn_mov_dpp(q, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, (lane & 4) ? up : q);
+}
+
+// Axis 1.  A wave owns a band of 16 rows and marches along x in tiles of 32 columns - two sub-tiles of 16, each with
+// its own tap blocks, both fed by one read of the window (v_mfma_f32_16x16x32_f16: the rate of the 32 x 32 x 16 form per
+// multiply-add).  The ring - hi[16][PITCH], lo[16][PITCH] in f16, PITCH = window + 8 - is half the size of a 32-row
+// band's, so EIGHT waves fit a CU, two per SIMD: one wave alone leaves half of the matrix pipe idle (a 32 x 32 x 16
+// MFMA every 32 cycles from one wave, every 16 from two: tools/ubench/mfma_valu_overlap.hip) and hides at most 4
+// vector instructions under each.  Window of the tile at x0: [x0 - Rp, x0 + 32 + Rp) = 32 NK columns, Rp = 16 (NK - 1)
+// >= R.  The loader takes the 32 columns a tile adds two tiles ahead: lane -> rows (lane >> 3) and + 8, columns
+// 4 (lane & 7) ...: 16-byte loads, 8 rows x 128 B per instruction.  The 32 columns lie in one slab; a slab starts
+// with them when they start on a multiple of 64.  LDS: 8 x (ring + references of 8 slabs x 16 rows) + the table W.
+// Flags: one byte per 16 x 32 tile, [band][tile]; the repair pass takes the two of a 32 x 32 unit together.
 template <int NK, int NP>
 __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int rows, int nseg) {
     extern __shared__ __attribute__((aligned(16))) float L[];
     constexpr int Rp = 16 * (NK - 1), RC = 32 * NK, PITCH = RC + 8, NSIDE = (Rp + 63) / 64;
-    constexpr int kStay = RC / 16;                    // tiles whose window holds a group of 16 columns
+    constexpr int kStay = NK;                         // tiles whose window holds a group of 32 columns
     constexpr int kWaveFloats = 16 * PITCH + 8 * 16;  // two f16 planes = 16 x PITCH floats, then the references
     static_assert(NSIDE <= 2, "at most 5 slabs per window");
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1701,51 +1717,69 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
     const int r0 = band * 16;
     if (r0 >= rows) return;
     if (p.run_if && *p.run_if == 0) return;
-    const int ntile = (p.nx + 15) / 16;
+    const int ntile = (p.nx + 31) / 32;
     const int tper = (ntile + nseg - 1) / nseg;
     const int t_first = seg * tper, t_last = min(t_first + tper, ntile);
     if (t_first >= t_last) return;
-#ifdef TOPO_S1_STAMPS
-    const bool stamping = p.wild_flag != nullptr && gw == 517;
-    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
-#endif
-    f16x8 twh[NK], twl[NK];
-    build_tap_blocks16<NK>(p.taps, R, p.tap_scale, lane, twh, twl);
+    f16x8 t0h[NK], t0l[NK], t1h[NK], t1l[NK];
+    build_tap_blocks16<NK>(p.taps, R, p.tap_scale, lane, 0, t0h, t0l);
+    build_tap_blocks16<NK>(p.taps, R, p.tap_scale, lane, 1, t1h, t1l);
     const bool full_band = r0 + 16 <= rows;
-    const int lr = lane >> 2, lc = 4 * (lane & 3);  // loader: row of the band, first of its 4 columns in the group
-    const float* const lrow = p.in + (size_t)min(r0 + lr, rows - 1) * p.nx;
-    auto load4 = [&](int col) {
-        if (col >= 0 && col + 4 <= p.nx) return *reinterpret_cast<const f4*>(lrow + col);
-        f4 v;
+    const int lr = lane >> 3, lc = 4 * (lane & 7);  // loader: rows lr and lr + 8 of the band, 4 columns from lc of the group
+    const float* const lrow0 = p.in + (size_t)min(r0 + lr, rows - 1) * p.nx;
+    const float* const lrow1 = p.in + (size_t)min(r0 + lr + 8, rows - 1) * p.nx;
+    struct Pre {
+        f4 a, b;  // rows lr, lr + 8
+    };
+    auto load = [&](int col0) {
+        Pre v;
+        const int col = col0 + lc;
+        if (col0 >= 0 && col0 + 32 <= p.nx) {
+            v.a = *reinterpret_cast<const f4*>(lrow0 + col);
+            v.b = *reinterpret_cast<const f4*>(lrow1 + col);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = lrow[reflect_index(col + e, p.nx)];
+            for (int e = 0; e < 4; ++e) {
+                const int cx = reflect_index(col + e, p.nx);
+                v.a[e] = lrow0[cx];
+                v.b[e] = lrow1[cx];
+            }
+        }
         return v;
     };
-    // the 16 columns from `col0` (a multiple of 16), this lane's four in v, into the ring at `slot`; c_old: the reference
-    // of their slab as the table has it (read ahead of time; not used when the slab starts here)
-    auto stage = [&](f4 v, int col0, int slot, float c_old, bool& bad, bool& ref_bad) {
-        float x[4];
+    // the 32 columns from `col0` (a multiple of 32) into the ring at `slot`; c_old: the references of their slab for
+    // the lane's two rows as the table has them (read ahead of time; not used when the slab starts here)
+    auto stage = [&](const Pre& v, int col0, int slot, float c_old0, float c_old1, bool& bad, bool& ref_bad) {
+        float x0[4], x1[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bool w = wild(v[e]);
-            bad |= w;
-            x[e] = w ? 0.0f : v[e];
+            const bool w0 = wild(v.a[e]), w1 = wild(v.b[e]);
+            bad |= w0 | w1;
+            x0[e] = w0 ? 0.0f : v.a[e];
+            x1[e] = w1 ? 0.0f : v.b[e];
         }
-        float c = c_old;
-        if ((col0 & 63) == 0) {  // (wave-uniform) the slab's first column: lane & 3 == 0 of every row holds its reference
-            ref_bad |= (lane & 3) == 0 && wild(v[0]);
-            c = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[0]), 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, false));
-            if ((lane & 3) == 0) ctab[(floor_div64(col0) & 7) * 16 + lr] = c;
+        float c0 = c_old0, c1 = c_old1;
+        if ((col0 & 63) == 0) {  // (wave-uniform) the slab's first column: lane & 7 == 0 of every row holds its reference
+            ref_bad |= (lane & 7) == 0 && (wild(v.a[0]) || wild(v.b[0]));
+            c0 = octet_first(x0[0], lane);
+            c1 = octet_first(x1[0], lane);
+            if ((lane & 7) == 0) {
+                ctab[(floor_div64(col0) & 7) * 16 + lr] = c0;
+                ctab[(floor_div64(col0) & 7) * 16 + lr + 8] = c1;
+            }
         }
         f16x4 dh, dl;
-        split4(x, -0.25f * c, dh, dl);
+        split4(x0, -0.25f * c0, dh, dl);
         *reinterpret_cast<f16x4*>(hi + lr * PITCH + slot + lc) = dh;
         *reinterpret_cast<f16x4*>(lo + lr * PITCH + slot + lc) = dl;
+        split4(x1, -0.25f * c1, dh, dl);
+        *reinterpret_cast<f16x4*>(hi + (lr + 8) * PITCH + slot + lc) = dh;
+        *reinterpret_cast<f16x4*>(lo + (lr + 8) * PITCH + slot + lc) = dl;
     };
     unsigned ref_wild = 0;  // slabs (slot bits) whose reference column holds a sample that is not a plain finite one
     int last_wild = kNoWild;
+    const int x_start = t_first * 32 - Rp;
     {
-        const int x_start = t_first * 16 - Rp;
         ctab[lane] = 0.0f;
         ctab[64 + lane] = 0.0f;
         __builtin_amdgcn_wave_barrier();
@@ -1753,24 +1787,28 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
         // written again, with the same value, when their first column is staged)
         unsigned used = 0;
         for (int s = floor_div64(x_start); s <= floor_div64(x_start + RC - 1); ++s) {
-            const float v = lrow[reflect_index(64 * s, p.nx)];
-            const bool w = wild(v);
-            if ((lane & 3) == 0) ctab[(s & 7) * 16 + lr] = w ? 0.0f : v;
-            if (__builtin_amdgcn_ballot_w64(w)) ref_wild |= 1u << (s & 7);
+            const int cx = reflect_index(64 * s, p.nx);
+            const float v0 = lrow0[cx], v1 = lrow1[cx];
+            const bool w0 = wild(v0), w1 = wild(v1);
+            if ((lane & 7) == 0) {
+                ctab[(s & 7) * 16 + lr] = w0 ? 0.0f : v0;
+                ctab[(s & 7) * 16 + lr + 8] = w1 ? 0.0f : v1;
+            }
+            if (__builtin_amdgcn_ballot_w64(w0 | w1)) ref_wild |= 1u << (s & 7);
             used |= 1u << (s & 7);
         }
         __builtin_amdgcn_wave_barrier();
         bool bad = false, ref_bad = false;  // (ref_bad: covered by the loop above)
-        for (int k0 = 0; k0 < RC; k0 += 64) {  // four groups in flight
-            f4 v[4];
+        for (int k0 = 0; k0 < RC; k0 += 96) {  // three groups in flight
+            Pre v[3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (k0 + 16 * u < RC) v[u] = load4(x_start + k0 + 16 * u + lc);
+            for (int u = 0; u < 3; ++u)
+                if (k0 + 32 * u < RC) v[u] = load(x_start + k0 + 32 * u);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (k0 + 16 * u < RC) {
-                    const int col0 = x_start + k0 + 16 * u;
-                    stage(v[u], col0, k0 + 16 * u, ctab[(floor_div64(col0) & 7) * 16 + lr], bad, ref_bad);
+            for (int u = 0; u < 3; ++u)
+                if (k0 + 32 * u < RC) {
+                    const int col0 = x_start + k0 + 32 * u, sl = (floor_div64(col0) & 7) * 16;
+                    stage(v[u], col0, k0 + 32 * u, ctab[sl + lr], ctab[sl + lr + 8], bad, ref_bad);
                 }
         }
         if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & used)) last_wild = t_first + kStay - 1;
@@ -1779,19 +1817,22 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
     const int n = lane & 15, kg = lane >> 4;
     const _Float16* const ah = hi + n * PITCH + 8 * kg;  // A: row n of the band, 8 window positions from 8 kg
     const _Float16* const al = lo + n * PITCH + 8 * kg;
-    S1_STAMP(0)
+    // the columns tile t + 1 adds are loaded while tile t - 1 is computed, staged behind tile t
+    Pre pre_next;
+    if (t_first + 1 < t_last) pre_next = load(x_start + RC);
     for (int t = t_first; t < t_last; ++t) {
-        const int x0 = t * 16;
+        const int x0 = t * 32;
         const bool more = t + 1 < t_last;
-        const int n0 = x0 - Rp + RC;  // the 16 columns the next tile adds
-        f4 pre;
-        float c_next = 0.0f;
+        const int n0 = x0 - Rp + RC;  // the 32 columns the next tile adds
+        const Pre pre = pre_next;
+        if (t + 2 < t_last) pre_next = load(n0 + 32);
+        float c_n0 = 0.0f, c_n1 = 0.0f;
         if (more) {
-            pre = load4(n0 + lc);
-            c_next = ctab[(floor_div64(n0) & 7) * 16 + lr];
+            const int sl = (floor_div64(n0) & 7) * 16;
+            c_n0 = ctab[sl + lr];
+            c_n1 = ctab[sl + lr + 8];
         }
-        S1_STAMP(1)
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
         int slot = base;
         f16x8 bh[3], bl[3];
         auto fetch = [&](int k) {
@@ -1801,59 +1842,53 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
             slot = slot >= RC ? slot - RC : slot;
         };
         fetch(0);
-        if (NK > 1) fetch(1);
+        fetch(1);
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
             if (s + 2 < NK) fetch((s + 2) % 3);
             __builtin_amdgcn_sched_barrier(0);
-            f16_products16<NP>(bh[s % 3], bl[s % 3], twh[s], twl[s], acc);
+            f16_products16<true, NP>(t0h[s], t0l[s], bh[s % 3], bl[s % 3], acc0);
+            f16_products16<true, NP>(t1h[s], t1l[s], bh[s % 3], bl[s % 3], acc1);
         }
-#ifdef TOPO_S1_STAMPS
-        if (stamping) {
-            asm volatile("s_nop 0" ::"v"(acc[0]));
-            S1_STAMP(2)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            S1_STAMP(3)
-        }
-#endif
         if (more) {
             bool bad = false, ref_bad = false;
-            stage(pre, n0, base, c_next, bad, ref_bad);  // over the oldest 16 columns
+            stage(pre, n0, base, c_n0, c_n1, bad, ref_bad);  // over the oldest 32 columns
             if ((n0 & 63) == 0) {  // the slab that starts here takes over the slot of the slab 8 before it
                 if (__builtin_amdgcn_ballot_w64(ref_bad)) ref_wild |= 1u << (floor_div64(n0) & 7);
                 else ref_wild &= ~(1u << (floor_div64(n0) & 7));
             }
             if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & (1u << (floor_div64(n0) & 7)))) last_wild = t + kStay;
         }
-        S1_STAMP(4)
         // the correction: the other slabs' references against the tile's own.  D: column n, rows 4 kg + v
         const int b = x0 >> 6, o = (x0 & 63) + n;
         const f4 cb = *reinterpret_cast<const f4*>(ctab + (b & 7) * 16 + 4 * kg);
-        f4 corr = {0.0f, 0.0f, 0.0f, 0.0f};
+        f4 corr0 = {0.0f, 0.0f, 0.0f, 0.0f}, corr1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int d = -NSIDE; d <= NSIDE; ++d) {
             if (d == 0) continue;
-            const float wd = wlds[(d + 2) * 64 + o];
+            const float w0 = wlds[(d + 2) * 64 + o], w1 = wlds[(d + 2) * 64 + o + 16];
             const f4 cs = *reinterpret_cast<const f4*>(ctab + ((b + d) & 7) * 16 + 4 * kg);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) corr[e] = fmaf(cs[e] - cb[e], wd, corr[e]);
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = cs[e] - cb[e];
+                corr0[e] = fmaf(dlt, w0, corr0[e]);
+                corr1[e] = fmaf(dlt, w1, corr1[e]);
+            }
         }
         if (lane == 0) p.flags[(size_t)band * ntile + t] = last_wild >= t ? 1 : 0;
-        const int ox = x0 + n;
-        if (ox < p.nx) {
+        {
+            const int ox = x0 + n;
             float* o0 = p.out + (size_t)(r0 + 4 * kg) * p.nx + ox;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                if (full_band || r0 + 4 * kg + v < rows) o0[(size_t)v * p.nx] = fmaf(acc[v], p.out_scale, corr[v]) + cb[v];
+                if (full_band || r0 + 4 * kg + v < rows) {
+                    if (ox < p.nx) o0[(size_t)v * p.nx] = fmaf(acc0[v], p.out_scale, corr0[v]) + cb[v];
+                    if (ox + 16 < p.nx) o0[(size_t)v * p.nx + 16] = fmaf(acc1[v], p.out_scale, corr1[v]) + cb[v];
+                }
         }
-        S1_STAMP(5)
-        base += 16;
+        base += 32;
         base = base >= RC ? base - RC : base;
     }
-#ifdef TOPO_S1_STAMPS
-    if (stamping && lane == 0)
-        for (int k = 0; k < 8; ++k) reinterpret_cast<unsigned long long*>(p.wild_flag)[k] = phase[k];
-#endif
 }
 
 
@@ -2138,11 +2173,11 @@ __global__ __launch_bounds__(64) void gauss_f16_repair_kernel(GaussArgs p, int u
         if (mine < units) {
             if (p.fine_cols == 0) {
                 mark = p.flags[mine] != 0;
-            } else {  // the four 16 x 16 tiles of the unit
-                const int fa = (int)(mine / units_b) * 2, fb = (int)(mine % units_b) * 2;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (fa + (e >> 1) < p.fine_rows && fb + (e & 1) < p.fine_cols) mark |= p.flags[(size_t)(fa + (e >> 1)) * p.fine_cols + fb + (e & 1)] != 0;
+            } else {  // the tiles of the unit
+                const int fa = (int)(mine / units_b) * p.fine_rpu, fb = (int)(mine % units_b) * p.fine_cpu;
+                for (int ea = 0; ea < p.fine_rpu; ++ea)
+                    for (int eb = 0; eb < p.fine_cpu; ++eb)
+                        if (fa + ea < p.fine_rows && fb + eb < p.fine_cols) mark |= p.flags[(size_t)(fa + ea) * p.fine_cols + fb + eb] != 0;
             }
         }
         unsigned long long marked = __builtin_amdgcn_ballot_w64(mark);
@@ -2450,14 +2485,14 @@ int run_axis0_f16(const Block& b, GaussArgs a, double sigma) {
 int run_axis1_s1(GaussArgs a, int rows, int nx) {
     Context& c = ctx();
     const int nk = s1_steps(a.radius);
-    const int bands = (rows + 15) / 16, ntile = (nx + 15) / 16;
+    const int bands = (rows + 15) / 16, ntile = (nx + 31) / 32;
     // one block of 8 waves per CU: the cut of a band's tiles into runs with the least rounds x (tiles per run + run-in),
     // runs no shorter than 512 columns
     const long slots = 8L * c.num_cu;
-    const int halo_tiles = 2 * nk;
+    const int halo_tiles = nk;
     int nseg = 1;
     long best = -1;
-    for (int n = 1; n <= std::max(1, ntile / 32); ++n) {
+    for (int n = 1; n <= std::max(1, ntile / 16); ++n) {
         const long rounds = ((long)bands * n + slots - 1) / slots;
         const long cost = rounds * ((ntile + n - 1) / n + halo_tiles);
         if (best < 0 || cost < best) {
@@ -2471,20 +2506,8 @@ int run_axis1_s1(GaussArgs a, int rows, int nx) {
     a.flags = (unsigned char*)flags;
     a.fine_rows = bands;
     a.fine_cols = ntile;
-#ifdef TOPO_S1_STAMPS
-    if (std::getenv("TOPO_AMD_S1_STAMPS")) {
-        void* st = nullptr;
-        TOPO_TRY(workspace(11, 64, &st));
-        TOPO_HIP(hipMemsetAsync(st, 0, 64, c.compute));
-        a.wild_flag = (int*)st;
-        TOPO_TRY(launch_s1_axis1_any(nk, waves, a, rows, nseg));
-        unsigned long long ph[8];
-        TOPO_HIP(hipMemcpyAsync(ph, st, 64, hipMemcpyDeviceToHost, c.compute));
-        TOPO_HIP(hipStreamSynchronize(c.compute));
-        std::fprintf(stderr, "s1 axis1 stamps (cycles): runin %llu loads %llu steps %llu wait %llu stage %llu store %llu\n", ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
-        a.wild_flag = nullptr;
-    } else
-#endif
+    a.fine_rpu = 2;
+    a.fine_cpu = 1;
     TOPO_TRY(launch_s1_axis1_any(nk, waves, a, rows, nseg));
     const int units_a = (rows + 31) / 32, units_b = (nx + 31) / 32;
     const long units = (long)units_a * units_b;
