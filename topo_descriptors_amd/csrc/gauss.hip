@@ -1679,6 +1679,22 @@ __device__ __forceinline__ void f16_products16(const f16x8& th, const f16x8& tl,
     }
 }
 
+// the same for two sub-tiles that share the data operand (axis 1: data is A), their chains alternating
+template <int NP>
+__device__ __forceinline__ void f16_products16_pair(const f16x8& t0h, const f16x8& t0l, const f16x8& t1h, const f16x8& t1l, const f16x8& dh,
+                                                    const f16x8& dl, f32x4& acc0, f32x4& acc1) {
+    if (NP >= 4) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dl, t0l, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dl, t1l, acc1, 0, 0, 0);
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, t0l, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, t1l, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dl, t0h, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dl, t1h, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, t0h, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, t1h, acc1, 0, 0, 0);
+}
+
 // a value of lane 8 r (the first of the 8 lanes that load row r) to all 8 of them
 __device__ __forceinline__ float octet_first(float v, int lane) {
     const int q = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, false);
@@ -1702,7 +1718,7 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
     constexpr int Rp = 16 * (NK - 1), RC = 32 * NK, PITCH = RC + 8, NSIDE = (Rp + 63) / 64;
     constexpr int kStay = NK;                         // tiles whose window holds a group of 32 columns
     constexpr int kWaveFloats = 16 * PITCH + 8 * 16;  // two f16 planes = 16 x PITCH floats, then the references
-    static_assert(NSIDE <= 2, "at most 5 slabs per window");
+    static_assert(NSIDE <= 2 && Rp % 32 == 0, "at most 5 slabs per window; groups of 32 columns inside one slab");
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int R = p.radius;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1832,34 +1848,8 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
             c_n0 = ctab[sl + lr];
             c_n1 = ctab[sl + lr + 8];
         }
-        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-        int slot = base;
-        f16x8 bh[3], bl[3];
-        auto fetch = [&](int k) {
-            bh[k] = *reinterpret_cast<const f16x8*>(ah + slot);
-            bl[k] = *reinterpret_cast<const f16x8*>(al + slot);
-            slot += 32;
-            slot = slot >= RC ? slot - RC : slot;
-        };
-        fetch(0);
-        fetch(1);
-#pragma unroll
-        for (int s = 0; s < NK; ++s) {
-            if (s + 2 < NK) fetch((s + 2) % 3);
-            __builtin_amdgcn_sched_barrier(0);
-            f16_products16<true, NP>(t0h[s], t0l[s], bh[s % 3], bl[s % 3], acc0);
-            f16_products16<true, NP>(t1h[s], t1l[s], bh[s % 3], bl[s % 3], acc1);
-        }
-        if (more) {
-            bool bad = false, ref_bad = false;
-            stage(pre, n0, base, c_n0, c_n1, bad, ref_bad);  // over the oldest 32 columns
-            if ((n0 & 63) == 0) {  // the slab that starts here takes over the slot of the slab 8 before it
-                if (__builtin_amdgcn_ballot_w64(ref_bad)) ref_wild |= 1u << (floor_div64(n0) & 7);
-                else ref_wild &= ~(1u << (floor_div64(n0) & 7));
-            }
-            if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & (1u << (floor_div64(n0) & 7)))) last_wild = t + kStay;
-        }
-        // the correction: the other slabs' references against the tile's own.  D: column n, rows 4 kg + v
+        // the correction (ahead of the products: nothing waits on LDS behind them): the other slabs' references against
+        // the tile's own.  D: column n, rows 4 kg + v
         const int b = x0 >> 6, o = (x0 & 63) + n;
         const f4 cb = *reinterpret_cast<const f4*>(ctab + (b & 7) * 16 + 4 * kg);
         f4 corr0 = {0.0f, 0.0f, 0.0f, 0.0f}, corr1 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1875,7 +1865,23 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
                 corr1[e] = fmaf(dlt, w1, corr1[e]);
             }
         }
-        if (lane == 0) p.flags[(size_t)band * ntile + t] = last_wild >= t ? 1 : 0;
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        int slot = base;
+        f16x8 bh[3], bl[3];
+        auto fetch = [&](int k) {
+            bh[k] = *reinterpret_cast<const f16x8*>(ah + slot);
+            bl[k] = *reinterpret_cast<const f16x8*>(al + slot);
+            slot += 32;
+            slot = slot >= RC ? slot - RC : slot;
+        };
+        fetch(0);
+        fetch(1);
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            if (s + 2 < NK) fetch((s + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            f16_products16_pair<NP>(t0h[s], t0l[s], t1h[s], t1l[s], bh[s % 3], bl[s % 3], acc0, acc1);
+        }
         {
             const int ox = x0 + n;
             float* o0 = p.out + (size_t)(r0 + 4 * kg) * p.nx + ox;
@@ -1885,6 +1891,16 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
                     if (ox < p.nx) o0[(size_t)v * p.nx] = fmaf(acc0[v], p.out_scale, corr0[v]) + cb[v];
                     if (ox + 16 < p.nx) o0[(size_t)v * p.nx + 16] = fmaf(acc1[v], p.out_scale, corr1[v]) + cb[v];
                 }
+        }
+        if (lane == 0) p.flags[(size_t)band * ntile + t] = last_wild >= t ? 1 : 0;
+        if (more) {
+            bool bad = false, ref_bad = false;
+            stage(pre, n0, base, c_n0, c_n1, bad, ref_bad);  // over the oldest 32 columns
+            if ((n0 & 63) == 0) {  // the slab that starts here takes over the slot of the slab 8 before it
+                if (__builtin_amdgcn_ballot_w64(ref_bad)) ref_wild |= 1u << (floor_div64(n0) & 7);
+                else ref_wild &= ~(1u << (floor_div64(n0) & 7));
+            }
+            if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & (1u << (floor_div64(n0) & 7)))) last_wild = t + kStay;
         }
         base += 32;
         base = base >= RC ? base - RC : base;
@@ -2403,7 +2419,8 @@ bool split_once(int steps) {
     return on && steps >= 10;
 }
 // NK steps of 32 window positions per 16-output tile: Rp = 16 (NK - 1) >= R
-int s1_steps(int R) { return (R + 15) / 16 + 1; }
+// (Rp a multiple of 32: the groups of 32 columns the march stages then never straddle a slab)
+int s1_steps(int R) { return (R + 31) / 32 * 2 + 1; }
 template <int NK>
 int launch_s1_axis1(long waves, const GaussArgs& a, int rows, int nseg) {
     Context& c = ctx();
@@ -2420,9 +2437,7 @@ int launch_s1_axis1(long waves, const GaussArgs& a, int rows, int nseg) {
 int launch_s1_axis1_any(int nk, long waves, const GaussArgs& a, int rows, int nseg) {
     switch (nk) {
         case 5: return launch_s1_axis1<5>(waves, a, rows, nseg);
-        case 6: return launch_s1_axis1<6>(waves, a, rows, nseg);
         case 7: return launch_s1_axis1<7>(waves, a, rows, nseg);
-        case 8: return launch_s1_axis1<8>(waves, a, rows, nseg);
         case 9: return launch_s1_axis1<9>(waves, a, rows, nseg);
     }
     set_error("gaussian (split-once matrix-core route): no kernel for this radius");
