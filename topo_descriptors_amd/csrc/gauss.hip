@@ -2037,6 +2037,12 @@ __global__ __launch_bounds__(512) void gauss_axis0_s1_kernel(GaussArgs p, int ti
     };
     if (tb + 1 < te) load_next(y_start + RR);
     for (int t = tb; t < te; ++t) {
+        // The block's waves stay within a tile of each other: a wave reads and writes 64-byte halves of 128-byte lines
+        // whose other halves are its neighbour's, and L2 only has both for HBM when they come close together (without
+        // the barrier: 1.56 x the plane fetched, 1.12 x written - the waves drift apart).
+        // Waves 4 ... 7 (the second wave of each SIMD) meet the barrier half a tile later, behind their products: the two
+        // waves of a SIMD then do their MFMAs in turns.
+        if (p.nchunks == 0 && wave < 4) __builtin_amdgcn_s_barrier();
         const int y0 = (tile_first + t) * 32;
         const bool more = t + 1 < te;
         const int n0 = y0 - Rp + RR;  // the 32 rows the next tile adds
@@ -2077,6 +2083,7 @@ __global__ __launch_bounds__(512) void gauss_axis0_s1_kernel(GaussArgs p, int ti
             __builtin_amdgcn_sched_barrier(0);
             f16_products16_pair_b<NP>(t0h[s], t0l[s], t1h[s], t1l[s], dh[s % 3], dl[s % 3], acc0, acc1);
         }
+        if (p.nchunks == 0 && wave >= 4) __builtin_amdgcn_s_barrier();
         if (xw + n < p.nx) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -2749,6 +2756,10 @@ int run_axis0_s1(const Block& b, GaussArgs a) {
     a.fine_cols = strips * 8;
     a.fine_rpu = 1;
     a.fine_cpu = 2;
+    {
+        const char* e = std::getenv("TOPO_AMD_S1_NOBARRIER");
+        a.nchunks = e && *e == '1' ? 1 : 0;
+    }
     switch (nk) {
         case 5: TOPO_TRY(launch_s1_axis0<5>(grid, a, tile_first, ntiles, per)); break;
         case 7: TOPO_TRY(launch_s1_axis0<7>(grid, a, tile_first, ntiles, per)); break;
