@@ -257,8 +257,7 @@ int gradient_shard_halo(double sigma, double sig_ratio) {
     if (sig_ratio == 0.0) sig_ratio = 1.0;
     if (sig_ratio != 1.0) return gradient_halo(sigma, sig_ratio);
     const int R = gaussian_radius(sigma);
-    // (radius 49 ... 121: + 32 rows, the split-once axis-0 kernel's slab references: gauss.hip, s1_rows_ok)
-    return (R >= mfma_min_radius(true) && R < 16) ? 17 : gaussian_reach(R) + 1;
+    return (R >= mfma_min_radius(true) && R < 16) ? 17 : R + 1;
 }
 
 // RAII-less helper for the host-buffer entry points
@@ -638,7 +637,6 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
             TOPO_TRY(build_disc((int)p0, &d));
             int R = p1 > 0.0 ? gaussian_radius(p1) : 0;
             if (R >= mfma_min_radius(false) && R < 16) R = 16;  // pre-smoothing on the matrix cores: see DESC_GAUSS
-            R = R > 0 ? gaussian_reach(R) : 0;
             *above = -d.dj_min + R;
             *below = d.dj_max + R;
             return TOPO_AMD_OK;
@@ -647,8 +645,7 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
             // (radius mfma_min_radius .. 15: the matrix-core kernels want the accumulation-offset row of every
             // 32-row tile inside the block, 16 rows from the tile's first row: gauss.hip, mfma_rows_ok)
             const int R = gaussian_radius(p0);
-            // (radius 49 ... 121: R + 32, the reference rows of the split-once axis-0 kernel: gauss.hip, s1_rows_ok)
-            *above = *below = (R >= mfma_min_radius(false) && R < 16) ? 16 : gaussian_reach(R);
+            *above = *below = (R >= mfma_min_radius(false) && R < 16) ? 16 : R;
             return TOPO_AMD_OK;
         }
         case TOPO_AMD_DESC_GRADIENT:

@@ -184,7 +184,6 @@ int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize,
                         int n_planes, double mean, double stdev, float* norm_out, float* dir_out);
 
 int gaussian_radius(double sigma);
-int gaussian_reach(int R);  // ghost rows for whole-DEM bits: R, + 32 where axis 0 takes the split-once kernel (gauss.hip)
 
 // What the library remembers about the DEMs it has seen (keyed by block pointer, rows and width; a few entries): the share
 // of tiles with fractional elevations in one block's run of the last TPI call, written by that block into pinned host

@@ -50,7 +50,7 @@ struct GaussArgs {
     uint32_t* wild_host;  // ... and this pinned host word of the DEM's memo entry (dem_memo_wild), or nullptr
     const int* run_if;  // two-pass f16 kernels behind a fused launch: return at once unless *run_if != 0 (nullptr: run)
     const float* wtab;  // split-once kernels: W[5][64], the taps an output lays over each slab of 64 (behind the plain taps)
-    int fine_rows, fine_cols, fine_rpu, fine_cpu;  // split-once kernels: flags is [fine_rows][fine_cols], fine_rpu x fine_cpu bytes per 32 x 32 unit (fine_cols 0: one)
+    int fine_rows, fine_cols;  // split-once axis-1 kernel: flags is [fine_rows bands of 16 rows][fine_cols tiles of 32 columns] (0: one byte per 32 x 32 unit)
 };
 
 // Register tiling shared by both axes: a thread produces TB consecutive outputs along the
@@ -1589,21 +1589,24 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
 }
 
 
-// ---- split once (radius 49 ... 121) ------------------------------------------------------------------------------
+// ---- split once: axis 1, radius 49 ... 121 -------------------------------------------------------------------------
 // The kernels above split every sample of a tile's window into its f16 pair again for every tile: 24 vector
-// instructions per 8 samples and step, ~2/3 of a step's time with one wave per SIMD (profiles/r03_gauss_f16.txt,
-// section 5).  Here a sample is split ONCE, when it is staged: the ring in LDS holds the two f16 planes and a step is
-// two 16-byte LDS reads and its MFMAs.  For that the offset a sample is taken against cannot belong to the tile: the
-// filter axis is cut into slabs of 64 (global multiples of 64) and every sample of a slab is taken against the
-// slab's reference sample c_s of the same row (axis 1: the slab's first column) or column (axis 0).  A tile's window
-// holds up to five slabs; with W_s[o] the sum of the taps that output o lays over slab s (a table of the host,
-// float64 sums rounded once) and b the tile's own slab
+// instructions per 8 samples and step (profiles/r03_gauss_f16.txt, section 5).  Here a sample is split ONCE, when it
+// is staged: the ring in LDS holds the two f16 planes and a step is two 16-byte LDS reads and its MFMAs.  For that the
+// offset a sample is taken against cannot belong to the tile: the row is cut into slabs of 64 columns (global
+// multiples of 64) and every sample of a slab is taken against the slab's reference c_s, the sample of its row in
+// the slab's first column.  A tile's window holds up to five slabs; with W_s[o] the sum of the taps that the output at
+// position o of its own slab lays over slab s (a table of the host: float64 sums, rounded once) and b the tile's slab
 //     out = c_b + [ scale * sum_k t_k (x_k - c_s(k)) / 4  +  sum_{s != b} (c_s - c_b) W_s ]
-// - the taps sum to 1 as far as the existing kernels' "+ c" assumes it.  |x - c_s| is the relief inside 64 samples
-// (the tile kernels: inside the 288 ... 320 of a window), so the products lose less; the correction costs 2 vector
-// instructions per output and slab.  Results depend on the global slab grid only, not on how the march is cut.
-// Samples that are not plain finite ones go in as 0 and mark the tiles whose windows hold them (or hold samples taken
-// against a reference that was one), as above: the repair pass recomputes those.
+// - the taps sum to 1 as far as the tile kernels' "+ c" assumes it.  |x - c_s| is the relief inside 64 samples (the
+// tile kernels: inside the 288 ... 320 of a window); the correction costs 2.5 vector instructions per output and slab.
+// Results depend on the global slab grid only, not on how the march is cut.  Samples that are not plain finite ones go
+// in as 0 and mark the tiles whose windows hold them (or hold samples taken against a reference that was one), as
+// above: the repair pass recomputes those.  (Axis 0 was built the same way - a wave owns 16 columns, slab references
+// on row 32 of each 64-row slab, R + 32 ghost rows for whole-DEM bits - and gives the tile kernel's time, 2.51 against
+// 2.56 ms at sigma 30.25: 16 columns are 64-byte halves of lines shared with the neighbour wave, 1.56 x the plane
+// fetched unless a block barrier per tile keeps the waves together, which takes the overlap away again; it is not in the
+// library: profiles/r04_gauss_split_once.txt.)
 __device__ __forceinline__ int floor_div64(int a) { return a >> 6; }  // arithmetic shift: floor for negative a
 
 // W_s[o] of the lane's output position o = 0 ... 63 inside its own slab, s - b = -2, -1, +1, +2
@@ -1618,12 +1621,6 @@ __device__ __forceinline__ SlabWeights slab_weights(const float* wtab, int o) {
     r.w[3] = wtab[4 * 64 + o];
     return r;
 }
-
-#ifdef TOPO_S1_STAMPS
-#define S1_STAMP(k) if (stamping) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); phase[k] += now_ - last_; last_ = now_; }
-#else
-#define S1_STAMP(k)
-#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -1663,23 +1660,8 @@ __device__ __forceinline__ void build_tap_blocks16(const float* taps, int R, flo
     }
 }
 
-// data pair (dh, dl) x tap pair (th, tl), the cross product with the taps' low part first (f16_products' order)
-template <bool DATA_IS_A, int NP>
-__device__ __forceinline__ void f16_products16(const f16x8& th, const f16x8& tl, const f16x8& dh, const f16x8& dl, f32x4& acc) {
-    if (DATA_IS_A) {
-        if (NP >= 4) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(dl, tl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, tl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(dl, th, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, th, acc, 0, 0, 0);
-    } else {
-        if (NP >= 4) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, dl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl, dh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, dl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(th, dh, acc, 0, 0, 0);
-    }
-}
-
-// the same for two sub-tiles that share the data operand (axis 1: data is A), their chains alternating
+// data pair (dh, dl) x the tap pairs of two sub-tiles that share it (axis 1: the data is the A operand), the cross
+// product with the taps' low part first (f16_products' order), the two chains alternating
 template <int NP>
 __device__ __forceinline__ void f16_products16_pair(const f16x8& t0h, const f16x8& t0l, const f16x8& t1h, const f16x8& t1l, const f16x8& dh,
                                                     const f16x8& dl, f32x4& acc0, f32x4& acc1) {
@@ -1693,22 +1675,6 @@ __device__ __forceinline__ void f16_products16_pair(const f16x8& t0h, const f16x
     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dl, t1h, acc1, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, t0h, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(dh, t1h, acc1, 0, 0, 0);
-}
-
-// ... and with the data as the B operand (axis 0)
-template <int NP>
-__device__ __forceinline__ void f16_products16_pair_b(const f16x8& t0h, const f16x8& t0l, const f16x8& t1h, const f16x8& t1l, const f16x8& dh,
-                                                      const f16x8& dl, f32x4& acc0, f32x4& acc1) {
-    if (NP >= 4) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0l, dl, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1l, dl, acc1, 0, 0, 0);
-    }
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0l, dh, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1l, dh, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0h, dl, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1h, dl, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t0h, dh, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(t1h, dh, acc1, 0, 0, 0);
 }
 
 // a value of lane 8 r (the first of the 8 lanes that load row r) to all 8 of them
@@ -1920,196 +1886,6 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
         }
         base += 32;
         base = base >= RC ? base - RC : base;
-    }
-}
-
-
-// Axis 0, the same scheme turned round.  A wave owns 16 columns and marches down the rows in tiles of 32 (two
-// sub-tiles of 16 output rows: the taps are the A operand, the window the B operand); its ring is column-major -
-// hi[16 columns][PITCH rows], lo[...] - so a lane's 8 window rows of a step are one 16-byte read.  A block is 8 waves
-// = 128 columns.  Loader: lane -> column lane & 15, rows 8 (lane >> 4) ... + 7 of the 32 rows a tile adds (dword loads, 4
-// rows x 64 B per instruction), two tiles ahead.  Slabs are 64 rows on the global grid; the reference of a slab is its
-// row 32 (every lane loads its own column's: no exchange between lanes), taken with the slab's first group.  A row block
-// therefore gives the whole DEM's bits when it carries R + 32 ghost rows (s1_rows_ok; topo_amd_halo_rows asks for
-// them): the reference row of every slab a wanted output's window touches is then inside the block.
-// Flags: one byte per 32-row tile and 16 columns, [tile][16-column band].
-template <int NK, int NP>
-__global__ __launch_bounds__(512) void gauss_axis0_s1_kernel(GaussArgs p, int tile_first, int ntiles, int tiles_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float L[];
-    constexpr int Rp = 16 * (NK - 1), RR = 32 * NK, PITCH = RR + 8, NSIDE = (Rp + 63) / 64;
-    constexpr int kStay = NK;
-    constexpr int kWaveFloats = 16 * PITCH + 8 * 16;
-    static_assert(NSIDE <= 2 && Rp % 32 == 0, "at most 5 slabs per window; groups of 32 rows inside one slab");
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const int R = p.radius;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* const wlds = L + 8 * kWaveFloats;  // W[5][64]
-    for (int k = threadIdx.x; k < 5 * 64; k += 512) wlds[k] = p.wtab[k];
-    __syncthreads();
-    _Float16* const hi = reinterpret_cast<_Float16*>(L + wave * kWaveFloats);
-    _Float16* const lo = hi + 16 * PITCH;
-    float* const ctab = L + wave * kWaveFloats + 16 * PITCH;  // [8 slabs][16 columns]
-    const int xw = blockIdx.x * 128 + 16 * wave;  // the wave's first column
-    if (xw >= p.nx) return;
-    const int tb = blockIdx.y * tiles_per_block, te = min(tb + tiles_per_block, ntiles);
-    if (tb >= te) return;
-    if (p.run_if && *p.run_if == 0) return;
-    f16x8 t0h[NK], t0l[NK], t1h[NK], t1l[NK];
-    build_tap_blocks16<NK>(p.taps, R, p.tap_scale, lane, 0, t0h, t0l);
-    build_tap_blocks16<NK>(p.taps, R, p.tap_scale, lane, 1, t1h, t1l);
-    const int n = lane & 15, kg = lane >> 4;
-    const int lx = min(xw + n, p.nx - 1);  // the lane's column (loader, operand and result alike)
-    const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
-    auto row_ptr = [&](int gy) {
-        gy = reflect_index(gy, p.gny);
-        gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
-        return p.in + (size_t)(gy - p.in_row0) * p.nx + lx;
-    };
-    struct Pre {
-        float x[8];  // rows row0 + 8 kg ... + 7 of the lane's column
-    };
-    auto load = [&](int row0) {
-        Pre v;
-        if (row0 >= row_lo && row0 + 32 <= row_hi) {
-            const float* b = p.in + (size_t)(row0 + 8 * kg - p.in_row0) * p.nx + lx;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v.x[e] = b[(size_t)e * p.nx];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v.x[e] = *row_ptr(row0 + 8 * kg + e);
-        }
-        return v;
-    };
-    const f32x2 quarter = {0.25f, 0.25f};
-    // the 32 rows from `row0` (a multiple of 32) into the ring at `slot`, taken against c (wild: the reference is not a
-    // plain finite sample)
-    auto stage = [&](Pre v, int slot, float c, bool& bad) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool w = wild(v.x[e]);
-            bad |= w;
-            v.x[e] = w ? 0.0f : v.x[e];
-        }
-        const f32x2 mcq = {-0.25f * c, -0.25f * c};
-        f16x8 dh, dl;
-        split8(v.x, quarter, mcq, dh, dl);
-        *reinterpret_cast<f16x8*>(hi + n * PITCH + slot + 8 * kg) = dh;
-        *reinterpret_cast<f16x8*>(lo + n * PITCH + slot + 8 * kg) = dl;
-    };
-    unsigned ref_wild = 0;  // slabs (slot bits) whose reference row holds a sample that is not a plain finite one
-    int last_wild = kNoWild;
-    const int y_start = (tile_first + tb) * 32 - Rp;
-    {
-        ctab[lane] = 0.0f;
-        ctab[64 + lane] = 0.0f;
-        __builtin_amdgcn_wave_barrier();
-        unsigned used = 0;
-        for (int s = floor_div64(y_start); s <= floor_div64(y_start + RR - 1); ++s) {
-            const float v = *row_ptr(64 * s + 32);
-            const bool w = wild(v);
-            if (kg == 0) ctab[(s & 7) * 16 + n] = w ? 0.0f : v;
-            if (__builtin_amdgcn_ballot_w64(w)) ref_wild |= 1u << (s & 7);
-            used |= 1u << (s & 7);
-        }
-        __builtin_amdgcn_wave_barrier();
-        bool bad = false;
-        for (int k0 = 0; k0 < RR; k0 += 96) {  // three groups in flight
-            Pre v[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (k0 + 32 * u < RR) v[u] = load(y_start + k0 + 32 * u);
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (k0 + 32 * u < RR) stage(v[u], k0 + 32 * u, ctab[(floor_div64(y_start + k0 + 32 * u) & 7) * 16 + n], bad);
-        }
-        if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & used)) last_wild = tb + kStay - 1;
-    }
-    int base = 0;  // ring row of input row y0 - Rp
-    const _Float16* const bh_ptr = hi + n * PITCH + 8 * kg;  // B: column n, 8 window rows from 8 kg
-    const _Float16* const bl_ptr = lo + n * PITCH + 8 * kg;
-    // the rows tile t + 1 adds are loaded while tile t - 1 is computed, staged behind tile t; with the first group of a
-    // slab comes the slab's reference row
-    Pre pre_next;
-    float ref_next = 0.0f;
-    auto load_next = [&](int row0) {
-        pre_next = load(row0);
-        if ((row0 & 63) == 0) ref_next = *row_ptr(row0 + 32);
-    };
-    if (tb + 1 < te) load_next(y_start + RR);
-    for (int t = tb; t < te; ++t) {
-        // The block's waves stay within a tile of each other: a wave reads and writes 64-byte halves of 128-byte lines
-        // whose other halves are its neighbour's, and L2 only has both for HBM when they come close together (without
-        // the barrier: 1.56 x the plane fetched, 1.12 x written - the waves drift apart).
-        // Waves 4 ... 7 (the second wave of each SIMD) meet the barrier half a tile later, behind their products: the two
-        // waves of a SIMD then do their MFMAs in turns.
-        if (p.nchunks == 0 && wave < 4) __builtin_amdgcn_s_barrier();
-        const int y0 = (tile_first + t) * 32;
-        const bool more = t + 1 < te;
-        const int n0 = y0 - Rp + RR;  // the 32 rows the next tile adds
-        const Pre pre = pre_next;
-        const float ref = ref_next;
-        if (t + 2 < te) load_next(n0 + 32);
-        const float c_tab = ctab[(floor_div64(n0) & 7) * 16 + n];
-        // the correction (ahead of the products): the other slabs' references against the tile's own.  D: column n,
-        // rows 4 kg + v of each sub-tile
-        const int b = y0 >> 6, o = (y0 & 63) + 4 * kg;
-        const float cb = ctab[(b & 7) * 16 + n];
-        f4 corr0 = {0.0f, 0.0f, 0.0f, 0.0f}, corr1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int d = -NSIDE; d <= NSIDE; ++d) {
-            if (d == 0) continue;
-            const float dlt = ctab[((b + d) & 7) * 16 + n] - cb;
-            const f4 w0 = *reinterpret_cast<const f4*>(wlds + (d + 2) * 64 + o), w1 = *reinterpret_cast<const f4*>(wlds + (d + 2) * 64 + o + 16);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                corr0[e] = fmaf(dlt, w0[e], corr0[e]);
-                corr1[e] = fmaf(dlt, w1[e], corr1[e]);
-            }
-        }
-        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-        int slot = base;
-        f16x8 dh[3], dl[3];
-        auto fetch = [&](int k) {
-            dh[k] = *reinterpret_cast<const f16x8*>(bh_ptr + slot);
-            dl[k] = *reinterpret_cast<const f16x8*>(bl_ptr + slot);
-            slot += 32;
-            slot = slot >= RR ? slot - RR : slot;
-        };
-        fetch(0);
-        fetch(1);
-#pragma unroll
-        for (int s = 0; s < NK; ++s) {
-            if (s + 2 < NK) fetch((s + 2) % 3);
-            __builtin_amdgcn_sched_barrier(0);
-            f16_products16_pair_b<NP>(t0h[s], t0l[s], t1h[s], t1l[s], dh[s % 3], dl[s % 3], acc0, acc1);
-        }
-        if (p.nchunks == 0 && wave >= 4) __builtin_amdgcn_s_barrier();
-        if (xw + n < p.nx) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int oy = y0 + 16 * m + 4 * kg + v;
-                    if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows)
-                        p.out[(size_t)(oy - p.out_row0) * p.nx + xw + n] = fmaf(m ? acc1[v] : acc0[v], p.out_scale, m ? corr1[v] : corr0[v]) + cb;
-                }
-        }
-        if (lane == 0) p.flags[(size_t)t * (gridDim.x * 8) + blockIdx.x * 8 + wave] = last_wild >= t ? 1 : 0;
-        if (more) {
-            bool bad = false;
-            float c = c_tab;
-            if ((n0 & 63) == 0) {  // a slab starts: its reference came with the rows; it takes over the slot of the slab 8 before it
-                const bool w = wild(ref);
-                c = w ? 0.0f : ref;
-                if (kg == 0) ctab[(floor_div64(n0) & 7) * 16 + n] = c;
-                if (__builtin_amdgcn_ballot_w64(w)) ref_wild |= 1u << (floor_div64(n0) & 7);
-                else ref_wild &= ~(1u << (floor_div64(n0) & 7));
-            }
-            stage(pre, base, c, bad);  // over the oldest 32 rows
-            if (__builtin_amdgcn_ballot_w64(bad) || (ref_wild & (1u << (floor_div64(n0) & 7)))) last_wild = t + kStay;
-        }
-        base += 32;
-        base = base >= RR ? base - RR : base;
     }
 }
 
@@ -2395,11 +2171,9 @@ __global__ __launch_bounds__(64) void gauss_f16_repair_kernel(GaussArgs p, int u
         if (mine < units) {
             if (p.fine_cols == 0) {
                 mark = p.flags[mine] != 0;
-            } else {  // the tiles of the unit
-                const int fa = (int)(mine / units_b) * p.fine_rpu, fb = (int)(mine % units_b) * p.fine_cpu;
-                for (int ea = 0; ea < p.fine_rpu; ++ea)
-                    for (int eb = 0; eb < p.fine_cpu; ++eb)
-                        if (fa + ea < p.fine_rows && fb + eb < p.fine_cols) mark |= p.flags[(size_t)(fa + ea) * p.fine_cols + fb + eb] != 0;
+            } else {  // the two 16-row bands of the unit
+                const int fa = (int)(mine / units_b) * 2, fb = (int)(mine % units_b);
+                mark = p.flags[(size_t)fa * p.fine_cols + fb] != 0 || (fa + 1 < p.fine_rows && p.flags[(size_t)(fa + 1) * p.fine_cols + fb] != 0);
             }
         }
         unsigned long long marked = __builtin_amdgcn_ballot_w64(mark);
@@ -2675,14 +2449,11 @@ int launch_f16_axis1_any(int steps, int mt, long waves, const GaussArgs& a, int 
 thread_local const int* t_run_if = nullptr;
 
 // axis 0 on the f16 route: tiles of 32 MT rows on the global grid, one flag byte per 32 x 32 unit
-bool s1_rows_ok(const Block& b, int R);
-int run_axis0_s1(const Block& b, GaussArgs a);
 int run_axis0_f16(const Block& b, GaussArgs a, double sigma) {
     Context& c = ctx();
     set_f16_scales(sigma, &a);
     a.run_if = t_run_if;
     a.wild_flag = nullptr;
-    if (split_once(f16_steps(a.radius)) && !t_axis0_one_tile && s1_rows_ok(b, a.radius)) return run_axis0_s1(b, a);
     const int mt = f16_mt(false, a.radius), tile = 32 * mt;
     const int tile_first = b.out_row0 / tile;
     const int ntiles = (b.out_row0 + b.out_rows - 1) / tile - tile_first + 1;
@@ -2701,74 +2472,6 @@ int run_axis0_f16(const Block& b, GaussArgs a, double sigma) {
     TOPO_TRY(launch_f16_axis0_any(f16_steps(a.radius), mt, grid, a, tile_first, ntiles, per));
     hipLaunchKernelGGL(gauss_f16_repair_kernel<false>, dim3((unsigned)std::min<long>(kRepairBlocks, (units + 63) / 64)), dim3(64), 0, c.compute,
                        a, ntiles * mt, strips * 4, tile_first * mt, 0);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
-}
-
-template <int NK>
-int launch_s1_axis0(dim3 grid, const GaussArgs& a, int tile_first, int ntiles, int per) {
-    Context& c = ctx();
-    static bool ready = false;
-    if (!ready) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis0_s1_kernel<NK, TOPO_F16_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ready = true;
-    }
-    const size_t lds = (8 * (size_t)(16 * (32 * NK + 8) + 8 * 16) + 5 * 64) * sizeof(float);
-    hipLaunchKernelGGL((gauss_axis0_s1_kernel<NK, TOPO_F16_NP>), grid, dim3(512), lds, c.compute, a, tile_first, ntiles, per);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
-}
-// Split-once axis 0 on a row block: the reference row (row 32) of every 64-row slab that the window of one of the
-// block's output rows touches is inside the block (reflected at the DEM's edges first, like the samples).  True for
-// the whole DEM and for blocks with R + 32 ghost rows (gaussian_reach); a block that comes with less takes the tile
-// kernels, whose results differ in the last bits.
-bool s1_rows_ok(const Block& b, int R) {
-    const int lo = b.out_row0 - R, hi = b.out_row0 + b.out_rows - 1 + R;
-    auto fdiv = [](int a) { return a >= 0 ? a / 64 : -((-a + 63) / 64); };
-    for (int s = fdiv(lo); s <= fdiv(hi); ++s) {
-        int y = 64 * s + 32;
-        const int period = 2 * b.gny;
-        y %= period;
-        if (y < 0) y += period;
-        y = y < b.gny ? y : period - 1 - y;
-        if (y < b.in_row0 || y >= b.in_row0 + b.in_rows) return false;
-    }
-    return true;
-}
-int run_axis0_s1(const Block& b, GaussArgs a) {
-    Context& c = ctx();
-    const int nk = s1_steps(a.radius);
-    const int tile_first = b.out_row0 / 32;
-    const int ntiles = (b.out_row0 + b.out_rows - 1) / 32 - tile_first + 1;
-    const int strips = (b.nx + 127) / 128;
-    // one block of 8 waves per CU marches down its strip of 128 columns; with fewer strips than CUs the tile runs are
-    // cut (each cut restages the window: runs of 256 rows or more)
-    int splits = (c.num_cu + strips - 1) / strips;
-    splits = std::max(1, std::min(splits, ntiles / 8 > 0 ? ntiles / 8 : 1));
-    if (strips >= c.num_cu) splits = 1;
-    const int per = (ntiles + splits - 1) / splits;
-    TOPO_TRY(check_grid_rows((ntiles + per - 1) / per, "gaussian (split-once axis 0)"));
-    dim3 grid(strips, (ntiles + per - 1) / per);
-    void* flags = nullptr;
-    TOPO_TRY(workspace(10, (size_t)ntiles * strips * 8, &flags));
-    a.flags = (unsigned char*)flags;
-    a.fine_rows = ntiles;
-    a.fine_cols = strips * 8;
-    a.fine_rpu = 1;
-    a.fine_cpu = 2;
-    {
-        const char* e = std::getenv("TOPO_AMD_S1_NOBARRIER");
-        a.nchunks = e && *e == '1' ? 1 : 0;
-    }
-    switch (nk) {
-        case 5: TOPO_TRY(launch_s1_axis0<5>(grid, a, tile_first, ntiles, per)); break;
-        case 7: TOPO_TRY(launch_s1_axis0<7>(grid, a, tile_first, ntiles, per)); break;
-        case 9: TOPO_TRY(launch_s1_axis0<9>(grid, a, tile_first, ntiles, per)); break;
-        default: set_error("gaussian (split-once matrix-core route): no kernel for this radius"); return TOPO_AMD_EUNSUP;
-    }
-    const long units = (long)ntiles * strips * 4;
-    hipLaunchKernelGGL(gauss_f16_repair_kernel<false>, dim3((unsigned)std::min<long>(kRepairBlocks, (units + 63) / 64)), dim3(64), 0, c.compute,
-                       a, ntiles, strips * 4, tile_first, 0);
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
@@ -2798,8 +2501,6 @@ int run_axis1_s1(GaussArgs a, int rows, int nx) {
     a.flags = (unsigned char*)flags;
     a.fine_rows = bands;
     a.fine_cols = ntile;
-    a.fine_rpu = 2;
-    a.fine_cpu = 1;
     TOPO_TRY(launch_s1_axis1_any(nk, waves, a, rows, nseg));
     const int units_a = (rows + 31) / 32, units_b = (nx + 31) / 32;
     const long units = (long)units_a * units_b;
@@ -3352,9 +3053,6 @@ int upload_resolution(int res_mode, const void* res_x, const void* res_y, int nx
 }  // namespace
 
 int gaussian_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
-// ghost rows with which a row block of the Gaussian has the whole DEM's bits: the radius, plus 32 where axis 0 takes the
-// split-once kernel (s1_rows_ok)
-int gaussian_reach(int R) { return R + (f16_route() && R <= 121 && split_once(f16_steps(R)) ? 32 : 0); }
 
 int mfma_min_radius(bool for_gradient) { return mfma_min_radius_impl(for_gradient); }
 
@@ -3545,7 +3243,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             if (taper && s1 - c1 < small + 32 && s1 - c1 > 0 && c1 < s1) c1 = std::max(c0 + 32, (s1 - small) / 32 * 32);  // leave the small last chunk
             if (c1 + 32 > s1 || c1 <= c0) c1 = s1;  // no sliver at the end
             // row shard with its exchange in flight: does the filter of these rows reach into the ghost rows?
-            chunks.push_back({c0, c1, gated && (c0 - gaussian_reach(R) < c.ghost.ghost_lo || c1 + gaussian_reach(R) > c.ghost.ghost_hi), false});
+            chunks.push_back({c0, c1, gated && (c0 - R < c.ghost.ghost_lo || c1 + R > c.ghost.ghost_hi), false});
             c0 = c1;
         }
         TOPO_REQUIRE(chunks.size() <= 64, "gradient: %zu row chunks (at most 64)", chunks.size());
