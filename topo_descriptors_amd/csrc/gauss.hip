@@ -1815,14 +1815,15 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
     const int n = lane & 15, kg = lane >> 4;
     const _Float16* const ah = hi + n * PITCH + 8 * kg;  // A: row n of the band, 8 window positions from 8 kg
     const _Float16* const al = lo + n * PITCH + 8 * kg;
-    // the columns tile t + 1 adds are loaded while tile t - 1 is computed, staged behind tile t
-    Pre pre_next;
-    if (t_first + 1 < t_last) pre_next = load(x_start + RC);
-    for (int t = t_first; t < t_last; ++t) {
+    // The columns tile t + 1 adds are loaded while tile t - 1 is computed and staged behind tile t: two register sets
+    // that swap roles from tile to tile (the loop below takes two tiles per turn, so nothing is copied and nothing
+    // waits for a load before its data is due).
+    Pre pre_a, pre_b;
+    if (t_first + 1 < t_last) pre_a = load(x_start + RC);
+    auto tile = [&](const int t, const Pre& pre, Pre& pre_next) {
         const int x0 = t * 32;
         const bool more = t + 1 < t_last;
         const int n0 = x0 - Rp + RC;  // the 32 columns the next tile adds
-        const Pre pre = pre_next;
         if (t + 2 < t_last) pre_next = load(n0 + 32);
         float c_n0 = 0.0f, c_n1 = 0.0f;
         if (more) {
@@ -1886,6 +1887,10 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
         }
         base += 32;
         base = base >= RC ? base - RC : base;
+    };
+    for (int t = t_first; t < t_last; t += 2) {
+        tile(t, pre_a, pre_b);
+        if (t + 1 < t_last) tile(t + 1, pre_b, pre_a);
     }
 }
 
