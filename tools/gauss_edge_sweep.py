@@ -11,7 +11,7 @@ rng = np.random.default_rng(3)
 rows_list = [1, 2, 3, 5, 16, 31, 32, 33, 47, 64, 65, 70]
 cols_list = [4, 8, 12, 28, 32, 36, 60, 64, 68, 96, 128, 132, 30, 67]
 bad = 0
-for sigma in (1.0, 3.25, 6.0, 10.0, 20.0, 30.25):
+for sigma in (1.0, 3.25, 6.0, 10.0, 13.0, 20.0, 30.25):
     worst = 0.0
     for ny, nx in itertools.product(rows_list, cols_list):
         dem = (1500 + 300 * rng.standard_normal((ny, nx))).astype(np.float32)
