@@ -280,9 +280,10 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
         3.25: "gauss_fused_f16_kernel (both passes of the radius-13 filter in one kernel on the f16 matrix pipe, the "
               "intermediate plane in LDS; the two-pass kernels queued behind it return at once on a DEM without "
               "non-finite samples); " + chunks,
-        30.25: "gauss_axis0_f16_kernel<18, 3, 2> + gauss_axis1_f16_kernel<18, 3, 1, 4> (banded Toeplitz products as three "
-               "v_mfma_f32_32x32x16_f16 per 16 taps, samples split into two f16 parts around the tile offset) + their "
-               "repair passes; " + chunks}
+        30.25: "gauss_axis0_f16_kernel<18, 3, 2> (banded Toeplitz products as three v_mfma_f32_32x32x16_f16 per 16 taps, "
+               "samples split into two f16 parts around the tile offset) + gauss_axis1_s1_kernel<9, 3> (samples split once, "
+               "against the reference of their 64-column slab; 16-row bands, two waves per SIMD, v_mfma_f32_16x16x32_f16) + "
+               "their repair passes; " + chunks}
     for sigma in (3.25, 30.25):
         fn = lambda: blk.gradient(sigma, [30.0], [-30.0], dx=o1, dy=o2, slope=o3, aspect=o4)  # noqa: E731
         entry(f"gradient_sigma{sigma}", time_kernel(fn, REPS, d), 20, grad_kernels[sigma])
