@@ -327,6 +327,41 @@ def test_gaussian_split_once_axis1(sigma):
             assert np.max(np.abs(g - t)) <= 1e-3 and not np.array_equal(g, t)  # (another kernel did run)
 
 
+def test_gaussian_of_a_raster_beyond_the_f16_range():
+    """ADVICE r03: the f16 matrix-core kernels stage samples beyond +-1e5 as 0 and leave their outputs to the repair pass;
+    a raster whose ordinary values lie out there (a DEM in millimetres) would be repaired pixel by pixel.  The library
+    samples a block at its first Gaussian / gradient call and gives such a raster to the vector-ALU kernels: the same
+    bits as with the matrix-core routes switched off, and float32 accuracy at that magnitude.  A NaN sea does not count."""
+    import subprocess, sys, tempfile
+    dem = orc.synthetic_dem(300, 520, seed=88) * np.float32(1000.0)  # 1.5e6 ... 3e6
+    sigmas = [3.25, 13.0]
+    got = [topo.dem(dem, s) for s in sigmas]
+    grad = topo.gradient(dem, 3.25, {"x": 25.0, "y": -25.0})
+    for s, g in zip(sigmas, got):
+        assert np.max(np.abs(g.astype(np.float64) - orc.gaussian_exact(dem, s))) <= 2.0  # (0.25 is one float32 ulp out there)
+    with tempfile.TemporaryDirectory() as tmp:
+        code = (
+            "import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "from topo_descriptors_amd import topo\n"
+            "from oracle import topo_oracle as orc\n"
+            "dem = orc.synthetic_dem(300, 520, seed=88) * np.float32(1000.0)\n"
+            "np.savez(%r, *([topo.dem(dem, s) for s in %r] + list(topo.gradient(dem, 3.25, {'x': 25.0, 'y': -25.0}))))\n"
+        ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(tmp, "valu.npz"), sigmas)
+        env = dict(os.environ, TOPO_AMD_GAUSS_MFMA_MIN_RADIUS="1000", TOPO_AMD_GRAD_MFMA_MIN_RADIUS="1000")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env)
+        valu = np.load(os.path.join(tmp, "valu.npz"))
+        for k, g in enumerate(got + list(grad)):
+            assert np.array_equal(g, valu["arr_%d" % k], equal_nan=True), k
+    sea = orc.synthetic_dem(300, 520, seed=88)
+    sea[:, :200] = np.nan  # 38 % of the samples: still the matrix-core route with its repair pass
+    from scipy import ndimage
+    res, want = topo.dem(sea, 13.0), ndimage.gaussian_filter(sea, 13.0)
+    assert np.array_equal(np.isnan(res), np.isnan(want))
+    fin = np.isfinite(want)
+    assert np.max(np.abs(res[fin] - want[fin])) <= 2e-3
+
+
 def check_gradient(got, ref_by_name, exact=None):
     dx, dy, slope, aspect = got
     for a in got:

@@ -67,6 +67,8 @@ struct DemMemo {
     int rows = 0, nx = 0;
     unsigned long used = 0;
     unsigned asked = 0;  // calls that asked "mostly fractional?" (every 32nd one is told no: the reporting kernels run again)
+    int large = -1;      // mostly samples beyond the matrix-core Gaussian's range? -1: not sampled yet
+    unsigned asked_large = 0;
 };
 constexpr int kMemos = 8;
 constexpr int kMemoWords = 4;
@@ -88,7 +90,7 @@ int memo_slot(const Block& b, bool create) {
         if (g_memo[k].used < g_memo[oldest].used) oldest = k;
     }
     if (!create) return -1;
-    g_memo[oldest] = DemMemo{b.in, b.in_rows, b.nx, ++g_memo_clock, 0};
+    g_memo[oldest] = DemMemo{b.in, b.in_rows, b.nx, ++g_memo_clock, 0, -1, 0};
     // (a launch in flight may still write the evicted entry's words: they are cleared here, and a late report for
     // another DEM can at worst pick the wrong first kernel once - the results do not depend on that choice)
     for (int w = 0; w < kMemoWords; ++w) g_memo_words[kMemoWords * oldest + w] = 0;
@@ -121,6 +123,46 @@ bool dem_memo_wild(const Block& b) {
         return false;
     }
     return *(volatile uint32_t*)(g_memo_words + kMemoWords * k + 2) != 0;
+}
+
+// 16384 samples on a regular grid over the block: how many are finite and beyond +-1e5 (kWild of gauss.hip: what the f16
+// matrix-core kernels stage as 0 and leave to their repair passes)
+__global__ __launch_bounds__(256) void large_sample_kernel(const float* in, size_t n, size_t stride, uint32_t* count) {
+    const size_t pos = ((size_t)blockIdx.x * 256 + threadIdx.x) * stride;
+    const float x = pos < n ? in[pos] : 0.0f;
+    const bool large = fabsf(x) > 1.0e5f && fabsf(x) <= 3.0e38f;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(large);
+    if ((threadIdx.x & 63) == 0 && m) __hip_atomic_fetch_add(count, (uint32_t)__builtin_popcountll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ADVICE r03 (medium, a): a raster whose ordinary values lie beyond 1e5 (a DEM in millimetres, a non-elevation raster)
+// would have every tile of the matrix-core Gaussian marked and every output recomputed by the repair pass's scalar
+// chains, ~100 x slower than the vector-ALU kernels.  The first Gaussian / gradient call on a block samples it (one
+// small launch and one stream synchronisation per DEM, again at every 32nd call: the buffer may hold other data by
+// then); with more than a quarter of the samples finite and beyond the limit the call takes the vector-ALU kernels,
+// which have no such limit.  Non-finite samples do not count: a DEM with a NaN sea is what the repair pass is for.
+bool dem_memo_mostly_large(const Block& b) {
+    static const bool on = [] {  // TOPO_AMD_GAUSS_LARGE_SAMPLE=0: never (A/B: tools/large_raster_time.py)
+        const char* e = std::getenv("TOPO_AMD_GAUSS_LARGE_SAMPLE");
+        return !(e && *e == '0');
+    }();
+    if (!on) return false;
+    const int k = memo_slot(b, true);
+    if (k < 0) return false;
+    DemMemo& m = g_memo[k];
+    if (m.large < 0 || ++m.asked_large % 32 == 0) {
+        Context& c = ctx();
+        uint32_t* word = g_memo_words + kMemoWords * k + 3;
+        if (hipStreamSynchronize(c.compute) != hipSuccess) return false;  // (no sampler of an earlier call in flight on this word)
+        *(volatile uint32_t*)word = 0;
+        const size_t n = (size_t)b.in_rows * b.nx;
+        constexpr size_t kSamples = 64 * 256;
+        const size_t stride = std::max<size_t>(1, n / kSamples);
+        hipLaunchKernelGGL(large_sample_kernel, dim3(64), dim3(256), 0, c.compute, b.in, n, stride, word);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c.compute) != hipSuccess) return false;
+        const size_t taken = std::min(kSamples, (n + stride - 1) / stride);
+        m.large = 4 * (size_t)*(volatile uint32_t*)word > taken ? 1 : 0;
+    }
+    return m.large == 1;
 }
 
 // Small parameter tables: pinned staging + async copy on the compute stream.  The previous

@@ -195,5 +195,8 @@ bool dem_memo_mostly_fractional(const Block& b);
 // plain finite one (non-finite, or beyond 1e5 in magnitude), and what that word said after the last finished call.
 uint32_t* dem_memo_wild_word(const Block& b);
 bool dem_memo_wild(const Block& b);
+// ... and whether more than a quarter of the block's samples are finite and beyond that limit (sampled once per DEM, one
+// stream synchronisation): such a raster takes the vector-ALU Gaussian kernels.
+bool dem_memo_mostly_large(const Block& b);
 
 }  // namespace topo

@@ -2306,7 +2306,11 @@ int mfma_min_radius_impl(bool for_gradient) {
     return for_gradient ? from_grad : from_gauss;
 }
 
+// set by launch_gaussian / launch_gradient for the call: the block's samples are mostly beyond the f16 kernels' range
+// (dem_memo_mostly_large): vector-ALU kernels
+thread_local bool t_no_mfma = false;
 bool mfma_radius(int R, int nx, bool for_gradient = false, bool small_ok = true) {
+    if (t_no_mfma) return false;
     // (any width from 4 columns: the loaders' 16-byte loads only need dword alignment, which a row of any length has;
     // TOPO_AMD_GAUSS_MFMA_ANY_WIDTH=0: multiples of 4 only, as before round 3)
     static const bool any_width = [] {
@@ -3061,7 +3065,16 @@ int gaussian_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
 
 int mfma_min_radius(bool for_gradient) { return mfma_min_radius_impl(for_gradient); }
 
+// (for the call: the matrix-core routes are closed to a block whose samples are mostly beyond their range)
+struct NoMfmaScope {
+    bool before;
+    explicit NoMfmaScope(const Block& b) : before(t_no_mfma) {
+        if (!t_no_mfma && f16_route()) t_no_mfma = dem_memo_mostly_large(b);
+    }
+    ~NoMfmaScope() { t_no_mfma = before; }
+};
 int launch_gaussian(const Block& b, double sigma_y, double sigma_x, float* out, bool small_ok) {
+    NoMfmaScope scope(b);
     for (int r = 0; r < b.out_rows; r += kMaxLaunchRows) {  // (one pass unless the block is taller than a launch covers)
         const int n = std::min(kMaxLaunchRows, b.out_rows - r);
         TOPO_TRY(smooth_rows(b, sigma_y, sigma_x, b.out_row0 + r, n, out + (size_t)r * b.nx, 0, 1, small_ok));
@@ -3111,6 +3124,7 @@ Block smoothed_rows_block(const Block& b) {
 int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode,
                     const void* res_x, const void* res_y, float* dx, float* dy, float* slope,
                     float* aspect) {
+    NoMfmaScope scope(b);
     if (b.out_rows > kMaxLaunchRows) {
         if (ctx().ghost.armed) return TOPO_AMD_EUNSUP;
         for (int r = 0; r < b.out_rows; r += kMaxLaunchRows) {

@@ -160,7 +160,9 @@ def dem(dem, sigma):
     ``scipy.ndimage.gaussian_filter`` - and exactly those when the smoothing runs on the matrix cores (Gaussian radius
     ``int(4 sigma + 0.5)`` of 4 ... 121, any DEM width from 4 columns): those kernels keep such samples
     (and absurd ones, ``|x| > 1e5``) out of the matrix pipe, mark the tiles whose windows hold one, and a repair pass
-    recomputes in float32, over each output's own window, exactly the outputs that see one.  The vector-ALU kernels
+    recomputes in float32, over each output's own window, exactly the outputs that see one.  (A raster whose ordinary
+    values lie beyond 1e5 - a DEM in millimetres - is recognised by sampling at the first call and smoothed by the
+    vector-ALU kernels instead.)  The vector-ALU kernels
     (shorter or much longer filters) pad their taps to chunks of 8 or 16 and spoil up to one chunk more
     towards lower indices.  ``tests/test_gpu_parity.py::test_gaussian_nan_footprint`` pins both.
     """
