@@ -49,7 +49,7 @@ while time.time() < t_end:
     what = rng.choice(["gradient", "gradient", "gauss", "sx", "valley"])
     try:
         if what == "gradient":
-            sigma = float(rng.choice([0.5, 0.75, 1.0, 1.25, 2.25, 3.25, 4.0, 5.75, 7.5, 12.0]))
+            sigma = float(rng.choice([0.5, 0.75, 1.0, 1.25, 2.25, 3.25, 4.0, 5.75, 7.5, 12.0, 13.0, 20.0, 30.25]))  # (from 12.25: split-once axis 1)
             ratio = float(rng.choice([1, 1, 1, 0.5, 2]))
             dx0 = float(rng.choice([30.0, 25.0, 50.0]))
             dy0 = float(rng.choice([-30.0, -25.0, 30.0]))
@@ -105,7 +105,7 @@ while time.time() < t_end:
                     if not np.array_equal(np.concatenate(parts[k]), got[k]):
                         fails.append(f"{ctx} row blocks nb={nb} {nm}")
         elif what == "gauss":
-            sigma = float(rng.choice([0.75, 1.5, 2.25, 3.25, 6.0, 9.5, 15.0]))
+            sigma = float(rng.choice([0.75, 1.5, 2.25, 3.25, 6.0, 9.5, 15.0, 20.0, 30.25]))
             ctx = f"gauss ny={ny} nx={nx} sigma={sigma}"
             counts["gauss"] += 1
             from scipy import ndimage
