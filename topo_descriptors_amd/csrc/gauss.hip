@@ -1774,6 +1774,19 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
         *reinterpret_cast<f16x4*>(hi + (lr + 8) * PITCH + slot + lc) = dh;
         *reinterpret_cast<f16x4*>(lo + (lr + 8) * PITCH + slot + lc) = dl;
     };
+    // The bands do not walk the row in step: band b's tile order is turned by turn_b tiles (tile = (position + turn_b) mod
+    // ntile), so its runs start somewhere else than its neighbours' and the one run that meets the end of the row goes
+    // on at its start (a second run-in for that run).  In step, all bands of the DEM sit on the same columns at the
+    // same time, 2^17 bytes apart on a 32768-wide DEM, and whether HBM's channels then collide depends on the physical
+    // pages: the + 30 ... 45 % slow mode most processes show on some boxes (profiles/r04_pitch_spread.txt; axis 1 alone at
+    // sigma 13 / 20: 1.66 / 1.86 ms or 2.40 / 2.43 ms in step, 1.79 / 1.88 ms turned).
+    const int run_len = t_last - t_first;
+    const int turn = p.group0 != 0 && ntile >= 64 ? (int)(((unsigned)band * 40503u) % (unsigned)ntile) : 0;
+    const int run_first = (t_first + turn) % ntile;
+    for (int part = 0; part < 2; ++part) {
+    const int t_first = part == 0 ? run_first : 0;
+    const int t_last = part == 0 ? min(run_first + run_len, ntile) : run_first + run_len - ntile;
+    if (t_first >= t_last) continue;
     unsigned ref_wild = 0;  // slabs (slot bits) whose reference column holds a sample that is not a plain finite one
     int last_wild = kNoWild;
     const int x_start = t_first * 32 - Rp;
@@ -1891,6 +1904,7 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
     for (int t = t_first; t < t_last; t += 2) {
         tile(t, pre_a, pre_b);
         if (t + 1 < t_last) tile(t + 1, pre_b, pre_a);
+    }
     }
 }
 
@@ -2510,6 +2524,11 @@ int run_axis1_s1(GaussArgs a, int rows, int nx) {
     a.flags = (unsigned char*)flags;
     a.fine_rows = bands;
     a.fine_cols = ntile;
+    static const bool turn = [] {  // TOPO_AMD_GAUSS_TURN=0: every band starts its run at the run's first tile (A/B)
+        const char* e = std::getenv("TOPO_AMD_GAUSS_TURN");
+        return !(e && *e == '0');
+    }();
+    a.group0 = turn ? 1 : 0;
     TOPO_TRY(launch_s1_axis1_any(nk, waves, a, rows, nseg));
     const int units_a = (rows + 31) / 32, units_b = (nx + 31) / 32;
     const long units = (long)units_a * units_b;
