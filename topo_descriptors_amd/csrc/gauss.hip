@@ -1945,8 +1945,8 @@ __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int t
     const bool band_on = 4 * (int)blockIdx.y + wave < ntile_rows;
     const int ntile = (p.nx + 63) / 64;
     const int tper = (ntile + nseg - 1) / nseg;
-    const int t_first = blockIdx.x * tper, t_last = min(t_first + tper, ntile);
-    if (t_first >= t_last) return;
+    const int seg_first = blockIdx.x * tper, seg_last = min(seg_first + tper, ntile);
+    if (seg_first >= seg_last) return;
     const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
     const bool rows_inside = y_blk - Rp >= row_lo && y_blk + 128 + Rp <= row_hi;
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1992,6 +1992,14 @@ __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int t
     const f32x2 quarter = {0.25f, 0.25f};
     const unsigned out_lane_off = (unsigned)(4 * g * p.nx + i) * 4u;
     const bool full_band = y_band >= p.out_row0 && y_band + 32 <= p.out_row0 + p.out_rows;
+    // The row blocks do not walk the DEM in step (gauss_axis1_s1_kernel has the reasons): row block y's tile order is turned
+    // by a number of tiles of its own, and the run that meets the end of the row goes on at its start (a second run-in).
+    const int turn = p.group0 != 0 && ntile >= 32 ? (int)(((unsigned)blockIdx.y * 40503u) % (unsigned)ntile) : 0;
+    const int run_first = (seg_first + turn) % ntile, run_len = seg_last - seg_first;
+    for (int part = 0; part < 2; ++part) {
+    const int t_first = part == 0 ? run_first : 0;
+    const int t_last = part == 0 ? min(run_first + run_len, ntile) : run_first + run_len - ntile;
+    if (t_first >= t_last) continue;
     const int u0 = BPT * t_first;                       // first block of the first tile
     const int u_start = u0 - (2 * Rp + CW - 1) / CW;    // run-in: the 2 Rp columns left of it
     const int u_last = BPT * t_last - 1;
@@ -2126,6 +2134,7 @@ __global__ __launch_bounds__(256) void gauss_fused_f16_kernel(GaussArgs p, int t
         if (more) store_raw(pre, rawbuf + (cur ^ 1) * (RAWR * CW));
         __syncthreads();
         cur ^= 1;
+    }
     }
 }
 
@@ -2413,6 +2422,14 @@ int launch_f16_axis1(long waves, const GaussArgs& a, int rows, int nseg) {
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
+// TOPO_AMD_GAUSS_TURN=0: every band / row block starts its run at the run's first tile (A/B of the turned tile order)
+bool gauss_turn() {
+    static const bool on = [] {
+        const char* e = std::getenv("TOPO_AMD_GAUSS_TURN");
+        return !(e && *e == '0');
+    }();
+    return on;
+}
 // split once (gauss_axis*_s1_kernel): radius 49 ... 121.  TOPO_AMD_GAUSS_SPLIT_ONCE=0: the tile kernels everywhere (A/B)
 bool split_once(int steps) {
     static const bool on = [] {
@@ -2524,11 +2541,7 @@ int run_axis1_s1(GaussArgs a, int rows, int nx) {
     a.flags = (unsigned char*)flags;
     a.fine_rows = bands;
     a.fine_cols = ntile;
-    static const bool turn = [] {  // TOPO_AMD_GAUSS_TURN=0: every band starts its run at the run's first tile (A/B)
-        const char* e = std::getenv("TOPO_AMD_GAUSS_TURN");
-        return !(e && *e == '0');
-    }();
-    a.group0 = turn ? 1 : 0;
+    a.group0 = gauss_turn() ? 1 : 0;
     TOPO_TRY(launch_s1_axis1_any(nk, waves, a, rows, nseg));
     const int units_a = (rows + 31) / 32, units_b = (nx + 31) / 32;
     const long units = (long)units_a * units_b;
@@ -2717,7 +2730,7 @@ int run_fused_f16(const Block& b, double sigma, float* out, int table_slot, cons
     a.nx = b.nx;
     a.out_row0 = b.out_row0;
     a.out_rows = b.out_rows;
-    a.group0 = 0;
+    a.group0 = gauss_turn() ? 1 : 0;
     a.flags = nullptr;
     a.run_if = nullptr;
     set_f16_scales(sigma, &a);
