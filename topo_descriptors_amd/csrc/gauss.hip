@@ -1460,8 +1460,15 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
     const bool full_band = r0 + 32 <= rows;
     const int ntile = (p.nx + TILE - 1) / TILE, nunit = (p.nx + 31) / 32;
     const int tper = (ntile + nseg - 1) / nseg;
-    const int t_first = seg * tper, t_last = min(t_first + tper, ntile);
-    if (t_first >= t_last) return;
+    const int seg_first = seg * tper, seg_last = min(seg_first + tper, ntile);
+    if (seg_first >= seg_last) return;
+    // (the bands do not walk the row in step: gauss_axis1_s1_kernel has the reasons)
+    const int turn = p.group0 != 0 && ntile >= 32 ? (int)(((unsigned)band * 40503u) % (unsigned)ntile) : 0;
+    const int run_first = (seg_first + turn) % ntile, run_len = seg_last - seg_first;
+    for (int part = 0; part < 2; ++part) {
+    const int t_first = part == 0 ? run_first : 0;
+    const int t_last = part == 0 ? min(run_first + run_len, ntile) : run_first + run_len - ntile;
+    if (t_first >= t_last) continue;
     int last_wild = kNoWild;
     {
         bool bad = false;
@@ -1585,6 +1592,7 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
         }
         base += TILE;
         base = base >= RC ? base - RC : base;
+    }
     }
 }
 
@@ -2557,6 +2565,7 @@ int run_axis1_f16(GaussArgs a, int rows, int nx, double sigma) {
     a.run_if = t_run_if;
     a.wild_flag = nullptr;
     const int steps = f16_steps(a.radius);
+    a.group0 = gauss_turn() ? 1 : 0;
     if (split_once(steps)) return run_axis1_s1(a, rows, nx);
     const int mt = f16_mt(true, a.radius);
     const int nw = steps == 18 && mt == 2 ? 3 : 4;
