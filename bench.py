@@ -285,6 +285,9 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
                "against the reference of their 64-column slab; 16-row bands, two waves per SIMD, v_mfma_f32_16x16x32_f16) + "
                "their repair passes; " + chunks}
     for sigma in (3.25, 30.25):
+        # the Gaussian primitive (topo.dem) at the two sigmas: 4 B read + 4 B written per pixel
+        entry(f"dem_sigma{sigma}", time_kernel(lambda: blk.gaussian(sigma, sigma, o1), REPS, d), 8,
+              grad_kernels[sigma].split(";")[0].replace(" + their repair passes", "") + " (no row chunks)")
         fn = lambda: blk.gradient(sigma, [30.0], [-30.0], dx=o1, dy=o2, slope=o3, aspect=o4)  # noqa: E731
         entry(f"gradient_sigma{sigma}", time_kernel(fn, REPS, d), 20, grad_kernels[sigma])
         fn = lambda: blk.gradient(sigma, [30.0], [-30.0], slope=o3, aspect=o4)  # noqa: E731
