@@ -13,7 +13,6 @@
 #include "common.hpp"
 #include "atan.hpp"
 
-#include <cstdio>
 #include <cstdlib>
 
 #include <cmath>
@@ -982,7 +981,7 @@ __global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int 
         if (more) {
             const int n0 = x0 - R + K8;  // the 32 columns the next tile adds
             if (full_band && n0 >= 0 && n0 + 32 <= p.nx) {  // scalar base + the per-lane byte offset: see axis 0
-                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)min(r0, rows - 32) * p.nx + max(0, min(n0, p.nx - 32)));
+                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)r0 * p.nx + n0);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) pre[q] = *reinterpret_cast<const float*>(rb + (size_t)(2 * q) * p.nx * 4 + in_lane_off);
             } else {
@@ -1496,7 +1495,7 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
         if (more) {
             const int n0 = x0 - Rp + RC;  // the columns the next tile adds
             if (full_band && n0 >= 0 && n0 + TILE <= p.nx) {
-                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)min(r0, rows - 32) * p.nx + max(0, min(n0, p.nx - 32)));
+                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)r0 * p.nx + n0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1616,19 +1615,6 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
 // fetched unless a block barrier per tile keeps the waves together, which takes the overlap away again; it is not in the
 // library: profiles/r04_gauss_split_once.txt.)
 __device__ __forceinline__ int floor_div64(int a) { return a >> 6; }  // arithmetic shift: floor for negative a
-
-// W_s[o] of the lane's output position o = 0 ... 63 inside its own slab, s - b = -2, -1, +1, +2
-struct SlabWeights {
-    float w[4];
-};
-__device__ __forceinline__ SlabWeights slab_weights(const float* wtab, int o) {
-    SlabWeights r;
-    r.w[0] = wtab[0 * 64 + o];
-    r.w[1] = wtab[1 * 64 + o];
-    r.w[2] = wtab[3 * 64 + o];
-    r.w[3] = wtab[4 * 64 + o];
-    return r;
-}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
