@@ -1820,6 +1820,7 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
     }
     int base = 0;  // ring column of input column x0 - Rp
     const int n = lane & 15, kg = lane >> 4;
+    const unsigned out_lane_off = (unsigned)(4 * kg * p.nx + n) * 4u;  // D: column n, rows 4 kg + v
     const _Float16* const ah = hi + n * PITCH + 8 * kg;  // A: row n of the band, 8 window positions from 8 kg
     const _Float16* const al = lo + n * PITCH + 8 * kg;
     // The columns tile t + 1 adds are loaded while tile t - 1 is computed and staged behind tile t: two register sets
@@ -1874,13 +1875,23 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
         }
         {
             const int ox = x0 + n;
-            float* o0 = p.out + (size_t)(r0 + 4 * kg) * p.nx + ox;
+            if (full_band && x0 + 32 <= p.nx) {  // (wave-uniform) every row and both sub-tiles: one base, immediate offsets
+                char* ub = reinterpret_cast<char*>(p.out + (size_t)r0 * p.nx + x0) + out_lane_off;
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (full_band || r0 + 4 * kg + v < rows) {
-                    if (ox < p.nx) o0[(size_t)v * p.nx] = fmaf(acc0[v], p.out_scale, corr0[v]) + cb[v];
-                    if (ox + 16 < p.nx) o0[(size_t)v * p.nx + 16] = fmaf(acc1[v], p.out_scale, corr1[v]) + cb[v];
+                for (int v = 0; v < 4; ++v) {
+                    float* o0 = reinterpret_cast<float*>(ub + (size_t)v * p.nx * 4);
+                    o0[0] = fmaf(acc0[v], p.out_scale, corr0[v]) + cb[v];
+                    o0[16] = fmaf(acc1[v], p.out_scale, corr1[v]) + cb[v];
                 }
+            } else {
+                float* o0 = p.out + (size_t)(r0 + 4 * kg) * p.nx + ox;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (full_band || r0 + 4 * kg + v < rows) {
+                        if (ox < p.nx) o0[(size_t)v * p.nx] = fmaf(acc0[v], p.out_scale, corr0[v]) + cb[v];
+                        if (ox + 16 < p.nx) o0[(size_t)v * p.nx + 16] = fmaf(acc1[v], p.out_scale, corr1[v]) + cb[v];
+                    }
+            }
         }
         if (lane == 0) p.flags[(size_t)band * ntile + t] = last_wild >= t ? 1 : 0;
         if (more) {
