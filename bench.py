@@ -466,6 +466,11 @@ def parity_spots(d, block, first_row, nx):
             "aspect_max_wrapped_err_deg_where_slope_gt_0.1": float(np.max(orc.wrapped_angle_diff(got[3][inner], want[3][inner])[steep])),
             "dx_rel_range": float(np.max(np.abs(got[0][inner] - want[0][inner])) / np.max(np.abs(want[0][inner]))),
             "window": [n - 2 * r, n - 2 * r]}
+        # the Gaussian primitive itself against the float64 evaluation of the same filter (whole sample: reflect at its edges)
+        blk.gaussian(sigma, sigma, o[0])
+        d.sync()
+        out[f"dem_sigma{sigma}"] = {"max_abs_err_m_vs_float64": float(np.max(np.abs(o[0].to_host().astype(np.float64) - orc.gaussian_exact(sample, sigma)))),
+                                    "window": [n, n]}
     window, dj, di, dist = d.sx_offsets(0.0, 500.0, 30.0, -30.0)
     blk.sx(dj, di, dist, window, 10.0, o[0])
     d.sync()
