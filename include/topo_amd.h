@@ -80,6 +80,30 @@ int topo_amd_memcpy_d2d(void* dst, const void* src, size_t bytes);
 int topo_amd_memset(void* dst, int value, size_t bytes);
 int topo_amd_sync(void);
 
+/* ---- what kernel routing may know about a raster ------------------------------------------------------------------------
+ * Results never depend on how a raster is cut into row blocks or shards, nor on what the library has seen before.  Nearly
+ * all kernel choices cannot change a bit (integer sums are exact whoever forms them).  Two can, in the last bits: the
+ * Gaussian / gradient of a raster whose ORDINARY values lie beyond 1e5 (a DEM in millimetres) runs on the vector-ALU kernels
+ * instead of the f16 matrix-core ones, and TPI alone on fractional elevations (discs from 19 px) sums x in units of 2^-k m
+ * with k = 8 ... 16 chosen from the raster's value range.  Both are properties of the WHOLE raster - its "class", read off a
+ * lattice of about 16 K samples of the GLOBAL grid (rows / columns step / 2 + i step, step = extent / 128):
+ *   - a block that is the whole raster (in_row0 == 0, in_rows == gny) is scanned by the library at the first call that
+ *     needs the class and remembered with the buffer until the library writes or frees the buffer - or the caller, having
+ *     written it with kernels of its own, says so with topo_amd_dem_changed;
+ *   - the host-buffer entry points scan the caller's array;
+ *   - a PARTIAL row block uses the class the calling thread declared: topo_amd_raster_scan_dev adds up the lattice points
+ *     of the rows each block owns (counts += {samples, samples finite and beyond 1e5}; range = {min, max} of the samples
+ *     within +-2^18; start from 0, 0 and +inf, -inf), topo_amd_raster_class_from_scan declares the sum;
+ *     topo_amd_shard_classify does both for a row shard, with an all-reduce over the communicator (collective).  A thread
+ *     that has declared nothing sees the last declaration of any thread; with none at all the raster is taken for an
+ *     ordinary DEM in metres (large = 0, range 0 ... 4096).  large < 0 withdraws the declarations.                       */
+int topo_amd_dem_changed(const void* dptr, size_t bytes); /* bytes == 0: the whole allocation dptr lies in */
+int topo_amd_raster_scan_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int own_row0, int own_rows,
+                             uint64_t counts[2], float range[2]);
+int topo_amd_raster_class_from_scan(const uint64_t counts[2], const float range[2]);
+int topo_amd_raster_class_set(int large, float lo, float hi);
+int topo_amd_raster_class_get(int* large, float* lo, float* hi);
+
 /* HIP-event stopwatch on the compute stream (what bench.py times kernels with). */
 int topo_amd_timer_start(void);
 int topo_amd_timer_stop(float* elapsed_ms); /* records, synchronises, returns ms        */
@@ -115,10 +139,16 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
 /* TPI and/or STD over the reference's disc (replaces topo.tpi topo.py:144-181 and topo.std
  * topo.py:272-307, called from topo.py:138 and :266).  Either output may be NULL.  STD is
  * float32 on the device (the Python wrapper widens to float64 like the reference).       */
-/* TPI alone (std_out == NULL), discs of 19 ... 101 px, tiles with fractional elevations: the neighbourhood sum is taken
- * on x in units of 2^-8 m (one integer chain; csrc/disc_wave_impl.hpp, tpi_scaled_march_kernel), at most 2^-9 m = 1.95 mm
- * off per sample and therefore on TPI; whole-metre DEMs, smaller discs and the fused TPI + STD call are exact to float32
- * rounding.  Environment TOPO_AMD_TPI_FRACTION_EXACT=1: the exact two-pass route (2^-16 m) for those tiles as well.     */
+/* Arithmetic.  Sums of trunc(x), trunc(x)^2 and of the fractional parts (units of 2^-16 m) are exact integers in every
+ * kernel, so the values do not depend on tiles, kernels or row blocks.  A sample that is not finite or beyond +-2^24 is
+ * MISSING: exactly the pixels whose disc holds one are NaN.  Samples beyond +-2^18 (a raster in millimetres) and windows
+ * with more relief than the 32-bit chains hold (nodata like -9999 next to terrain) take exact multi-limb passes (slower).
+ * TPI alone (std_out == NULL), discs of 19 ... 101 px, windows with fractional elevations: the neighbourhood sum is taken
+ * on x in units of 2^-k m (one integer chain; csrc/disc_wave_impl.hpp, tpi_scaled_march_kernel), k = 8 for an ordinary DEM
+ * (at most 2^-9 m = 1.95 mm off per sample and therefore on TPI), up to 16 for rasters of small values (the raster class,
+ * above); an output row whose own window holds more relief than that chain unwraps exactly is computed by the exact
+ * general kernel - decided per row on the rows every row block that computes it holds.  Whole-metre DEMs, smaller discs
+ * and the fused TPI + STD call are exact to float32 rounding.  TOPO_AMD_TPI_FRACTION_EXACT=1: the exact two-pass route.  */
 int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int size,
                          int out_row0, int out_rows, float* tpi_out, float* std_out);
 
@@ -133,15 +163,12 @@ int topo_amd_tpi_multi_dev(const float* in, int in_rows, int in_row0, int gny, i
  * (replaces topo.dem topo.py:62-80 and the pre-smoothing at topo.py:173, :298).  A sigma of
  * 0 skips that axis.  The intermediate plane lives in the library's own workspace.       */
 /* Gaussian / gradient, matrix-core routes (filter radius 4 ... 121): a sample that is not finite, or larger than 1e5 in
- * magnitude (a raster in centimetres or millimetres, a sentinel like 1e20), is "wild": its outputs are recomputed by
- * slower repair passes with exactly ndimage.gaussian_filter's footprint, and a DEM on which the fused short-filter
- * kernel met one is remembered (by block pointer) and takes the two-pass kernels on later calls.  Results are the same
- * either way.  A raster whose ORDINARY values lie beyond 1e5 (a DEM in millimetres) does not go that way: the first
- * Gaussian / gradient call on a block samples it (16384 samples, one small launch and one synchronisation of the
- * library's stream per block pointer, again at every 32nd call), and with more than a quarter of the samples finite and
- * beyond the limit the call runs on the vector-ALU kernels, which have no such limit (8192^2, sigma 3.25 / 13: 0.45 / 0.71 ms
- * against 21.9 / 68.3 ms through the repair passes).  Row blocks of such a raster are classified one by one: their last
- * bits may differ from the whole raster's.  TOPO_AMD_GAUSS_LARGE_SAMPLE=0 switches the sampling off.                   */
+ * magnitude (a sentinel like 1e20), is "wild": its outputs are recomputed by slower repair passes with exactly
+ * ndimage.gaussian_filter's footprint (a block on which the fused short-filter kernel met one is remembered and takes the
+ * two-pass kernels on later calls: the same bits).  A raster whose ORDINARY values lie beyond 1e5 (a DEM in millimetres)
+ * runs on the vector-ALU kernels, which have no such limit (8192^2, sigma 3.25 / 13: 0.45 / 0.71 ms against 21.9 / 68.3 ms
+ * through the repair passes): a property of the whole raster (the raster class, above), so every row block of it takes
+ * the same kernels.  TOPO_AMD_GAUSS_LARGE_SAMPLE=0: always the matrix-core kernels.                                    */
 int topo_amd_gaussian_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
                           double sigma_y, double sigma_x, int out_row0, int out_rows,
                           float* out);
@@ -256,6 +283,9 @@ int topo_amd_comm_destroy(void);
 int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_above,
                                  int halo_below);
 int topo_amd_halo_wait(void);
+/* Collective: the class of the WHOLE sharded raster (above) for the calling thread's later topo_amd_shard_* calls.  owned:
+ * the first row this rank owns (device pointer), rows_local of them starting at global row row0.                       */
+int topo_amd_shard_classify(const float* owned, int rows_local, int row0, int gny, int nx);
 /* Round 4: a sharded call is ONE launch per kernel - the interior rows, then, behind a device-side gate the
  * communication stream opens when the ghost rows have landed, the seam rows - with a clean-up launch behind the
  * exchange's event for blocks that found the gate closed for longer than TOPO_AMD_GATE_WAIT_US (100).  Reads and

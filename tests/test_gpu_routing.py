@@ -1,0 +1,268 @@
+"""Kernel routing is a function of the data and the global grid only: results do not depend on how a
+raster is cut into row blocks, nor on what the library has seen before.  Rasters that exercise every data-dependent
+route - nodata next to terrain, NaN / inf, samples beyond 2^18 and beyond 2^24, fractional elevations, millimetres - in
+2 / 3 / 5 row blocks against one block, bit for bit; the same rasters against the float64 evaluation of the reference's
+formulas (the limb path of the general disc kernel is exact where round 4's float chains were not); host-buffer calls on
+buffers of one shape with other data against fresh processes."""
+import os
+import subprocess
+import sys
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import topo_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+from topo_descriptors_amd import _lib, device as d, shard, topo  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GNY, NX = 400, 512
+
+
+def run_blocks(dem, nblocks, above, below, call):
+    """Like tests/test_gpu_blocks.py, plus what an application that holds a raster in pieces does once: the class of the
+    WHOLE raster, added up from the blocks (include/topo_amd.h, "what kernel routing may know about a raster")."""
+    gny, nx = dem.shape
+    if nblocks > 1:
+        scan = d.RasterScan()
+        for row0, rows in shard.split_rows(gny, nblocks):
+            dev = d.DeviceArray.from_host(dem[row0:row0 + rows])
+            scan.add(d.Block(dev, row0=row0, gny=gny))
+            dev.free()
+        scan.declare()
+    pieces = None
+    try:
+        for row0, rows in shard.split_rows(gny, nblocks):
+            lo, hi = max(0, row0 - above), min(gny, row0 + rows + below)
+            dev = d.DeviceArray.from_host(dem[lo:hi])
+            outs = call(d.Block(dev, row0=lo, gny=gny), row0, rows)
+            d.sync()
+            host = [o.to_host() for o in outs]
+            pieces = [[h] for h in host] if pieces is None else [p + [h] for p, h in zip(pieces, host)]
+            for o in outs:
+                o.free()
+            dev.free()
+    finally:
+        d.forget_raster_class()
+    return [np.concatenate(p, axis=0) for p in pieces]
+
+
+def hard_rasters():
+    base_i = orc.synthetic_dem(GNY, NX, seed=5, integer=True)
+    base_f = orc.synthetic_dem(GNY, NX, seed=6, integer=False)
+    out = {}
+    a = base_i.copy(); a[GNY // 2 + 3, NX // 3] = np.nan; out["int+nan"] = a
+    a = base_f.copy(); a[GNY // 2 + 3, NX // 3] = np.nan; out["frac+nan"] = a
+    a = base_i.copy(); a[:, : NX // 8] = -9999.0; out["int+nodata_cols"] = a
+    a = base_f.copy(); a[GNY // 2 - 20: GNY // 2 + 9, NX // 4:] = -9999.0; out["frac+nodata_rows_at_seam"] = a
+    a = base_f.copy(); a[GNY // 3 + 7, 40:90] = -9999.0; out["frac+nodata_line"] = a
+    a = base_i.copy(); a[GNY // 2 + 5, NX // 2] = 1.0e20; out["int+1e20"] = a
+    a = base_i.copy(); a[GNY // 3: GNY // 3 + 30, NX // 2:] = -3.4028235e38; out["int+fltmin_block"] = a
+    a = base_i.copy(); a[GNY // 2 + 1, NX // 2 + 5] = np.inf; out["int+inf"] = a
+    a = base_f.copy(); a[: GNY // 2 + 11] = np.rint(a[: GNY // 2 + 11]); out["half_int_half_frac"] = a
+    out["mm"] = (base_f * 1000.0).astype(np.float32)
+    a = base_f.copy(); a[GNY // 2 + 9:] *= 1000.0; out["half_m_half_mm"] = a.astype(np.float32)
+    return out
+
+
+RASTERS = hard_rasters()
+
+
+def same_bits(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", sorted(RASTERS))
+@pytest.mark.parametrize("size", [6, 7, 31, 67])
+def test_tpi_std_row_blocks_of_hard_rasters(name, size):
+    dem = RASTERS[name]
+    up, down = shard.halo_rows(_lib.DESC_TPI, size)
+    for what in ("tpi", "tpi_std"):
+        def call(blk, row0, rows, what=what):
+            t = d.DeviceArray(rows, NX)
+            s = d.DeviceArray(rows, NX) if what == "tpi_std" else None
+            blk.tpi_std(size, tpi=t, std=s, out_row0=row0, out_rows=rows)
+            return [t] + ([s] if s is not None else [])
+        whole = run_blocks(dem, 1, up, down, call)
+        for nb in (2, 3, 5):
+            parts = run_blocks(dem, nb, up, down, call)
+            for k, (p, w) in enumerate(zip(parts, whole)):
+                assert same_bits(p, w), (name, size, what, k, nb, int((~((p == w) | (np.isnan(p) & np.isnan(w)))).sum()))
+
+
+@pytest.mark.parametrize("name", sorted(RASTERS))
+@pytest.mark.parametrize("sigma", [3.25, 13.0])
+def test_gradient_row_blocks_of_hard_rasters(name, sigma):
+    dem = RASTERS[name]
+    up, down = shard.halo_rows(_lib.DESC_GRADIENT, sigma)
+
+    def call(blk, row0, rows):
+        outs = [d.DeviceArray(rows, NX) for _ in range(4)]
+        blk.gradient(sigma, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3], out_row0=row0, out_rows=rows)
+        return outs
+
+    whole = run_blocks(dem, 1, up, down, call)
+    for nb in (2, 3, 5):
+        parts = run_blocks(dem, nb, up, down, call)
+        for k, (p, w) in enumerate(zip(parts, whole)):
+            assert same_bits(p, w), (name, sigma, k, nb)
+
+
+def missing_footprint(dem, size):
+    """Pixels whose disc (the reference's zero-padded convolution, centre included) holds a missing sample."""
+    bad = (~np.isfinite(dem)) | (np.abs(np.trunc(np.nan_to_num(dem, nan=0.0, posinf=0.0, neginf=0.0))) >= 2.0 ** 24)
+    hits, _ = orc._disc_sum_f64(bad.astype(np.float64), size, drop_centre=False)
+    return hits > 0
+
+
+@pytest.mark.parametrize("name", ["int+nan", "frac+nan", "int+1e20", "int+fltmin_block", "int+inf"])
+@pytest.mark.parametrize("size", [7, 67])
+def test_missing_samples_have_the_footprint_of_the_disc(name, size):
+    """A sample that is not finite, or beyond +-2^24, is missing: exactly the pixels whose disc holds one are NaN, every
+    other pixel has the value of the clean DEM's formula (the reference's FFT convolution would spread it over the array)."""
+    dem = RASTERS[name]
+    t, s = topo.tpi_std(dem, size)
+    nan = missing_footprint(dem, size)
+    assert np.array_equal(np.isnan(t), nan) and np.array_equal(np.isnan(s), nan)
+    clean = np.where(np.isfinite(dem) & (np.abs(dem) < 2.0 ** 24), dem, 0.0).astype(np.float32)
+    et, es = orc.tpi_exact(clean, size), orc.std_exact(clean, size)
+    assert np.max(np.abs(t[~nan] - et[~nan])) <= 2.5e-4 + (2.0 ** -9 if name.startswith("frac") else 0.0)
+    assert np.max(np.abs(s[~nan] - es[~nan])) <= 1e-4 * np.max(es[~nan])
+    alone = topo.tpi(dem, size)
+    assert np.array_equal(np.isnan(alone), nan)
+    assert np.max(np.abs(alone[~nan] - et[~nan])) <= 2.5e-4 + (2.0 ** -9 if name.startswith("frac") else 0.0)
+
+
+@pytest.mark.parametrize("name", ["int+nodata_cols", "frac+nodata_rows_at_seam", "frac+nodata_line", "mm", "half_m_half_mm"])
+@pytest.mark.parametrize("size", [7, 31, 67])
+def test_wide_relief_and_large_values_are_exact(name, size):
+    """Nodata next to terrain and rasters in millimetres leave the 32-bit integer chains; the limb passes keep the sums
+    exact (round 4's float chains were several metres off on STD next to -9999)."""
+    dem = RASTERS[name]
+    t, s = topo.tpi_std(dem, size)
+    et, es = orc.tpi_exact(dem, size), orc.std_exact(dem, size)
+    scale = max(1.0, float(np.max(np.abs(dem))) / 4096.0)  # float32 output rounding grows with the values
+    assert np.max(np.abs(t - et)) <= 2.5e-4 * scale, (name, size)
+    assert np.max(np.abs(s - es)) <= 1e-4 * np.max(es), (name, size)
+    assert np.array_equal(topo.std(dem, size), s.astype(np.float64))
+
+
+@pytest.mark.parametrize("kind", ["unit_range", "kilometres", "constant_fraction", "flat"])
+def test_scaled_tpi_on_rasters_of_small_values(kind):
+    """the scaled one-chain route quantised every raster to 2^-8, whatever its values.  The unit now
+    follows the raster's value range (2^-8 ... 2^-16), so a normalised surface or a DEM in kilometres keeps 1e-4 of ITS
+    range, and a constant fractional offset stays inside the bound."""
+    base = orc.synthetic_dem(300, 384, seed=21, integer=False)
+    if kind == "unit_range":
+        dem = ((base - base.min()) / (base.max() - base.min())).astype(np.float32)
+    elif kind == "kilometres":
+        dem = (base / 1000.0).astype(np.float32)
+    elif kind == "constant_fraction":
+        dem = (np.rint(base) + 0.002).astype(np.float32)
+    else:
+        dem = (500.0 + 0.01 * (base - base.mean())).astype(np.float32)
+    for size in (19, 67):
+        got = topo.tpi(dem, size)
+        want = orc.tpi_exact(dem, size)
+        tol = max(1e-4 * float(np.max(np.abs(want))), 2.5e-4 * max(1.0, float(np.max(np.abs(dem))) / 4096.0))
+        if kind == "constant_fraction":
+            tol = 2.0 ** -9 + 2.5e-4
+        assert np.max(np.abs(got - want)) <= tol, (kind, size, float(np.max(np.abs(got - want))), tol)
+
+
+_CHILD = r"""
+import sys, time, zlib
+import numpy as np
+sys.path.insert(0, %(repo)r)
+from oracle import topo_oracle as orc
+from topo_descriptors_amd import topo
+kind = sys.argv[1]
+dem = orc.synthetic_dem(2048, 2048, seed=33, integer=False)
+if kind == "mm":
+    dem = (dem * 1000.0).astype(np.float32)
+topo.tpi(orc.synthetic_dem(64, 64, seed=1), 7)   # library and device initialised outside the timed calls
+out = {}
+for what in ("gauss", "grad", "tpi"):
+    best = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        if what == "gauss":
+            r = [topo.dem(dem, 3.25)]
+        elif what == "grad":
+            r = topo.gradient(dem, 3.25, {"x": np.array([30.0]), "y": np.array([-30.0])})
+        else:
+            r = [topo.tpi(dem, 67)]
+        best = min(best, time.perf_counter() - t0)
+    crc = 0
+    for plane in r:
+        crc = zlib.crc32(np.ascontiguousarray(plane).tobytes(), crc)
+    print(what, crc, best)
+"""
+
+
+def _fresh(kind):
+    out = subprocess.run([sys.executable, "-c", _CHILD % {"repo": REPO}, kind], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = {}
+    for line in out.stdout.strip().splitlines():
+        what, crc, sec = line.split()
+        res[what] = (int(crc), float(sec))
+    return res
+
+
+def test_host_calls_do_not_depend_on_what_the_library_saw_before():
+    """Same-shape host-buffer calls normal -> mm -> normal: the allocator hands the same device addresses out again, and
+    round 4 kept a routing verdict per address.  Every call must give the bits a fresh process gives, in at most 3 x its
+    time (the stale verdicts cost 50 - 100 x on the mm raster and 2 - 3 x on the ordinary one)."""
+    fresh = {"normal": _fresh("normal"), "mm": _fresh("mm")}
+    base = orc.synthetic_dem(2048, 2048, seed=33, integer=False)
+    rasters = {"normal": base, "mm": (base * 1000.0).astype(np.float32)}
+    res = {"x": np.array([30.0]), "y": np.array([-30.0])}
+    topo.tpi(orc.synthetic_dem(64, 64, seed=1), 7)
+    for kind in ("normal", "mm", "normal", "mm", "normal"):
+        dem = rasters[kind]
+        for what in ("gauss", "grad", "tpi"):
+            best = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter()
+                if what == "gauss":
+                    r = [topo.dem(dem, 3.25)]
+                elif what == "grad":
+                    r = topo.gradient(dem, 3.25, res)
+                else:
+                    r = [topo.tpi(dem, 67)]
+                best = min(best, time.perf_counter() - t0)
+            crc = 0
+            for plane in r:
+                crc = zlib.crc32(np.ascontiguousarray(plane).tobytes(), crc)
+            want_crc, want_sec = fresh[kind][what]
+            assert crc == want_crc, (kind, what)
+            assert best <= 3.0 * want_sec + 0.02, (kind, what, best, want_sec)
+
+
+def test_resident_buffer_refilled_through_the_library():
+    """A device-resident block refilled with another raster (memcpy_h2d, the synthetic DEM): the class and the remembered
+    tile statistics go with the old data."""
+    n = 1024
+    normal = orc.synthetic_dem(n, n, seed=44, integer=False)
+    mm = (normal * 1000.0).astype(np.float32)
+    dev = d.DeviceArray(n, n)
+    out = d.DeviceArray(n, n)
+    fresh = {}
+    for kind, dem in (("normal", normal), ("mm", mm)):
+        one = d.DeviceArray.from_host(dem)
+        d.Block(one).gaussian(3.25, 3.25, out)
+        d.sync()
+        fresh[kind] = out.to_host()
+        one.free()
+    for kind in ("normal", "mm", "normal", "mm"):
+        dev.upload_rows(normal if kind == "normal" else mm)
+        d.Block(dev).gaussian(3.25, 3.25, out)
+        d.sync()
+        assert np.array_equal(out.to_host(), fresh[kind], equal_nan=True), kind
+    dev.free()
+    out.free()

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -55,27 +56,30 @@ int workspace(int slot, size_t bytes, void** out) {
         }
         TOPO_HIP(hipMalloc(&c.ws[slot], bytes));
         c.ws_bytes[slot] = bytes;
+        dem_memo_forget(c.ws[slot], bytes);  // (a recycled address)
     }
     *out = c.ws[slot];
     return TOPO_AMD_OK;
 }
 
-// ---- dem_memo (common.hpp) ---------------------------------------------------------------------------------------------
+// ---- dem_memo and the raster class (common.hpp) -------------------------------------------------------------------------
 namespace {
 struct DemMemo {
     const void* in = nullptr;
     int rows = 0, nx = 0;
     unsigned long used = 0;
-    unsigned asked = 0;  // calls that asked "mostly fractional?" (every 32nd one is told no: the reporting kernels run again)
-    int large = -1;      // mostly samples beyond the matrix-core Gaussian's range? -1: not sampled yet
-    unsigned asked_large = 0;
+    unsigned asked = 0;     // calls that asked "wild?" (every 32nd one is told no: the fused kernel looks again; time only)
+    bool cls_valid = false;  // the block is a whole raster and has been scanned
+    RasterClass cls;
 };
 constexpr int kMemos = 8;
 constexpr int kMemoWords = 4;
 DemMemo g_memo[kMemos];
 uint32_t* g_memo_words = nullptr;  // pinned: kMemoWords words per entry: tiles, fractional tiles, wild sample seen
 unsigned long g_memo_clock = 0;
+std::mutex g_memo_mu;              // (several driver threads: topo_amd_shard_layout is per thread for them)
 
+// g_memo_mu held
 int memo_slot(const Block& b, bool create) {
     if (!g_memo_words) {
         if (hipHostMalloc((void**)&g_memo_words, kMemos * kMemoWords * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return -1;
@@ -90,80 +94,237 @@ int memo_slot(const Block& b, bool create) {
         if (g_memo[k].used < g_memo[oldest].used) oldest = k;
     }
     if (!create) return -1;
-    g_memo[oldest] = DemMemo{b.in, b.in_rows, b.nx, ++g_memo_clock, 0, -1, 0};
+    g_memo[oldest] = DemMemo{b.in, b.in_rows, b.nx, ++g_memo_clock, 0, false, RasterClass()};
     // (a launch in flight may still write the evicted entry's words: they are cleared here, and a late report for
-    // another DEM can at worst pick the wrong first kernel once - the results do not depend on that choice)
+    // another DEM can at worst pick the slower first kernel once - the results do not depend on that choice)
     for (int w = 0; w < kMemoWords; ++w) g_memo_words[kMemoWords * oldest + w] = 0;
     return oldest;
 }
 }  // namespace
 
 uint32_t* dem_memo_report(const Block& b) {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
     const int k = memo_slot(b, true);
     return k < 0 ? nullptr : g_memo_words + kMemoWords * k;
 }
 bool dem_memo_mostly_fractional(const Block& b) {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
     const int k = memo_slot(b, false);
     if (k < 0) return false;
-    // (a buffer may be refilled with other data: every 32nd call takes the default order, whose kernels report afresh)
-    if (++g_memo[k].asked % 32 == 0) return false;
+    // (both routes report afresh on every call, so a wrong guess costs one slower call and corrects itself)
     const uint32_t tiles = *(volatile uint32_t*)(g_memo_words + kMemoWords * k), frac = *(volatile uint32_t*)(g_memo_words + kMemoWords * k + 1);
     return tiles > 0 && 2 * frac > tiles;
 }
 
 uint32_t* dem_memo_wild_word(const Block& b) {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
     const int k = memo_slot(b, true);
     return k < 0 ? nullptr : g_memo_words + kMemoWords * k + 2;
 }
 bool dem_memo_wild(const Block& b) {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
     const int k = memo_slot(b, false);
     if (k < 0) return false;
-    if (++g_memo[k].asked % 32 == 0) {  // the buffer may hold other data by now: let the fused kernel look again
+    if (++g_memo[k].asked % 32 == 0) {  // (a caller may have rewritten the buffer with kernels of its own and not said so)
         *(volatile uint32_t*)(g_memo_words + kMemoWords * k + 2) = 0;
         return false;
     }
     return *(volatile uint32_t*)(g_memo_words + kMemoWords * k + 2) != 0;
 }
-
-// 16384 samples on a regular grid over the block: how many are finite and beyond +-1e5 (kWild of gauss.hip: what the f16
-// matrix-core kernels stage as 0 and leave to their repair passes)
-__global__ __launch_bounds__(256) void large_sample_kernel(const float* in, size_t n, size_t stride, uint32_t* count) {
-    const size_t pos = ((size_t)blockIdx.x * 256 + threadIdx.x) * stride;
-    const float x = pos < n ? in[pos] : 0.0f;
-    const bool large = fabsf(x) > 1.0e5f && fabsf(x) <= 3.0e38f;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(large);
-    if ((threadIdx.x & 63) == 0 && m) __hip_atomic_fetch_add(count, (uint32_t)__builtin_popcountll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// ADVICE r03 (medium, a): a raster whose ordinary values lie beyond 1e5 (a DEM in millimetres, a non-elevation raster)
-// would have every tile of the matrix-core Gaussian marked and every output recomputed by the repair pass's scalar
-// chains, ~100 x slower than the vector-ALU kernels.  The first Gaussian / gradient call on a block samples it (one
-// small launch and one stream synchronisation per DEM, again at every 32nd call: the buffer may hold other data by
-// then); with more than a quarter of the samples finite and beyond the limit the call takes the vector-ALU kernels,
-// which have no such limit.  Non-finite samples do not count: a DEM with a NaN sea is what the repair pass is for.
-bool dem_memo_mostly_large(const Block& b) {
-    static const bool on = [] {  // TOPO_AMD_GAUSS_LARGE_SAMPLE=0: never (A/B: tools/large_raster_time.py)
-        const char* e = std::getenv("TOPO_AMD_GAUSS_LARGE_SAMPLE");
-        return !(e && *e == '0');
-    }();
-    if (!on) return false;
-    const int k = memo_slot(b, true);
-    if (k < 0) return false;
-    DemMemo& m = g_memo[k];
-    if (m.large < 0 || ++m.asked_large % 32 == 0) {
-        Context& c = ctx();
-        uint32_t* word = g_memo_words + kMemoWords * k + 3;
-        if (hipStreamSynchronize(c.compute) != hipSuccess) return false;  // (no sampler of an earlier call in flight on this word)
-        *(volatile uint32_t*)word = 0;
-        const size_t n = (size_t)b.in_rows * b.nx;
-        constexpr size_t kSamples = 64 * 256;
-        const size_t stride = std::max<size_t>(1, n / kSamples);
-        hipLaunchKernelGGL(large_sample_kernel, dim3(64), dim3(256), 0, c.compute, b.in, n, stride, word);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c.compute) != hipSuccess) return false;
-        const size_t taken = std::min(kSamples, (n + stride - 1) / stride);
-        m.large = 4 * (size_t)*(volatile uint32_t*)word > taken ? 1 : 0;
+// every entry whose block overlaps [p, p + bytes) (bytes == 0: that starts at p) is dropped
+void dem_memo_forget(const void* p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    const uintptr_t lo = (uintptr_t)p, hi = lo + (bytes ? bytes : 1);
+    for (int k = 0; k < kMemos; ++k) {
+        DemMemo& m = g_memo[k];
+        if (!m.in) continue;
+        const uintptr_t a = (uintptr_t)m.in, b = a + (size_t)m.rows * m.nx * sizeof(float);
+        if (a < hi && lo < b) {
+            m = DemMemo();
+            if (g_memo_words)
+                for (int w = 0; w < kMemoWords; ++w) g_memo_words[kMemoWords * k + w] = 0;
+        }
     }
-    return m.large == 1;
 }
+
+// ---- lattice scan of a raster (the raster class) ---------------------------------------------------------------------------
+// The lattice belongs to the GLOBAL grid: rows step_r / 2 + i step_r, columns step_c / 2 + j step_c with step = extent / 128
+// (about 16 K points), so the scans of the row blocks of a raster add up to the scan of the whole raster, point for point.
+namespace {
+constexpr float kClassLarge = 1.0e5f;     // kWild of gauss.hip: what the f16 matrix-core kernels stage as 0 and repair
+constexpr float kClassOrdinary = 262144.0f;  // kAbsLim of the disc kernels
+struct Scan {
+    unsigned long long taken = 0, large = 0;
+    float lo = INFINITY, hi = -INFINITY;
+    void add(float x) {
+        ++taken;
+        const float a = std::fabs(x);
+        if (a > kClassLarge && a <= 3.0e38f) ++large;
+        if (a <= kClassOrdinary) {  // (false for NaN)
+            lo = std::min(lo, x);
+            hi = std::max(hi, x);
+        }
+    }
+};
+inline int lattice_step(int extent) { return std::max(1, extent / 128); }
+RasterClass class_of(const Scan& s) {
+    RasterClass c;
+    c.large = 4 * s.large > s.taken;
+    c.lo = s.lo;
+    c.hi = s.hi;
+    return c;
+}
+__device__ __forceinline__ uint32_t ordered_bits(float f) {  // unsigned order = float order (finite values)
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+float from_ordered_bits(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    std::memcpy(&f, &u, sizeof(f));
+    return f;
+}
+// words: [0] taken, [1] large, [2] min key, [3] max key (pinned host memory)
+__global__ __launch_bounds__(256) void raster_scan_kernel(const float* in, int in_rows, int in_row0, int nx, int own_row0, int own_rows,
+                                                          int step_r, int step_c, int ni, int nj, uint32_t* words) {
+    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int i = idx / nj, j = idx - i * nj;
+    const int r = step_r / 2 + i * step_r, c = step_c / 2 + j * step_c;
+    const bool take = i < ni && r >= own_row0 && r < own_row0 + own_rows && r >= in_row0 && r < in_row0 + in_rows && c < nx;
+    const float x = take ? in[(size_t)(r - in_row0) * nx + c] : 0.0f;
+    const float a = fabsf(x);
+    const bool large = take && a > kClassLarge && a <= 3.0e38f;
+    const bool ordinary = take && a <= kClassOrdinary;
+    uint32_t kmin = ordinary ? ordered_bits(x) : 0xffffffffu, kmax = ordinary ? ordered_bits(x) : 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, m));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, m));
+    }
+    const unsigned long long mt = __builtin_amdgcn_ballot_w64(take), ml = __builtin_amdgcn_ballot_w64(large);
+    if ((threadIdx.x & 63) == 0 && mt) {
+        __hip_atomic_fetch_add(words, (uint32_t)__builtin_popcountll(mt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (ml) __hip_atomic_fetch_add(words + 1, (uint32_t)__builtin_popcountll(ml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_min(words + 2, kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_max(words + 3, kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+uint32_t* g_scan_words = nullptr;  // pinned
+std::mutex g_scan_mu;
+// scans the lattice points in rows [own_row0, own_row0 + own_rows) of the block; synchronises the compute stream
+int scan_block(const Block& b, int own_row0, int own_rows, Scan* out) {
+    std::lock_guard<std::mutex> lock(g_scan_mu);
+    Context& c = ctx();
+    if (!g_scan_words) TOPO_HIP(hipHostMalloc((void**)&g_scan_words, 4 * sizeof(uint32_t), hipHostMallocMapped));
+    TOPO_HIP(hipStreamSynchronize(c.compute));  // (no scan of an earlier call in flight on the words; the block's data are final)
+    g_scan_words[0] = g_scan_words[1] = 0;
+    g_scan_words[2] = 0xffffffffu;
+    g_scan_words[3] = 0u;
+    const int step_r = lattice_step(b.gny), step_c = lattice_step(b.nx);
+    const int ni = (b.gny - step_r / 2 + step_r - 1) / step_r, nj = (b.nx - step_c / 2 + step_c - 1) / step_c;
+    const long n = (long)ni * nj;
+    hipLaunchKernelGGL(raster_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.compute, b.in, b.in_rows, b.in_row0, b.nx,
+                       own_row0, own_rows, step_r, step_c, ni, nj, g_scan_words);
+    TOPO_HIP(hipGetLastError());
+    TOPO_HIP(hipStreamSynchronize(c.compute));
+    out->taken += g_scan_words[0];
+    out->large += g_scan_words[1];
+    if (g_scan_words[2] <= g_scan_words[3]) {
+        out->lo = std::min(out->lo, from_ordered_bits(g_scan_words[2]));
+        out->hi = std::max(out->hi, from_ordered_bits(g_scan_words[3]));
+    }
+    return TOPO_AMD_OK;
+}
+// the same lattice on a host array (the host-buffer entry points: no launch, no synchronisation)
+RasterClass scan_host(const float* dem, int ny, int nx) {
+    Scan s;
+    const int step_r = lattice_step(ny), step_c = lattice_step(nx);
+    for (int r = step_r / 2; r < ny; r += step_r)
+        for (int c = step_c / 2; c < nx; c += step_c) s.add(dem[(size_t)r * nx + c]);
+    return class_of(s);
+}
+
+// what the calling thread declared for its partial row blocks (topo_amd_raster_class_set); a thread that has declared
+// nothing sees the last declaration of any thread (set up once, drive from worker threads: like topo_amd_shard_layout)
+thread_local bool t_declared = false;
+thread_local RasterClass t_declared_class;
+std::mutex g_declared_mu;
+bool g_declared = false;
+RasterClass g_declared_class;
+RasterClass declared_class() {
+    if (t_declared) return t_declared_class;
+    std::lock_guard<std::mutex> lock(g_declared_mu);
+    return g_declared ? g_declared_class : RasterClass();
+}
+
+// The class of the call in flight on this thread: set by the outermost entry point, resolved when a launcher first asks.
+thread_local const Block* t_call_block = nullptr;  // the block the outermost entry point was given
+thread_local bool t_class_known = false;
+thread_local RasterClass t_class;
+}  // namespace
+
+RasterClass current_class() {
+    if (t_class_known) return t_class;
+    RasterClass c = declared_class();
+    const Block* b = t_call_block;
+    if (b != nullptr && b->in_row0 == 0 && b->in_rows == b->gny) {
+        // the block IS the raster: its own scan, remembered with the block
+        bool have = false;
+        {
+            std::lock_guard<std::mutex> lock(g_memo_mu);
+            const int k = memo_slot(*b, true);
+            if (k >= 0 && g_memo[k].cls_valid) {
+                c = g_memo[k].cls;
+                have = true;
+            }
+        }
+        if (!have) {
+            Scan s;
+            if (scan_block(*b, 0, b->gny, &s) == TOPO_AMD_OK) {
+                c = class_of(s);
+                std::lock_guard<std::mutex> lock(g_memo_mu);
+                const int k = memo_slot(*b, true);
+                if (k >= 0) {
+                    g_memo[k].cls = c;
+                    g_memo[k].cls_valid = true;
+                }
+            }
+        }
+    }
+    t_class = c;
+    t_class_known = true;
+    return c;
+}
+
+namespace {
+// Around the launchers of one entry point.  The outermost scope on a thread names the block (or, for the host-buffer
+// entry points, the class found on the caller's array); scopes inside it - the device entry points the host-buffer ones
+// call, the Gaussian in front of a disc - change nothing, so a smoothed plane inherits the class of the DEM it came from.
+struct ClassScope {
+    bool outer;
+    explicit ClassScope(const Block& b) : outer(t_call_block == nullptr && !t_class_known) {
+        if (outer) t_call_block = &b;
+    }
+    explicit ClassScope(const RasterClass& c) : outer(t_call_block == nullptr && !t_class_known) {
+        if (outer) {
+            t_class = c;
+            t_class_known = true;
+        }
+    }
+    ~ClassScope() {
+        if (outer) {
+            t_call_block = nullptr;
+            t_class_known = false;
+        }
+    }
+    ClassScope(const ClassScope&) = delete;
+    ClassScope& operator=(const ClassScope&) = delete;
+};
+inline void forget_plane(const void* p, int rows, int nx) {
+    if (p) dem_memo_forget(p, (size_t)rows * nx * sizeof(float));
+}
+}  // namespace
 
 // Small parameter tables: pinned staging + async copy on the compute stream.  The previous
 // content is remembered so a loop over the same parameters uploads nothing.
@@ -275,6 +436,7 @@ int tpi_std_block(const Block& b, int size, double sigma, float* tpi_out, float*
     g.out_row0 = s0;
     g.out_rows = s1 - s0;
     TOPO_TRY(launch_gaussian(g, sigma, sigma, (float*)plane));
+    dem_memo_forget(plane, (size_t)(s1 - s0) * b.nx * sizeof(float));  // (the workspace holds another plane now)
     Block d = b;
     d.in = (const float*)plane;
     d.in_row0 = s0;
@@ -313,11 +475,17 @@ struct HostRun {
     std::vector<std::thread> touchers;
     ~HostRun() {
         ready();
-        for (void* p : bufs) (void)hipFree(p);
+        for (size_t k = 0; k < bufs.size(); ++k) {
+            dem_memo_forget(bufs[k], sizes[k]);
+            (void)hipFree(bufs[k]);
+        }
     }
+    std::vector<size_t> sizes;
     int alloc(void** p, size_t bytes) {
         TOPO_HIP(hipMalloc(p, bytes));
         bufs.push_back(*p);
+        sizes.push_back(bytes);
+        dem_memo_forget(*p, bytes);  // (the allocator hands the same addresses out again: nothing is known about this one)
         return TOPO_AMD_OK;
     }
     void prefault(void* host, size_t bytes) {
@@ -355,10 +523,160 @@ struct HostRun {
     }
 };
 
+float* shift(float* p, int rows, int nx) { return p ? p + (size_t)rows * nx : nullptr; }
+
 int download(void* host, const void* dev, size_t bytes) {
     if (!host) return TOPO_AMD_OK;
     TOPO_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx().compute));
     return TOPO_AMD_OK;
+}
+
+// ---- upload || kernels || download in row chunks -------------------------------------------------------
+// A host-buffer call used to be three serial steps - 18.7 ms up, 1.3 ms of kernels, 19.9 ms down for TPI 67 px on 16384^2 -
+// over a link that carries both directions at once (48.6 GB/s each way against 57 one way, profiles/r01_host_path.txt).  Row
+// blocks give the single block's bits, so the call is cut into row chunks: the calling thread uploads chunk k on one
+// stream and, as soon as the rows a chunk's outputs depend on are on the device, enqueues its kernels (on the block view
+// "the rows uploaded so far") on the compute stream; a second host thread downloads the output rows of every finished
+// chunk on a third stream (its own thread because copies to and from pageable memory block the caller).
+// TOPO_AMD_HOST_PIPELINE=0: one chunk (the old order).  TOPO_AMD_HOST_CHUNK_MB: size of a chunk of the DEM (default 64).
+struct HostPlane {
+    float* host;
+    float* dev;
+};
+int pipeline_chunk_rows(int ny, int nx) {
+    static const bool on = [] {
+        const char* e = std::getenv("TOPO_AMD_HOST_PIPELINE");
+        return !(e && *e == '0');
+    }();
+    static const double chunk_mb = [] {
+        const char* e = std::getenv("TOPO_AMD_HOST_CHUNK_MB");
+        return e && *e ? std::max(1.0, std::atof(e)) : 64.0;
+    }();
+    if (!on) return ny;
+    // whole tile rows of every kernel (60 and 64: 960), at least 960 rows
+    long rows = (long)(chunk_mb * 1048576.0 / ((double)nx * sizeof(float)));
+    rows = std::max(960L, rows / 960 * 960);
+    return rows * 3 > ny ? ny : (int)rows;  // fewer than three chunks: nothing to overlap
+}
+// compute(view_rows, out_row0, out_rows): enqueue the kernels that write output rows [out_row0, out_row0 + out_rows) of
+// every plane, reading rows [0, view_rows) of d_in.  above / below: rows of the DEM an output row depends on.
+// upload == false: the DEM is on the device already (later scales of a multi-scale call).
+template <class Compute>
+int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, int above, int below, bool upload,
+                  const std::vector<HostPlane>& outs, Compute&& compute) {
+    Context& c = ctx();
+    const int chunk = pipeline_chunk_rows(ny, nx);
+    const int nchunks = (ny + chunk - 1) / chunk;
+    const size_t row_bytes = (size_t)nx * sizeof(float);
+    (void)above;
+    if (nchunks < 3) {
+        if (upload) TOPO_HIP(hipMemcpyAsync(d_in, dem, (size_t)ny * row_bytes, hipMemcpyHostToDevice, c.compute));
+        const int rc = compute(ny, 0, ny);
+        if (rc != TOPO_AMD_OK && rc != TOPO_AMD_EEMPTY) return rc;
+        run.ready();
+        for (const HostPlane& o : outs) TOPO_TRY(download(o.host, o.dev, (size_t)ny * row_bytes));
+        TOPO_HIP(hipStreamSynchronize(c.compute));
+        return rc;
+    }
+    if (!c.up) {
+        TOPO_HIP(hipStreamCreateWithFlags(&c.up, hipStreamNonBlocking));
+        TOPO_HIP(hipStreamCreateWithFlags(&c.down, hipStreamNonBlocking));
+    }
+    while ((int)c.pipe_events.size() < 2 * nchunks) {
+        hipEvent_t e = nullptr;
+        TOPO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c.pipe_events.push_back(e);
+    }
+    hipEvent_t* up_done = c.pipe_events.data();
+    hipEvent_t* computed = c.pipe_events.data() + nchunks;
+    std::mutex mu;
+    std::condition_variable cv;
+    int ready_chunks = 0;  // chunks whose kernels are enqueued and whose event is recorded
+    bool failed = false;
+    int down_rc = TOPO_AMD_OK;
+    std::string down_error;
+    const int device = c.device;
+    std::thread downloader([&] {
+        (void)hipSetDevice(device);
+        run.ready();  // the result arrays have their pages
+        for (int j = 0; j < nchunks; ++j) {
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return ready_chunks > j || failed; });
+                if (failed) return;
+            }
+            const int r0 = j * chunk, r1 = std::min(ny, r0 + chunk);
+            hipError_t e = hipStreamWaitEvent(c.down, computed[j], 0);
+            for (size_t k = 0; k < outs.size() && e == hipSuccess; ++k)
+                if (outs[k].host)
+                    e = hipMemcpyAsync(outs[k].host + (size_t)r0 * nx, outs[k].dev + (size_t)r0 * nx, (size_t)(r1 - r0) * row_bytes,
+                                       hipMemcpyDeviceToHost, c.down);
+            if (e != hipSuccess) {
+                down_rc = TOPO_AMD_EHIP;
+                down_error = std::string("download of a row chunk failed: ") + hipGetErrorString(e);
+                return;
+            }
+        }
+        if (hipStreamSynchronize(c.down) != hipSuccess) {
+            down_rc = TOPO_AMD_EHIP;
+            down_error = "hipStreamSynchronize(download stream) failed";
+        }
+    });
+    int rc = TOPO_AMD_OK, next = 0;
+    bool empty = false;
+    auto fail = [&](int code) {
+        rc = code;
+        std::lock_guard<std::mutex> lock(mu);
+        failed = true;
+    };
+    for (int k = 0; k < nchunks && rc == TOPO_AMD_OK; ++k) {
+        const int u0 = k * chunk, u1 = std::min(ny, u0 + chunk);
+        if (upload) {
+            hipError_t e = hipMemcpyAsync(d_in + (size_t)u0 * nx, dem + (size_t)u0 * nx, (size_t)(u1 - u0) * row_bytes,
+                                          hipMemcpyHostToDevice, c.up);
+            if (e == hipSuccess) e = hipEventRecord(up_done[k], c.up);
+            if (e != hipSuccess) {
+                set_error("upload of a row chunk failed: %s", hipGetErrorString(e));
+                fail(TOPO_AMD_EHIP);
+                break;
+            }
+        }
+        const int uploaded = upload ? u1 : ny;
+        while (next < nchunks && std::min(ny, std::min(ny, next * chunk + chunk) + below) <= uploaded) {
+            const int r0 = next * chunk, r1 = std::min(ny, r0 + chunk);
+            if (upload && hipStreamWaitEvent(c.compute, up_done[k], 0) != hipSuccess) {
+                set_error("hipStreamWaitEvent(compute, upload) failed");
+                fail(TOPO_AMD_EHIP);
+                break;
+            }
+            const int r = compute(uploaded, r0, r1 - r0);
+            if (r != TOPO_AMD_OK && r != TOPO_AMD_EEMPTY) {
+                fail(r);
+                break;
+            }
+            if (r == TOPO_AMD_EEMPTY) empty = true;  // (Sx: every plane was written; reported at the end)
+            if (hipEventRecord(computed[next], c.compute) != hipSuccess) {
+                set_error("hipEventRecord(computed chunk) failed");
+                fail(TOPO_AMD_EHIP);
+                break;
+            }
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                ready_chunks = ++next;
+            }
+            cv.notify_all();
+        }
+    }
+    cv.notify_all();
+    downloader.join();
+    (void)hipStreamSynchronize(c.compute);
+    if (upload) (void)hipStreamSynchronize(c.up);
+    if (rc != TOPO_AMD_OK) return rc;
+    if (down_rc != TOPO_AMD_OK) {
+        set_error("%s", down_error.c_str());
+        return down_rc;
+    }
+    return empty ? TOPO_AMD_EEMPTY : TOPO_AMD_OK;
 }
 
 }  // namespace
@@ -368,7 +686,9 @@ using namespace topo;
 
 namespace {
 int check_gate_errors();
-constexpr size_t kGateBytes = 16384;  // the gate word, then (from byte 256) one "gave up" byte per block of a launch
+uint32_t g_giveups_reported = 0;  // value of the give-up counter at the last topo_amd_gate_giveups
+uint32_t g_giveups_probed = 0;    //                              ... at the last look of the mode logic
+int g_probe_calls = 0;            // careful calls whose completion nobody has looked at yet (the probe event stands behind the last of them)
 }
 
 extern "C" {
@@ -425,6 +745,8 @@ int topo_amd_init(int device) {
     TOPO_HIP(hipMalloc((void**)&c.gate_word, kGateBytes));
     TOPO_HIP(hipMemset(c.gate_word, 0, kGateBytes));
     TOPO_HIP(hipHostMalloc((void**)&c.gate_timeouts, 64, hipHostMallocMapped));
+    g_giveups_reported = g_giveups_probed = 0;
+    g_probe_calls = 0;
     c.gate_timeouts[0] = 0;  // blocks that gave up at a closed gate (careful mode)
     c.gate_timeouts[4] = 0;  // blocks whose wait ran out (lean mode): an error
     c.gate_epoch = 0;
@@ -478,6 +800,11 @@ int topo_amd_shutdown(void) {
     (void)hipEventDestroy(c.t1);
     (void)hipStreamDestroy(c.compute);
     (void)hipStreamDestroy(c.comm);
+    if (c.up) {
+        (void)hipStreamDestroy(c.up);
+        (void)hipStreamDestroy(c.down);
+    }
+    for (hipEvent_t e : c.pipe_events) (void)hipEventDestroy(e);
     if (c.aux) {
         (void)hipStreamDestroy(c.aux);
         for (auto& e : c.aux_ready) (void)hipEventDestroy(e);
@@ -504,6 +831,7 @@ int topo_amd_malloc(void** dptr, size_t bytes) {
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dptr != nullptr, "topo_amd_malloc: NULL result pointer");
     TOPO_HIP(hipMalloc(dptr, bytes ? bytes : 4));
+    dem_memo_forget(*dptr, bytes ? bytes : 4);
     return TOPO_AMD_OK;
 }
 
@@ -511,6 +839,11 @@ int topo_amd_free(void* dptr) {
     TOPO_TRY(require_ready());
     if (dptr) {
         TOPO_HIP(hipStreamSynchronize(ctx().compute));
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dptr) == hipSuccess) dem_memo_forget(base, size);
+        else (void)hipGetLastError();
+        dem_memo_forget(dptr, 0);
         TOPO_HIP(hipFree(dptr));
     }
     return TOPO_AMD_OK;
@@ -532,6 +865,7 @@ int topo_amd_host_free(void* hptr) {
 
 int topo_amd_memcpy_h2d(void* dst, const void* src, size_t bytes) {
     TOPO_TRY(require_ready());
+    dem_memo_forget(dst, bytes);
     TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().compute));
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     return TOPO_AMD_OK;
@@ -552,12 +886,14 @@ int topo_amd_memcpy_d2h(void* dst, const void* src, size_t bytes) {
 
 int topo_amd_memcpy_d2d(void* dst, const void* src, size_t bytes) {
     TOPO_TRY(require_ready());
+    dem_memo_forget(dst, bytes);
     TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().compute));
     return TOPO_AMD_OK;
 }
 
 int topo_amd_memset(void* dst, int value, size_t bytes) {
     TOPO_TRY(require_ready());
+    dem_memo_forget(dst, bytes);
     TOPO_HIP(hipMemsetAsync(dst, value, bytes, ctx().compute));
     return TOPO_AMD_OK;
 }
@@ -569,8 +905,6 @@ void gate_probe_poll();
 }  // namespace topo
 
 namespace {
-uint32_t g_giveups_reported = 0;  // value of the give-up counter at the last topo_amd_gate_giveups
-uint32_t g_giveups_probed = 0;    //                              ... at the last look of the mode logic
 // lean mode: a block's wait at the gate ran out (gate.hpp) - the seam rows of that call were computed from ghost rows
 // that had not arrived.  Reported once, by the next call that synchronises; the library is careful from then on.
 int check_gate_errors() {
@@ -598,7 +932,7 @@ int topo_amd_gate_giveups(unsigned* count) {
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(count != nullptr, "gate_giveups: NULL output");
     const uint32_t now = *(volatile uint32_t*)ctx().gate_timeouts;
-    *count = now - g_giveups_reported;
+    *count = now - g_giveups_reported;  // (both reset by topo_amd_init)
     g_giveups_reported = now;
     return TOPO_AMD_OK;
 }
@@ -645,7 +979,82 @@ int topo_amd_mark_elapsed(int from, int to, float* elapsed_ms) {
 int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed, int integer_valued) {
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(out && rows >= 1 && nx >= 1, "synth_dem: bad arguments");
+    forget_plane(out, rows, nx);
     return launch_synth(out, rows, row0, nx, seed, integer_valued != 0);
+}
+
+// ---- the raster class (common.hpp) ----------------------------------------------------------------------------------
+int topo_amd_dem_changed(const void* dptr, size_t bytes) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(dptr != nullptr, "dem_changed: NULL pointer");
+    if (bytes == 0) {  // the whole allocation
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dptr) == hipSuccess) dem_memo_forget(base, size);
+        else (void)hipGetLastError();
+    }
+    dem_memo_forget(dptr, bytes);
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_raster_scan_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int own_row0, int own_rows,
+                             uint64_t counts[2], float range[2]) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(in && counts && range && gny >= 1 && nx >= 1 && in_rows >= 1 && in_row0 >= 0 && in_row0 + in_rows <= gny,
+                 "raster_scan: bad block");
+    TOPO_REQUIRE(own_rows >= 0 && own_row0 >= in_row0 && own_row0 + own_rows <= in_row0 + in_rows,
+                 "raster_scan: rows [%d, %d) are not inside the block's rows [%d, %d)", own_row0, own_row0 + own_rows, in_row0,
+                 in_row0 + in_rows);
+    Block b{in, in_rows, in_row0, gny, nx, own_row0, own_rows};
+    Scan s;
+    s.lo = range[0];
+    s.hi = range[1];
+    TOPO_TRY(scan_block(b, own_row0, own_rows, &s));
+    counts[0] += s.taken;
+    counts[1] += s.large;
+    range[0] = s.lo;
+    range[1] = s.hi;
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_raster_class_set(int large, float lo, float hi) {
+    if (large < 0) {  // forget the declaration (this thread's and the process-wide one)
+        t_declared = false;
+        std::lock_guard<std::mutex> lock(g_declared_mu);
+        g_declared = false;
+        return TOPO_AMD_OK;
+    }
+    TOPO_REQUIRE(!(lo != lo) && !(hi != hi), "raster_class_set: NaN range");
+    RasterClass c;
+    c.large = large != 0;
+    c.lo = lo;
+    c.hi = hi;
+    t_declared = true;
+    t_declared_class = c;
+    std::lock_guard<std::mutex> lock(g_declared_mu);
+    g_declared = true;
+    g_declared_class = c;
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_raster_class_from_scan(const uint64_t counts[2], const float range[2]) {
+    TOPO_REQUIRE(counts && range, "raster_class_from_scan: NULL argument");
+    Scan s;
+    s.taken = counts[0];
+    s.large = counts[1];
+    s.lo = range[0];
+    s.hi = range[1];
+    const RasterClass c = class_of(s);
+    return topo_amd_raster_class_set(c.large ? 1 : 0, c.lo, c.hi);
+}
+
+int topo_amd_raster_class_get(int* large, float* lo, float* hi) {
+    TOPO_REQUIRE(large && lo && hi, "raster_class_get: NULL output");
+    const RasterClass c = declared_class();
+    *large = c.large ? 1 : 0;
+    *lo = c.lo;
+    *hi = c.hi;
+    return TOPO_AMD_OK;
 }
 
 // ---- geometry helpers ---------------------------------------------------------------------
@@ -717,6 +1126,9 @@ int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int
                          int out_row0, int out_rows, float* tpi_out, float* std_out) {
     TOPO_TRY(require_ready());
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    ClassScope cls(b);
+    forget_plane(tpi_out, out_rows, nx);
+    forget_plane(std_out, out_rows, nx);
     return tpi_std_block(b, size, 0.0, tpi_out, std_out);
 }
 
@@ -726,6 +1138,8 @@ int topo_amd_tpi_multi_dev(const float* in, int in_rows, int in_row0, int gny, i
     TOPO_REQUIRE(n_sizes >= 1 && sizes && tpi_outs, "tpi_multi: no sizes");
     for (int k = 0; k < n_sizes; ++k) TOPO_REQUIRE(tpi_outs[k], "tpi_multi: NULL output plane %d", k);
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
+    ClassScope cls(b);
+    for (int k = 0; k < n_sizes; ++k) forget_plane(tpi_outs[k], out_rows, nx);
     // sizes that have a two-disc kernel (disc_pair.hip) go through it in pairs - the smallest with the next one up,
     // so that the shared ring is no larger than it has to be - the rest one by one
     std::vector<int> order(n_sizes), left;
@@ -762,6 +1176,8 @@ int topo_amd_gaussian_dev(const float* in, int in_rows, int in_row0, int gny, in
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     const int R = gaussian_radius(sigma_y);
     TOPO_TRY(check_block(b, R, R, "gaussian"));
+    ClassScope cls(b);
+    forget_plane(out, out_rows, nx);
     return launch_gaussian(b, sigma_y, sigma_x, out);
 }
 
@@ -770,6 +1186,8 @@ int topo_amd_sobel_dev(const float* in, int in_rows, int in_row0, int gny, int n
     TOPO_TRY(require_ready());
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     TOPO_TRY(check_block(b, 1, 1, "sobel"));
+    forget_plane(dx_out, out_rows, nx);
+    forget_plane(dy_out, out_rows, nx);
     return launch_sobel(b, dx_out, dy_out);
 }
 
@@ -781,6 +1199,8 @@ int topo_amd_gradient_dev(const float* in, int in_rows, int in_row0, int gny, in
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     const int h = gradient_halo(sigma, sig_ratio);
     TOPO_TRY(check_block(b, h, h, "gradient"));
+    ClassScope cls(b);
+    for (float* o : {dx_out, dy_out, slope_out, aspect_out}) forget_plane(o, out_rows, nx);
     return launch_gradient(b, sigma, sig_ratio, res_mode, res_x, res_y, dx_out, dy_out, slope_out,
                            aspect_out);
 }
@@ -799,6 +1219,7 @@ int topo_amd_sx_dev(const float* in, int in_rows, int in_row0, int gny, int nx, 
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     // rows of the zero frame need no neighbours, interior rows never reach outside the DEM
     TOPO_TRY(check_block(b, up, down, "sx"));
+    forget_plane(out, out_rows, nx);
     return launch_sx(b, dj, di, dist, n_off, window, height, out);
 }
 
@@ -825,6 +1246,7 @@ int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, in
     sx_multi_reach(n_az, first, dj, dist, &up, &down);
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     TOPO_TRY(check_block(b, up, down, "sx_multi"));
+    for (int k = 0; k < n_az; ++k) forget_plane(outs[k], out_rows, nx);
     return launch_sx_multi(b, n_az, first, dj, di, dist, window, height, outs);
 }
 
@@ -837,6 +1259,8 @@ int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny
     (void)valley_ridge_reach(ksize, n_angles, &up, &down);
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     TOPO_TRY(check_block(b, up, down, "valley_ridge"));
+    forget_plane(norm_out, out_rows, nx);
+    forget_plane(dir_out, out_rows, nx);
     return launch_valley_ridge(b, taps, ksize, angles, n_angles, n_planes, mean, stdev, norm_out, dir_out);
 }
 
@@ -853,40 +1277,21 @@ int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigm
     TOPO_REQUIRE(dem && ny >= 1 && nx >= 1, "tpi_std: bad DEM");
     TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
     const size_t bytes = (size_t)ny * nx * sizeof(float);
-    // TOPO_AMD_TRACE_HOST=1: where a host-buffer call spends its time (stderr, this entry point only)
-    static const bool trace = std::getenv("TOPO_AMD_TRACE_HOST") != nullptr;
-    double t_prev = 0.0;
-    auto lap = [&](const char* what) {
-        if (!trace) return;
-        (void)hipStreamSynchronize(ctx().compute);
-        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        if (what) std::fprintf(stderr, "topo_amd_tpi_std_f32 %-22s %8.2f ms\n", what, (t - t_prev) * 1e3);
-        t_prev = t;
-    };
-    lap(nullptr);
-    {
-        HostRun run;
-        void *d_in = nullptr, *d_tpi = nullptr, *d_std = nullptr;
-        TOPO_TRY(run.alloc(&d_in, bytes));
-        if (tpi_out) TOPO_TRY(run.alloc(&d_tpi, bytes));
-        if (std_out) TOPO_TRY(run.alloc(&d_std, bytes));
-        lap("hipMalloc");
-        run.prefault(tpi_out, bytes);
-        run.prefault(std_out, bytes);
-        TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
-        lap("upload");
-        Block b{(const float*)d_in, ny, 0, ny, nx, 0, ny};
-        TOPO_TRY(tpi_std_block(b, size, sigma, (float*)d_tpi, (float*)d_std));
-        lap("kernels");
-        run.ready();
-        lap("wait for result pages");
-        TOPO_TRY(download(tpi_out, d_tpi, bytes));
-        TOPO_TRY(download(std_out, d_std, bytes));
-        TOPO_HIP(hipStreamSynchronize(ctx().compute));
-        lap("download");
-    }
-    lap("hipFree");
-    return TOPO_AMD_OK;
+    ClassScope cls(scan_host(dem, ny, nx));  // the raster class from the caller's array: no launch, no synchronisation
+    int above = 0, below = 0;
+    TOPO_TRY(topo_amd_halo_rows(TOPO_AMD_DESC_TPI, (double)size, sigma, &above, &below));
+    HostRun run;
+    void *d_in = nullptr, *d_tpi = nullptr, *d_std = nullptr;
+    TOPO_TRY(run.alloc(&d_in, bytes));
+    if (tpi_out) TOPO_TRY(run.alloc(&d_tpi, bytes));
+    if (std_out) TOPO_TRY(run.alloc(&d_std, bytes));
+    run.prefault(tpi_out, bytes);
+    run.prefault(std_out, bytes);
+    return run_pipelined(run, dem, (float*)d_in, ny, nx, above, below, true, {{tpi_out, (float*)d_tpi}, {std_out, (float*)d_std}},
+                         [&](int view_rows, int r0, int rows) {
+                             Block b{(const float*)d_in, view_rows, 0, ny, nx, r0, rows};
+                             return tpi_std_block(b, size, sigma, shift((float*)d_tpi, r0, nx), shift((float*)d_std, r0, nx));
+                         });
 }
 
 int topo_amd_tpi_std_multi_f32(const float* dem, int ny, int nx, int n_scales, const int32_t* sizes,
@@ -903,6 +1308,7 @@ int topo_amd_tpi_std_multi_f32(const float* dem, int ny, int nx, int n_scales, c
         any_std |= s;
     }
     const size_t bytes = (size_t)ny * nx * sizeof(float);
+    ClassScope cls(scan_host(dem, ny, nx));
     HostRun run;
     void *d_in = nullptr, *d_tpi = nullptr, *d_std = nullptr;
     TOPO_TRY(run.alloc(&d_in, bytes));
@@ -912,17 +1318,19 @@ int topo_amd_tpi_std_multi_f32(const float* dem, int ny, int nx, int n_scales, c
         if (tpi_outs && tpi_outs[k]) run.prefault(tpi_outs[k], bytes);
         if (std_outs && std_outs[k]) run.prefault(std_outs[k], bytes);
     }
-    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
-    Block b{(const float*)d_in, ny, 0, ny, nx, 0, ny};
+    // scale 0 rides on the upload; every scale overlaps its kernels with its own downloads (the two device planes are
+    // reused, so a scale starts when the one before it is down)
     for (int k = 0; k < n_scales; ++k) {
         float* t = tpi_outs && tpi_outs[k] ? (float*)d_tpi : nullptr;
-        float* s = std_outs && std_outs[k] ? (float*)d_std : nullptr;
-        TOPO_TRY(tpi_std_block(b, sizes[k], sigmas ? sigmas[k] : 0.0, t, s));
-        if (k == 0) run.ready();
-        if (t) TOPO_TRY(download(tpi_outs[k], d_tpi, bytes));  // stream-ordered: the next scale's kernels wait for it
-        if (s) TOPO_TRY(download(std_outs[k], d_std, bytes));
+        float* sd = std_outs && std_outs[k] ? (float*)d_std : nullptr;
+        int above = 0, below = 0;
+        TOPO_TRY(topo_amd_halo_rows(TOPO_AMD_DESC_TPI, (double)sizes[k], sigmas ? sigmas[k] : 0.0, &above, &below));
+        TOPO_TRY(run_pipelined(run, dem, (float*)d_in, ny, nx, above, below, k == 0,
+                               {{t ? tpi_outs[k] : nullptr, t}, {sd ? std_outs[k] : nullptr, sd}}, [&](int view_rows, int r0, int rows) {
+                                   Block b{(const float*)d_in, view_rows, 0, ny, nx, r0, rows};
+                                   return tpi_std_block(b, sizes[k], sigmas ? sigmas[k] : 0.0, shift(t, r0, nx), shift(sd, r0, nx));
+                               }));
     }
-    TOPO_HIP(hipStreamSynchronize(ctx().compute));
     return TOPO_AMD_OK;
 }
 
@@ -939,19 +1347,19 @@ int topo_amd_std_f32(const float* dem, int ny, int nx, int size, double sigma, f
 int topo_amd_gauss_f32(const float* dem, int ny, int nx, double sigma_y, double sigma_x, float* out) {
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && out && ny >= 1 && nx >= 1, "gauss: bad arguments");
+    TOPO_REQUIRE(sigma_y >= 0.0 && sigma_x >= 0.0, "gaussian: negative sigma");
     const size_t bytes = (size_t)ny * nx * sizeof(float);
+    ClassScope cls(scan_host(dem, ny, nx));
+    int above = 0, below = 0;
+    TOPO_TRY(topo_amd_halo_rows(TOPO_AMD_DESC_GAUSS, sigma_y, 0.0, &above, &below));
     HostRun run;
     void *d_in = nullptr, *d_out = nullptr;
     TOPO_TRY(run.alloc(&d_in, bytes));
     TOPO_TRY(run.alloc(&d_out, bytes));
     run.prefault(out, bytes);
-    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
-    TOPO_TRY(topo_amd_gaussian_dev((const float*)d_in, ny, 0, ny, nx, sigma_y, sigma_x, 0, ny,
-                                   (float*)d_out));
-    run.ready();
-    TOPO_TRY(download(out, d_out, bytes));
-    TOPO_HIP(hipStreamSynchronize(ctx().compute));
-    return TOPO_AMD_OK;
+    return run_pipelined(run, dem, (float*)d_in, ny, nx, above, below, true, {{out, (float*)d_out}}, [&](int view_rows, int r0, int rows) {
+        return topo_amd_gaussian_dev((const float*)d_in, view_rows, 0, ny, nx, sigma_y, sigma_x, r0, rows, shift((float*)d_out, r0, nx));
+    });
 }
 
 int topo_amd_sobel_f32(const float* dem, int ny, int nx, float* dx_out, float* dy_out) {
@@ -965,13 +1373,11 @@ int topo_amd_sobel_f32(const float* dem, int ny, int nx, float* dx_out, float* d
     TOPO_TRY(run.alloc(&d_dy, bytes));
     run.prefault(dx_out, bytes);
     run.prefault(dy_out, bytes);
-    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
-    TOPO_TRY(topo_amd_sobel_dev((const float*)d_in, ny, 0, ny, nx, 0, ny, (float*)d_dx, (float*)d_dy));
-    run.ready();
-    TOPO_TRY(download(dx_out, d_dx, bytes));
-    TOPO_TRY(download(dy_out, d_dy, bytes));
-    TOPO_HIP(hipStreamSynchronize(ctx().compute));
-    return TOPO_AMD_OK;
+    return run_pipelined(run, dem, (float*)d_in, ny, nx, 1, 1, true, {{dx_out, (float*)d_dx}, {dy_out, (float*)d_dy}},
+                         [&](int view_rows, int r0, int rows) {
+                             return topo_amd_sobel_dev((const float*)d_in, view_rows, 0, ny, nx, r0, rows, shift((float*)d_dx, r0, nx),
+                                                       shift((float*)d_dy, r0, nx));
+                         });
 }
 
 int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double sig_ratio,
@@ -980,6 +1386,7 @@ int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && ny >= 1 && nx >= 1, "gradient: bad DEM");
     const size_t bytes = (size_t)ny * nx * sizeof(float);
+    ClassScope cls(scan_host(dem, ny, nx));
     HostRun run;
     void *d_in = nullptr, *d_o[4] = {nullptr, nullptr, nullptr, nullptr};
     float* host_out[4] = {dx_out, dy_out, slope_out, aspect_out};
@@ -987,9 +1394,9 @@ int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double
     for (int k = 0; k < 4; ++k)
         if (host_out[k]) TOPO_TRY(run.alloc(&d_o[k], bytes));
     for (int k = 0; k < 4; ++k) run.prefault(host_out[k], bytes);
-    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
     const void *rx = res_x, *ry = res_y;
     if (res_mode == TOPO_AMD_RES_2D) {
+        TOPO_REQUIRE(res_x && res_y, "gradient: resolution arrays are NULL");
         void *d_rx = nullptr, *d_ry = nullptr;
         TOPO_TRY(run.alloc(&d_rx, bytes));
         TOPO_TRY(run.alloc(&d_ry, bytes));
@@ -998,33 +1405,42 @@ int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double
         rx = d_rx;
         ry = d_ry;
     }
-    TOPO_TRY(topo_amd_gradient_dev((const float*)d_in, ny, 0, ny, nx, sigma, sig_ratio, res_mode, rx,
-                                   ry, 0, ny, (float*)d_o[0], (float*)d_o[1], (float*)d_o[2],
-                                   (float*)d_o[3]));
-    run.ready();
-    for (int k = 0; k < 4; ++k) TOPO_TRY(download(host_out[k], d_o[k], bytes));
-    TOPO_HIP(hipStreamSynchronize(ctx().compute));
-    return TOPO_AMD_OK;
+    const int h = gradient_halo(sigma, sig_ratio == 0.0 ? 1.0 : sig_ratio);
+    std::vector<HostPlane> outs;
+    for (int k = 0; k < 4; ++k) outs.push_back({host_out[k], (float*)d_o[k]});
+    return run_pipelined(run, dem, (float*)d_in, ny, nx, h, h, true, outs, [&](int view_rows, int r0, int rows) {
+        const void *cx = rx, *cy = ry;
+        if (res_mode == TOPO_AMD_RES_2D) {  // [out_rows x nx], aligned with the output rows
+            cx = (const float*)rx + (size_t)r0 * nx;
+            cy = (const float*)ry + (size_t)r0 * nx;
+        }
+        return topo_amd_gradient_dev((const float*)d_in, view_rows, 0, ny, nx, sigma, sig_ratio, res_mode, cx, cy, r0, rows,
+                                     shift((float*)d_o[0], r0, nx), shift((float*)d_o[1], r0, nx), shift((float*)d_o[2], r0, nx),
+                                     shift((float*)d_o[3], r0, nx));
+    });
 }
 
 int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const int32_t* di,
                     const double* dist, int n_off, int window, double height, float* out) {
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && out && ny >= 1 && nx >= 1, "sx: bad arguments");
+    TOPO_REQUIRE(dj && di && dist && n_off >= 0, "sx: NULL argument");
     const size_t bytes = (size_t)ny * nx * sizeof(float);
+    int up = 0, down = 0;
+    for (int n = 0; n < n_off; ++n) {
+        if (std::isnan(dist[n])) continue;
+        up = std::max(up, -dj[n]);
+        down = std::max(down, dj[n]);
+    }
     HostRun run;
     void *d_in = nullptr, *d_out = nullptr;
     TOPO_TRY(run.alloc(&d_in, bytes));
     TOPO_TRY(run.alloc(&d_out, bytes));
     run.prefault(out, bytes);
-    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
-    const int rc = topo_amd_sx_dev((const float*)d_in, ny, 0, ny, nx, dj, di, dist, n_off, window, height, 0, ny,
-                                   (float*)d_out);
-    if (rc != TOPO_AMD_OK && rc != TOPO_AMD_EEMPTY) return rc;  // EEMPTY: the plane was zero-filled
-    run.ready();
-    TOPO_TRY(download(out, d_out, bytes));
-    TOPO_HIP(hipStreamSynchronize(ctx().compute));
-    return rc;
+    return run_pipelined(run, dem, (float*)d_in, ny, nx, up, down, true, {{out, (float*)d_out}}, [&](int view_rows, int r0, int rows) {
+        return topo_amd_sx_dev((const float*)d_in, view_rows, 0, ny, nx, dj, di, dist, n_off, window, height, r0, rows,
+                               shift((float*)d_out, r0, nx));
+    });
 }
 
 int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int32_t* first,
@@ -1039,14 +1455,17 @@ int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int3
     TOPO_TRY(run.alloc(&d_in, bytes));
     for (int k = 0; k < n_az; ++k) TOPO_TRY(run.alloc((void**)&d_out[k], bytes));
     for (int k = 0; k < n_az; ++k) run.prefault(outs[k], bytes);
-    TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
-    const int rc = topo_amd_sx_multi_dev((const float*)d_in, ny, 0, ny, nx, n_az, first, dj, di, dist, window,
-                                         height, 0, ny, d_out.data());
-    if (rc != TOPO_AMD_OK && rc != TOPO_AMD_EEMPTY) return rc;  // EEMPTY: every plane was written
-    run.ready();
-    for (int k = 0; k < n_az; ++k) TOPO_TRY(download(outs[k], d_out[k], bytes));
-    TOPO_HIP(hipStreamSynchronize(ctx().compute));
-    return rc;
+    TOPO_REQUIRE(first && dj && di && dist && window, "sx_multi: NULL argument");
+    int up = 0, down = 0;
+    sx_multi_reach(n_az, first, dj, dist, &up, &down);
+    std::vector<HostPlane> planes;
+    for (int k = 0; k < n_az; ++k) planes.push_back({outs[k], d_out[k]});
+    std::vector<float*> moved(n_az);
+    return run_pipelined(run, dem, (float*)d_in, ny, nx, up, down, true, planes, [&](int view_rows, int r0, int rows) {
+        for (int k = 0; k < n_az; ++k) moved[k] = shift(d_out[k], r0, nx);
+        return topo_amd_sx_multi_dev((const float*)d_in, view_rows, 0, ny, nx, n_az, first, dj, di, dist, window, height, r0, rows,
+                                     moved.data());  // (EEMPTY: every plane was written)
+    });
 }
 
 int topo_amd_valley_ridge_f32(const float* dem, int ny, int nx, const float* taps, const int32_t* ksize,
@@ -1229,6 +1648,40 @@ int topo_amd_shard_layout_get(int* halo_above, int* halo_below) {
     return TOPO_AMD_OK;
 }
 
+// Collective: every rank scans the lattice points of the rows it owns, the scans are added up (three all-reduces of a few
+// bytes, once per DEM), and the class of the WHOLE raster is declared for the calling thread's later topo_amd_shard_* calls -
+// so every shard takes the kernels the single-GPU run of the raster takes.  `owned`: the first row the rank owns.
+int topo_amd_shard_classify(const float* owned, int rows_local, int row0, int gny, int nx) {
+    TOPO_TRY(require_ready());
+    TOPO_REQUIRE(owned && rows_local >= 1 && row0 >= 0 && row0 + rows_local <= gny && nx >= 1, "shard_classify: bad arguments");
+    Block b{owned, rows_local, row0, gny, nx, row0, rows_local};
+    Scan s;
+    TOPO_TRY(scan_block(b, row0, rows_local, &s));
+    if (g_comm.size > 1) {
+        TOPO_REQUIRE(g_comm.comm != nullptr, "shard_classify: call topo_amd_comm_init first");
+        Context& c = ctx();
+        void* d = nullptr;
+        TOPO_TRY(workspace(0, 64, &d));
+        struct Wire {
+            unsigned long long counts[2];
+            float lo, hi;
+        } w{{s.taken, s.large}, s.lo, s.hi};
+        TOPO_HIP(hipMemcpyAsync(d, &w, sizeof(w), hipMemcpyHostToDevice, c.compute));
+        char* base = (char*)d;
+        TOPO_NCCL(ncclAllReduce(base, base, 2, ncclUint64, ncclSum, g_comm.comm, c.compute));
+        TOPO_NCCL(ncclAllReduce(base + 16, base + 16, 1, ncclFloat, ncclMin, g_comm.comm, c.compute));
+        TOPO_NCCL(ncclAllReduce(base + 20, base + 20, 1, ncclFloat, ncclMax, g_comm.comm, c.compute));
+        TOPO_HIP(hipMemcpyAsync(&w, d, sizeof(w), hipMemcpyDeviceToHost, c.compute));
+        TOPO_HIP(hipStreamSynchronize(c.compute));
+        s.taken = w.counts[0];
+        s.large = w.counts[1];
+        s.lo = w.lo;
+        s.hi = w.hi;
+    }
+    const RasterClass cls = class_of(s);
+    return topo_amd_raster_class_set(cls.large ? 1 : 0, cls.lo, cls.hi);
+}
+
 int topo_amd_halo_wait(void) {
     TOPO_TRY(require_ready());
     if (g_comm.halo_pending) {
@@ -1349,8 +1802,6 @@ uint32_t gate_timeout_ticks() {
     }();
     return v;
 }
-// careful calls whose completion nobody has looked at yet (the probe event stands behind the last of them)
-int g_probe_calls = 0;
 void gate_probe_poll() {
     Context& c = ctx();
     if (c.gate_mode != 0 || !c.gate_probe_pending || hipEventQuery(c.gate_probe) != hipSuccess) return;
@@ -1367,9 +1818,14 @@ void gate_probe_poll() {
 // The gate of the exchange just started, careful or lean (Context::gate_mode; TOPO_AMD_GATE_MODE=careful / lean pins it).
 Gate make_gate(bool* lean) {
     Context& c = ctx();
+    // TOPO_AMD_GATE_MODE: careful (the default: a block that finds the gate closed for long leaves its seam tiles to the
+    // clean-up launch behind the exchange's event - right whatever the neighbour ranks do, whoever reads the outputs),
+    // lean (no clean-up launch, no event wait: a neighbour later than TOPO_AMD_GATE_TIMEOUT_MS is an ERROR that only
+    // the next synchronising library call reports - for applications that do call one), auto (careful until a
+    // few calls found the gate open, then lean).
     static const int pinned = [] {
         const char* e = std::getenv("TOPO_AMD_GATE_MODE");
-        return e && e[0] == 'l' ? 1 : e && e[0] == 'c' ? 2 : 0;
+        return e && e[0] == 'l' ? 1 : e && e[0] == 'a' ? 0 : 2;
     }();
     if (pinned) c.gate_mode = c.gate_mode == 2 ? 2 : pinned;  // (an error always ends lean mode)
     gate_probe_poll();
@@ -1459,7 +1915,7 @@ int run_gated(float* block, const Shard& s, int above, int below, bool device_ga
     c.ghost.gate.epoch = c.gate_epoch;
     c.ghost.ghost_lo = s.whole.in_row0 < s.row0 ? s.row0 : -(1 << 30);  // rows above the owned ones that exist: ghost rows
     c.ghost.ghost_hi = s.whole.in_row0 + s.whole.in_rows > end ? end : (1 << 30);
-    c.ghost.slots = kGateBytes - 256;
+    c.ghost.slots = kGateSlots;
     c.ghost.armed = true;
     const int rc = fn(s.whole, s.row0, s.rows_local);
     const bool taken = !c.ghost.armed;
@@ -1469,7 +1925,6 @@ int run_gated(float* block, const Shard& s, int above, int below, bool device_ga
     return run_three(block, s, above, below, fn, true);
 }
 
-float* shift(float* p, int rows, int nx) { return p ? p + (size_t)rows * nx : nullptr; }
 
 }  // namespace
 }  // namespace topo
@@ -1485,6 +1940,9 @@ int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int 
     TOPO_TRY(shard_view(&block, above, below, "shard_tpi_std"));
     block += shard_view_offset(above, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, above, below);
+    ClassScope cls(s.owned);  // (one rank: the shard is the raster; otherwise what topo_amd_shard_classify / _raster_class_set declared)
+    forget_plane(tpi_out, rows_local, nx);
+    forget_plane(std_out, rows_local, nx);
     // (tile rows of the first kernel: 60 for the ring kernels of STD and the marching TPI kernels, 64 for the TPI rings)
     const int tile_rows = std_out ? 60 : (size <= 17 ? 64 : 60);
     return run_fused(block, s, above, below, tile_rows, [&](const Block& view, int o0, int on) {
@@ -1504,6 +1962,8 @@ int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int
     TOPO_TRY(shard_view(&block, h, h, "shard_gradient"));
     block += shard_view_offset(h, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, h, h);
+    ClassScope cls(s.owned);
+    for (float* o : {dx_out, dy_out, slope_out, aspect_out}) forget_plane(o, rows_local, nx);
     return run_gated(block, s, h, h, false, [&](const Block& view, int o0, int on) {
         Block b = view;
         b.out_row0 = o0;

@@ -52,6 +52,8 @@ struct Block {
 // the seam rows whose stencils read ghost rows.  The communication stream writes `epoch` into `*word` once the
 // ghost rows of the exchange have landed (topo_amd_halo_exchange_start); the blocks that reach a seam part
 // before that wait for it.  word == nullptr: no gate (the ghost rows are already final).
+constexpr size_t kGateBytes = 16384;             // the gate word, then (from byte 256) one "gave up" byte per block of a launch
+constexpr size_t kGateSlots = kGateBytes - 256;  // blocks a gated launch may have
 struct Gate {
     const uint32_t* word;
     uint32_t epoch;
@@ -107,6 +109,8 @@ struct Context {
     size_t lds_per_block = 65536;
     hipStream_t compute = nullptr;   // every kernel goes here
     hipStream_t comm = nullptr;      // RCCL ghost-row traffic
+    hipStream_t up = nullptr, down = nullptr;  // the copies of a pipelined host-buffer call (capi.hip, run_pipelined; created on first use)
+    std::vector<hipEvent_t> pipe_events;        // its events: uploaded chunk k, computed chunk k
     hipStream_t aux = nullptr;       // bandwidth-bound epilogues running next to matrix-core kernels (created on first use)
     hipEvent_t aux_ready[64] = {};    // compute -> aux, one per chunk
     hipEvent_t aux_done = nullptr;   // aux -> compute
@@ -185,18 +189,35 @@ int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize,
 
 int gaussian_radius(double sigma);
 
-// What the library remembers about the DEMs it has seen (keyed by block pointer, rows and width; a few entries): the share
-// of tiles with fractional elevations in one block's run of the last TPI call, written by that block into pinned host
-// memory (no stream operation, no synchronisation; a call reads what the last finished call left).  A DEM remembered
-// as mostly fractional starts with the kernel that suits it (tpi_scaled_march_kernel<TAKE_ALL>).
+// ---- the raster class: what kernel routing may know about the WHOLE raster -------------------------------------------
+// Two kernel choices change the last bits of a result (never its correctness): the Gaussian / gradient of a raster whose
+// ordinary values lie beyond the f16 matrix-core kernels' range runs on the vector-ALU kernels, and TPI alone on
+// fractional elevations sums x in units of 2^-k m with k taken from the raster's value range.  Both are decided from a
+// sample of the WHOLE raster on a lattice of the GLOBAL grid (topo_amd_raster_scan_dev), never from the block of one call:
+// a block that is the whole raster is scanned by the library (remembered per buffer until the library writes the buffer
+// or topo_amd_dem_changed names it); the host-buffer entry points scan the caller's array; a partial row block uses what
+// the application declared for its thread (topo_amd_raster_class_set; shard.py all-reduces the scans of the shards), an
+// ordinary DEM in metres if nothing was declared.  So every row block of a raster takes the whole raster's kernels.
+struct RasterClass {
+    bool large = false;   // more than a quarter of the lattice samples are finite and beyond +-1e5
+    float lo = 0.0f, hi = 4096.0f;  // smallest / largest ordinary lattice sample (finite, within +-2^18); lo > hi: none seen
+};
+RasterClass current_class();  // of the call in flight on this thread (capi.hip sets it around the launchers)
+
+// What the library remembers about the blocks it has seen (keyed by block pointer, rows and width; a few entries) - TIME
+// only, never bits: the share of tiles with fractional elevations in one block's run of the last TPI call, written by
+// that block into pinned host memory (no stream operation, no synchronisation; a call reads what the last finished call
+// left).  A DEM remembered as mostly fractional starts with the kernel that suits it (tpi_scaled_march_kernel<TAKE_ALL>:
+// the same bits as the two-launch route, pixel by pixel).  An entry is dropped whenever the library writes or frees memory
+// that overlaps its block (dem_memo_forget: uploads, copies, memset, the synthetic DEM, every output plane, the
+// workspaces, topo_amd_free) and by topo_amd_dem_changed.
 uint32_t* dem_memo_report(const Block& b);           // the pinned words {tiles, fractional tiles} of this DEM's entry
 bool dem_memo_mostly_fractional(const Block& b);
 // The same memory for the Gaussian's fused matrix-core kernel: the word it sets when it stages a sample that is not a
-// plain finite one (non-finite, or beyond 1e5 in magnitude), and what that word said after the last finished call.
+// plain finite one (non-finite, or beyond 1e5 in magnitude), and what that word said after the last finished call
+// (the two-pass kernels give the fused kernel's bits).
 uint32_t* dem_memo_wild_word(const Block& b);
 bool dem_memo_wild(const Block& b);
-// ... and whether more than a quarter of the block's samples are finite and beyond that limit (sampled once per DEM, one
-// stream synchronisation): such a raster takes the vector-ALU Gaussian kernels.
-bool dem_memo_mostly_large(const Block& b);
+void dem_memo_forget(const void* p, size_t bytes);
 
 }  // namespace topo

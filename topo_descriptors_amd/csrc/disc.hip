@@ -40,8 +40,10 @@ struct DiscArgs {
     int taps;
 };
 
-enum Pass { kPassA = 0, kPassU = 1, kPassU2 = 2, kPassF = 3, kPassT2 = 4 };
+enum Pass { kPassU = 1, kPassU2 = 2, kPassF = 3, kPassInd = 4, kPassUL = 5, kPassU2L = 6 };
 enum Flags { kFlagFrac = 1, kFlagBad = 2 };
+constexpr float kOrdinaryLim = 262144.0f;   // 2^18 (kAbsLim of the wave-shift kernels)
+constexpr float kMissingLim = 16777216.0f;  // 2^24: beyond it (or not finite) a sample is missing
 
 __device__ __forceinline__ float load_padded(const DiscArgs& p, int gy, int gx) {
     // zero padding outside the global DEM; rows outside the block only feed unused outputs
@@ -50,31 +52,37 @@ __device__ __forceinline__ float load_padded(const DiscArgs& p, int gy, int gx) 
     return p.in[(size_t)by * p.nx + gx];
 }
 
-// What one staging pass writes to LDS for a DEM sample v (c is an integer-valued offset):
-//   A   float  v - c                      U   int32  trunc(v) - c
-//   U2  uint32 (trunc(v) - c)^2           F   float  v - trunc(v)
-//   T2  float  (trunc(v) - c)^2           (float fallback of U2)
+// What one staging pass writes to LDS for a DEM sample v (c is an integer-valued offset), always an integer:
+//   U    int32  trunc(v) - c                U2   uint32 (trunc(v) - c)^2
+//   F    int32  the fractional part in units of 2^-16 m (like the wave-shift kernels)
+// and on tiles the 32-bit sums cannot hold (samples beyond 2^18, more relief than the row sums of u^2 take, non-finite
+// samples), LIMBS that can (disc_wave_impl.hpp, Stage):
+//   Ind  1 per sample that is not ordinary, + 2^16 per missing one        UL   u in two limbs (missing samples: u = 0)
+//   U2L  u^2 in limbs of 16 bits, the last one taking what is left
 template <int PASS>
-__device__ __forceinline__ uint32_t transform(float v, float c, int ci) {
-    if (PASS == kPassA) return __float_as_uint(v - c);
+__device__ __forceinline__ uint32_t transform(float v, int ci, int aux) {
     const float t = truncf(v);
-    if (PASS == kPassF) return __float_as_uint(v - t);
-    if (PASS == kPassT2) {
-        const float u = t - c;
-        return __float_as_uint(u * u);
+    if (PASS == kPassF) return (uint32_t)(int)rintf((v - t) * 65536.0f);
+    if (PASS == kPassInd || PASS == kPassUL || PASS == kPassU2L) {
+        const bool missing = !(fabsf(t) < kMissingLim);
+        if (PASS == kPassInd) return (missing ? 65536u : 0u) | ((missing || fabsf(t) > kOrdinaryLim) ? 1u : 0u);
+        const int u = missing ? 0 : (int)t - ci;
+        if (PASS == kPassUL) return aux == 0 ? ((uint32_t)u & 0xffffu) : (uint32_t)(u >> 16);
+        const uint64_t w = (uint64_t)((int64_t)u * (int64_t)u) >> (16 * (aux & 3));
+        return (aux & 4) ? (uint32_t)w : ((uint32_t)w & 0xffffu);
     }
     const int u = (int)t - ci;
     if (PASS == kPassU) return (uint32_t)u;
     return (uint32_t)u * (uint32_t)u;
 }
 
-// Stage one transformed tile and turn every LDS row into a prefix sum in place:
-// L[r][0] = 0, L[r][k] = sum of the first k staged values of row r (T = float or integer).
-// Returns block-wide flags: fractional elevations present / samples the exact integer
-// pipeline cannot take (non-finite, or |trunc(v) - c| > ulim).
-template <int PASS, typename T>
+// Stage one transformed tile and turn every LDS row into a prefix sum in place (uint32, modulo 2^32: differences are
+// exact while a row-window sum stays below 2^32).  L[r][0] = 0, L[r][k] = sum of the first k staged values of row r.
+// Returns block-wide flags (kPassU): fractional elevations present / samples the plain 32-bit passes cannot take
+// (non-finite, |trunc(v)| > 2^18, or |trunc(v) - c| > ulim).
+template <int PASS>
 __device__ int stage_and_scan(const DiscArgs& p, uint32_t* L, int stride, int rows_l, int cols_v,
-                              int gy0, int gx0, float c, int ci, float ulim) {
+                              int gy0, int gx0, float c, int ci, float ulim, int aux = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     int flags = 0;
@@ -86,9 +94,9 @@ __device__ int stage_and_scan(const DiscArgs& p, uint32_t* L, int stride, int ro
             if (PASS == kPassU) {
                 const float t = truncf(v);
                 if (v != t) flags |= kFlagFrac;
-                if (!(fabsf(t - c) <= ulim)) flags |= kFlagBad;  // also catches NaN / inf
+                if (!(fabsf(t - c) <= ulim) || !(fabsf(t) <= kOrdinaryLim)) flags |= kFlagBad;  // also catches NaN / inf
             }
-            row[k] = transform<PASS>(v, c, ci);
+            row[k] = transform<PASS>(v, ci, aux);
         }
     }
     int all = 0;
@@ -100,15 +108,15 @@ __device__ int stage_and_scan(const DiscArgs& p, uint32_t* L, int stride, int ro
         __syncthreads();
     }
     for (int r = threadIdx.x; r < rows_l; r += kThreads) {
-        T* row = reinterpret_cast<T*>(L + r * stride);
-        T run = (T)0;
-        row[0] = (T)0;
+        uint32_t* row = L + r * stride;
+        uint32_t run = 0;
+        row[0] = 0;
         int k = 1;
         for (; k + 3 <= cols_v; k += 4) {
-            const T v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3];
-            const T s0 = run + v0;
-            const T s1 = s0 + v1;
-            const T s2 = s1 + v2;
+            const uint32_t v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3];
+            const uint32_t s0 = run + v0;
+            const uint32_t s1 = s0 + v1;
+            const uint32_t s2 = s1 + v2;
             run = s2 + v3;
             row[k] = s0;
             row[k + 1] = s1;
@@ -124,30 +132,30 @@ __device__ int stage_and_scan(const DiscArgs& p, uint32_t* L, int stride, int ro
     return all;
 }
 
-// One prefix difference per disc row; ACC is the accumulator type (float, int32, uint64).
-template <int NOUT, typename T, typename ACC>
-__device__ __forceinline__ void gather(const DiscArgs& p, const uint32_t* L, int stride, int col,
-                                       int row_first, ACC (&acc)[NOUT]) {
+// One prefix difference per disc row (exact modulo 2^32), accumulated in 64 bits; SIGNED: the differences are int32.
+template <int NOUT, bool SIGNED>
+__device__ __forceinline__ void gather(const DiscArgs& p, const uint32_t* L, int stride, int col, int row_first, int64_t (&acc)[NOUT]) {
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) acc[k] = (ACC)0;
+    for (int k = 0; k < NOUT; ++k) acc[k] = 0;
     for (int d = 0; d < p.n_disc_rows; ++d) {
         const int packed = p.runs[d];  // wave-uniform: scalar load
         const int lo = packed & 0xffff;
         const int hi = packed >> 16;
-        const T* base = reinterpret_cast<const T*>(L) + (row_first + d) * stride + col;
+        const uint32_t* base = L + (row_first + d) * stride + col;
 #pragma unroll
         for (int k = 0; k < NOUT; ++k) {
-            const T* rowp = base + (2 * k) * stride;
-            acc[k] += (ACC)(T)(rowp[hi + 1] - rowp[lo]);
+            const uint32_t* rowp = base + (2 * k) * stride;
+            const uint32_t dlt = rowp[hi + 1] - rowp[lo];
+            acc[k] += SIGNED ? (int64_t)(int32_t)dlt : (int64_t)(uint64_t)dlt;
         }
     }
 }
 
-// value of one staged sample recovered from the prefix row: P[k+1] - P[k]
-template <typename T>
-__device__ __forceinline__ T sample(const uint32_t* L, int idx) {
-    const T* q = reinterpret_cast<const T*>(L) + idx;
-    return (T)(q[1] - q[0]);
+__device__ __forceinline__ double int128_to_double(__int128 v) {
+    const bool neg = v < 0;
+    const unsigned __int128 mag = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    const double d = (double)(uint64_t)(mag >> 64) * 18446744073709551616.0 + (double)(uint64_t)mag;
+    return neg ? -d : d;
 }
 
 template <bool WANT_TPI, bool WANT_STD, int TILE_H>
@@ -166,93 +174,61 @@ __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
     const int gy0 = oy0 + p.dj_min;
     const int gx0 = ox0 + p.di_min;
 
-    // integer offset near the local elevation (tile centre, clamped into the DEM)
+    // integer offset near the local elevation (tile centre, clamped into the DEM and the block's view).  Every sum below is
+    // an exact integer and the finalisation removes c again, so the results do not depend on it.
     int cy = min(max(oy0 + TILE_H / 2, 0), p.gny - 1);
     cy = min(max(cy, p.in_row0), p.in_row0 + p.in_rows - 1);
     const int cx = min(ox0 + kTileW / 2, p.nx - 1);
     float c = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
-    if (!(fabsf(c) < 1.0e9f)) c = 0.0f;  // NaN/inf/huge centre: no offset
+    if (!(fabsf(c) < kMissingLim)) c = 0.0f;  // NaN/inf/huge centre: no offset
     const int ci = (int)c;
 
     const int col = threadIdx.x & (kTileW - 1);
     const int phase = threadIdx.x >> 7;
-    // indices (without the per-output row term) of the pixel itself and of the zeroed tap
-    const int self_idx = (phase - p.dj_min) * stride + col - p.di_min;
-    const int ctr_idx = (phase + p.centre_dj - p.dj_min) * stride + col + p.centre_di - p.di_min;
 
-    // per-output sums in float64 at the end: s1 = sum (trunc(x) - c), s2 = sum (trunc(x) - c)^2,
-    // sf = sum frac(x); self_a / ctr_a = trunc(x) - c and self_f / ctr_f = frac(x) of the pixel
-    // and of the zeroed tap
-    double s1[NOUT], s2[NOUT], sf[NOUT], self_a[NOUT], ctr_a[NOUT], self_f[NOUT], ctr_f[NOUT];
+    // exact per-output sums over the n taps (a tap outside the DEM reads x = 0, the zero padding of mode="same")
+    int64_t su[NOUT], su2[NOUT], sg[NOUT], ind[NOUT];
 #pragma unroll
-    for (int k = 0; k < NOUT; ++k) s1[k] = s2[k] = sf[k] = self_a[k] = ctr_a[k] = self_f[k] = ctr_f[k] = 0.0;
+    for (int k = 0; k < NOUT; ++k) su[k] = su2[k] = sg[k] = ind[k] = 0;
 
-    // Exact pipeline first: integer prefix sums cannot round.  ulim keeps one row-window sum
-    // of u^2 below 2^32 so the wrap-around uint32 prefix differences stay exact.  Tiles with
-    // non-finite or out-of-range samples take the float32 pipeline instead (NaN propagates).
+    // ulim keeps one row-window sum of u^2 below 2^32 so that the wrap-around uint32 prefix differences stay exact
     const float ulim = fminf(46000.0f, floorf(sqrtf(4294967295.0f / (float)(p.halo_cols + 1))));
-    int flags = stage_and_scan<kPassU, int>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim);
-    bool use_float = (flags & kFlagBad) != 0;
-    if (!use_float) {
-        int su[NOUT];
-        gather<NOUT, int, int>(p, L, stride, col, phase, su);
-#pragma unroll
-        for (int k = 0; k < NOUT; ++k) {
-            s1[k] = (double)su[k];
-            if (WANT_TPI) {
-                self_a[k] = (double)sample<int>(L, self_idx + 2 * k * stride);
-                ctr_a[k] = (double)sample<int>(L, ctr_idx + 2 * k * stride);
-            }
-        }
+    const int flags = stage_and_scan<kPassU>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim);
+    const bool limbs = (flags & kFlagBad) != 0;
+    if (!limbs) {
+        gather<NOUT, true>(p, L, stride, col, phase, su);
         if (WANT_STD) {
             __syncthreads();
-            stage_and_scan<kPassU2, uint32_t>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim);
-            unsigned long long q[NOUT];
-            gather<NOUT, uint32_t, unsigned long long>(p, L, stride, col, phase, q);
-#pragma unroll
-            for (int k = 0; k < NOUT; ++k) s2[k] = (double)q[k];
+            stage_and_scan<kPassU2>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim);
+            gather<NOUT, false>(p, L, stride, col, phase, su2);
         }
-    }
-    __syncthreads();
-    if (use_float) {
-        float fa[NOUT];
-        stage_and_scan<kPassA, float>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, 0.0f);
-        gather<NOUT, float, float>(p, L, stride, col, phase, fa);
+    } else {
+        int64_t part[NOUT];
+        __syncthreads();
+        stage_and_scan<kPassInd>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim);
+        gather<NOUT, false>(p, L, stride, col, phase, ind);
+        __syncthreads();
+        stage_and_scan<kPassUL>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim, 0);
+        gather<NOUT, false>(p, L, stride, col, phase, su);
+        __syncthreads();
+        stage_and_scan<kPassUL>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim, 1);
+        gather<NOUT, true>(p, L, stride, col, phase, part);
 #pragma unroll
-        for (int k = 0; k < NOUT; ++k) {
-            s1[k] = (double)fa[k];
-            if (WANT_TPI) {
-                self_a[k] = (double)sample<float>(L, self_idx + 2 * k * stride);
-                ctr_a[k] = (double)sample<float>(L, ctr_idx + 2 * k * stride);
-            }
-        }
+        for (int k = 0; k < NOUT; ++k) su[k] += part[k] * 65536;
         if (WANT_STD) {
-            __syncthreads();
-            stage_and_scan<kPassT2, float>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, 0.0f);
-            gather<NOUT, float, float>(p, L, stride, col, phase, fa);
+            for (int limb = 0; limb < 3; ++limb) {
+                __syncthreads();
+                stage_and_scan<kPassU2L>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim, limb | (limb == 2 ? 4 : 0));
+                gather<NOUT, false>(p, L, stride, col, phase, part);
 #pragma unroll
-            for (int k = 0; k < NOUT; ++k) s2[k] = (double)fa[k];
-            __syncthreads();
+                for (int k = 0; k < NOUT; ++k) su2[k] += (int64_t)((uint64_t)part[k] << (16 * limb));
+            }
         }
     }
     if (flags & kFlagFrac) {
-        // fractional parts: small positive floats, their float32 prefix sums are harmless
-        float ff[NOUT];
-        stage_and_scan<kPassF, float>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, 0.0f);
-        gather<NOUT, float, float>(p, L, stride, col, phase, ff);
-#pragma unroll
-        for (int k = 0; k < NOUT; ++k) {
-            sf[k] = (double)ff[k];
-            if (use_float) s1[k] -= sf[k];  // keep s1 = sum of (trunc(x) - c) in both pipelines
-            if (WANT_TPI) {
-                self_f[k] = (double)sample<float>(L, self_idx + 2 * k * stride);
-                ctr_f[k] = (double)sample<float>(L, ctr_idx + 2 * k * stride);
-                if (use_float) {
-                    self_a[k] -= self_f[k];
-                    ctr_a[k] -= ctr_f[k];
-                }
-            }
-        }
+        __syncthreads();
+        stage_and_scan<kPassF>(p, L, stride, rows_l, cols_v, gy0, gx0, c, ci, ulim);
+        gather<NOUT, true>(p, L, stride, col, phase, sg);
     }
 
     const int gx = ox0 + col;
@@ -263,21 +239,39 @@ __global__ __launch_bounds__(kThreads) void disc_prefix_kernel(DiscArgs p) {
         const int oy = oy0 + phase + 2 * k;
         if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
         const size_t o = (size_t)(oy - p.out_row0) * p.nx + gx;
-        // With the padded taps staged as trunc = 0 (u = -c), s1 + n c is the exact integer sum of
-        // trunc(x) over the in-domain taps: the results do not depend on the tile's choice of c.
-        const double cd = (double)c;
-        const double sum_x = (s1[k] + cd * n) + sf[k];
+        // load_padded gives x = 0 for a tap outside the DEM, staged as u = -c like any other sample: with the full tap count n,
+        // sum trunc(x) = Su + c n and sum trunc(x)^2 = Su2 + 2 c Su + c^2 n hold as they stand (exact integers: c drops out).
+        const __int128 cI = ci;
+        const int64_t T = su[k] + (int64_t)ci * (int64_t)p.taps;              // sum of trunc(x) over the n taps (padding: 0)
+        const __int128 S2 = (__int128)su2[k] + 2 * cI * su[k] + cI * cI * p.taps;  // sum of trunc(x)^2
+        const double sf = (double)sg[k] * (1.0 / 65536.0);
+        const double sum_x = (double)T + sf;
+        const bool missing = (ind[k] >> 16) != 0, ordinary = (ind[k] & 0xffff) == 0;
         if (WANT_TPI) {
-            const double x_self = (self_a[k] + cd) + self_f[k];
-            const double x_ctr = (ctr_a[k] + cd) + ctr_f[k];
+            const int sy = oy, sx = gx;
+            const int cy2 = oy + p.centre_dj, cx2 = gx + p.centre_di;
+            const double x_self = (double)load_padded(p, sy, sx);
+            const double x_ctr = (double)load_padded(p, cy2, cx2);
             // (n-1) may be 0 for size 1 -> non-finite like the reference
-            p.tpi[o] = (float)(x_self - (sum_x - x_ctr) / (n - 1.0));
+            const float v = (float)(x_self - (sum_x - x_ctr) / (n - 1.0));
+            p.tpi[o] = missing ? __uint_as_float(0x7fc00000u) : v;
         }
         if (WANT_STD) {
-            const double sum_t2 = s2[k] + 2.0 * cd * s1[k] + cd * cd * n;
-            double var = (sum_t2 - sum_x * sum_x / n) / (n - 1.0);
-            if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
-            p.sd[o] = (float)sqrt(var);
+            float v;
+            if (ordinary) {
+                const double sum_t2 = (double)(int64_t)S2;  // below 2^53
+                double var = (sum_t2 - sum_x * sum_x / n) / (n - 1.0);
+                if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
+                v = (float)sqrt(var);
+            } else {
+                // samples beyond 2^18 in the disc: 2^32 (n s2 - s1^2) exactly in 128 bits (disc_wave_impl.hpp, std_from_exact_sums)
+                const __int128 A = (__int128)p.taps * S2 - (__int128)T * T;
+                const __int128 num = (A << 32) - (((__int128)T * sg[k]) << 17) - (__int128)sg[k] * sg[k];
+                double var = int128_to_double(num) * (1.0 / 4294967296.0) / (n * (n - 1.0));
+                if (var < 0.0) var = 0.0;
+                v = (float)sqrt(var);
+            }
+            p.sd[o] = missing ? __uint_as_float(0x7fc00000u) : v;
         }
     }
 }

@@ -12,8 +12,13 @@
 //   * the fractional parts in units of 2^-16 m (the quantisation of the wave-shift kernels), the
 //     same way, read only when the block has a fractional sample at all;
 //   * trunc(x)^2 for STD: float64 (exact below 2^53; 32 bits are not enough for long runs).
-// A block with a non-finite sample or |trunc(x)| > 65536 takes float64 planes for everything (the
-// first version of this path): the prefix pass raises a flag that the host reads before the gather.
+// A block with a non-finite sample or |trunc(x)| > 65536 takes float64 planes for everything: the prefix pass raises a
+// flag that the host reads before the gather.  Those planes are exact integers as well - trunc(x) (below 2^24: a sample
+// beyond that, or not finite, is MISSING, staged as 0 and counted in a plane of its own), the fractional parts, and
+// trunc(x)^2 in two planes (the bits above and below 2^24: either sum stays below 2^53 down any column) - so a prefix
+// difference does not depend on where the planes start, i.e. on the row block: a pixel whose disc holds a missing sample
+// is NaN (exactly those pixels), every other pixel is the rounding of exact sums - by the expression of the narrow planes
+// where sum trunc(x)^2 fits float64 (the same bits as a block without such samples gives), in 128-bit integers beyond.
 #include "common.hpp"
 
 namespace topo {
@@ -29,7 +34,9 @@ struct BigArgs {
     const float* in;
     double* qt;   // prefix over rows of trunc(x),   (rows + 1) x nx
     double* qf;   // prefix of the fractional parts in units of 2^-16 m
-    double* qt2;  // prefix of trunc(x)^2 (only when STD is wanted)
+    double* qt2;  // prefix of trunc(x)^2 (only when STD is wanted); float64 planes: of its bits from 2^24 up
+    double* qt2b; // float64 planes: prefix of the low 24 bits of trunc(x)^2
+    double* qc;   // float64 planes: prefix of the count of missing samples
     uint32_t* it;   // the same as uint32 running sums (wrap-around allowed): trunc(x)
     uint32_t* ifr;  // fractional parts in units of 2^-16 m
     int* flags;     // BigFlags, raised by big_prefix_int_kernel
@@ -47,22 +54,30 @@ struct BigArgs {
 __global__ __launch_bounds__(kThreads) void big_prefix_kernel(BigArgs p) {
     const int x = blockIdx.x * kThreads + threadIdx.x;
     if (x >= p.nx) return;
-    double st = 0.0, sf = 0.0, st2 = 0.0;
+    double st = 0.0, sf = 0.0, st2 = 0.0, st2b = 0.0, sc = 0.0;
     p.qt[x] = 0.0;
     p.qf[x] = 0.0;
-    if (p.qt2) p.qt2[x] = 0.0;
+    p.qc[x] = 0.0;
+    if (p.qt2) p.qt2[x] = p.qt2b[x] = 0.0;
     const float* src = p.in + (size_t)(p.p_row0 - p.in_row0) * p.nx + x;
     for (int r = 0; r < p.p_rows; ++r) {
         const float v = src[(size_t)r * p.nx];
-        const float t = truncf(v);
+        const bool missing = !(fabsf(truncf(v)) < 16777216.0f);  // not finite, or beyond +-2^24
+        const float t = missing ? 0.0f : truncf(v);
         st += (double)t;
-        sf += (double)rintf((v - t) * 65536.0f);  // the units of the narrow planes: finite sums agree bit for bit
+        sf += missing ? 0.0 : (double)rintf((v - t) * 65536.0f);  // the units of the narrow planes: finite sums agree bit for bit
+        sc += missing ? 1.0 : 0.0;
         const size_t o = (size_t)(r + 1) * p.nx + x;
         p.qt[o] = st;
         p.qf[o] = sf;
+        p.qc[o] = sc;
         if (p.qt2) {
-            st2 += (double)t * (double)t;
+            const double t2 = (double)t * (double)t;  // below 2^48: exact
+            const double hi = floor(t2 * (1.0 / 16777216.0));
+            st2 += hi;
+            st2b += t2 - hi * 16777216.0;
             p.qt2[o] = st2;
+            p.qt2b[o] = st2b;
         }
     }
 }
@@ -216,7 +231,9 @@ __global__ __launch_bounds__(kThreads) void big_disc_kernel(BigArgs p) {
     const int ox = blockIdx.x * kThreads + threadIdx.x;
     const int oy = p.out_row0 + blockIdx.y;
     if (ox >= p.nx) return;
-    double st = 0.0, sf = 0.0, st2 = 0.0;
+    // every term is an exact integer in float64 (the planes are; a difference of two entries of a column is the sum of a
+    // run, far below 2^53), and so are the sums over the disc's columns up to 2^53
+    double st = 0.0, sf = 0.0, st2 = 0.0, st2b = 0.0, sc = 0.0;
     for (int k = 0; k < p.size; ++k) {
         const unsigned packed = (unsigned)p.runs[k];  // wave-uniform
         const int lo = (int)(packed & 0xffffu) - 32768, hi = (int)(packed >> 16) - 32768;
@@ -229,11 +246,17 @@ __global__ __launch_bounds__(kThreads) void big_disc_kernel(BigArgs p) {
         const size_t a = (size_t)top * p.nx + x, b = (size_t)bot * p.nx + x;
         st += p.qt[a] - p.qt[b];
         sf += p.qf[a] - p.qf[b];
-        if (WANT_STD) st2 += p.qt2[a] - p.qt2[b];
+        sc += p.qc[a] - p.qc[b];
+        if (WANT_STD) {
+            st2 += p.qt2[a] - p.qt2[b];
+            st2b += p.qt2b[a] - p.qt2b[b];
+        }
     }
     const double n = (double)p.taps;
     const double s1 = st + sf * (1.0 / 65536.0);
     const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
+    const bool missing = sc > 0.0;
+    const float nan = __uint_as_float(0x7fc00000u);
     if (WANT_TPI) {
         const double xs = (double)p.in[(size_t)(oy - p.in_row0) * p.nx + ox];
         const int cy = oy + p.centre, cx = ox + p.centre;
@@ -241,12 +264,26 @@ __global__ __launch_bounds__(kThreads) void big_disc_kernel(BigArgs p) {
         if (p.centre != 0)
             x_ctr = (cy >= 0 && cy < p.gny && cx >= 0 && cx < p.nx)
                         ? (double)p.in[(size_t)(cy - p.in_row0) * p.nx + cx] : 0.0;
-        p.tpi[o] = (float)(xs - (s1 - x_ctr) / (n - 1.0));
+        p.tpi[o] = missing ? nan : (float)(xs - (s1 - x_ctr) / (n - 1.0));
     }
     if (WANT_STD) {
-        double var = (st2 - s1 * s1 / n) / (n - 1.0);
-        if (var < 0.0) var = 0.0;  // keeps NaN, like np.clip
-        p.sd[o] = (float)sqrt(var);
+        const double s2 = st2 * 16777216.0 + st2b;  // exact while it stays below 2^53
+        double var;
+        if (st2 < 268435456.0) {  // sum trunc(x)^2 below 2^52 + 2^46: the expression of the narrow planes, on the same exact sums
+            var = (s2 - s1 * s1 / n) / (n - 1.0);
+        } else {
+            // 2^32 (n s2 - s1^2) with s1 = T + Sg / 2^16, exactly, in 128 bits (disc_wave_impl.hpp, std_from_exact_sums)
+            const __int128 T = (__int128)(long long)st, Sg = (__int128)(long long)sf;
+            const __int128 S2 = (((__int128)(long long)st2) << 24) + (__int128)(long long)st2b;
+            const __int128 A = (__int128)p.taps * S2 - T * T;
+            const __int128 num = (A << 32) - ((T * Sg) << 17) - Sg * Sg;
+            const bool neg = num < 0;
+            const unsigned __int128 mag = neg ? (unsigned __int128)(-num) : (unsigned __int128)num;
+            const double d = (double)(unsigned long long)(mag >> 64) * 18446744073709551616.0 + (double)(unsigned long long)mag;
+            var = (neg ? -d : d) * (1.0 / 4294967296.0) / (n * (n - 1.0));
+        }
+        if (var < 0.0) var = 0.0;
+        p.sd[o] = missing ? nan : (float)sqrt(var);
     }
 }
 
@@ -322,9 +359,11 @@ int launch_disc_big(const Block& b, const DiscRuns& disc, float* tpi_out, float*
         return TOPO_AMD_OK;
     }
     // non-finite or absurd samples: float64 planes, so that NaN propagates and nothing wraps
-    TOPO_TRY(workspace(4, plane, &q0));
+    TOPO_TRY(workspace(4, 3 * plane, &q0));
     TOPO_TRY(workspace(5, plane, &q1));
     a.qt = (double*)q0;
+    a.qt2b = (double*)((char*)q0 + plane);
+    a.qc = (double*)((char*)q0 + 2 * plane);
     a.qf = (double*)q1;
 
     hipLaunchKernelGGL(big_prefix_kernel, dim3((b.nx + kThreads - 1) / kThreads), dim3(kThreads), 0,

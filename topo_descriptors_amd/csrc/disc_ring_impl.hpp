@@ -711,6 +711,48 @@ constexpr bool std_ring_both_fits(int size) {
 // 12.56 -> 10.81 (profiles/r03_std_ring_both.txt).
 enum StdRingMode { kStdMain = 0, kStdBoth = 2 };
 
+// One row of a tile at the DEM's border (std_ring_kernel): m = the taps of the pixel's disc inside the DEM (the rows of every
+// column run that are, over the columns that are), then the general kernel's expressions on the same exact sums - the
+// float64 form where m < n, the integer form where the disc is whole - hence its bits.  The samples outside the DEM were
+// staged as u = 0, so sum trunc(x) = Su + c m and sum trunc(x)^2 = Su2 + 2 c Su + c^2 m.
+template <int SIZE, bool WANT_TPI>
+__device__ __attribute__((noinline)) void std_ring_border_row(int gny, int nx, int oy, int ocol, int ci, u32x4 su, u32x4 su2, u32x4 ctr,
+                                                              float* sd_out, float* tpi_out) {
+    using G = RGeo<SIZE, 4>;
+    const double n = (double)G::T.taps;
+    const double inv_n = 1.0 / n, inv_nm1 = 1.0 / (n - 1.0), inv_nn1 = 1.0 / (n * (n - 1.0));
+    int mt[4] = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int k = 0; k < SIZE; ++k) {
+        const int rin = max(min(oy + G::T.hi[k], gny - 1) - max(oy + G::T.lo[k], 0) + 1, 0);  // wave-uniform
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = ocol + t + k - G::M;
+            mt[t] += (col >= 0 && col < nx) ? rin : 0;
+        }
+    }
+    Vec4<float> out_s, out_t;
+    const double cd = (double)ci;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double m = (double)mt[t];
+        const double dsu = (double)(int)su[t], dsu2 = (double)su2[t];
+        const double s1 = dsu + cd * m;  // sum of trunc(x) over the taps inside the DEM: exact
+        if (mt[t] == G::T.taps) {
+            out_s.v[t] = std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1);
+        } else {
+            const double s2 = dsu2 + 2.0 * cd * dsu + cd * cd * m;
+            out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
+        }
+        if (WANT_TPI) {
+            const double xd = (double)((int)ctr[t] + ci);
+            out_t.v[t] = (float)(xd - (s1 - xd) * inv_nm1);
+        }
+    }
+    *reinterpret_cast<Vec4<float>*>(sd_out) = out_s;
+    if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(tpi_out) = out_t;
+}
+
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
 __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = RGeo<SIZE, 4>;
@@ -933,6 +975,7 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
         const bool cols_inside = ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= p.nx - 1;
         int s0 = C::PAD - 1 + wave;
         int tmode = kTileDone;  // what the map says about the current tile
+        bool btile = false;     // the current tile has pixels whose discs leave the DEM (their taps outside it read 0)
 #pragma unroll 1
         for (int ph = 0; ph < nphase; ++ph) {
             const int tile = tile0 + ph / PPT;
@@ -964,9 +1007,14 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                 if (BOTH) {
                     tmode = candidate(tile) ? kNeedsFraction : kTileDone;  // (kTileDone here: not this pass's)
                 } else {
+                    // (round 5: the tiles at the DEM's border are this kernel's too - they were the general kernel's, a
+                    // trailing launch over 3 % of the pixels at an eighth of this kernel's rate on an under-filled grid: 20 %
+                    // of an 8192^2 step at 7 px.  The samples outside the DEM are staged as u = 0, and a pixel's in-domain
+                    // tap count m - plain geometry - puts the offset back: sum trunc(x) = Su + c m, see the finalisation.)
                     const int oy0 = oyS + (ph / PPT) * C::TH;
                     const bool rows_inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1;
-                    tmode = !rows_inside || !cols_inside ? kTileGeneral : kTileDone;
+                    btile = !rows_inside || !cols_inside;
+                    tmode = kTileDone;
                     if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
                 }
             }
@@ -1014,6 +1062,12 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                         *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
                         if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
                     }
+                } else if (btile && lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
+                    // (a call, not inlined: what this rare row needs in registers must not weigh on the chains above)
+                    std_ring_border_row<SIZE, WANT_TPI>(p.gny, p.nx, oy, ocol, ci, u32x4{su[0], su[1], su[2], su[3]},
+                                                        u32x4{su2[0], su2[1], su2[2], su2[3]}, u32x4{ctr[0], ctr[1], ctr[2], ctr[3]},
+                                                        p.sd + (size_t)(oy - p.out_row0) * p.nx + ocol,
+                                                        WANT_TPI ? p.tpi + (size_t)(oy - p.out_row0) * p.nx + ocol : nullptr);
                 } else if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
                     const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
                     Vec4<float> out_s, out_t;

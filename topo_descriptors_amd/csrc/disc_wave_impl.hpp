@@ -16,6 +16,8 @@
 // neighbours first, cut into XCD-contiguous runs so that the ghost rows two tiles share meet in
 // one L2).
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -59,6 +61,8 @@ struct WaveArgs {
     float* tpi2;        // ring kernel for a pair of disc sizes: TPI of the smaller disc
     int scaled;         // TPI alone, tiles with fractional elevations: 1 = the scaled one-chain route (tpi_scaled_march_kernel)
     uint32_t* report;   // pinned host words {tiles, tiles with fractional samples} of ONE block's run (dem_memo), or nullptr
+    float unit;         // the scaled route: samples are summed as rint(unit x), unit = 2^8 ... 2^16 (scaled_unit)
+    uint64_t* rowmask;  // per tile of state kTileGeneralRows: the rows (bit = row of the tile) the general kernel is to write
 };
 
 // One launch, several row blocks ("parts").  An ordinary call has one part.  A sharded call (capi.hip, run_fused)
@@ -167,8 +171,12 @@ inline int make_parts(const Block& b, const WaveArgs& a0, int tile_h, int strip_
     }
     if (want_defer) {
         void* defer = nullptr;  // the same sizes in every launch of a group, so the same slices of one allocation
-        TOPO_TRY(workspace(8, defer_off[n], &defer));
-        for (int k = 0; k < n; ++k) ps->a[k].defer = (uint8_t*)defer + defer_off[k];
+        const size_t masks_at = (defer_off[n] + 15) & ~(size_t)15;  // one uint64 per tile behind the state bytes
+        TOPO_TRY(workspace(8, masks_at + defer_off[n] * sizeof(uint64_t), &defer));
+        for (int k = 0; k < n; ++k) {
+            ps->a[k].defer = (uint8_t*)defer + defer_off[k];
+            ps->a[k].rowmask = (uint64_t*)((uint8_t*)defer + masks_at) + defer_off[k];
+        }
     }
     if (want_sums) {
         void* sums = nullptr;
@@ -376,10 +384,23 @@ __device__ __forceinline__ Vec4<float> load_row4(const WaveArgs& p, int gy, int 
 // fractional parts in integer units of 2^-16 m (exact as well) and exists only on fractional DEMs.  Tiles holding non-finite or absurd samples (|u| so
 // large that one 67-row column sum of u^2 passes 2^32, e.g. -9999 nodata next to real terrain)
 // run float chains on a = x - c and (trunc(x) - c)^2 instead, so NaN propagates and nothing wraps.
-enum Stage { kStU = 0, kStU2 = 1, kStF = 2, kStA = 3, kStT2 = 4, kStS = 5 };
-// kStS: x in units of 2^-8 m, rounded to the nearest integer - an ABSOLUTE quantisation (no offset), so the value does not
-// depend on which tile, run or row block stages the sample (tpi_scaled_march_kernel).
-constexpr float kScaledUnit = 256.0f;
+enum Stage { kStU = 0, kStU2 = 1, kStF = 2, kStS = 5, kStInd = 6, kStUL = 7, kStU2L = 8 };
+// The general kernel on tiles the 32-bit integer chains cannot hold - samples beyond +-2^18 (a raster in millimetres), more
+// relief than the chains of u^2 take (nodata next to terrain), non-finite samples.  Still exact integers, in LIMBS:
+//   kStInd  per sample (not ordinary: non-finite or |trunc(x)| > 2^18) + 2^16 (missing: non-finite or |trunc(x)| >= 2^24): the
+//           chain counts both kinds per disc;
+//   kStUL   u = trunc(x) - c in two limbs (low 16 bits, the rest), missing samples as u = 0;
+//   kStU2L  u^2 (< 2^50) in limbs of 16 bits, the last one taking what is left (< 2^18).
+// Every limb sum over a disc fits 32 bits, the limbs add up to exact 64-bit sums, and the finalisation works on exact
+// integers (128-bit where it must), so the result does not depend on c, on the tile or on what else the block has in view:
+// a pixel whose disc holds a missing sample is NaN (exactly those pixels: the footprint of the disc), a pixel whose disc holds
+// ordinary samples only gets the bits every other kernel gives it, and the rest - discs with samples beyond 2^18 - are the
+// float64 rounding of the exact variance / mean.
+constexpr float kMissingLim = 16777216.0f;  // 2^24 (where float32 stops holding every integer): |u| < 2^25 whatever c is, u^2 < 2^50, 8192 of them < 2^63
+constexpr int kScratchPlanes = 6;            // planes of per-row sums a block of the general kernel keeps between its passes
+// kStS: x in units of 1 / unit m (unit = 2^8 ... 2^16, one value per call: WaveArgs::unit), rounded to the nearest integer - an
+// ABSOLUTE quantisation (no offset), so the value does not depend on which tile, run or row block stages the sample
+// (tpi_scaled_march_kernel).  stage_value<kStS> takes the unit in the place of the offset c.
 
 // sqrt(max(0, (s2 - s1^2/n) / (n-1))) from the float64 sums.  The variance stays in float64 (the
 // difference cancels a few hundred-fold), but 1/n and 1/(n-1) are multiplied in and the root is
@@ -406,22 +427,50 @@ __device__ __forceinline__ float std_from_int_sums(int su, uint64_t su2, uint32_
     const float f = fmaf((float)(uint32_t)(num >> 32), 4294967296.0f, (float)(uint32_t)num);
     return __builtin_amdgcn_sqrtf(f * inv_nn1);
 }
+// The limb path's finalisation of a pixel whose disc holds samples beyond 2^18: everything is an exact integer -
+//   T = sum trunc(x) = Su + c m,   S2 = sum trunc(x)^2 = Su2 + 2 c Su + c^2 m   (m in-domain taps of n),
+//   F = sum of the fractional parts = Sg / 2^16,   n s2 - s1^2 = (n S2 - T^2) - 2 T F - F^2
+// - so 2^32 (n s2 - s1^2) is formed exactly in 128 bits (< 2^110), goes to float64 in one step (two conversions and an
+// addition: a fixed function of an exact integer) and STD = sqrt(max(0, that / (2^32 n (n - 1)))) with the tail of
+// std_from_sums.  No c, no tile, no block view enters the value.
+__device__ __forceinline__ double int128_to_double(__int128 v) {
+    const bool neg = v < 0;
+    const unsigned __int128 mag = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    const double d = (double)(uint64_t)(mag >> 64) * 18446744073709551616.0 + (double)(uint64_t)mag;
+    return neg ? -d : d;
+}
+__device__ __forceinline__ float std_from_exact_sums(int64_t T, __int128 S2, int sg, int n, double inv_nn1) {
+    const __int128 A = (__int128)n * S2 - (__int128)T * T;
+    const __int128 num = (A << 32) - (((__int128)T * sg) << 17) - (__int128)sg * sg;
+    double var = int128_to_double(num) * (1.0 / 4294967296.0) * inv_nn1;
+    if (var < 0.0) var = 0.0;
+    return sqrtf((float)var);
+}
 enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4 };
+// The per-tile byte map (WaveArgs::defer).  kTileDone: finished; kTileGeneral: left to the general kernel (disc_wave_kernel);
+// kNeedsFraction: its sums of trunc(x) are done, the fraction / scaled pass finishes it.
+// kTileGeneralRows: the general kernel writes only the rows named in WaveArgs::rowmask (the scaled route left them: their
+// own windows hold more relief than its unwrapping takes; the other rows of the tile are done)
+enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2, kTileGeneralRows = 3 };
 
+// aux: kStUL the limb (0 / 1); kStU2L the limb (bits 0-1) and "the last limb: all the bits that are left" (bit 2)
 template <int WHAT>
-__device__ __forceinline__ uint32_t stage_value(float x, float c, int ci) {
-    if (WHAT == kStA) return __float_as_uint(x - c);
-    if (WHAT == kStS) return (uint32_t)(int)rintf(x * kScaledUnit);
+__device__ __forceinline__ uint32_t stage_value(float x, float c, int ci, int aux = 0) {
+    if (WHAT == kStS) return (uint32_t)(int)rintf(x * c);
     const float t = truncf(x);
+    if (WHAT == kStInd || WHAT == kStUL || WHAT == kStU2L) {
+        const bool missing = !(fabsf(t) < kMissingLim);  // (NaN: missing)
+        if (WHAT == kStInd) return (missing ? 65536u : 0u) | ((missing || fabsf(t) > 262144.0f) ? 1u : 0u);
+        const int u = missing ? 0 : (int)t - ci;  // |u| < 2^25
+        if (WHAT == kStUL) return aux == 0 ? ((uint32_t)u & 0xffffu) : (uint32_t)(u >> 16);
+        const uint64_t w = (uint64_t)((int64_t)u * (int64_t)u) >> (16 * (aux & 3));
+        return (aux & 4) ? (uint32_t)w : ((uint32_t)w & 0xffffu);
+    }
     // the fractional part in units of 2^-16 m, as an integer: |x - t| < 1, so 3409 of them stay far
     // inside int32, the sums are exact (hence the same for every row block and every kernel that
     // forms them, and a running prefix may be carried from tile to tile), and the quantisation,
     // at most 7.6e-6 m per sample, is two orders below the reference's own float32-FFT floor
     if (WHAT == kStF) return (uint32_t)(int)rintf((x - t) * 65536.0f);
-    if (WHAT == kStT2) {
-        const float u = t - c;
-        return __float_as_uint(u * u);
-    }
     const int u = (int)t - ci;
     if (WHAT == kStU) return (uint32_t)u;
     return (uint32_t)u * (uint32_t)u;
@@ -452,7 +501,7 @@ __device__ __forceinline__ void block_range(int* flag_word, int lo, int hi) {
 // range (kStS only): smallest and largest staged value of the window, padded samples (0) included.
 template <int SIZE, int TH, int NWAVES, int WHAT, typename T, bool ABS_CLASS = false>
 __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, int* flag_word, int gy0,
-                                            int gx, float c, int ci, float lim32, float limcv, int* range = nullptr) {
+                                            int gx, float c, int ci, float lim32, float limcv, int* range = nullptr, int aux = 0) {
     constexpr int NROWS = TH + SIZE - 1;
     constexpr int SL = (NROWS + NWAVES - 1) / NWAVES;
     T* Q = reinterpret_cast<T*>(lds);
@@ -464,6 +513,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     for (int k = 0; k < SL; ++k) v[k] = load_row4(p, gy0 + wave * SL + k, gx);
     int flags = 0;
     uint32_t umax = 0;  // largest |trunc(x) - c| seen, as float bits (NaN / inf sort above all)
+    uint32_t tmax = 0;  // largest |trunc(x)| (the builds with STD: a sample beyond 2^18 sends the tile to the limb path whatever c is)
     bool frac = false;
     int smin = 0x7fffffff, smax = -0x7fffffff - 1;
     Vec4<T> run{{(T)0, (T)0, (T)0, (T)0}};
@@ -484,9 +534,10 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
                     const float d = t - c;
                     frac |= ok && (x != t);
                     umax = max(umax, ok ? (__float_as_uint(ABS_CLASS ? t : d) & 0x7fffffffu) : 0u);
+                    if (!ABS_CLASS) tmax = max(tmax, ok ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
                     bits = ok ? (uint32_t)(int)d : 0u;
                 } else {
-                    bits = ok ? stage_value<WHAT>(x, c, ci) : 0u;
+                    bits = ok ? stage_value<WHAT>(x, c, ci, aux) : 0u;
                     if (WHAT == kStS && ABS_CLASS) {  // the take-all scaled build classifies the window itself
                         const float t = truncf(x);
                         frac |= ok && (x != t);
@@ -508,7 +559,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     if (kClassify) {
         if (frac) flags |= kTileFrac;
         if (!ABS_CLASS && umax > __float_as_uint(lim32)) flags |= kTileWide;
-        if (umax > __float_as_uint(ABS_CLASS ? kAbsLim : limcv)) flags |= kTileFloat;  // also NaN / inf
+        if (umax > __float_as_uint(ABS_CLASS ? kAbsLim : limcv) || tmax > __float_as_uint(kAbsLim)) flags |= kTileFloat;  // also NaN / inf
     }
     *reinterpret_cast<Vec4<T>*>(TOT + wave * ROWW + lane * NC) = run;
     // tile flags: one ballot per bit inside the wave, one LDS atomic per wave, and the barrier the
@@ -588,7 +639,7 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
         bool marked = false;
         if (take) {
             if (p.map_th == 0) {
-                marked = p.defer[mine] == 1;  // kTileGeneral (2 = waiting for tpi_fraction_march_kernel)
+                marked = (p.defer[mine] & 1) != 0;  // kTileGeneral or kTileGeneralRows (2 = waiting for tpi_fraction_march_kernel)
             } else {
                 // the map belongs to the marching kernels' geometry (same strips, rows of map_th): this
                 // tile is taken when a map tile that shares output rows with it is marked.  Rows of
@@ -616,6 +667,8 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
         const int tile = base + __builtin_ctzll(todo) * nb;
         todo &= todo - 1;
         const bool row_major = p.defer != nullptr && p.map_th != 0;
+        // the rows to write: all of them, or - a tile the scaled route left in part - the rows it names
+        const uint64_t rows_wanted = (p.defer != nullptr && p.map_th == 0 && p.defer[tile] == kTileGeneralRows) ? p.rowmask[tile] : ~0ull;
         const int ox0 = (row_major ? tile % tiles_x : tile / tiles_y) * G::TILE_W;
         const int oy0 = (p.out_row0 / TH + (row_major ? tile / tiles_x : tile % tiles_y)) * TH;  // global multiples of TH
         const int gx = ox0 - G::X0 + lane * NC;
@@ -624,14 +677,14 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
         cy = min(max(cy, p.in_row0), p.in_row0 + p.in_rows - 1);
         const int cx = min(ox0 + G::TILE_W / 2, p.nx - 1);
         float c = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
-        if (!(fabsf(c) <= (ABS_CLASS ? kAbsLim : 1.0e9f))) c = 0.0f;
+        if (!(fabsf(c) < kMissingLim)) c = 0.0f;  // (any value would do: the sums are exact integers and the results do not depend on it)
         const int ci = (int)c;
         const bool border = gy0 < 0 || gy0 + NROWS > p.gny || ox0 - G::X0 < 0 || ox0 - G::X0 + ROWW > p.nx;
 
         // per-row sums live in this block's scratch planes between the passes (registers cannot
-        // hold RW x NC x 4 values next to the chain): plane 0 Su (int32) or Sa (float bits),
-        // 1/2 Su2 low/high word or St2 (float bits in 1), 3 Sf.  Written and read by the same lane.
-        uint32_t* plane = p.scratch + (size_t)blockIdx.x * (4 * TH * ROWW) + lane * NC;
+        // hold RW x NC x 4 values next to the chain): plane 0 Su (int32), 1/2 Su2 low/high 16-bit half sums, 3 Sf; on a tile
+        // of the limb path 0/4 Su (64 bits), 1/2 Su2 (64 bits), 5 the counts of kStInd.  Written and read by the same lane.
+        uint32_t* plane = p.scratch + (size_t)blockIdx.x * (kScratchPlanes * TH * ROWW) + lane * NC;
         auto put = [&](int which, int jj, const uint32_t (&val)[NC]) {
             Vec4<uint32_t> x{{val[0], val[1], val[2], val[3]}};
             *reinterpret_cast<Vec4<uint32_t>*>(plane + (which * TH + jj) * ROWW) = x;
@@ -652,7 +705,7 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
         auto finalise_row = [&](int jj, const Vec4<uint32_t>& q0, const Vec4<uint32_t>& q1,
                                 const Vec4<uint32_t>& q2, const Vec4<uint32_t>& q3) {
             const int oy = oy0 + jj;
-            if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) return;
+            if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows || !((rows_wanted >> jj) & 1)) return;
             Vec4<float> xs{{0.f, 0.f, 0.f, 0.f}};
             if (WANT_TPI) xs = *reinterpret_cast<const Vec4<float>*>(p.in + (size_t)(oy - p.in_row0) * p.nx + ocol);
             Vec4<float> out_t, out_s;
@@ -666,14 +719,9 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                     m = d_hi >= d_lo ? (double)((int)pl[d_hi + 1] - (int)pl[d_lo]) : 0.0;
                 }
                 const double sf = (double)(int)q3.v[t] * (1.0 / 65536.0);  // exact in float64
-                double su, su2;  // sums of u and u^2 over the in-domain taps
-                if (!use_float) {
-                    su = (double)(int)q0.v[t];
-                    su2 = (double)q2.v[t] * 65536.0 + (double)q1.v[t];  // q2 = 0 unless the tile is wide
-                } else {
-                    su = (double)__uint_as_float(q0.v[t]) - sf;  // Sa = Su + Sf
-                    su2 = (double)__uint_as_float(q1.v[t]);
-                }
+                // sums of u and u^2 over the in-domain taps
+                const double su = (double)(int)q0.v[t];
+                const double su2 = (double)q2.v[t] * 65536.0 + (double)q1.v[t];  // q2 = 0 unless the tile is wide
                 const double cd = (double)c;
                 // su + c m is an exact integer (= sum of trunc(x)), so the result does not depend on
                 // which c the tile happened to use
@@ -682,7 +730,7 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                     // (per pixel, not per tile: a window of whole metres inside a tile that has fractional samples
                     // elsewhere must get the bits the ring kernel, whose flags cover a batch of rows, gives it; found
                     // by the randomised row-block check once a run's hand-over depended on the run's extent)
-                    if (!use_float && m == n && q3.v[t] == 0) {
+                    if (m == n && q3.v[t] == 0) {
                         out_s.v[t] = std_from_int_sums((int)q0.v[t], ((uint64_t)q2.v[t] << 16) + q1.v[t], (uint32_t)G::T.taps,
                                                        (float)inv_nn1);
                     } else {
@@ -699,6 +747,68 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                     }
                     out_t.v[t] = (float)((double)xs.v[t] - (s1 - x_ctr) * inv_nm1);
                 }
+            }
+            const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+            if (WANT_STD) *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+            if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+        };
+        // a row of a tile of the limb path, from the scratch planes
+        auto finalise_limb_row = [&](int jj) {
+            const int oy = oy0 + jj;
+            if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows || !((rows_wanted >> jj) & 1)) return;
+            Vec4<float> xs{{0.f, 0.f, 0.f, 0.f}};
+            if (WANT_TPI) xs = *reinterpret_cast<const Vec4<float>*>(p.in + (size_t)(oy - p.in_row0) * p.nx + ocol);
+            const Vec4<uint32_t> ul = get(0, jj), uh = get(4, jj), ind = get(5, jj);
+            Vec4<uint32_t> wl{{0u, 0u, 0u, 0u}}, wh{{0u, 0u, 0u, 0u}}, q3{{0u, 0u, 0u, 0u}};
+            if (WANT_STD) {
+                wl = get(1, jj);
+                wh = get(2, jj);
+            }
+            if (frac) q3 = get(3, jj);
+            Vec4<float> out_t, out_s;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                int mi = G::T.taps;
+                if (border) {
+                    const int d_lo = max(G::T.off_min, -(ocol + t));
+                    const int d_hi = min(G::T.off_max, p.nx - 1 - (ocol + t));
+                    const unsigned short* pl = PL + jj * (SIZE + 1) - G::T.off_min;
+                    mi = d_hi >= d_lo ? (int)pl[d_hi + 1] - (int)pl[d_lo] : 0;
+                }
+                const int64_t Su = (int64_t)(((uint64_t)uh.v[t] << 32) | ul.v[t]);
+                const uint64_t Su2 = ((uint64_t)wh.v[t] << 32) | wl.v[t];
+                const int sg = (int)q3.v[t];
+                const int64_t T = Su + (int64_t)ci * mi;  // sum of trunc(x): whatever c was
+                const __int128 S2 = (__int128)Su2 + 2 * (__int128)ci * Su + (__int128)((int64_t)ci * ci) * mi;  // sum of trunc(x)^2
+                const double sf = (double)sg * (1.0 / 65536.0);
+                const double s1 = (double)T + sf;
+                const bool missing = (ind.v[t] >> 16) != 0, ordinary = (ind.v[t] & 0xffffu) == 0;
+                float sd_v, tpi_v = 0.0f;
+                if (ordinary) {
+                    // a disc of ordinary samples: the expressions of every other kernel on the same exact sums
+                    if (mi == G::T.taps && sg == 0) {
+                        // n S2 - T^2 = n Su2 - Su^2 (std_from_int_sums), below 2^60 here
+                        const uint64_t num = (uint64_t)((__int128)G::T.taps * S2 - (__int128)T * T);
+                        const float f = fmaf((float)(uint32_t)(num >> 32), 4294967296.0f, (float)(uint32_t)num);
+                        sd_v = __builtin_amdgcn_sqrtf(f * (float)inv_nn1);
+                    } else {
+                        sd_v = std_from_sums(s1, (double)(int64_t)S2, inv_n, inv_nm1);
+                    }
+                } else {
+                    sd_v = std_from_exact_sums(T, S2, sg, G::T.taps, inv_nn1);
+                }
+                if (WANT_TPI) {
+                    const int cy2 = oy + G::T.centre, cx2 = ocol + t + G::T.centre;
+                    double x_ctr = (double)xs.v[t];
+                    if (G::T.centre != 0) {
+                        const bool in = cy2 >= 0 && cy2 < p.gny && cx2 >= 0 && cx2 < p.nx;
+                        x_ctr = in ? (double)p.in[(size_t)(cy2 - p.in_row0) * p.nx + cx2] : 0.0;
+                    }
+                    tpi_v = (float)((double)xs.v[t] - (s1 - x_ctr) * inv_nm1);
+                }
+                // a missing sample in the disc (non-finite, or beyond +-2^24): no value
+                out_s.v[t] = missing ? __uint_as_float(0x7fc00000u) : sd_v;
+                out_t.v[t] = missing ? __uint_as_float(0x7fc00000u) : tpi_v;
             }
             const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
             if (WANT_STD) *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
@@ -755,27 +865,44 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
             }
             }
         } else {
-            __syncthreads();
-            stage_prefix<SIZE, TH, NWAVES, kStA, float>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
+            // the limb path (Stage, above): counts of the samples that are not ordinary / missing, then u and u^2 limb by limb
+            auto limb_pass = [&](auto what_tag, int aux, int plo, int phi, int shift, bool is_signed, bool first) {
+                constexpr int WHAT = decltype(what_tag)::value;
+                __syncthreads();
+                stage_prefix<SIZE, TH, NWAVES, WHAT, uint32_t>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv, nullptr, aux);
 #pragma unroll 1
-            for (int k = 0; k < RW; ++k) {
-                float acc[NC];
-                wave_disc_sum<SIZE, float>(reinterpret_cast<const float*>(lds_u), wave + k * NWAVES, lane, acc);
-                const uint32_t bits[NC] = {__float_as_uint(acc[0]), __float_as_uint(acc[1]),
-                                           __float_as_uint(acc[2]), __float_as_uint(acc[3])};
-                put(0, wave + k * NWAVES, bits);
-            }
+                for (int k = 0; k < RW; ++k) {
+                    const int jj = wave + k * NWAVES;
+                    uint32_t acc[NC];  // the limb's sum over the disc: below 2^32 (as a signed number for the upper limb of u)
+                    wave_disc_sum<SIZE, uint32_t, 0, kPipe>(lds_u, jj, lane, acc);
+                    if (phi < 0) {
+                        put(plo, jj, acc);
+                        continue;
+                    }
+                    Vec4<uint32_t> lo{{0u, 0u, 0u, 0u}}, hi{{0u, 0u, 0u, 0u}};
+                    if (!first) {
+                        lo = get(plo, jj);
+                        hi = get(phi, jj);
+                    }
+                    uint32_t nlo[NC], nhi[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) {
+                        const uint64_t add = (is_signed ? (uint64_t)(int64_t)(int)acc[t] : (uint64_t)acc[t]) << shift;
+                        const uint64_t v = (((uint64_t)hi.v[t] << 32) | lo.v[t]) + add;
+                        nlo[t] = (uint32_t)v;
+                        nhi[t] = (uint32_t)(v >> 32);
+                    }
+                    put(plo, jj, nlo);
+                    put(phi, jj, nhi);
+                }
+            };
+            limb_pass(std::integral_constant<int, kStInd>{}, 0, 5, -1, 0, false, true);
+            limb_pass(std::integral_constant<int, kStUL>{}, 0, 0, 4, 0, false, true);
+            limb_pass(std::integral_constant<int, kStUL>{}, 1, 0, 4, 16, true, false);
             if (WANT_STD) {
-            __syncthreads();
-            stage_prefix<SIZE, TH, NWAVES, kStT2, float>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
-#pragma unroll 1
-            for (int k = 0; k < RW; ++k) {
-                float acc[NC];
-                wave_disc_sum<SIZE, float>(reinterpret_cast<const float*>(lds_u), wave + k * NWAVES, lane, acc);
-                const uint32_t bits[NC] = {__float_as_uint(acc[0]), __float_as_uint(acc[1]),
-                                           __float_as_uint(acc[2]), __float_as_uint(acc[3])};
-                put(1, wave + k * NWAVES, bits);
-            }
+                limb_pass(std::integral_constant<int, kStU2L>{}, 0, 1, 2, 0, false, true);
+                limb_pass(std::integral_constant<int, kStU2L>{}, 1, 1, 2, 16, false, false);
+                limb_pass(std::integral_constant<int, kStU2L>{}, 2 | 4, 1, 2, 32, false, false);
             }
         }
         if (frac) {
@@ -790,14 +917,17 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
         }
 
         // ---- finalise the leftover rows from the scratch planes ------------------------------------
-        if (!direct) {
+        if (use_float) {
+#pragma unroll 1
+            for (int k = 0; k < RW; ++k) finalise_limb_row(wave + k * NWAVES);
+        } else if (!direct) {
 #pragma unroll 1
             for (int k = 0; k < RW; ++k) {
                 const int jj = wave + k * NWAVES;
                 const Vec4<uint32_t> q0 = get(0, jj);
                 Vec4<uint32_t> q1{{0u, 0u, 0u, 0u}}, q2{{0u, 0u, 0u, 0u}}, q3{{0u, 0u, 0u, 0u}};
                 if (WANT_STD) q1 = get(1, jj);
-                if (WANT_STD && wide && !use_float) q2 = get(2, jj);
+                if (WANT_STD && wide) q2 = get(2, jj);
                 if (frac) q3 = get(3, jj);
                 finalise_row(jj, q0, q1, q2, q3);
             }
@@ -909,7 +1039,7 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
         for (int s = 0; s < NC; ++s) {
             const float x = v[k].v[s];
             if (SCALED) {
-                const uint32_t q = ok ? stage_value<kStS>(x, 0.0f, 0) : 0u;
+                const uint32_t q = ok ? stage_value<kStS>(x, p.unit, 0) : 0u;
                 if (ok || padded) {
                     smin = min(smin, (int)q);
                     smax = max(smax, (int)q);
@@ -973,7 +1103,6 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
 // left to the general kernel; its sums of trunc(x), which are exact whatever the fractional parts
 // are, go to p.sums instead of TPI, and the tile is marked kNeedsFraction for
 // tpi_fraction_march_kernel, which adds the sum of the fractional parts and finalises.
-enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2 };
 
 template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
 __device__ __forceinline__ void tpi_march_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
@@ -1017,8 +1146,11 @@ __device__ __forceinline__ void tpi_march_kernel_body(const WaveArgs& p, int til
 #endif
 #pragma unroll 1
     for (int tile = first; tile < last; ++tile) {
+        // (the scaled route decides row by row what it can take of a tile with a non-finite or absurd sample: its pass gets
+        // the tile, not the general kernel)
+        const uint8_t left_to = ALLOW_FRAC && p.scaled != 0 ? kNeedsFraction : kTileGeneral;
         if (deferred_in_a_row >= kGiveUp) {
-            if (threadIdx.x == 0) p.defer[tile] = 1;
+            if (threadIdx.x == 0) p.defer[tile] = left_to;
             continue;
         }
         const int ty = tile % tiles_y;
@@ -1047,7 +1179,7 @@ __device__ __forceinline__ void tpi_march_kernel_body(const WaveArgs& p, int til
         }
         const bool fraction = ALLOW_FRAC && !leave && frac_hist != 0;  // sums only, TPI later
         if (threadIdx.x == 0) {
-            p.defer[tile] = leave ? kTileGeneral : (fraction ? kNeedsFraction : kTileDone);
+            p.defer[tile] = leave ? left_to : (fraction ? kNeedsFraction : kTileDone);
             *flag_word = 0;  // every thread has read it; the next atomicOr is behind a barrier
         }
         if (leave) {
@@ -1159,6 +1291,7 @@ int launch_parts(K1 kernel_one, K kernel, long grid, int threads, size_t lds, Wa
         TOPO_HIP(hipGetLastError());
         return TOPO_AMD_OK;
     }
+    TOPO_REQUIRE(ps.gate.word == nullptr || (size_t)grid <= kGateSlots, "a gated launch of %ld blocks (at most %zu)", grid, kGateSlots);
     TOPO_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, c.compute, ps, tiles_x);
     TOPO_HIP(hipGetLastError());
@@ -1355,6 +1488,24 @@ int launch_fraction_march(const Block& b, float* tpi_out) {
 // launch on a DEM the library remembers as mostly fractional (dem_memo): the whole-metre launch in front of it would
 // stage every tile only to find it fractional (7.1 ms against 5 ms at 67 px on 32768^2).  A window of whole metres gets the
 // whole-metre kernel's bits here too (S = 256 sum trunc(x) exactly).
+// The unit of the scaled route: the largest power of two between 2^8 and 2^16 that keeps n x (value range of the raster) x
+// unit below 2^30 and |x| unit below 2^28 - from the raster class (common.hpp: a lattice sample of the WHOLE raster, the same
+// for every row block of it).  An ordinary DEM in metres gets 2^8 (error <= 2^-9 m per sample); a raster of small values -
+// kilometres, a normalised surface - gets finer units, so that the error stays below 4e-6 of its value range whatever the
+// range is.  (The tile-by-tile test in the kernel guards the exactness of the unwrapping; this only sets the precision.)
+inline float scaled_unit(int taps) {
+    const RasterClass c = current_class();
+    int k = 8;
+    if (c.lo <= c.hi) {
+        const double range = std::max((double)c.hi - (double)c.lo, 1e-30);
+        const double mag = std::max(std::max(std::fabs((double)c.lo), std::fabs((double)c.hi)), 1e-30);
+        const int k_range = (int)std::floor(std::log2(1073741824.0 / ((double)taps * range)));
+        const int k_mag = (int)std::floor(std::log2(268435456.0 / mag));
+        k = std::max(8, std::min(16, std::min(k_range, k_mag)));
+    }
+    return std::ldexp(1.0f, k);
+}
+
 template <int SIZE, int TH, int NWAVES, bool TAKE_ALL = false>
 __device__ __forceinline__ void tpi_scaled_march_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = Geo<SIZE>;
@@ -1391,6 +1542,8 @@ __device__ __forceinline__ void tpi_scaled_march_kernel_body(const WaveArgs& p, 
         if (!any) return;  // the same for every thread of the block
     }
 
+    const double inv_unit = 1.0 / (double)p.unit;  // a power of two
+    int* rowlo = flag_word + 4;  // the row-by-row test (below): range of every staged row, 2 x 192 words, then the answer
     bool carry = false;
     int hlo[kHist + 1], hhi[kHist + 1];  // range of the new rows of this tile ([0]) and of the tiles above it
 #pragma unroll
@@ -1423,14 +1576,14 @@ __device__ __forceinline__ void tpi_scaled_march_kernel_body(const WaveArgs& p, 
 #ifdef MARCH_STAMPS
             long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #endif
-            flags = stage_march<SIZE, TH, NWAVES, TAKE_ALL ? 3 : 2>(p, Q, flag_word, gy0, gx MARCH_STAMP_PASS, range);
+            flags = stage_march<SIZE, TH, NWAVES, 3>(p, Q, flag_word, gy0, gx MARCH_STAMP_PASS, range);
 #pragma unroll
             for (int k = kHist; k >= 1; --k) hlo[k] = hlo[k - 1], hhi[k] = hhi[k - 1];
             hlo[0] = __builtin_amdgcn_readfirstlane(range[0]);
             hhi[0] = __builtin_amdgcn_readfirstlane(range[1]);
         } else {
             __syncthreads();  // the previous tile's image is done with
-            flags = stage_prefix<SIZE, TH, NWAVES, kStS, uint32_t, TAKE_ALL>(p, lds_u, flag_word, gy0, gx, 0.0f, 0, 0.0f, 0.0f, range);
+            flags = stage_prefix<SIZE, TH, NWAVES, kStS, uint32_t, true>(p, lds_u, flag_word, gy0, gx, p.unit, 0, 0.0f, 0.0f, range);
 #pragma unroll
             for (int k = 0; k <= kHist; ++k) {  // the whole window was staged: its range stands for every tile in it
                 hlo[k] = __builtin_amdgcn_readfirstlane(range[0]);
@@ -1442,22 +1595,76 @@ __device__ __forceinline__ void tpi_scaled_march_kernel_body(const WaveArgs& p, 
         for (int k = 1; k <= kHist; ++k) wlo = min(wlo, hlo[k]), whi = max(whi, hhi[k]);
         // the unwrapping below is exact for every pixel of the tile when n x (range of the window) < 2^31
         const bool fits = (long long)G::T.taps * ((long long)whi - (long long)wlo) < (1ll << 31);
-        const bool leave = TAKE_ALL && (flags & kTileFloat) != 0;  // a non-finite or absurd sample: the general kernel
+        // a non-finite or absurd sample in the window: like a window with too much relief, it is taken row by row - the rows
+        // whose own windows are free of such samples are this kernel's (the sums are integers modulo 2^32: what a bad sample
+        // leaves in the prefix image cancels in every difference that does not span it), the others the general kernel's
+        const bool leave = (flags & kTileFloat) != 0;
         if (TAKE_ALL && (flags & kTileFrac)) ++seen_frac;
+        // The window as a whole holds too much relief (nodata next to terrain): the test is made row by row, each output
+        // row on ITS OWN window - rows oy - M ... oy + M of the strip's staged columns, which every row block that computes
+        // the row holds - so that which rows go to the exact general kernel is a function of the data and the global
+        // grid, not of the rows a block happens to have in view (when the whole window passes, every row's does).
+        uint64_t rows_out = 0;
+        if (!fits || leave) {
+            for (int r = wave; r < NROWS; r += NWAVES) {
+                const bool ok = row4_inside(p, gy0 + r, gx);
+                const Vec4<float> v = load_row4(p, gy0 + r, gx);
+                int lo = 0x7fffffff, hi = -0x7fffffff - 1;
+#pragma unroll
+                for (int s2 = 0; s2 < NC; ++s2) {
+                    const int q = (int)stage_value<kStS>(v.v[s2], p.unit, 0);
+                    // (a sample the integer chain cannot take - non-finite, beyond 2^18 - counts as the widest range)
+                    const bool bad = !(fabsf(truncf(v.v[s2])) <= kAbsLim);
+                    lo = ok ? (bad ? -0x7fffffff - 1 : min(lo, q)) : lo;
+                    hi = ok ? (bad ? 0x7fffffff : max(hi, q)) : hi;
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    lo = min(lo, __shfl_xor(lo, m));
+                    hi = max(hi, __shfl_xor(hi, m));
+                }
+                if (lane == 0) {
+                    rowlo[r] = lo;
+                    rowlo[192 + r] = hi;
+                }
+            }
+            __syncthreads();
+            static_assert(TH <= 64 && NROWS <= 192, "one ballot holds the tile's rows");
+            if (wave == 0) {
+                bool fail = false;
+                if (lane < TH) {
+                    int lo = 0x7fffffff, hi = -0x7fffffff - 1;
+                    for (int k = 0; k < SIZE; ++k) {
+                        lo = min(lo, rowlo[lane + k]);
+                        hi = max(hi, rowlo[192 + lane + k]);
+                    }
+                    fail = lo <= hi && (long long)G::T.taps * ((long long)hi - (long long)lo) >= (1ll << 31);
+                }
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(fail);
+                if (lane == 0) {
+                    rowlo[384] = (int)(uint32_t)m;
+                    rowlo[385] = (int)(uint32_t)(m >> 32);
+                }
+            }
+            __syncthreads();
+            rows_out = ((uint64_t)(uint32_t)rowlo[385] << 32) | (uint32_t)rowlo[384];
+            rows_out = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rows_out >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)rows_out);
+        }
         if (threadIdx.x == 0) {
-            p.defer[tile] = fits && !leave ? kTileDone : kTileGeneral;
+            p.defer[tile] = rows_out != 0 ? kTileGeneralRows : kTileDone;
+            if (rows_out != 0) p.rowmask[tile] = rows_out;
             flag_word[0] = 0;
             flag_word[2] = 0x7fffffff;  // (every thread has read flags and range; the next atomics are behind a barrier)
             flag_word[3] = -0x7fffffff - 1;
         }
         carry = !leave;  // (a window with such a sample is not carried on: the next tile is staged and classified in full)
-        if (!fits || leave) continue;  // the general kernel takes the tile (exact)
 
 #pragma unroll 1
         for (int k = 0; k < RW; ++k) {
             const int jj = wave + k * NWAVES;
             const int oy = oy0 + jj;
-            if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
+            if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows || ((rows_out >> jj) & 1)) continue;
             const int ocol = ox0 + lane * NC;
             const bool live = lane < G::NVL && ocol < p.nx;
             const size_t xi = live ? (size_t)(oy - p.in_row0) * p.nx + ocol : 0;
@@ -1474,7 +1681,7 @@ __device__ __forceinline__ void tpi_scaled_march_kernel_body(const WaveArgs& p, 
             for (int t = 0; t < NC; ++t) {
                 const uint32_t qc = hi.v[t] - lo.v[t];
                 const int off = (int)(acc[t] - (uint32_t)G::T.taps * qc);  // S - n q_ctr, exact (see above)
-                const double s1 = ((double)G::T.taps * (double)(int)qc + (double)off) * (1.0 / (double)kScaledUnit);
+                const double s1 = ((double)G::T.taps * (double)(int)qc + (double)off) * inv_unit;
                 const double x = (double)xs.v[t];
                 out_t.v[t] = (float)(x - (s1 - x) * inv_nm1);
             }
@@ -1503,8 +1710,9 @@ int launch_scaled_march(const Block& b, float* tpi_out) {
     WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
                nullptr, nullptr, nullptr, 0, 0};
     a.scaled = 1;
+    a.unit = scaled_unit(G::T.taps);
     a.report = TAKE_ALL ? dem_memo_report(b) : nullptr;
-    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16;
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16 + 388 * sizeof(int);
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
@@ -1851,7 +2059,7 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferr
     // persistent blocks fill the chip (whole XCD rounds: the tile list is cut into XCD-contiguous runs)
     const long grid = march_grid(c, blocks_per_cu, ntiles);
     void* scratch = nullptr;
-    TOPO_TRY(workspace(2, (size_t)grid * 4 * TH * ROWW * sizeof(uint32_t), &scratch));
+    TOPO_TRY(workspace(2, (size_t)grid * kScratchPlanes * TH * ROWW * sizeof(uint32_t), &scratch));
     for (int k = 0; k < kMaxParts; ++k) ps.a[k].scratch = (uint32_t*)scratch;
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);  // (this kernel deals its tiles round-robin: only the shifts matter)
     return launch_parts(disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, disc_wave_kernel_parts<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, grid, NWAVES * 64, lds, ps, tiles_x);

@@ -3103,11 +3103,16 @@ int gaussian_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
 
 int mfma_min_radius(bool for_gradient) { return mfma_min_radius_impl(for_gradient); }
 
-// (for the call: the matrix-core routes are closed to a block whose samples are mostly beyond their range)
+// (for the call: the matrix-core routes are closed to a raster whose samples are mostly beyond their range - a property of
+// the WHOLE raster, common.hpp RasterClass, so that every row block of it takes the same kernels)
 struct NoMfmaScope {
     bool before;
-    explicit NoMfmaScope(const Block& b) : before(t_no_mfma) {
-        if (!t_no_mfma && f16_route()) t_no_mfma = dem_memo_mostly_large(b);
+    explicit NoMfmaScope(const Block&) : before(t_no_mfma) {
+        static const bool on = [] {  // TOPO_AMD_GAUSS_LARGE_SAMPLE=0: never (A/B: tools/large_raster_time.py)
+            const char* e = std::getenv("TOPO_AMD_GAUSS_LARGE_SAMPLE");
+            return !(e && *e == '0');
+        }();
+        if (on && !t_no_mfma && f16_route()) t_no_mfma = current_class().large;
     }
     ~NoMfmaScope() { t_no_mfma = before; }
 };

@@ -59,6 +59,37 @@ def sync():
     _lib.check(_lib.lib().topo_amd_sync(), "topo_amd_sync")
 
 
+class RasterScan:
+    """The class of a raster that is held as several row blocks (include/topo_amd.h, "what kernel routing may know about
+    a raster"): ``add`` the rows each block owns, then ``declare`` - the calling thread's partial row blocks then take the
+    kernels the whole raster takes.  (A block that is the whole raster needs none of this.)"""
+
+    def __init__(self):
+        self.counts = (C.c_uint64 * 2)(0, 0)
+        self.range = (C.c_float * 2)(np.inf, -np.inf)
+
+    def add(self, block, own_row0=None, own_rows=None):
+        """``block``: a :class:`Block`; the rows it OWNS default to all of its rows (give them when blocks overlap)."""
+        o0 = block.row0 if own_row0 is None else own_row0
+        on = block.rows if own_rows is None else own_rows
+        _lib.check(_lib.lib().topo_amd_raster_scan_dev(*block._head(), int(o0), int(on), self.counts, self.range),
+                   "raster_scan_dev")
+        return self
+
+    def declare(self):
+        _lib.check(_lib.lib().topo_amd_raster_class_from_scan(self.counts, self.range), "raster_class_from_scan")
+
+
+def forget_raster_class():
+    """Withdraw what :meth:`RasterScan.declare` (or ``ShardedDEM``) declared: partial row blocks are ordinary DEMs again."""
+    _lib.check(_lib.load().topo_amd_raster_class_set(-1, 0.0, 0.0), "raster_class_set")
+
+
+def dem_changed(array):
+    """Tell the library that ``array`` (a :class:`DeviceArray`) was written by something other than the library."""
+    _lib.check(_lib.lib().topo_amd_dem_changed(array.ptr, array.nbytes), "dem_changed")
+
+
 def timer_start():
     _lib.check(_lib.lib().topo_amd_timer_start(), "timer_start")
 
