@@ -346,13 +346,13 @@ def test_gate_modes_give_the_single_block_bits(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     results = {}
     for name, env in (("three_launches", {"TOPO_AMD_SHARD_FUSED": "0"}), ("careful", {"TOPO_AMD_GATE_MODE": "careful"}),
-                      ("lean", {"TOPO_AMD_GATE_MODE": "lean"}), ("auto", {})):
+                      ("lean", {"TOPO_AMD_GATE_MODE": "lean"}), ("auto", {"TOPO_AMD_GATE_MODE": "auto"}), ("default", {})):
         out = subprocess.run([sys.executable, "-c", _GATE_CHILD % root], cwd=root, env=dict(os.environ, **env),
                              capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, (name, out.stderr[-3000:])
         results[name] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     base = results["three_launches"]["crc"]
-    for name in ("careful", "lean", "auto"):
+    for name in ("careful", "lean", "auto", "default"):
         assert results[name]["crc"] == base, name
     assert results["lean"]["gave_up"] == 0  # (lean blocks wait; a wait that runs out is an error, not a statistic)
     # and against the single block, in this process

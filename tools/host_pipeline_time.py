@@ -62,8 +62,8 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "child":
         child(n)
         return
-    for env in ({"TOPO_AMD_HOST_PIPELINE": "0"}, {}, {"TOPO_AMD_HOST_CHUNK_MB": "32"}, {"TOPO_AMD_HOST_CHUNK_MB": "128"},
-                {"TOPO_AMD_HOST_CHUNK_MB": "256"}):
+    for env in ({"TOPO_AMD_HOST_PIPELINE": "0"}, {}, {"TOPO_AMD_HOST_PIPELINE": "thread"}, {"TOPO_AMD_HOST_PIPELINE": "inline"},
+                {"TOPO_AMD_HOST_CHUNK_MB": "128"}):
         print(env or "default (64 MB chunks)", flush=True)
         e = dict(os.environ)
         e.update(env)

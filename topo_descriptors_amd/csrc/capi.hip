@@ -589,6 +589,26 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
     }
     hipEvent_t* up_done = c.pipe_events.data();
     hipEvent_t* computed = c.pipe_events.data() + nchunks;
+    // Page-locked arrays (topo_amd_host_alloc, hipHostRegister): every copy is asynchronous, and the calling thread issues the
+    // downloads itself, behind each chunk's kernels.  Pageable arrays: copies block their caller, so the downloads go to a
+    // second thread (tools/ubench/pipe_paths.hip: 23.4 / 23.9 ms for 2 x 1 GiB against 38 - 39 ms one after the other).
+    // TOPO_AMD_HOST_PIPELINE=thread / inline forces one or the other.
+    static const int forced_mode = [] {
+        const char* e = std::getenv("TOPO_AMD_HOST_PIPELINE");
+        return e && *e == 't' ? 1 : (e && *e == 'i' ? 2 : 0);
+    }();
+    auto page_locked = [](const void* p) {
+        if (!p) return true;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return attr.type == hipMemoryTypeHost;
+    };
+    bool all_locked = !upload || page_locked(dem);
+    for (const HostPlane& o : outs) all_locked = all_locked && page_locked(o.host);
+    const bool inline_downloads = forced_mode == 2 || (forced_mode == 0 && all_locked);
     std::mutex mu;
     std::condition_variable cv;
     int ready_chunks = 0;  // chunks whose kernels are enqueued and whose event is recorded
@@ -596,7 +616,9 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
     int down_rc = TOPO_AMD_OK;
     std::string down_error;
     const int device = c.device;
+    if (inline_downloads) run.ready();
     std::thread downloader([&] {
+        if (inline_downloads) return;
         (void)hipSetDevice(device);
         run.ready();  // the result arrays have their pages
         for (int j = 0; j < nchunks; ++j) {
@@ -660,6 +682,18 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
                 fail(TOPO_AMD_EHIP);
                 break;
             }
+            if (inline_downloads) {
+                hipError_t e = hipStreamWaitEvent(c.down, computed[next], 0);
+                for (size_t q = 0; q < outs.size() && e == hipSuccess; ++q)
+                    if (outs[q].host)
+                        e = hipMemcpyAsync(outs[q].host + (size_t)r0 * nx, outs[q].dev + (size_t)r0 * nx, (size_t)(r1 - r0) * row_bytes,
+                                           hipMemcpyDeviceToHost, c.down);
+                if (e != hipSuccess) {
+                    set_error("download of a row chunk failed: %s", hipGetErrorString(e));
+                    fail(TOPO_AMD_EHIP);
+                    break;
+                }
+            }
             {
                 std::lock_guard<std::mutex> lock(mu);
                 ready_chunks = ++next;
@@ -669,6 +703,10 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
     }
     cv.notify_all();
     downloader.join();
+    if (inline_downloads && hipStreamSynchronize(c.down) != hipSuccess && rc == TOPO_AMD_OK) {
+        set_error("hipStreamSynchronize(download stream) failed");
+        rc = TOPO_AMD_EHIP;
+    }
     (void)hipStreamSynchronize(c.compute);
     if (upload) (void)hipStreamSynchronize(c.up);
     if (rc != TOPO_AMD_OK) return rc;
@@ -732,9 +770,7 @@ int topo_amd_init(int device) {
         // and leave the exchange for the end of the launch: Sx, kernel trace in profiles/r04_shard_fused.txt)
         int least = 0, greatest = 0;
         TOPO_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const char* e = std::getenv("TOPO_AMD_COMM_PRIORITY");
-        if (e && *e == '0') TOPO_HIP(hipStreamCreateWithFlags(&c.comm, hipStreamNonBlocking));
-        else TOPO_HIP(hipStreamCreateWithPriority(&c.comm, hipStreamNonBlocking, greatest));
+        TOPO_HIP(hipStreamCreateWithPriority(&c.comm, hipStreamNonBlocking, greatest));
     }
     TOPO_HIP(hipEventCreateWithFlags(&c.halo_done, hipEventDisableTiming));
     TOPO_HIP(hipEventCreateWithFlags(&c.input_ready, hipEventDisableTiming));
@@ -1146,10 +1182,7 @@ int topo_amd_tpi_multi_dev(const float* in, int in_rows, int in_row0, int gny, i
     for (int k = 0; k < n_sizes; ++k) order[k] = k;
     std::sort(order.begin(), order.end(), [&](int x, int y) { return sizes[x] < sizes[y]; });
     std::vector<char> done(n_sizes, 0);
-    static const bool pairs_on = [] {
-        const char* e = std::getenv("TOPO_AMD_TPI_PAIRS");  // 0 switches the two-disc kernel off (A/B runs)
-        return !(e && e[0] == '0');
-    }();
+    constexpr bool pairs_on = true;
     for (int i = 0; i + 1 < n_sizes && pairs_on; ++i) {
         const int a = order[i], c = order[i + 1];
         if (done[a] || done[c] || !tpi_pair_covers(sizes[a], sizes[c])) continue;
@@ -1555,12 +1588,9 @@ __global__ void stamp_kernel(uint32_t* word, uint32_t value) {
     __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // writes the current epoch into the gate word, in stream order on the communication stream: a stream memory
-// operation where the runtime has one (no kernel, no CU), a one-thread kernel otherwise (TOPO_AMD_GATE_STAMP=kernel)
+// operation where the runtime has one (no kernel, no CU), a one-thread kernel otherwise
 int stamp_gate(Context& c) {
-    static int mode = [] {
-        const char* e = std::getenv("TOPO_AMD_GATE_STAMP");
-        return e && e[0] == 'k' ? 1 : 0;
-    }();
+    static int mode = 0;
     if (mode == 0) {
         if (hipStreamWriteValue32(c.comm, c.gate_word, c.gate_epoch, 0) == hipSuccess) return TOPO_AMD_OK;
         (void)hipGetLastError();
@@ -1812,8 +1842,6 @@ void gate_probe_poll() {
     g_giveups_probed = now;
     g_probe_calls = 0;
     if (c.gate_clean_calls >= 3) c.gate_mode = 1;
-    if (std::getenv("TOPO_AMD_DEBUG_GATE"))
-        std::fprintf(stderr, "gate probe: give-ups so far %u, clean careful calls %d -> mode %d\n", now, c.gate_clean_calls, c.gate_mode);
 }
 // The gate of the exchange just started, careful or lean (Context::gate_mode; TOPO_AMD_GATE_MODE=careful / lean pins it).
 Gate make_gate(bool* lean) {

@@ -434,12 +434,9 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
     }
     // sizes the wave-shift kernels do not cover (even, 1, 2, beyond 101): the prefix-plane path from
     // this size on, the LDS-gather kernel below it
-    static const int big_from = [] {
-        const char* e = std::getenv("TOPO_AMD_DISC_BIG_MIN_SIZE");
-        // measured at 8192^2 (tools/generic_vs_big.py): size 66 TPI 2.24 ms (gather) / 2.05 ms (planes), STD
-        // 4.23 / 4.44; size 84 4.79 / 2.40 and 9.51 / 5.41
-        return e && *e ? std::atoi(e) : 70;
-    }();
+    constexpr int big_from = 70;
+    // measured at 8192^2 (tools/generic_vs_big.py): size 66 TPI 2.24 ms (gather) / 2.05 ms (planes), STD
+    // 4.23 / 4.44; size 84 4.79 / 2.40 and 9.51 / 5.41
     if (disc.size >= big_from) return launch_disc_big(b, disc, tpi_out, std_out);
     const int n_rows = disc.dj_max - disc.dj_min + 1;
     const int halo_cols = disc.di_max - disc.di_min;

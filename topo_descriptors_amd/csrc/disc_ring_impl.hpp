@@ -709,55 +709,20 @@ constexpr bool std_ring_both_fits(int size) {
 // marked for the general kernel.  One read of the DEM instead of the general kernel's three staging passes:
 // 32768^2 with fractional elevations, STD 7 px 6.97 -> 4.10 ms, 17 px 8.34 -> 5.18, 31 px 10.88 -> 7.99, 41 px
 // 12.56 -> 10.81 (profiles/r03_std_ring_both.txt).
-enum StdRingMode { kStdMain = 0, kStdBoth = 2 };
-
-// One row of a tile at the DEM's border (std_ring_kernel): m = the taps of the pixel's disc inside the DEM (the rows of every
-// column run that are, over the columns that are), then the general kernel's expressions on the same exact sums - the
-// float64 form where m < n, the integer form where the disc is whole - hence its bits.  The samples outside the DEM were
-// staged as u = 0, so sum trunc(x) = Su + c m and sum trunc(x)^2 = Su2 + 2 c Su + c^2 m.
-template <int SIZE, bool WANT_TPI>
-__device__ __attribute__((noinline)) void std_ring_border_row(int gny, int nx, int oy, int ocol, int ci, u32x4 su, u32x4 su2, u32x4 ctr,
-                                                              float* sd_out, float* tpi_out) {
-    using G = RGeo<SIZE, 4>;
-    const double n = (double)G::T.taps;
-    const double inv_n = 1.0 / n, inv_nm1 = 1.0 / (n - 1.0), inv_nn1 = 1.0 / (n * (n - 1.0));
-    int mt[4] = {0, 0, 0, 0};
-#pragma unroll 1
-    for (int k = 0; k < SIZE; ++k) {
-        const int rin = max(min(oy + G::T.hi[k], gny - 1) - max(oy + G::T.lo[k], 0) + 1, 0);  // wave-uniform
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int col = ocol + t + k - G::M;
-            mt[t] += (col >= 0 && col < nx) ? rin : 0;
-        }
-    }
-    Vec4<float> out_s, out_t;
-    const double cd = (double)ci;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const double m = (double)mt[t];
-        const double dsu = (double)(int)su[t], dsu2 = (double)su2[t];
-        const double s1 = dsu + cd * m;  // sum of trunc(x) over the taps inside the DEM: exact
-        if (mt[t] == G::T.taps) {
-            out_s.v[t] = std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1);
-        } else {
-            const double s2 = dsu2 + 2.0 * cd * dsu + cd * cd * m;
-            out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
-        }
-        if (WANT_TPI) {
-            const double xd = (double)((int)ctr[t] + ci);
-            out_t.v[t] = (float)(xd - (s1 - xd) * inv_nm1);
-        }
-    }
-    *reinterpret_cast<Vec4<float>*>(sd_out) = out_s;
-    if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(tpi_out) = out_t;
-}
+// kStdBorder (round 5): the tiles at the DEM's border, which kStdMain leaves out (their discs reach outside the DEM: the
+// in-domain tap count m enters the finalisation).  They were the general kernel's - a trailing launch over 3 % of the pixels
+// at an eighth of this kernel's rate on an under-filled grid, 20 % of an 8192^2 step at 7 px - and are now a second launch of
+// THIS kernel over the list of those tiles (built by the host: global geometry), with the finalisation for m < n.  A launch of
+// its own, not a branch in kStdMain: kStdMain sits at the register limit, and everything added to its phase loop showed up
+// as spills in the chains.
+enum StdRingMode { kStdMain = 0, kStdBorder = 1, kStdBoth = 2 };
 
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
 __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = RGeo<SIZE, 4>;
     using C = StdRingCfg<SIZE>;
     constexpr bool BOTH = MODE == kStdBoth;
+    constexpr bool BORDER = MODE == kStdBorder;
     constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW, HIST = C::HIST;
     constexpr int PITCH = (BOTH ? 3 : 2) * G::W;  // dwords per ring row: the u image, the u^2 image (and the image of the fractional parts)
     constexpr int DL = G::DL;
@@ -803,10 +768,18 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
     int seen_general = 0;
 
 #pragma unroll 1
-    for (int tile0 = first; tile0 < last;) {
+    for (int pos = first; pos < last;) {
+        // a run: consecutive tiles of one strip (kStdBorder: consecutive entries of the list that are)
+        int tile0 = pos, run_tiles;
+        if (BORDER) {
+            tile0 = p.border_list[pos];
+            run_tiles = 1;
+            while (pos + run_tiles < last && p.border_list[pos + run_tiles] == tile0 + run_tiles && (tile0 + run_tiles) % tiles_y != 0) ++run_tiles;
+        } else {
+            run_tiles = min(last - tile0, tiles_y - tile0 % tiles_y);
+        }
         const int ty0 = tile0 % tiles_y;
         const int strip = tile0 / tiles_y;
-        const int run_tiles = min(last - tile0, tiles_y - ty0);
         const int nphase = run_tiles * PPT;
         const int ox0 = strip * G::TILE_W;
         const int oyS = (p.out_row0 / C::TH + ty0) * C::TH;
@@ -839,7 +812,7 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                 any = any || __builtin_amdgcn_ballot_w64(mine < tile0 + run_tiles && candidate(mine < tile0 + run_tiles ? mine : tile0)) != 0;
             }
             if (!any) {
-                tile0 += run_tiles;
+                pos += run_tiles;
                 continue;
             }
         } else {
@@ -859,7 +832,7 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
             }
             if (odd == 4) {
                 for (int t = tile0 + (int)threadIdx.x; t < tile0 + run_tiles; t += NW * 64) p.defer[t] = kTileGeneral;
-                tile0 += run_tiles;
+                pos += run_tiles;
                 continue;
             }
         }
@@ -975,7 +948,6 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
         const bool cols_inside = ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= p.nx - 1;
         int s0 = C::PAD - 1 + wave;
         int tmode = kTileDone;  // what the map says about the current tile
-        bool btile = false;     // the current tile has pixels whose discs leave the DEM (their taps outside it read 0)
 #pragma unroll 1
         for (int ph = 0; ph < nphase; ++ph) {
             const int tile = tile0 + ph / PPT;
@@ -988,18 +960,26 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                 if (wlo <= whi && abs(mid - ci) > lim32 / 4) {
                     const uint32_t delta = (uint32_t)(mid - ci);
                     const uint32_t d2 = delta * delta;
+                    // k: how many of a column's rows up to this one hold a SAMPLE (any constant added to it cancels in the
+                    // differences the chains take).  A row or column outside the DEM (or the block's view) was staged as u = 0
+                    // and stays so - it stands for "no tap", not for a sample at the old offset - so it must not move with c
+                    // (round 5: the tiles at the DEM's border are computed here now).
+                    const int n_old = C::PRO + ph * B - R;  // stream row of the oldest row in the ring
                     for (int idx = threadIdx.x; idx < R * G::W; idx += NW * 64) {
                         const int sl = idx / G::W, col = idx - sl * G::W;
-                        int k = sl - wslot;  // rows since the oldest one in the ring (any offset would do)
-                        k = k < 0 ? k + R : k;
+                        int since = sl - wslot;  // rows since the oldest one in the ring
+                        since = since < 0 ? since + R : since;
+                        const int gcol_r = gx0 + col;
+                        const int k = (gcol_r >= 0 && gcol_r < p.nx) ? min(max(gy0 + n_old + since + 1, rmin), rmax) : 0;
                         uint32_t* q = Q + sl * PITCH + col;
                         const uint32_t q1 = q[0];
                         q[G::W] = q[G::W] - 2u * delta * q1 + d2 * (uint32_t)k;
                         q[0] = q1 - delta * (uint32_t)k;  // (the fractional parts do not depend on c)
                     }
                     if (stager) {
-                        run_u2 = run_u2 - 2u * delta * run_u + d2 * (uint32_t)(R - 1);
-                        run_u = run_u - delta * (uint32_t)(R - 1);
+                        const int k = col_ok ? min(max(gy0 + n_old + R, rmin), rmax) : 0;  // through the newest row
+                        run_u2 = run_u2 - 2u * delta * run_u + d2 * (uint32_t)k;
+                        run_u = run_u - delta * (uint32_t)k;
                     }
                     ci = mid;
                     __syncthreads();
@@ -1007,15 +987,16 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                 if (BOTH) {
                     tmode = candidate(tile) ? kNeedsFraction : kTileDone;  // (kTileDone here: not this pass's)
                 } else {
-                    // (round 5: the tiles at the DEM's border are this kernel's too - they were the general kernel's, a
-                    // trailing launch over 3 % of the pixels at an eighth of this kernel's rate on an under-filled grid: 20 %
-                    // of an 8192^2 step at 7 px.  The samples outside the DEM are staged as u = 0, and a pixel's in-domain
-                    // tap count m - plain geometry - puts the offset back: sum trunc(x) = Su + c m, see the finalisation.)
                     const int oy0 = oyS + (ph / PPT) * C::TH;
                     const bool rows_inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1;
-                    btile = !rows_inside || !cols_inside;
-                    tmode = kTileDone;
-                    if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
+                    if (BORDER) {
+                        // (a tile the main launch has not left for this one - it found it fractional, or too wide - stays as it is)
+                        tmode = p.defer[tile] == kTileBorder ? kTileDone : kTileGeneral;
+                        if (threadIdx.x == 0 && tmode == kTileDone) p.defer[tile] = (uint8_t)kTileDone;
+                    } else {
+                        tmode = !rows_inside || !cols_inside ? (p.border_later ? kTileBorder : kTileGeneral) : kTileDone;
+                        if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
+                    }
                 }
             }
             // the windows of this phase hold only finite samples within lim32 of c (kStdMain: and whole ones)?
@@ -1062,12 +1043,48 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                         *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
                         if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
                     }
-                } else if (btile && lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
-                    // (a call, not inlined: what this rare row needs in registers must not weigh on the chains above)
-                    std_ring_border_row<SIZE, WANT_TPI>(p.gny, p.nx, oy, ocol, ci, u32x4{su[0], su[1], su[2], su[3]},
-                                                        u32x4{su2[0], su2[1], su2[2], su2[3]}, u32x4{ctr[0], ctr[1], ctr[2], ctr[3]},
-                                                        p.sd + (size_t)(oy - p.out_row0) * p.nx + ocol,
-                                                        WANT_TPI ? p.tpi + (size_t)(oy - p.out_row0) * p.nx + ocol : nullptr);
+                } else if (BORDER) {
+                    // The samples outside the DEM were staged as u = 0, so with m = the taps of the pixel's disc inside it,
+                    // sum trunc(x) = Su + c m and sum trunc(x)^2 = Su2 + 2 c Su + c^2 m: 64-bit integers, then the float tail
+                    // of every kernel (std_from_border_sums).  m: one count for the row where only the top / bottom edge cuts
+                    // the discs (scalar), a difference of the table of column heights where only the left / right edge does,
+                    // the loop over the columns in the four corners.
+                    const bool rows_cut = oy - G::M < 0 || oy + G::M > p.gny - 1;
+                    int m_rows = G::T.taps;
+                    if (rows_cut) {
+                        m_rows = 0;
+#pragma unroll 1
+                        for (int k = 0; k < SIZE; ++k) m_rows += max(min(oy + G::T.hi[k], p.gny - 1) - max(oy + G::T.lo[k], 0) + 1, 0);
+                    }
+                    if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
+                        const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+                        Vec4<float> out_s, out_t;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int ox = ocol + t;
+                            const int k0 = max(0, G::M - ox), k1 = min(SIZE - 1, p.nx - 1 - ox + G::M);  // column offsets inside the DEM
+                            int m = m_rows;
+                            if (k0 != 0 || k1 != SIZE - 1) {
+                                if (!rows_cut) {
+                                    m = k1 >= k0 ? G::T.colpre[k1 + 1] - G::T.colpre[k0] : 0;
+                                } else {
+                                    m = 0;
+#pragma unroll 1
+                                    for (int k = k0; k <= k1; ++k) m += max(min(oy + G::T.hi[k], p.gny - 1) - max(oy + G::T.lo[k], 0) + 1, 0);
+                                }
+                            }
+                            out_s.v[t] = m == G::T.taps ? std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1)
+                                                        : std_from_border_sums((int64_t)(int)su[t], (uint64_t)su2[t], ci, m, (uint32_t)G::T.taps,
+                                                                               (float)inv_nn1);
+                            if (WANT_TPI) {
+                                const int xi = (int)ctr[t] + ci;
+                                // sum of trunc(x) over the taps inside the DEM = su + c m: exact, fits int32
+                                out_t.v[t] = (float)((double)xi - (double)((int)su[t] + ci * m - xi) * inv_nm1);
+                            }
+                        }
+                        *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+                        if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+                    }
                 } else if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
                     const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
                     Vec4<float> out_s, out_t;
@@ -1096,11 +1113,11 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
             __syncthreads();
             fold((ph + 1) & 1);
         }
-        tile0 += run_tiles;
+        pos += run_tiles;
     }
     // what this block's run looked like, for the next call on this DEM (dem_memo, common.hpp): tiles, and tiles it left to
     // the general kernel (fractional elevations, mostly)
-    if (!BOTH && p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
+    if (!BOTH && !BORDER && p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
         __hip_atomic_store(p.report + 1, (uint32_t)seen_general, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(p.report, (uint32_t)(last > first ? last - first : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1137,19 +1154,57 @@ int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
     int tiles_x = 0;
     long ntiles = 0;
     a.report = MODE == kStdMain ? dem_memo_report(b) : nullptr;
+    a.border_later = MODE == kStdMain && c.seams.n == 0 ? 1 : 0;  // (an ordinary call: launch_std_ring_border follows)
     TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
-    void* defer = ps.a[0].defer;
     TOPO_TRY(launch_parts(std_ring_kernel<SIZE, WANT_TPI, MODE>, std_ring_kernel_parts<SIZE, WANT_TPI, MODE>, grid, C::NW * 64, kLds, ps, tiles_x));
-    if (std::getenv("TOPO_AMD_DEBUG_MAP")) {  // diagnostic: how many tiles were left to the general kernel
-        std::vector<uint8_t> h((size_t)ntiles);
-        TOPO_HIP(hipMemcpyAsync(h.data(), defer, (size_t)ntiles, hipMemcpyDeviceToHost, c.compute));
-        TOPO_HIP(hipStreamSynchronize(c.compute));
-        long cnt[4] = {0, 0, 0, 0};
-        for (uint8_t v : h) ++cnt[v & 3];
-        std::fprintf(stderr, "std_ring<%d>: %ld tiles: done %ld, general %ld, other %ld\n", SIZE, ntiles, cnt[0], cnt[1], cnt[2] + cnt[3]);
+    return TOPO_AMD_OK;
+}
+
+// The tiles at the DEM's border of an ordinary (not sharded) call: std_ring_kernel<kStdBorder> over the list of them.
+template <int SIZE, bool WANT_TPI>
+int launch_std_ring_border(const Block& b, float* tpi_out, float* std_out) {
+    using G = RGeo<SIZE, 4>;
+    using C = StdRingCfg<SIZE>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0, 0};
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_kernel<SIZE, WANT_TPI, kStdBorder>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)C::LDS));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_kernel<SIZE, WANT_TPI, kStdBorder>, C::NW * 64,
+                                                              C::LDS));
+        blocks_per_cu = nblk < 1 ? 1 : (nblk > 2 ? 2 : nblk);
     }
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));  // (the main launch's slices of the tile map)
+    const int tiles_y = ps.tiles_y[0];
+    // the kernel's own test (std_ring_kernel_body), on the global grid
+    std::vector<int32_t> list;
+    for (int strip = 0; strip < tiles_x; ++strip) {
+        const int ox0 = strip * G::TILE_W;
+        const bool cols_inside = ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= b.nx - 1;
+        for (int ty = 0; ty < tiles_y; ++ty) {
+            const int oy0 = (b.out_row0 / C::TH + ty) * C::TH;
+            const bool rows_inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= b.gny - 1;
+            if (!rows_inside || !cols_inside) list.push_back(strip * tiles_y + ty);
+        }
+    }
+    if (list.empty()) return TOPO_AMD_OK;
+    void* d_list = nullptr;
+    TOPO_TRY(upload_table(0, list.data(), list.size() * sizeof(int32_t), &d_list));
+    ps.a[0].border_list = (const int32_t*)d_list;
+    const long n = (long)list.size();
+    const long grid = march_grid(c, blocks_per_cu, n);
+    const PartRun deal{0, (int)(n / grid), 0, (int)(n % grid), 1};
+    hipLaunchKernelGGL((std_ring_kernel<SIZE, WANT_TPI, kStdBorder>), dim3((unsigned)grid), dim3(C::NW * 64), C::LDS, c.compute, ps.a[0], tiles_x,
+                       tiles_y, deal);
+    TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
 

@@ -20,6 +20,7 @@ struct DiscTable {
     int num_runs = 0;
     int run_lo[SIZE] = {};         // the distinct pairs
     int run_hi[SIZE] = {};
+    int colpre[SIZE + 1] = {};     // taps in the columns before offset index k (colpre[SIZE] = taps)
 };
 
 template <int SIZE>
@@ -56,6 +57,7 @@ constexpr DiscTable<SIZE> make_disc_table() {
         }
         t.run_of[i] = found;
     }
+    for (int i = 0; i < SIZE; ++i) t.colpre[i + 1] = t.colpre[i] + (t.hi[i] - t.lo[i] + 1);
     return t;
 }
 

@@ -63,6 +63,8 @@ struct WaveArgs {
     uint32_t* report;   // pinned host words {tiles, tiles with fractional samples} of ONE block's run (dem_memo), or nullptr
     float unit;         // the scaled route: samples are summed as rint(unit x), unit = 2^8 ... 2^16 (scaled_unit)
     uint64_t* rowmask;  // per tile of state kTileGeneralRows: the rows (bit = row of the tile) the general kernel is to write
+    const int32_t* border_list;  // std_ring_kernel<kStdBorder>: the tiles at the DEM's border (indices of the main launch's tile list)
+    int border_later;            // std_ring_kernel<kStdMain>: 1 = leave those tiles to that launch (kTileBorder), 0 = to the general kernel
 };
 
 // One launch, several row blocks ("parts").  An ordinary call has one part.  A sharded call (capi.hip, run_fused)
@@ -121,6 +123,27 @@ struct WaveParts {
     }                                                                                                   \
     _Pragma("unroll 1") for (int part_ = 1; part_ < ps.n; ++part_) {                                    \
         __syncthreads();                                                                                \
+        body(ps.a[part_], tiles_x, ps.tiles_y[part_], ps.run[part_], vb_, nb_);                         \
+    }
+
+// One copy of the body for all parts, in a loop: the kernels of the slower paths (the general kernel, the fraction and
+// scaled passes, the second marching kernel of STD) are launched through this form only - an ordinary call is ps.n == 1
+// with no gate - which is a third of the code of "one kernel for ordinary calls + a parts kernel with two copies".
+#define TOPO_RUN_PARTS_LOOP(body)                                                                       \
+    const int nb_ = (int)gridDim.x;                                                                     \
+    const int vb_ = (nb_ & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (nb_ >> 3) + (int)(blockIdx.x >> 3); \
+    int first_part_ = 0;                                                                                \
+    if (ps.cleanup) {                                                                                   \
+        if (ps.gate.skipped[blockIdx.x] == 0) return;                                                   \
+        __syncthreads();                                                                                \
+        if (threadIdx.x == 0) ps.gate.skipped[blockIdx.x] = 0;                                          \
+        first_part_ = 1;                                                                                \
+    }                                                                                                   \
+    _Pragma("unroll 1") for (int part_ = first_part_; part_ < ps.n; ++part_) {                          \
+        if (part_ == 1 && !ps.cleanup) {                                                                \
+            if (!gate_wait(ps.gate, blockIdx.x) && ps.gate.errors == nullptr) return;                   \
+        }                                                                                               \
+        if (part_ > 0) __syncthreads();                                                                 \
         body(ps.a[part_], tiles_x, ps.tiles_y[part_], ps.run[part_], vb_, nb_);                         \
     }
 
@@ -427,6 +450,18 @@ __device__ __forceinline__ float std_from_int_sums(int su, uint64_t su2, uint32_
     const float f = fmaf((float)(uint32_t)(num >> 32), 4294967296.0f, (float)(uint32_t)num);
     return __builtin_amdgcn_sqrtf(f * inv_nn1);
 }
+// The same for a pixel of whole metres some of whose taps lie outside the DEM (they read 0, and n is still the full tap
+// count): with m taps inside, T = sum trunc(x) = Su + c m and S2 = sum trunc(x)^2 = Su2 + 2 c Su + c^2 m are exact 64-bit
+// integers (|T| < 2^31, S2 < 2^49 for ordinary samples), n S2 - T^2 is the exact numerator whatever c the sums were taken
+// with, and the tail is std_from_int_sums'.  Round 5: every kernel finalises such pixels with THIS function (they had the
+// float64 form: ~100 instructions per pixel, which made the tiles at the DEM's border several times dearer than the others).
+__device__ __forceinline__ float std_from_border_sums(int64_t su, uint64_t su2, int ci, int m, uint32_t n, float inv_nn1) {
+    const int64_t T = su + (int64_t)ci * m;
+    const int64_t S2 = (int64_t)su2 + 2 * (int64_t)ci * su + (int64_t)ci * ci * m;
+    const uint64_t num = (uint64_t)n * (uint64_t)S2 - (uint64_t)(T * T);
+    const float f = fmaf((float)(uint32_t)(num >> 32), 4294967296.0f, (float)(uint32_t)num);
+    return __builtin_amdgcn_sqrtf(f * inv_nn1);
+}
 // The limb path's finalisation of a pixel whose disc holds samples beyond 2^18: everything is an exact integer -
 //   T = sum trunc(x) = Su + c m,   S2 = sum trunc(x)^2 = Su2 + 2 c Su + c^2 m   (m in-domain taps of n),
 //   F = sum of the fractional parts = Sg / 2^16,   n s2 - s1^2 = (n S2 - T^2) - 2 T F - F^2
@@ -451,7 +486,8 @@ enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4 };
 // kNeedsFraction: its sums of trunc(x) are done, the fraction / scaled pass finishes it.
 // kTileGeneralRows: the general kernel writes only the rows named in WaveArgs::rowmask (the scaled route left them: their
 // own windows hold more relief than its unwrapping takes; the other rows of the tile are done)
-enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2, kTileGeneralRows = 3 };
+// kTileBorder: a tile at the DEM's border, waiting for std_ring_kernel<kStdBorder> (even: the general kernel passes it by)
+enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2, kTileGeneralRows = 3, kTileBorder = 4 };
 
 // aux: kStUL the limb (0 / 1); kStU2L the limb (bits 0-1) and "the last limb: all the bits that are left" (bit 2)
 template <int WHAT>
@@ -733,6 +769,9 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                     if (m == n && q3.v[t] == 0) {
                         out_s.v[t] = std_from_int_sums((int)q0.v[t], ((uint64_t)q2.v[t] << 16) + q1.v[t], (uint32_t)G::T.taps,
                                                        (float)inv_nn1);
+                    } else if (q3.v[t] == 0) {  // whole metres, taps outside the DEM
+                        out_s.v[t] = std_from_border_sums((int64_t)(int)q0.v[t], ((uint64_t)q2.v[t] << 16) + q1.v[t], ci, (int)m,
+                                                          (uint32_t)G::T.taps, (float)inv_nn1);
                     } else {
                         const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
                         out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
@@ -786,8 +825,8 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                 float sd_v, tpi_v = 0.0f;
                 if (ordinary) {
                     // a disc of ordinary samples: the expressions of every other kernel on the same exact sums
-                    if (mi == G::T.taps && sg == 0) {
-                        // n S2 - T^2 = n Su2 - Su^2 (std_from_int_sums), below 2^60 here
+                    if (sg == 0) {
+                        // n S2 - T^2 (= n Su2 - Su^2 when the disc is whole: std_from_int_sums / std_from_border_sums), below 2^60 here
                         const uint64_t num = (uint64_t)((__int128)G::T.taps * S2 - (__int128)T * T);
                         const float f = fmaf((float)(uint32_t)(num >> 32), 4294967296.0f, (float)(uint32_t)num);
                         sd_v = __builtin_amdgcn_sqrtf(f * (float)inv_nn1);
@@ -939,12 +978,8 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
 }
 
 template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
-__global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
-    TOPO_RUN_ONE((disc_wave_kernel_body<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>));
-}
-template <int SIZE, int TH, int NWAVES, bool WANT_TPI, bool WANT_STD>
-__global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel_parts(WaveParts ps, int tiles_x) {
-    TOPO_RUN_PARTS((disc_wave_kernel_body<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>));
+__global__ __launch_bounds__(NWAVES * 64) void disc_wave_kernel(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS_LOOP((disc_wave_kernel_body<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>));
 }
 
 // ---- TPI alone on tiles of whole metres: the marching build --------------------------------------
@@ -1286,13 +1321,17 @@ inline long march_grid(Context& c, int blocks_per_cu, long ntiles) {
 template <class K1, class K>
 int launch_parts(K1 kernel_one, K kernel, long grid, int threads, size_t lds, WaveParts& ps, int tiles_x) {
     Context& c = ctx();
-    if (ps.n == 1) {  // an ordinary call
-        hipLaunchKernelGGL(kernel_one, dim3((unsigned)grid), dim3(threads), lds, c.compute, ps.a[0], tiles_x, ps.tiles_y[0], ps.run[0]);
-        TOPO_HIP(hipGetLastError());
-        return TOPO_AMD_OK;
+    if constexpr (!std::is_same<K1, std::nullptr_t>::value) {
+        if (ps.n == 1) {  // an ordinary call
+            hipLaunchKernelGGL(kernel_one, dim3((unsigned)grid), dim3(threads), lds, c.compute, ps.a[0], tiles_x, ps.tiles_y[0], ps.run[0]);
+            TOPO_HIP(hipGetLastError());
+            return TOPO_AMD_OK;
+        }
     }
     TOPO_REQUIRE(ps.gate.word == nullptr || (size_t)grid <= kGateSlots, "a gated launch of %ld blocks (at most %zu)", grid, kGateSlots);
-    TOPO_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (a kernel that serves ordinary calls too had its LDS size set by its launcher, once)
+    if constexpr (!std::is_same<K1, std::nullptr_t>::value)
+        TOPO_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, c.compute, ps, tiles_x);
     TOPO_HIP(hipGetLastError());
     if (ps.gate.word != nullptr && ps.gate.errors == nullptr) {  // (lean mode: no clean-up, see Context::gate_mode)
@@ -1432,12 +1471,8 @@ __device__ __forceinline__ void tpi_fraction_march_kernel_body(const WaveArgs& p
 }
 
 template <int SIZE, int TH, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
-    TOPO_RUN_ONE((tpi_fraction_march_kernel_body<SIZE, TH, NWAVES>));
-}
-template <int SIZE, int TH, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel_parts(WaveParts ps, int tiles_x) {
-    TOPO_RUN_PARTS((tpi_fraction_march_kernel_body<SIZE, TH, NWAVES>));
+__global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS_LOOP((tpi_fraction_march_kernel_body<SIZE, TH, NWAVES>));
 }
 
 template <int SIZE, int TH, int NWAVES>
@@ -1463,7 +1498,7 @@ int launch_fraction_march(const Block& b, float* tpi_out) {
     TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, true, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
-    return launch_parts(tpi_fraction_march_kernel<SIZE, TH, NWAVES>, tpi_fraction_march_kernel_parts<SIZE, TH, NWAVES>, grid, NWAVES * 64, lds, ps, tiles_x);
+    return launch_parts(nullptr, tpi_fraction_march_kernel<SIZE, TH, NWAVES>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 // ---- TPI on tiles with fractional elevations: the scaled one-chain route (round 4) -----------------------------------
@@ -1695,12 +1730,8 @@ __device__ __forceinline__ void tpi_scaled_march_kernel_body(const WaveArgs& p, 
 }
 
 template <int SIZE, int TH, int NWAVES, bool TAKE_ALL = false>
-__global__ __launch_bounds__(NWAVES * 64) void tpi_scaled_march_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
-    TOPO_RUN_ONE((tpi_scaled_march_kernel_body<SIZE, TH, NWAVES, TAKE_ALL>));
-}
-template <int SIZE, int TH, int NWAVES, bool TAKE_ALL = false>
-__global__ __launch_bounds__(NWAVES * 64) void tpi_scaled_march_kernel_parts(WaveParts ps, int tiles_x) {
-    TOPO_RUN_PARTS((tpi_scaled_march_kernel_body<SIZE, TH, NWAVES, TAKE_ALL>));
+__global__ __launch_bounds__(NWAVES * 64) void tpi_scaled_march_kernel(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS_LOOP((tpi_scaled_march_kernel_body<SIZE, TH, NWAVES, TAKE_ALL>));
 }
 
 template <int SIZE, int TH, int NWAVES, bool TAKE_ALL = false>
@@ -1729,8 +1760,7 @@ int launch_scaled_march(const Block& b, float* tpi_out) {
     TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
-    return launch_parts(tpi_scaled_march_kernel<SIZE, TH, NWAVES, TAKE_ALL>, tpi_scaled_march_kernel_parts<SIZE, TH, NWAVES, TAKE_ALL>, grid,
-                        NWAVES * 64, lds, ps, tiles_x);
+    return launch_parts(nullptr, tpi_scaled_march_kernel<SIZE, TH, NWAVES, TAKE_ALL>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 // ---- STD on tiles of whole metres: the second marching kernel ------------------------------------
@@ -1976,10 +2006,8 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
                         // sum of u, what the general kernel's first chain yields: |ci n| < 2^30, |su| < 2^25
                         out_s.v[t] = std_from_int_sums(sv.v[t] - ci * G::T.taps, (uint64_t)acc[t], (uint32_t)G::T.taps, (float)inv_nn1);
                     } else {
-                        const double s1 = (double)sv.v[t];
-                        const double su = s1 - cd * m;
-                        const double s2 = su2 + 2.0 * cd * su + cd * cd * m;
-                        out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
+                        out_s.v[t] = std_from_border_sums((int64_t)sv.v[t] - (int64_t)ci * (int)m, (uint64_t)acc[t], ci, (int)m,
+                                                          (uint32_t)G::T.taps, (float)inv_nn1);
                     }
                 }
                 *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
@@ -1994,12 +2022,8 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
 }
 
 template <int SIZE, int TH, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void std_march_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
-    TOPO_RUN_ONE((std_march_kernel_body<SIZE, TH, NWAVES>));
-}
-template <int SIZE, int TH, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void std_march_kernel_parts(WaveParts ps, int tiles_x) {
-    TOPO_RUN_PARTS((std_march_kernel_body<SIZE, TH, NWAVES>));
+__global__ __launch_bounds__(NWAVES * 64) void std_march_kernel(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS_LOOP((std_march_kernel_body<SIZE, TH, NWAVES>));
 }
 
 template <int SIZE, int TH, int NWAVES>
@@ -2026,7 +2050,7 @@ int launch_std_march(const Block& b, float* std_out) {
     TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, true, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
-    return launch_parts(std_march_kernel<SIZE, TH, NWAVES>, std_march_kernel_parts<SIZE, TH, NWAVES>, grid, NWAVES * 64, lds, ps, tiles_x);
+    return launch_parts(nullptr, std_march_kernel<SIZE, TH, NWAVES>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 // only_deferred: process the tiles a preceding launch_march of the same geometry marked.
@@ -2062,7 +2086,7 @@ int launch_wave(const Block& b, float* tpi_out, float* std_out, bool only_deferr
     TOPO_TRY(workspace(2, (size_t)grid * kScratchPlanes * TH * ROWW * sizeof(uint32_t), &scratch));
     for (int k = 0; k < kMaxParts; ++k) ps.a[k].scratch = (uint32_t*)scratch;
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);  // (this kernel deals its tiles round-robin: only the shifts matter)
-    return launch_parts(disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, disc_wave_kernel_parts<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, grid, NWAVES * 64, lds, ps, tiles_x);
+    return launch_parts(nullptr, disc_wave_kernel<SIZE, TH, NWAVES, WANT_TPI, WANT_STD>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 }  // namespace
@@ -2094,14 +2118,8 @@ inline int env_int(const char* name, int fallback) {
     const char* e = std::getenv(name);
     return e ? std::atoi(e) : fallback;
 }
-inline int std_march_min_size() {
-    static const int v = env_int("TOPO_AMD_STD_MARCH_MIN", 31);
-    return v;
-}
-inline int tpi_march_min_size() {
-    static const int v = env_int("TOPO_AMD_TPI_MARCH_MIN", 1);
-    return v;
-}
+constexpr int std_march_min_size() { return 31; }
+constexpr int tpi_march_min_size() { return 1; }
 // Disc size from which TPI on tiles with fractional elevations takes the two marching passes
 // (sum of trunc(x), then sum of the fractional parts) instead of the general kernel.
 // Disc size from which TPI takes the ring build (disc_ring_impl.hpp) instead of tpi_march_kernel
@@ -2111,41 +2129,20 @@ inline int tpi_march_min_size() {
 // to 17 px, because with fractional elevations the two-image pass (kRingBoth) halves the time there (7 px 5.36 ->
 // 2.48 ms, 13 px 5.82 -> 3.60, 17 px 6.00 -> 3.79, profiles/r03_tpi_ring_both.txt) while whole metres cost the
 // same to 15 px and 5 % more at 17 (2.43 against 2.32 ms).
-inline int tpi_ring_min_size() {
-    static const int v = env_int("TOPO_AMD_TPI_RING_MIN", 5);
-    return v;
-}
+constexpr int tpi_ring_min_size() { return 5; }
 // Disc size from which STD / TPI + STD take the one-pass ring kernel (TOPO_AMD_STD_RING_MIN; 999 = never).  Same-box
 // A/B on the 32768^2 bench DEM (tools/std_time.py, profiles/r02_std_ring.txt), ring kernel against what it replaces:
 // STD 7 px 3.10 / 5.67 ms, 17 px 3.77 / 6.40, 31 px 5.28 / 7.89, 45 px 6.76 / 9.70, 65 px 9.37 / 12.78, 67 px 10.33 /
 // 13.61; TPI + STD 67 px 10.86 / 14.22.  Identical bits (CRC-32 of both planes, whole metres and fractional DEM).
-inline int std_ring_min_size() {
-    static const int v = env_int("TOPO_AMD_STD_RING_MIN", 5);
-    return v;
-}
-inline int tpi_ring_max_size() {
-    static const int v = env_int("TOPO_AMD_TPI_RING_MAX", 17);
-    return v;
-}
-// TOPO_AMD_STD_RING_BOTH=0 / TOPO_AMD_TPI_RING_BOTH=0: fractional tiles of the ring sizes go the older ways (A/B runs; same bits)
-inline bool std_ring_both() {
-    static const int v = env_int("TOPO_AMD_STD_RING_BOTH", 1);
-    return v != 0;
-}
-inline bool tpi_ring_both() {
-    static const int v = env_int("TOPO_AMD_TPI_RING_BOTH", 1);
-    return v != 0;
-}
+constexpr int std_ring_min_size() { return 5; }
+constexpr int tpi_ring_max_size() { return 17; }
 // TOPO_AMD_TPI_FRACTION_EXACT=1: tiles with fractional elevations take the exact two-pass route (2^-16 m) instead of the
 // scaled one-chain route (2^-8 m, tpi_scaled_march_kernel)
 inline bool tpi_fraction_scaled() {
     static const int v = env_int("TOPO_AMD_TPI_FRACTION_EXACT", 0);
     return v == 0;
 }
-inline int tpi_fraction_min_size() {
-    static const int v = env_int("TOPO_AMD_TPI_FRACTION_MIN", 17);
-    return v;
-}
+constexpr int tpi_fraction_min_size() { return 17; }
 
 template <int SIZE>
 int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
@@ -2157,15 +2154,18 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
         if (std_out && SIZE >= std_ring_min_size()) {
             // one staging pass: u and u^2 rings side by side (disc_ring_impl.hpp), then the general kernel over
             // the tiles it marked (its map has this kernel's strips and rows of 60)
+            const bool border_pass = ctx().seams.n == 0;  // (a sharded call leaves the tiles at the DEM's border to the general kernel)
             if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out)));
             else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out)));
+            if (border_pass) {
+                if (tpi_out) TOPO_TRY((launch_std_ring_border<SIZE, true>(b, tpi_out, std_out)));
+                else TOPO_TRY((launch_std_ring_border<SIZE, false>(b, nullptr, std_out)));
+            }
             if constexpr (std_ring_both_fits(SIZE)) {
                 // tiles with fractional elevations: one more pass of the ring kernel with a third image (the
                 // fractional parts) instead of the general kernel's three staging passes
-                if (std_ring_both()) {
-                    if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true, kStdBoth>(b, tpi_out, std_out)));
-                    else TOPO_TRY((launch_std_ring<SIZE, false, kStdBoth>(b, nullptr, std_out)));
-                }
+                if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true, kStdBoth>(b, tpi_out, std_out)));
+                else TOPO_TRY((launch_std_ring<SIZE, false, kStdBoth>(b, nullptr, std_out)));
             }
             if (tpi_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH);
             return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH);
@@ -2194,28 +2194,16 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
     // elevations get their exact sum of trunc(x) there and the sum of the fractional parts in the
     // second; the general kernel takes what neither could (non-finite or absurd samples)
     // the ring build (disc_ring_impl.hpp) is compiled for the sizes it wins at and for the headline sizes (A/B)
-    constexpr bool kRing = ring_fits(SIZE, 8) && (SIZE <= 17 || SIZE == 65 || SIZE == 67);
+    constexpr bool kRing = ring_both_fits(SIZE) && SIZE <= 17;
     if constexpr (kRing) {
         if (SIZE >= tpi_ring_min_size() && SIZE <= tpi_ring_max_size()) {
             using RC = RingCfg<SIZE, 8>;
             constexpr int map_tw = RGeo<SIZE, 8>::TILE_W;
-            if constexpr (ring_both_fits(SIZE) && SIZE <= 17) {
-                // whole-metre tiles in the first pass; tiles with fractional elevations in ONE second pass with two
-                // rings (trunc(x) and the fractional parts); what neither could take in the general kernel.  On the
-                // 32768^2 bench DEM with fractional elevations: 7 px 5.36 -> 2.48 ms, 17 px 5.31 -> 3.79 ms
-                // (profiles/r03_tpi_ring_both.txt), bit for bit the planes of the older routes
-                if (tpi_ring_both()) {
-                    TOPO_TRY((launch_ring<SIZE, 8, kRingMark>(b, tpi_out)));
-                    TOPO_TRY((launch_ring<SIZE, 8, kRingBoth>(b, tpi_out)));
-                    return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true, RC::TH, map_tw);
-                }
-            }
-            if (SIZE < tpi_fraction_min_size()) {
-                TOPO_TRY((launch_ring<SIZE, 8, kRingMain>(b, tpi_out)));
-            } else {
-                TOPO_TRY((launch_ring<SIZE, 8, kRingMainFrac>(b, tpi_out)));
-                TOPO_TRY((launch_ring<SIZE, 8, kRingFraction>(b, tpi_out)));
-            }
+            // whole-metre tiles in the first pass; tiles with fractional elevations in ONE second pass with two rings
+            // (trunc(x) and the fractional parts); what neither could take in the general kernel.  On the 32768^2 bench
+            // DEM with fractional elevations: 7 px 5.36 -> 2.48 ms, 17 px 5.31 -> 3.79 ms (profiles/r03_tpi_ring_both.txt)
+            TOPO_TRY((launch_ring<SIZE, 8, kRingMark>(b, tpi_out)));
+            TOPO_TRY((launch_ring<SIZE, 8, kRingBoth>(b, tpi_out)));
             return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true, RC::TH, map_tw);
         }
     }

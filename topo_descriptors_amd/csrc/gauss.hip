@@ -724,454 +724,8 @@ __device__ __forceinline__ void fill_toeplitz_table(float* wz, const float* taps
     for (int n = threadIdx.x; n < K + kWzPad; n += blockDim.x) wz[n] = (n >= 31 && n - 31 <= 2 * R) ? taps[n - 31] : 0.0f;
 }
 
-// Axis 0.  The block owns columns [128 b, 128 b + 128) and a run of row tiles, top to bottom; the input
-// rows of the current window live in a ring of K8 + 32 LDS rows, K8 = K rounded up to 8 (the 32 spare ones
-// receive the next tile's rows while this tile is computed: one barrier per tile).  Everything the ring is
-// addressed with is a multiple of 8 rows, so a group of 4 MFMA steps (8 rows) and a loader pass (8 rows) never
-// straddle the wrap: the wrap is scalar arithmetic and the LDS addresses are one register plus immediates.
-//
-// One wave per SIMD issues every instruction at 4+ cycles, and every vector-ALU instruction costs the matrix
-// pipe 8-16 cycles (profiles/r02_mfma_chain.txt), so the per-tile bookkeeping is kept on the scalar unit: row
-// addresses are a scalar base plus a per-lane offset that never changes (the reflecting / clamping form only
-// where the 32 rows touch the DEM or block edge: 140 quarter-rate instructions, 950 cycles a tile).
-__global__ __launch_bounds__(256) void gauss_axis0_mfma_kernel(GaussArgs p, int tile_first, int ntiles, int tiles_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float L[];
-    const int R = p.radius, K = 32 + 2 * R, K8 = (K + 7) / 8 * 8, RR = K8 + 32;
-    float* ring = L;
-    float* wz = L + RR * kMfmaCols;  // K + kWzPad entries
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const int x0 = blockIdx.x * kMfmaCols;
-    const int tb = blockIdx.y * tiles_per_block, te = min(tb + tiles_per_block, ntiles);
-    if (tb >= te) return;
-    fill_toeplitz_table(wz, p.taps, R, K);
-    for (int n = threadIdx.x; n < RR * kMfmaCols; n += 256) ring[n] = 0.0f;
-    __syncthreads();
-    // loader: 32 threads x 16 bytes per row, 8 rows per pass of the block (2 per wave)
-    const int lc = min(x0 + (int)(threadIdx.x & 31) * 4, p.nx - 4);  // (columns past nx: clamped, never stored)
-    const int lr = threadIdx.x >> 5;
-    auto row_ptr = [&](int gy) {
-        gy = reflect_index(gy, p.gny);
-        gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
-        return p.in + (size_t)(gy - p.in_row0) * p.nx + lc;
-    };
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const unsigned in_lane_off = (unsigned)(lr * p.nx + lc) * 4u;          // bytes from the first of 8 rows
-    float* const ring_lane = ring + lr * kMfmaCols + (threadIdx.x & 31) * 4;  // this thread's slot in a group of 8 rows
-    const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
-    {
-        const int y0 = (tile_first + tb) * 32;
-        for (int k = 0; k < K8; k += 8) *reinterpret_cast<f4*>(ring_lane + k * kMfmaCols) = *reinterpret_cast<const f4*>(row_ptr(y0 - R + k + lr));
-    }
-    int base = 0;  // ring slot of input row y0 - R
-    __syncthreads();
-    const int xw = 32 * wave + j;
-    const unsigned out_lane_off = (unsigned)(4 * h * p.nx + xw) * 4u;
-    const int NG = K8 / 8;  // groups of 4 steps; the steps past K / 2 meet taps that are exactly 0
-#ifdef TOPO_GAUSS_STAMPS
-    long long st[6] = {0, 0, 0, 0, 0, 0};
-#define STAMP(n) { const long long now_ = __builtin_amdgcn_s_memtime(); st[n] += now_ - last_; last_ = now_; }
-    long long last_ = __builtin_amdgcn_s_memtime();
-#else
-#define STAMP(n)
-#endif
-    for (int t = tb; t < te; ++t) {
-        const int y0 = (tile_first + t) * 32;
-        f4 pre[4];
-        const bool more = t + 1 < te;
-        if (more) {
-            const int n0 = y0 - R + K8;  // the 32 rows the next tile adds
-            if (n0 >= row_lo && n0 + 32 <= row_hi) {
-                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)(n0 - p.in_row0) * p.nx);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pre[q] = *reinterpret_cast<const f4*>(rb + (size_t)(8 * q) * p.nx * 4 + in_lane_off);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pre[q] = *reinterpret_cast<const f4*>(row_ptr(n0 + 8 * q + lr));
-            }
-        }
-        int sc = base + R + 16;
-        sc = sc >= RR ? sc - RR : sc;
-        const float c = finite_or_zero(ring[sc * kMfmaCols + xw]);  // the column's sample at the tile's middle row
-        f32x16 acc;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-        const float* wl = wz + (h - j + 31);
-        const float* bl = ring + h * kMfmaCols + xw;
-        int slot = base;  // ring row of the next group to fetch
-        auto fetch = [&](int g, float (&a)[4], float (&b)[4]) {
-            const float* bp = bl + slot * kMfmaCols;
-            const float* wp = wl + 8 * g;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = wp[2 * u];
-                b[u] = bp[2 * u * kMfmaCols];
-            }
-            slot += 8;
-            slot = slot >= RR ? slot - RR : slot;
-        };
-        // the offsets come off two samples at a time (v_pk_add_f32 on the pair a ds_read2 returns)
-        const f32x2 cc = {c, c};
-        auto run1 = [&](const float (&a)[4], const float (&b)[4]) {
-            const f32x2 s0 = pk_sub(f32x2{b[0], b[1]}, cc), s1 = pk_sub(f32x2{b[2], b[3]}, cc);
-            mfma_operands_ready();
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], s0[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], s0[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], s1[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], s1[1], acc, 0, 0, 0);
-        };
-        auto run = [&](const float (&a)[4], const float (&b)[4], const float (&a2)[4], const float (&b2)[4]) {
-            const f32x2 s0 = pk_sub(f32x2{b[0], b[1]}, cc), s1 = pk_sub(f32x2{b[2], b[3]}, cc);
-            const f32x2 s2 = pk_sub(f32x2{b2[0], b2[1]}, cc), s3 = pk_sub(f32x2{b2[2], b2[3]}, cc);
-            mfma_operands_ready();
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], s0[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], s0[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], s1[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], s1[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0], s2[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1], s2[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[2], s3[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[3], s3[1], acc, 0, 0, 0);
-        };
-        // A wave issues in order and a dependent MFMA waits 64 cycles for the one before it.  A phase: the offsets
-        // come off the operands of groups g, g + 1 (fetched a phase ago), then their 8 MFMAs go out with the LDS reads
-        // and the scalar bookkeeping of groups g + 2, g + 3 spread one behind each (16 issue slots of 4 cycles sit
-        // in an MFMA's shadow; bunched at the phase edge the same instructions left the pipe idle 160 cycles in
-        // 680).  The fence between phases keeps the scheduler from sinking a read next to its use.
-        auto sub = [&](const float (&d)[4], const float (&d2)[4], f32x2 (&s)[4]) {
-            s[0] = pk_sub(f32x2{d[0], d[1]}, cc);
-            s[1] = pk_sub(f32x2{d[2], d[3]}, cc);
-            s[2] = pk_sub(f32x2{d2[0], d2[1]}, cc);
-            s[3] = pk_sub(f32x2{d2[2], d2[3]}, cc);
-            mfma_operands_ready();
-        };
-        auto mm = [&](const float (&w)[4], const float (&w2)[4], const f32x2 (&s)[4]) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], s[0][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], s[0][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], s[1][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], s[1][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[0], s[2][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[1], s[2][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[2], s[3][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[3], s[3][1], acc, 0, 0, 0);
-        };
-        STAMP(0)
-        float a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
-        fetch(0, a0, b0);
-        fetch(1, a1, b1);
-        int g = 0;
-        for (; g + 4 <= NG; g += 4) {
-            f32x2 s[4];
-            sub(b0, b1, s);
-            fetch(g + 2, a2, b2);
-            fetch(g + 3, a3, b3);
-            mm(a0, a1, s);
-            spread_behind_mfmas();
-            sub(b2, b3, s);
-            fetch(g + 4, a0, b0);
-            fetch(g + 5, a1, b1);
-            mm(a2, a3, s);
-            spread_behind_mfmas();
-        }
-        {  // 0-3 groups left; a0, a1 hold the first two
-            const int rem = NG - g;
-            if (rem == 3) fetch(g + 2, a2, b2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (rem >= 2) run(a0, b0, a1, b1);
-            else if (rem == 1) run1(a0, b0);
-            if (rem == 3) run1(a2, b2);
-        }
-        STAMP(1)
-        if (more) {
-            int s8 = base + K8;  // multiples of 8 all: a pass of 8 rows never straddles the wrap
-            s8 = s8 >= RR ? s8 - RR : s8;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<f4*>(ring_lane + s8 * kMfmaCols) = pre[q];
-                s8 += 8;
-                s8 = s8 >= RR ? s8 - RR : s8;
-            }
-        }
-        STAMP(2)
-        {
-            // A non-finite sample anywhere in the tile's padded band makes EVERY output of its column non-finite (the
-            // taps outside an output's window are zeros, and 0 x NaN = 0 x inf = NaN), so one accumulator per lane
-            // tells: the tile is marked for gauss_mfma_repair_kernel.  (An output that is non-finite by right - its own
-            // window holds the sample - marks the tile too and is recomputed to the same value.)
-            const bool bad = !(fabsf(acc[0] + c) <= 3.0e38f);
-            const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
-            if (lane == 0) p.flags[((size_t)t * gridDim.x + blockIdx.x) * 4 + wave] = any != 0 ? 1 : 0;
-        }
-        const int ox = x0 + xw;
-        if (ox < p.nx) {
-            if (y0 >= p.out_row0 && y0 + 32 <= p.out_row0 + p.out_rows) {
-                // whole tile inside the output rows: a scalar base per register row plus the per-lane byte offset
-                // (16 stores and their 16 additions; the guarded form below costs 1700 cycles a tile in compares
-                // and branches)
-                char* ub = reinterpret_cast<char*>(p.out + (size_t)(y0 - p.out_row0) * p.nx + x0);
-#pragma unroll
-                for (int v = 0; v < 16; ++v)
-                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + out_lane_off) = c + acc[v];
-            } else {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int oy = y0 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                    if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = c + acc[v];
-                }
-            }
-        }
-        STAMP(3)
-        base += 32;
-        base = base >= RR ? base - RR : base;
-        __syncthreads();
-        STAMP(4)
-    }
-#ifdef TOPO_GAUSS_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x == 7 && blockIdx.y == 0)
-        printf("axis0 stamps (clocks over %d tiles): head %lld  mfma %lld  ring-write %lld  store %lld  barrier %lld\n",
-               te - tb, st[0], st[1], st[2], st[3], st[4]);
-#endif
-}
-
-// Axis 1.  Every wave owns a band of 32 rows and marches along x; its window of input columns lives in a
-// ring of K8 + 32 LDS columns (odd row pitch: the 32 rows of an A-operand read fall into 32 banks).  Waves
-// never talk to each other.  `in` holds plane rows [0, rows); a row's result depends on that row alone.
-__global__ __launch_bounds__(256) void gauss_axis1_mfma_kernel(GaussArgs p, int rows, int nseg) {
-    extern __shared__ __attribute__((aligned(16))) float L[];
-    const int R = p.radius, K = 32 + 2 * R, K8 = (K + 7) / 8 * 8, RC = K8 + 32, pitch = RC + 1;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* wz = L;
-    float* ring = L + (K + kWzPad) + wave * (32 * pitch + 32);
-    float* crow = ring + 32 * pitch;
-    fill_toeplitz_table(wz, p.taps, R, K);
-    for (int n = lane; n < 32 * pitch; n += 64) ring[n] = 0.0f;
-    __syncthreads();
-    // a band's columns are cut into nseg runs of tiles, one wave each (each run restages its 2 R halo columns):
-    // 32768 rows give 1024 bands, enough for 4 waves on every CU; shorter planes need the cut to fill the chip
-    const int gw = blockIdx.x * 4 + wave;
-    const int band = gw / nseg, seg = gw - band * nseg;
-    const int r0 = band * 32;
-    if (r0 >= rows) return;
-    const int i = lane & 31, h = lane >> 5;
-    // loader: lanes 0-31 / 32-63 take two rows per pass, 32 consecutive columns
-    auto load_cols = [&](int xfirst, int q) {  // rows 2 q + h, columns xfirst + i
-        const int r = min(r0 + 2 * q + h, rows - 1);
-        const int cx = reflect_index(xfirst + i, p.nx);
-        return p.in[(size_t)r * p.nx + cx];
-    };
-    const unsigned in_lane_off = (unsigned)(h * p.nx + i) * 4u;
-    const unsigned out_lane_off = (unsigned)(4 * h * p.nx + i) * 4u;
-    const bool full_band = r0 + 32 <= rows;
-    const int ntile = (p.nx + 31) / 32;
-    const int tper = (ntile + nseg - 1) / nseg;
-    const int t_first = seg * tper, t_last = min(t_first + tper, ntile);
-    if (t_first >= t_last) return;
-    for (int k0 = 0; k0 < K8; k0 += 32) {
-        if (k0 + i < K8) {
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + k0 + i] = load_cols(t_first * 32 - R + k0, q);
-        }
-    }
-    int base = 0;  // ring column of input column x0 - R
-    const int NG = K8 / 8;
-    for (int t = t_first; t < t_last; ++t) {
-        const int x0 = t * 32;
-        float pre[16];
-        const bool more = t + 1 < t_last;
-        if (more) {
-            const int n0 = x0 - R + K8;  // the 32 columns the next tile adds
-            if (full_band && n0 >= 0 && n0 + 32 <= p.nx) {  // scalar base + the per-lane byte offset: see axis 0
-                const char* rb = reinterpret_cast<const char*>(p.in + (size_t)r0 * p.nx + n0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) pre[q] = *reinterpret_cast<const float*>(rb + (size_t)(2 * q) * p.nx * 4 + in_lane_off);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) pre[q] = load_cols(n0, q);
-            }
-        }
-        int sc = base + R + 16;
-        sc = sc >= RC ? sc - RC : sc;
-        const float c = finite_or_zero(ring[i * pitch + sc]);  // the row's sample at the tile's middle column
-        if (h == 0) crow[i] = c;
-        f32x16 acc;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-        const float* wl = wz + (h - i + 31);
-        const float* al = ring + i * pitch + h;
-        int slot = base;  // ring column of the next group to fetch
-        auto fetch = [&](int g, float (&a)[4], float (&b)[4]) {
-            const float* ap = al + slot;
-            const float* wp = wl + 8 * g;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = ap[2 * u];
-                b[u] = wp[2 * u];
-            }
-            slot += 8;
-            slot = slot >= RC ? slot - RC : slot;
-        };
-        const f32x2 cc = {c, c};  // packed subtractions, fenced phases: see axis 0
-        auto run1 = [&](const float (&a)[4], const float (&b)[4]) {
-            const f32x2 s0 = pk_sub(f32x2{a[0], a[1]}, cc), s1 = pk_sub(f32x2{a[2], a[3]}, cc);
-            mfma_operands_ready();
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[0], b[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[1], b[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[0], b[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[1], b[3], acc, 0, 0, 0);
-        };
-        auto run = [&](const float (&a)[4], const float (&b)[4], const float (&a2)[4], const float (&b2)[4]) {
-            const f32x2 s0 = pk_sub(f32x2{a[0], a[1]}, cc), s1 = pk_sub(f32x2{a[2], a[3]}, cc);
-            const f32x2 s2 = pk_sub(f32x2{a2[0], a2[1]}, cc), s3 = pk_sub(f32x2{a2[2], a2[3]}, cc);
-            mfma_operands_ready();
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[0], b[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s0[1], b[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[0], b[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s1[1], b[3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2[0], b2[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s2[1], b2[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3[0], b2[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s3[1], b2[3], acc, 0, 0, 0);
-        };
-        auto sub = [&](const float (&d)[4], const float (&d2)[4], f32x2 (&s)[4]) {
-            s[0] = pk_sub(f32x2{d[0], d[1]}, cc);
-            s[1] = pk_sub(f32x2{d[2], d[3]}, cc);
-            s[2] = pk_sub(f32x2{d2[0], d2[1]}, cc);
-            s[3] = pk_sub(f32x2{d2[2], d2[3]}, cc);
-            mfma_operands_ready();
-        };
-        auto mm = [&](const float (&w)[4], const float (&w2)[4], const f32x2 (&s)[4]) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[0][0], w[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[0][1], w[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[1][0], w[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[1][1], w[3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[2][0], w2[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[2][1], w2[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[3][0], w2[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s[3][1], w2[3], acc, 0, 0, 0);
-        };
-        float a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
-        fetch(0, a0, b0);
-        fetch(1, a1, b1);
-        int g = 0;
-        for (; g + 4 <= NG; g += 4) {
-            f32x2 s[4];
-            sub(a0, a1, s);
-            fetch(g + 2, a2, b2);
-            fetch(g + 3, a3, b3);
-            mm(b0, b1, s);
-            spread_behind_mfmas();
-            sub(a2, a3, s);
-            fetch(g + 4, a0, b0);
-            fetch(g + 5, a1, b1);
-            mm(b2, b3, s);
-            spread_behind_mfmas();
-        }
-        {  // 0-3 groups left; a0, a1 hold the first two
-            const int rem = NG - g;
-            if (rem == 3) fetch(g + 2, a2, b2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (rem >= 2) run(a0, b0, a1, b1);
-            else if (rem == 1) run1(a0, b0);
-            if (rem == 3) run1(a2, b2);
-        }
-        if (more) {
-            int sl = base + K8;
-            sl = (sl >= RC ? sl - RC : sl) + i;
-            sl = sl >= RC ? sl - RC : sl;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) ring[(2 * q + h) * pitch + sl] = pre[q];
-        }
-        {
-            // Here a non-finite sample spoils its own ROW of the tile (the data is the A operand), and a lane holds
-            // 16 rows of one column: NaN and inf survive a sum, so 15 additions and one class test stand for 16 tests.
-            float ssum = acc[0];
-#pragma unroll
-            for (int v = 1; v < 16; ++v) ssum += acc[v];
-            const bool bad = !(fabsf(ssum + c) <= 3.0e38f);
-            const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
-            if (lane == 0) p.flags[(size_t)band * ntile + t] = any != 0 ? 1 : 0;
-        }
-        const int ox = x0 + i;  // D: column = lane & 31
-        float cr[16];  // the offsets of the 16 rows this lane holds: requested together, one wait
-#pragma unroll
-        for (int v = 0; v < 16; ++v) cr[v] = crow[(v & 3) + 8 * (v >> 2) + 4 * h];
-        __builtin_amdgcn_sched_barrier(0);
-        if (ox < p.nx) {
-            if (full_band) {
-                char* ub = reinterpret_cast<char*>(p.out + (size_t)r0 * p.nx + x0);
-#pragma unroll
-                for (int v = 0; v < 16; ++v)
-                    *reinterpret_cast<float*>(ub + (size_t)((v & 3) + 8 * (v >> 2)) * p.nx * 4 + out_lane_off) = cr[v] + acc[v];
-            } else {
-                float* o = p.out + (size_t)(r0 + 4 * h) * p.nx + ox;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int ri = (v & 3) + 8 * (v >> 2);
-                    if (r0 + 4 * h + ri < rows) o[(size_t)ri * p.nx] = cr[v] + acc[v];
-                }
-            }
-        }
-        base += 32;
-        base = base >= RC ? base - RC : base;
-    }
-}
-
-// Repair pass of the matrix-core Gaussian.  The banded-Toeplitz products multiply the zero taps
-// outside an output's own 2 R + 1 window in like the others, and 0 x NaN is NaN: a non-finite sample spoils all 32
-// outputs of every tile whose padded band holds it, up to 31 + 6 rows / columns beyond what
-// ndimage.gaussian_filter spoils (reference topo.py:80).  The MFMA kernels mark such tiles; this kernel takes the
-// marked ones again tap by tap - the same offset c, the same differences x - c, the ascending chain of fused
-// multiply-adds over the output's own window only - so an output is NaN exactly where its window holds a
-// non-finite sample, as in the reference, and a finite window gets the value the matrix cores give it.  On a DEM
-// without non-finite samples the launch is a scan of the flag bytes (64 per ballot).
-template <bool AXIS1>
-__global__ __launch_bounds__(64) void gauss_mfma_repair_kernel(GaussArgs p, int units_a, int units_b, int first_a, int rows_plane) {
-    // AXIS1 false: unit (a, b) = row tile first_a + a (32 rows on the global grid), columns 32 b ... 32 b + 31
-    // AXIS1 true:  unit (a, b) = band a (plane rows 32 a ...), columns 32 b ...
-    const int lane = threadIdx.x;
-    const long units = (long)units_a * units_b;
-    const int R = p.radius;
-    for (long base = (long)blockIdx.x * 64; base < units; base += (long)gridDim.x * 64) {
-        const long mine = base + lane;
-        unsigned long long marked = __builtin_amdgcn_ballot_w64(mine < units && p.flags[mine < units ? mine : 0] != 0);
-        while (marked) {
-            const int bit = __builtin_ctzll(marked);
-            marked &= marked - 1;
-            const long u = base + bit;
-            const int a = (int)(u / units_b), b = (int)(u % units_b);
-            const int j = lane & 31, h = lane >> 5;  // lane: column (axis 0) or row (axis 1) j, 16 outputs each
-            if (!AXIS1) {
-                const int y0 = (first_a + a) * 32, x = 32 * b + j;
-                if (x >= p.nx) continue;
-                auto in_at = [&](int gy) {
-                    gy = reflect_index(gy, p.gny);
-                    gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
-                    return p.in[(size_t)(gy - p.in_row0) * p.nx + x];
-                };
-                const float c = finite_or_zero(in_at(y0 + 16));
-                for (int k = 0; k < 16; ++k) {
-                    const int oy = y0 + 16 * h + k;
-                    if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
-                    float acc = 0.0f;
-                    for (int q = 0; q <= 2 * R; ++q) acc = fmaf(p.taps[q], in_at(oy - R + q) - c, acc);
-                    p.out[(size_t)(oy - p.out_row0) * p.nx + x] = c + acc;
-                }
-            } else {
-                const int r = 32 * a + j, x0 = 32 * b;
-                if (r >= rows_plane) continue;
-                const float* row = p.in + (size_t)r * p.nx;
-                const float c = finite_or_zero(row[reflect_index(x0 + 16, p.nx)]);
-                for (int k = 0; k < 16; ++k) {
-                    const int ox = x0 + 16 * h + k;
-                    if (ox >= p.nx) continue;
-                    float acc = 0.0f;
-                    for (int q = 0; q <= 2 * R; ++q) acc = fmaf(p.taps[q], row[reflect_index(ox - R + q, p.nx)] - c, acc);
-                    p.out[(size_t)r * p.nx + ox] = c + acc;
-                }
-            }
-        }
-    }
-}
+// (the float32 matrix-core kernels of round 2 - v_mfma_f32_32x32x2_f32, 11.3 ms at sigma 30.25 - were retired in round 5:
+// docs/DESIGN_HISTORY.md, profiles/r02_gauss_mfma.txt, r03_gauss_f16.txt keep their numbers)
 
 // ---- the banded products on the f16 matrix pipe (round 3) ------------------------------------------------
 // v_mfma_f32_32x32x16_f16 does 16 x the multiply-adds of the f32 instruction per cycle.  A float32 difference
@@ -2297,10 +1851,7 @@ int upload_weights(int slot, double sigma, int kb, GaussArgs* a) {
 
 // wide tiling for long filters, narrow for short ones (fewer padded taps)
 bool wide_tiling(int radius) {
-    static const int from = [] {
-        const char* e = std::getenv("TOPO_AMD_GAUSS_WIDE_MIN_RADIUS");
-        return e && *e ? std::atoi(e) : 24;
-    }();
+    constexpr int from = 24;
     return radius >= from;
 }
 
@@ -2325,12 +1876,9 @@ int mfma_min_radius_impl(bool for_gradient) {
         const char* e = std::getenv("TOPO_AMD_GAUSS_MFMA_MIN_RADIUS");
         return std::max(kMfmaSmallFloor, e && *e ? std::atoi(e) : 4);
     }();
-    static const int from_grad = [] {
-        const char* e = std::getenv("TOPO_AMD_GRAD_MFMA_MIN_RADIUS");
-        // (round 3: 4, was 8: with both passes in one kernel the route is 6.1 ms at sigma 1.25 on 32768^2, the
-        // vector-ALU kernel with the epilogue fused in 7.4)
-        return std::max(kMfmaSmallFloor, e && *e ? std::atoi(e) : 4);
-    }();
+    static const int from_grad = from_gauss;
+    // (round 3: 4, was 8: with both passes in one kernel the route is 6.1 ms at sigma 1.25 on 32768^2, the
+    // vector-ALU kernel with the epilogue fused in 7.4)
     return for_gradient ? from_grad : from_gauss;
 }
 
@@ -2339,13 +1887,8 @@ int mfma_min_radius_impl(bool for_gradient) {
 thread_local bool t_no_mfma = false;
 bool mfma_radius(int R, int nx, bool for_gradient = false, bool small_ok = true) {
     if (t_no_mfma) return false;
-    // (any width from 4 columns: the loaders' 16-byte loads only need dword alignment, which a row of any length has;
-    // TOPO_AMD_GAUSS_MFMA_ANY_WIDTH=0: multiples of 4 only, as before round 3)
-    static const bool any_width = [] {
-        const char* e = std::getenv("TOPO_AMD_GAUSS_MFMA_ANY_WIDTH");
-        return !(e && *e == '0');
-    }();
-    return R >= std::max(small_ok ? kMfmaSmallFloor : 16, mfma_min_radius_impl(for_gradient)) && R <= 121 && (any_width || nx % 4 == 0) && nx >= 4;
+    // (any width from 4 columns: the loaders' 16-byte loads only need dword alignment, which a row of any length has)
+    return R >= std::max(small_ok ? kMfmaSmallFloor : 16, mfma_min_radius_impl(for_gradient)) && R <= 121 && nx >= 4;
 }
 
 // the accumulation-offset row of every axis-0 tile that holds one of the block's output rows is inside the block
@@ -2363,27 +1906,15 @@ int upload_plain_weights(int slot, double sigma, GaussArgs* a) {
 }
 
 // ---- f16 route: scales, step count, dispatch over the step count ----
-bool f16_route() {
-    static const bool on = [] {
-        const char* e = std::getenv("TOPO_AMD_GAUSS_F16");
-        return !(e && *e == '0');
-    }();
-    return on;
-}
 #ifndef TOPO_F16_NP
 #define TOPO_F16_NP 3  // products per tap block: th h + tm h + th l (4 adds tm l: 7 % slower, same error; lab builds)
 #endif
 int f16_steps(int R);
 thread_local bool t_axis0_one_tile = false;  // set around the two-pass launches queued behind a fused launch
 // two MFMA tiles per offset (MT = 2): axis 1 always; axis 0 from radius 32 (the offset row is 32 rows into a
-// 64-row tile).  TOPO_AMD_GAUSS_F16_MT=1 keeps one tile everywhere (A/B).
+// 64-row tile).
 int f16_mt(bool axis1, int R) {
-    static const int forced = [] {
-        const char* e = std::getenv("TOPO_AMD_GAUSS_F16_MT");
-        return e && *e ? std::atoi(e) : 0;
-    }();
-    if (forced == 1) return 1;
-    if (axis1) return forced == 2 || f16_steps(R) < 18 ? 2 : 1;  // the widest window fits LDS 3 times with MT = 2: 2.95 ms against 2.66 with MT = 1
+    if (axis1) return f16_steps(R) < 18 ? 2 : 1;  // the widest window fits LDS 3 times with MT = 2: 2.95 ms against 2.66 with MT = 1
     // (behind a fused launch - radius 32 ... 47 of the gradient - the two-pass kernels must give the fused kernel's bits,
     // and its bands are 32-row tiles)
     if (t_axis0_one_tile) return 1;
@@ -2427,14 +1958,8 @@ int launch_f16_axis1(long waves, const GaussArgs& a, int rows, int nseg) {
     TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
-// TOPO_AMD_GAUSS_TURN=0: every band / row block starts its run at the run's first tile (A/B of the turned tile order)
-bool gauss_turn() {
-    static const bool on = [] {
-        const char* e = std::getenv("TOPO_AMD_GAUSS_TURN");
-        return !(e && *e == '0');
-    }();
-    return on;
-}
+// (every band / row block turns its tile order by a number of tiles of its own: profiles/r04_pitch_spread.txt)
+constexpr bool gauss_turn() { return true; }
 // split once (gauss_axis*_s1_kernel): radius 49 ... 121.  TOPO_AMD_GAUSS_SPLIT_ONCE=0: the tile kernels everywhere (A/B)
 bool split_once(int steps) {
     static const bool on = [] {
@@ -2595,7 +2120,6 @@ int run_axis1_f16(GaussArgs a, int rows, int nx, double sigma) {
 }
 
 int run_axis0_mfma(const Block& b, double sigma, float* out, int table_slot) {
-    Context& c = ctx();
     GaussArgs a{};
     TOPO_TRY(upload_plain_weights(table_slot, sigma, &a));
     a.in = b.in;
@@ -2607,41 +2131,10 @@ int run_axis0_mfma(const Block& b, double sigma, float* out, int table_slot) {
     a.out_row0 = b.out_row0;
     a.out_rows = b.out_rows;
     a.group0 = 0;
-    const int K = 32 + 2 * a.radius;
-    const size_t lds = ((size_t)((K + 32 + 7) / 8 * 8) * kMfmaCols + (K + kWzPad)) * sizeof(float);
-    static bool ready = false;
-    if (!ready) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis0_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-        ready = true;
-    }
-    if (f16_route()) return run_axis0_f16(b, a, sigma);
-    const int tile_first = b.out_row0 / 32;  // row tiles sit on global multiples of 32 (the accumulation offsets)
-    const int ntiles = (b.out_row0 + b.out_rows - 1) / 32 - tile_first + 1;
-    const int strips = (b.nx + kMfmaCols - 1) / kMfmaCols;
-    // one block per CU marches down its strip; with fewer strips than CUs the tile runs are cut (each cut
-    // restages 2 R rows)
-    int splits = (2 * c.num_cu + strips - 1) / strips;
-    splits = std::max(1, std::min(splits, ntiles / 8 > 0 ? ntiles / 8 : 1));
-    if (strips >= c.num_cu) splits = 1;
-    const int per = (ntiles + splits - 1) / splits;
-    TOPO_TRY(check_grid_rows((ntiles + per - 1) / per, "gaussian (matrix-core axis 0)"));
-    dim3 grid(strips, (ntiles + per - 1) / per);
-    // one flag byte per 32 x 32 output tile (every tile writes its own: nothing to clear), then the repair pass
-    const long units = (long)ntiles * strips * 4;
-    void* flags = nullptr;
-    TOPO_TRY(workspace(10, (size_t)units, &flags));
-    a.flags = (unsigned char*)flags;
-    hipLaunchKernelGGL(gauss_axis0_mfma_kernel, grid, dim3(256), lds, c.compute, a, tile_first, ntiles, per);
-    TOPO_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gauss_mfma_repair_kernel<false>, dim3((unsigned)std::min<long>(kRepairBlocks, (units + 63) / 64)), dim3(64), 0, c.compute,
-                       a, ntiles, strips * 4, tile_first, 0);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
+    return run_axis0_f16(b, a, sigma);
 }
 
 int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, int table_slot) {
-    Context& c = ctx();
     GaussArgs a{};
     TOPO_TRY(upload_plain_weights(table_slot, sigma, &a));
     a.in = in;
@@ -2653,44 +2146,7 @@ int run_axis1_mfma(const float* in, int rows, int nx, double sigma, float* out, 
     a.out_row0 = 0;
     a.out_rows = rows;
     a.group0 = 0;
-    if (f16_route()) return run_axis1_f16(a, rows, nx, sigma);
-    const int K = 32 + 2 * a.radius;
-    const size_t lds = ((size_t)(K + kWzPad) + 4 * (size_t)(32 * ((K + 32 + 7) / 8 * 8 + 1) + 32)) * sizeof(float);
-    static bool ready = false;
-    if (!ready) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis1_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-        ready = true;
-    }
-    const int bands = (rows + 31) / 32;
-    const int ntile = (nx + 31) / 32;
-    // The ring takes the whole LDS: one block of 4 waves per CU, so the chip runs 4 num_cu waves at a time and a
-    // grid one wave over that takes twice as long (171 bands x 6 runs = 1026 waves: 21.5 ms instead of 14.5 for
-    // the gradient at sigma 30.25).  Pick the cut with the least rounds x (tiles per run + the 2 R halo a run
-    // restages), runs no shorter than 16 tiles.
-    const long slots = 4L * c.num_cu;
-    const int halo_tiles = (2 * a.radius + 31) / 32;
-    int nseg = 1;
-    long best = -1;
-    for (int n = 1; n <= std::max(1, ntile / 16); ++n) {
-        const long rounds = ((long)bands * n + slots - 1) / slots;
-        const long cost = rounds * ((ntile + n - 1) / n + halo_tiles);
-        if (best < 0 || cost < best) {
-            best = cost;
-            nseg = n;
-        }
-    }
-    const long waves = (long)bands * nseg;
-    const long units = (long)bands * ntile;
-    void* flags = nullptr;
-    TOPO_TRY(workspace(10, (size_t)units, &flags));
-    a.flags = (unsigned char*)flags;
-    hipLaunchKernelGGL(gauss_axis1_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, c.compute, a, rows, nseg);
-    TOPO_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gauss_mfma_repair_kernel<true>, dim3((unsigned)std::min<long>(kRepairBlocks, (units + 63) / 64)), dim3(64), 0, c.compute,
-                       a, bands, ntile, 0, rows);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
+    return run_axis1_f16(a, rows, nx, sigma);
 }
 
 // ---- one kernel for both passes (radius 4 ... 16, one sigma) ----
@@ -2699,14 +2155,11 @@ bool fused_radius(int R, bool wide_too) {
         const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED");
         return !(e && *e == '0');
     }();
-    static const int max_r = [] {
-        const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED_MFMA_MAX_RADIUS");
-        return e && *e ? std::atoi(e) : 47;
-    }();
+    constexpr int max_r = 47;
     // (the raw blocks and rings of 10 steps no longer fit LDS.)  Radius 32 ... 47 only where the caller says so - the
     // gradient, whose smooth shares HBM with the epilogue (sigma 10: 7.9 -> 6.7 ms); alone the two passes with 64-row
     // tiles on axis 0 are faster there (Gaussian sigma 10: 3.3 ms against 4.4)
-    return on && f16_route() && R >= kMfmaSmallFloor && R <= std::min(wide_too ? 47 : 31, max_r);
+    return on && R >= kMfmaSmallFloor && R <= std::min(wide_too ? 47 : 31, max_r);
 }
 template <int S, int CW>
 int launch_fused_f16(dim3 grid, const GaussArgs& a, int tile_first, int ntile_rows, int nseg) {
@@ -2945,12 +2398,9 @@ int launch_axis1_grad_pf(const GaussArgs& a, const GradArgs& g, size_t lds) {
 // smoothed along axis 0) fused with the gradient epilogue described by g.
 int run_axis1_grad(const float* in, int s_row0, int s_rows, int gny, int nx, double sigma,
                    const GradArgs& g, int table_slot) {
-    static const int wide_from = [] {
-        const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED_WIDE_MIN_RADIUS");
-        // 16-wide tap chunks pay from radius ~60: 4.13 (narrow) / 3.92 ms (wide) at radius 64, 3.33 / 3.65
-        // at radius 56 on 16384^2 (tools/gauss_fused_sweep.sh)
-        return e && *e ? std::atoi(e) : 60;
-    }();
+    constexpr int wide_from = 60;
+    // 16-wide tap chunks pay from radius ~60: 4.13 (narrow) / 3.92 ms (wide) at radius 64, 3.33 / 3.65
+    // at radius 56 on 16384^2 (tools/gauss_fused_sweep.sh)
     const bool wide = gaussian_radius(sigma) >= wide_from;
     GaussArgs a{};
     TOPO_TRY(upload_weights(table_slot, sigma, wide ? 16 : 8, &a));
@@ -2976,12 +2426,9 @@ int run_axis1_wave_grad(const float* in, int s_row0, int s_rows, double sigma, c
     const int d_lo = -fdiv(R + GC - 1, GC), d_hi = fdiv(R + GC - 1, GC);
     const int nsteps = d_hi - d_lo + 1;
     const int nvl = 64 - (d_hi - d_lo);  // lanes of a wavefront that produce output
-    static const int min_lanes = [] {
-        const char* e = std::getenv("TOPO_AMD_GAUSS_WAVE_MIN_LANES");
-        // below ~42 of 64 output lanes (radius > 176, sigma > ~44) the transpose path is faster:
-        // 11.2 vs 9.0 ms at sigma 50, 68 vs 17 ms at sigma 107 on 16384^2 (tools/gauss_long_crossover.py)
-        return e && *e ? std::atoi(e) : 42;
-    }();
+    constexpr int min_lanes = 42;
+    // below ~42 of 64 output lanes (radius > 176, sigma > ~44) the transpose path is faster:
+    // 11.2 vs 9.0 ms at sigma 50, 68 vs 17 ms at sigma 107 on 16384^2 (tools/gauss_long_crossover.py)
     if (nvl < min_lanes) return TOPO_AMD_EUNSUP;
     std::vector<double> w(2 * R + 1);
     double sum = 0.0;
@@ -3112,7 +2559,7 @@ struct NoMfmaScope {
             const char* e = std::getenv("TOPO_AMD_GAUSS_LARGE_SAMPLE");
             return !(e && *e == '0');
         }();
-        if (on && !t_no_mfma && f16_route()) t_no_mfma = current_class().large;
+        if (on && !t_no_mfma) t_no_mfma = current_class().large;
     }
     ~NoMfmaScope() { t_no_mfma = before; }
 };
@@ -3243,19 +2690,13 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             // 12 x 2752 6.31 / 9.40, 16 x 2048 6.31 / 9.59, 32 x 1024 6.64 / 11.20; one stream: 6.71 / 10.43
             return std::max(256, e && *e ? std::atoi(e) : 4096);
         }();
-        static const bool use_aux = [] {
-            const char* e = std::getenv("TOPO_AMD_GRAD_AUX");
-            return !(e && *e == '0');
-        }();
+        constexpr bool use_aux = true;
         // A short block (a row shard: 4096 rows) in few chunks leaves the smooth of its first chunk and the epilogue of its
         // last one uncovered: the fused route (one kernel per chunk, nothing restaged across a cut but Rp rows) goes in at
         // least 6 chunks of 512 rows or more, the two-pass route (every chunk restages 2 R rows on axis 0: 24 % at
         // radius 121 and 1024 rows) in at least 3.  One 4096-row shard in loop-back, sigma 3.25 / 30.25, ms per step
         // (profiles/r04_shard_fused.txt): 2 chunks 0.98 / 1.56, 3: 0.95 / 1.55, 4: 0.83 / 1.60, 6: 0.81 / 1.73, 8: 0.85 / 1.91.
-        static const int kMinChunksEnv = [] {
-            const char* e = std::getenv("TOPO_AMD_GRAD_MIN_CHUNKS");
-            return std::max(0, std::min(64, e && *e ? std::atoi(e) : 0));
-        }();
+        constexpr int kMinChunksEnv = 0;
         const int kMinChunks = kMinChunksEnv ? kMinChunksEnv
                                              : std::max(2, std::min(fused_radius(gaussian_radius(sigma), true) ? 6 : 3, b.out_rows / 512));
         if (!c.aux) {
@@ -3289,10 +2730,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         // the one processed LAST run uncovered, so those two chunks are a quarter of the others (>= 256 rows).  Processing
         // order = row order, except in a row shard, where the first chunk processed is the second in row order (the top
         // one waits for the exchange).
-        static const bool taper_on = [] {
-            const char* e = std::getenv("TOPO_AMD_GRAD_TAPER");
-            return !(e && *e == '0');
-        }();
+        constexpr bool taper_on = true;
         // (32768^2, sigma 3.25: 5.76 -> 5.52 ms; a 4096-row shard in 6 chunks LOSES 7 % with a 256-row first chunk, so only
         // blocks whose chunks are 2048 rows and more are tapered; sigma 30.25: no difference either way)
         const bool taper = taper_on && nch >= 4 && (s1 - s0) / nch >= 2048;
@@ -3432,12 +2870,9 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
         if (!mfma) TOPO_TRY(run_axis0(rows, sigma, (float*)plane_a, 1, false));
         // short and medium filters: LDS-tiled axis 1 (9.8 vs 13.6 ms at sigma 3.25 on 32768^2); long
         // filters: wave-shift axis 1 (26.7 vs 27.8 ms at sigma 30.25) while enough lanes produce output
-        static const int fused_max = [] {
-            const char* e = std::getenv("TOPO_AMD_GAUSS_FUSED_MAX_RADIUS");
-            // the LDS-tiled fused kernel while its tile fits (320 columns: radius 92), the wave-shift one
-            // beyond: 2.67 vs 3.63 ms at radius 32, 3.33 vs 4.07 at 56, 4.60 vs 5.17 at 92 on 16384^2
-            return e && *e ? std::atoi(e) : 92;
-        }();
+        constexpr int fused_max = 92;
+        // the LDS-tiled fused kernel while its tile fits (320 columns: radius 92), the wave-shift one
+        // beyond: 2.67 vs 3.63 ms at radius 32, 3.33 vs 4.07 at 56, 4.60 vs 5.17 at 92 on 16384^2
         if (!mfma) {
             if (gaussian_radius(sigma) <= fused_max) {
                 const int r = run_axis1_grad((const float*)plane_a, s0, s_rows, b.gny, b.nx, sigma, g, 2);

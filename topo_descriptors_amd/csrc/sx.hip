@@ -765,29 +765,17 @@ int launch_sx(const Block& b, const int32_t* dj, const int32_t* di, const double
     }
     // chains along the direction that needs the fewest comparisons (padding included): down the columns, along the
     // rows, or along one of the two diagonals (whose tile is 15 columns wider: its own LDS stride)
-    static const bool diag_on = [] {
-        const char* e = std::getenv("TOPO_AMD_SX_DIAG");
-        return !(e && *e == '0');
-    }();
-    static const int diag_min_saving = [] {
-        const char* e = std::getenv("TOPO_AMD_SX_DIAG_MIN_SAVING");
-        // 32768^2, azimuth 45: radius 2000 m 428 -> 366 comparisons 28.4 -> 25.0 ms; 1000 m 146 -> 132: 8.45 -> 8.10;
-        // 500 m 42 -> 36: 3.90 -> 3.99 (hence the floor below)
-        return e && *e ? std::atoi(e) : 5;
-    }();
-    static const int diag_min_cost = [] {
-        const char* e = std::getenv("TOPO_AMD_SX_DIAG_MIN_COST");
-        return e && *e ? std::atoi(e) : 100;
-    }();
+    constexpr bool diag_on = true;
+    constexpr int diag_min_saving = 5;
+    // 32768^2, azimuth 45: radius 2000 m 428 -> 366 comparisons 28.4 -> 25.0 ms; 1000 m 146 -> 132: 8.45 -> 8.10;
+    // 500 m 42 -> 36: 3.90 -> 3.99 (hence the floor below)
+    constexpr int diag_min_cost = 100;
     const int cols_d = a.cols_l + kSxOwn - 1;
     const int stride_d = sx_stride_for(cols_d);
     const size_t lds_d = (size_t)(a.rows_l + 8) * stride_d * sizeof(float);
     const bool diag_fits = diag_on && stride_d != 0 && lds_d <= 160 * 1024;
-    // pairs: any two chains of one length with the same weights, bit for bit (TOPO_AMD_SX_PAIRS=0: none)
-    static const bool pairs_on = [] {
-        const char* e = std::getenv("TOPO_AMD_SX_PAIRS");
-        return !(e && *e == '0');
-    }();
+    // pairs: any two chains of one length with the same weights, bit for bit
+    constexpr bool pairs_on = true;
     auto pair_up = [&](const auto& all, auto& singles, auto& pairs, auto second) {
         std::vector<char> used(all.size(), 0);
         for (size_t i = 0; i < all.size(); ++i) {
@@ -1101,11 +1089,7 @@ int launch_sx_group(const Block& b, const std::vector<SectorPoints>& sec, int a0
 int launch_sx_multi(const Block& b, int n_az, const int32_t* first, const int32_t* dj, const int32_t* di,
                     const double* dist, const int32_t* window, double height, float* const* outs) {
     // at most this much LDS per block, so that three blocks still share a CU
-    static const size_t kGroupLds = [] {
-        const char* e = std::getenv("TOPO_AMD_SX_GROUP_LDS_KIB");
-        const int kib = e && *e ? std::atoi(e) : 48;
-        return (size_t)std::min(std::max(kib, 1), 160) * 1024;
-    }();
+    constexpr size_t kGroupLds = 48 * 1024;
     std::vector<SectorPoints> sec(n_az);
     for (int k = 0; k < n_az; ++k) {
         TOPO_REQUIRE(window[k] >= 0 && first[k + 1] >= first[k], "sx_multi: bad sector %d", k);
