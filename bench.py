@@ -118,11 +118,11 @@ def kernel_sources_sha256():
 
 def measured_traffic(ny, nx, size, world):
     """HBM bytes per launch of the TPI kernel from the committed rocprofv3 PMC passes
-    (profiles/r04_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this exact
+    (profiles/r05_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this exact
     workload), with the git head and the kernel-source hash the profile was taken at.  The number is nulled
     when the workload or the sources differ from the profiled ones."""
-    info = {"traffic": None, "traffic_profile_head": None, "traffic_profile": "profiles/r04_tpi67_traffic.json"}
-    path = os.path.join(REPO, "profiles", "r04_tpi67_traffic.json")
+    info = {"traffic": None, "traffic_profile_head": None, "traffic_profile": "profiles/r05_tpi67_traffic.json"}
+    path = os.path.join(REPO, "profiles", "r05_tpi67_traffic.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -140,13 +140,13 @@ def measured_traffic(ny, nx, size, world):
 
 
 def valu_bound(ny, nx, size, world, kernel_ms):
-    """What bounds the kernel in practice: vector-ALU issue.  profiles/r04_tpi67_valu_bound.json (tools/valu_bound.py)
+    """What bounds the kernel in practice: vector-ALU issue.  profiles/r05_tpi67_valu_bound.json (tools/valu_bound.py)
     prices the kernel's own instruction stream - the row loop's instructions by issue class from the ISA, the rest
     from the launch's SQ_INSTS_VALU counter - with the issue costs measured on the GPU; the fraction is that time
     over the measured one.  Nulled when the workload or the kernel sources differ from the profiled ones."""
-    info = {"valu_bound_ms": None, "frac_of_valu_bound": None, "valu_bound_profile": "profiles/r04_tpi67_valu_bound.json"}
+    info = {"valu_bound_ms": None, "frac_of_valu_bound": None, "valu_bound_profile": "profiles/r05_tpi67_valu_bound.json"}
     try:
-        with open(os.path.join(REPO, "profiles", "r04_tpi67_valu_bound.json")) as fh:
+        with open(os.path.join(REPO, "profiles", "r05_tpi67_valu_bound.json")) as fh:
             prof = json.load(fh)
     except (OSError, ValueError):
         info["valu_bound_note"] = "no committed profile"
@@ -261,12 +261,12 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
             # what bounds STD in practice: vector-ALU issue too (tools/valu_bound.py std: the launch's SQ_INSTS_VALU priced at
             # the phase loop's mix of issue classes)
             try:
-                with open(os.path.join(REPO, "profiles", "r04_std67_valu_bound.json")) as fh:
+                with open(os.path.join(REPO, "profiles", "r05_std67_valu_bound.json")) as fh:
                     prof = json.load(fh)
                 if prof.get("kernel_sources_sha256") == kernel_sources_sha256() and prof.get("valu_bound_ms"):
                     out["std_s67"]["valu_bound_ms"] = prof["valu_bound_ms"]
                     out["std_s67"]["frac_of_valu_bound"] = round(prof["valu_bound_ms"] / out["std_s67"]["ms"], 4)
-                    out["std_s67"]["valu_bound_profile"] = "profiles/r04_std67_valu_bound.json"
+                    out["std_s67"]["valu_bound_profile"] = "profiles/r05_std67_valu_bound.json"
                 else:
                     out["std_s67"]["valu_bound_note"] = "kernel sources changed since tools/valu_bound.py std ran"
             except (OSError, ValueError):
@@ -579,6 +579,8 @@ def main():
     d.synth_dem(rows_local, nx, row0=row0, seed=0, out=block, out_row=first_row)
     out = d.DeviceArray(rows_local, nx)
     d.sync()
+    if sharded:
+        sd.classify()  # collective: the class of the whole raster (every shard takes the kernels the single GPU takes)
 
     if not sharded:
         blk = d.Block(block)

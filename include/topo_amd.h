@@ -12,7 +12,8 @@
  *     message is available from topo_amd_last_error() (thread-local).
  *   - arrays are C-contiguous float32, ny rows x nx columns, row pitch == nx.
  *   - *_f32 entry points take HOST pointers, do upload -> kernels -> download and return
- *     when the result is in the caller's buffer.  Nothing is retained after return.
+ *     when the result is in the caller's buffer.  No pointer is retained after return (the
+ *     device planes are: topo_amd_release_host_planes).
  *   - *_dev entry points take DEVICE pointers obtained from topo_amd_malloc, enqueue on the
  *     library's compute stream and return immediately; call topo_amd_sync() before reading.
  *   - row-block form: a device block holds `in_rows` consecutive rows of a global
@@ -92,17 +93,20 @@ int topo_amd_sync(void);
  *     written it with kernels of its own, says so with topo_amd_dem_changed;
  *   - the host-buffer entry points scan the caller's array;
  *   - a PARTIAL row block uses the class the calling thread declared: topo_amd_raster_scan_dev adds up the lattice points
- *     of the rows each block owns (counts += {samples, samples finite and beyond 1e5}; range = {min, max} of the samples
- *     within +-2^18; start from 0, 0 and +inf, -inf), topo_amd_raster_class_from_scan declares the sum;
+ *     of the rows each block owns (counts += {samples, samples finite and beyond 1e5, samples with a fractional part};
+ *     range = {min, max} of the samples within +-2^18; start from 0, 0, 0 and +inf, -inf),
+ *     topo_amd_raster_class_from_scan declares the sum (the share of fractional samples only picks which exact disc
+ *     kernels run first: time, never bits);
  *     topo_amd_shard_classify does both for a row shard, with an all-reduce over the communicator (collective).  A thread
  *     that has declared nothing sees the last declaration of any thread; with none at all the raster is taken for an
- *     ordinary DEM in metres (large = 0, range 0 ... 4096).  large < 0 withdraws the declarations.                       */
+ *     ordinary DEM in whole metres (large = 0, range 0 ... 4096, no fractional samples).  large < 0 withdraws the
+ *     declarations.                                                                                                      */
 int topo_amd_dem_changed(const void* dptr, size_t bytes); /* bytes == 0: the whole allocation dptr lies in */
 int topo_amd_raster_scan_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int own_row0, int own_rows,
-                             uint64_t counts[2], float range[2]);
-int topo_amd_raster_class_from_scan(const uint64_t counts[2], const float range[2]);
-int topo_amd_raster_class_set(int large, float lo, float hi);
-int topo_amd_raster_class_get(int* large, float* lo, float* hi);
+                             uint64_t counts[3], float range[2]);
+int topo_amd_raster_class_from_scan(const uint64_t counts[3], const float range[2]);
+int topo_amd_raster_class_set(int large, float lo, float hi, float frac_share);
+int topo_amd_raster_class_get(int* large, float* lo, float* hi, float* frac_share);
 
 /* HIP-event stopwatch on the compute stream (what bench.py times kernels with). */
 int topo_amd_timer_start(void);
@@ -231,6 +235,10 @@ int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny
 int topo_amd_mean_std_dev(const float* in, size_t count, double* mean, double* stdev);
 
 /* ---- descriptors, host-buffer form (single block, whole DEM) -------------------------- */
+/* Upload, kernels and download run in row chunks on three streams (upload || kernels || download: row blocks give the
+ * single block's bits), page-locked arrays (topo_amd_host_alloc) and pageable ones alike.  The device planes a call needs
+ * are kept for the next call (grow-only); topo_amd_release_host_planes() gives them back to the device.                  */
+int topo_amd_release_host_planes(void);
 int topo_amd_tpi_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
 int topo_amd_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
 int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigma,

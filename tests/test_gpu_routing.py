@@ -266,3 +266,37 @@ def test_resident_buffer_refilled_through_the_library():
         assert np.array_equal(out.to_host(), fresh[kind], equal_nan=True), kind
     dev.free()
     out.free()
+
+
+@pytest.mark.parametrize("size", [43, 65, 67])
+def test_std_on_fractional_elevations_by_three_marching_passes(size):
+    """STD / TPI + STD at 43 ... 67 px on a raster of mostly fractional elevations: three marching passes (sums of trunc(x),
+    of (trunc(x) - c)^2, of the fractional parts) instead of the general kernel's three staging passes per tile (VERDICT r04
+    item 2b).  The route is picked from the share of fractional samples in the raster class - time only: the same raster as
+    row blocks WITHOUT a declared class (taken for whole metres: ring kernel, then the general kernel) must give the same
+    bits, and both the float64 evaluation of the reference's formula."""
+    gny, nx = 360, 512
+    dem = orc.synthetic_dem(gny, nx, seed=100 + size, integer=False)
+    dem[150:215, 100:330] = np.rint(dem[150:215, 100:330])  # whole metres inside: the integer form of those windows
+    dem[40:44, 400:440] = -9999.0                            # nodata: tiles with too much relief for the 32-bit chains
+    t, s = topo.tpi_std(dem, size)
+    et, es = orc.tpi_exact(dem, size), orc.std_exact(dem, size)
+    assert np.max(np.abs(t - et)) <= 2.5e-4 * 3.0, size     # (-9999 next to terrain: float32 output rounding of larger values)
+    assert np.max(np.abs(s - es)) <= 1e-4 * np.max(es), size
+    assert np.array_equal(topo.std(dem, size), s.astype(np.float64))
+    up, down = shard.halo_rows(_lib.DESC_TPI, size)
+    d.forget_raster_class()
+    for nb in (2, 3):
+        pieces_t, pieces_s = [], []
+        for row0, rows in shard.split_rows(gny, nb):
+            lo, hi = max(0, row0 - up), min(gny, row0 + rows + down)
+            dev = d.DeviceArray.from_host(dem[lo:hi])
+            to, so = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+            d.Block(dev, row0=lo, gny=gny).tpi_std(size, tpi=to, std=so, out_row0=row0, out_rows=rows)
+            d.sync()
+            pieces_t.append(to.to_host())
+            pieces_s.append(so.to_host())
+            for a in (dev, to, so):
+                a.free()
+        assert np.array_equal(np.concatenate(pieces_t), t), (size, nb, "tpi")
+        assert np.array_equal(np.concatenate(pieces_s), s), (size, nb, "std")

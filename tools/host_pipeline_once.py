@@ -19,6 +19,16 @@ lib = _lib.lib()
 if "warm_pageable" in sys.argv:
     from topo_descriptors_amd import topo
     topo.tpi(np.zeros((4096, 4096), np.float32), 67)
+if "bench" in sys.argv:  # exactly what bench.py's end_to_end section does
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from topo_descriptors_amd import device as d
+    print(bench.end_to_end(d, _lib, 67))
+    sys.exit(0)
+if "big_pageable" in sys.argv:
+    from topo_descriptors_amd import topo
+    w = topo.tpi(np.rint(1900.0 + 300.0 * np.random.default_rng(1).standard_normal((n, n))).astype(np.float32), 67)
+    del w
 dem = np.rint(1900.0 + 300.0 * np.random.default_rng(0).standard_normal((n, n))).astype(np.float32)
 hin, hout = C.c_void_p(), C.c_void_p()
 _lib.check(lib.topo_amd_host_alloc(C.byref(hin), dem.nbytes), "host_alloc")

@@ -155,12 +155,13 @@ namespace {
 constexpr float kClassLarge = 1.0e5f;     // kWild of gauss.hip: what the f16 matrix-core kernels stage as 0 and repair
 constexpr float kClassOrdinary = 262144.0f;  // kAbsLim of the disc kernels
 struct Scan {
-    unsigned long long taken = 0, large = 0;
+    unsigned long long taken = 0, large = 0, frac = 0;
     float lo = INFINITY, hi = -INFINITY;
     void add(float x) {
         ++taken;
         const float a = std::fabs(x);
         if (a > kClassLarge && a <= 3.0e38f) ++large;
+        if (a <= 3.0e38f && x != std::trunc(x)) ++frac;
         if (a <= kClassOrdinary) {  // (false for NaN)
             lo = std::min(lo, x);
             hi = std::max(hi, x);
@@ -171,6 +172,7 @@ inline int lattice_step(int extent) { return std::max(1, extent / 128); }
 RasterClass class_of(const Scan& s) {
     RasterClass c;
     c.large = 4 * s.large > s.taken;
+    c.frac_share = s.taken ? (float)((double)s.frac / (double)s.taken) : 0.0f;
     c.lo = s.lo;
     c.hi = s.hi;
     return c;
@@ -185,7 +187,7 @@ float from_ordered_bits(uint32_t k) {
     std::memcpy(&f, &u, sizeof(f));
     return f;
 }
-// words: [0] taken, [1] large, [2] min key, [3] max key (pinned host memory)
+// words: [0] taken, [1] large, [2] min key, [3] max key, [4] fractional (pinned host memory)
 __global__ __launch_bounds__(256) void raster_scan_kernel(const float* in, int in_rows, int in_row0, int nx, int own_row0, int own_rows,
                                                           int step_r, int step_c, int ni, int nj, uint32_t* words) {
     const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256) void raster_scan_kernel(const float* in, int i
     const float a = fabsf(x);
     const bool large = take && a > kClassLarge && a <= 3.0e38f;
     const bool ordinary = take && a <= kClassOrdinary;
+    const bool fractional = take && a <= 3.0e38f && x != truncf(x);
     uint32_t kmin = ordinary ? ordered_bits(x) : 0xffffffffu, kmax = ordinary ? ordered_bits(x) : 0u;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -203,9 +206,11 @@ __global__ __launch_bounds__(256) void raster_scan_kernel(const float* in, int i
         kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, m));
     }
     const unsigned long long mt = __builtin_amdgcn_ballot_w64(take), ml = __builtin_amdgcn_ballot_w64(large);
+    const unsigned long long mf = __builtin_amdgcn_ballot_w64(fractional);
     if ((threadIdx.x & 63) == 0 && mt) {
         __hip_atomic_fetch_add(words, (uint32_t)__builtin_popcountll(mt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (ml) __hip_atomic_fetch_add(words + 1, (uint32_t)__builtin_popcountll(ml), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (mf) __hip_atomic_fetch_add(words + 4, (uint32_t)__builtin_popcountll(mf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_fetch_min(words + 2, kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_fetch_max(words + 3, kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -216,9 +221,9 @@ std::mutex g_scan_mu;
 int scan_block(const Block& b, int own_row0, int own_rows, Scan* out) {
     std::lock_guard<std::mutex> lock(g_scan_mu);
     Context& c = ctx();
-    if (!g_scan_words) TOPO_HIP(hipHostMalloc((void**)&g_scan_words, 4 * sizeof(uint32_t), hipHostMallocMapped));
+    if (!g_scan_words) TOPO_HIP(hipHostMalloc((void**)&g_scan_words, 8 * sizeof(uint32_t), hipHostMallocMapped));
     TOPO_HIP(hipStreamSynchronize(c.compute));  // (no scan of an earlier call in flight on the words; the block's data are final)
-    g_scan_words[0] = g_scan_words[1] = 0;
+    g_scan_words[0] = g_scan_words[1] = g_scan_words[4] = 0;
     g_scan_words[2] = 0xffffffffu;
     g_scan_words[3] = 0u;
     const int step_r = lattice_step(b.gny), step_c = lattice_step(b.nx);
@@ -230,6 +235,7 @@ int scan_block(const Block& b, int own_row0, int own_rows, Scan* out) {
     TOPO_HIP(hipStreamSynchronize(c.compute));
     out->taken += g_scan_words[0];
     out->large += g_scan_words[1];
+    out->frac += g_scan_words[4];
     if (g_scan_words[2] <= g_scan_words[3]) {
         out->lo = std::min(out->lo, from_ordered_bits(g_scan_words[2]));
         out->hi = std::max(out->hi, from_ordered_bits(g_scan_words[3]));
@@ -475,17 +481,31 @@ struct HostRun {
     std::vector<std::thread> touchers;
     ~HostRun() {
         ready();
-        for (size_t k = 0; k < bufs.size(); ++k) {
-            dem_memo_forget(bufs[k], sizes[k]);
-            (void)hipFree(bufs[k]);
-        }
+        for (size_t k = 0; k < bufs.size(); ++k) dem_memo_forget(bufs[k], sizes[k]);  // (the planes stay; what was known about their content goes)
     }
     std::vector<size_t> sizes;
+    // the k-th plane this call asks for is the k-th plane of the context's pool (Context::host_planes), grown when it must be
     int alloc(void** p, size_t bytes) {
-        TOPO_HIP(hipMalloc(p, bytes));
+        Context& c = ctx();
+        const size_t k = bufs.size();
+        if (c.host_planes.size() <= k) {
+            c.host_planes.resize(k + 1, nullptr);
+            c.host_plane_bytes.resize(k + 1, 0);
+        }
+        if (c.host_plane_bytes[k] < bytes) {
+            if (c.host_planes[k]) {
+                TOPO_HIP(hipStreamSynchronize(c.compute));
+                TOPO_HIP(hipFree(c.host_planes[k]));
+                c.host_planes[k] = nullptr;
+                c.host_plane_bytes[k] = 0;
+            }
+            TOPO_HIP(hipMalloc(&c.host_planes[k], bytes));
+            c.host_plane_bytes[k] = bytes;
+        }
+        *p = c.host_planes[k];
         bufs.push_back(*p);
         sizes.push_back(bytes);
-        dem_memo_forget(*p, bytes);  // (the allocator hands the same addresses out again: nothing is known about this one)
+        dem_memo_forget(*p, c.host_plane_bytes[k]);  // (another call's data: nothing is known about this plane)
         return TOPO_AMD_OK;
     }
     void prefault(void* host, size_t bytes) {
@@ -836,6 +856,8 @@ int topo_amd_shutdown(void) {
     (void)hipEventDestroy(c.t1);
     (void)hipStreamDestroy(c.compute);
     (void)hipStreamDestroy(c.comm);
+    for (void* q : c.host_planes)
+        if (q) (void)hipFree(q);
     if (c.up) {
         (void)hipStreamDestroy(c.up);
         (void)hipStreamDestroy(c.down);
@@ -896,6 +918,21 @@ int topo_amd_host_alloc(void** hptr, size_t bytes) {
 int topo_amd_host_free(void* hptr) {
     TOPO_TRY(require_ready());
     if (hptr) TOPO_HIP(hipHostFree(hptr));
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_release_host_planes(void) {
+    TOPO_TRY(require_ready());
+    Context& c = ctx();
+    TOPO_HIP(hipStreamSynchronize(c.compute));
+    for (size_t k = 0; k < c.host_planes.size(); ++k) {
+        if (c.host_planes[k]) {
+            dem_memo_forget(c.host_planes[k], c.host_plane_bytes[k]);
+            TOPO_HIP(hipFree(c.host_planes[k]));
+        }
+    }
+    c.host_planes.clear();
+    c.host_plane_bytes.clear();
     return TOPO_AMD_OK;
 }
 
@@ -1034,7 +1071,7 @@ int topo_amd_dem_changed(const void* dptr, size_t bytes) {
 }
 
 int topo_amd_raster_scan_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int own_row0, int own_rows,
-                             uint64_t counts[2], float range[2]) {
+                             uint64_t counts[3], float range[2]) {
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(in && counts && range && gny >= 1 && nx >= 1 && in_rows >= 1 && in_row0 >= 0 && in_row0 + in_rows <= gny,
                  "raster_scan: bad block");
@@ -1048,23 +1085,25 @@ int topo_amd_raster_scan_dev(const float* in, int in_rows, int in_row0, int gny,
     TOPO_TRY(scan_block(b, own_row0, own_rows, &s));
     counts[0] += s.taken;
     counts[1] += s.large;
+    counts[2] += s.frac;
     range[0] = s.lo;
     range[1] = s.hi;
     return TOPO_AMD_OK;
 }
 
-int topo_amd_raster_class_set(int large, float lo, float hi) {
+int topo_amd_raster_class_set(int large, float lo, float hi, float frac_share) {
     if (large < 0) {  // forget the declaration (this thread's and the process-wide one)
         t_declared = false;
         std::lock_guard<std::mutex> lock(g_declared_mu);
         g_declared = false;
         return TOPO_AMD_OK;
     }
-    TOPO_REQUIRE(!(lo != lo) && !(hi != hi), "raster_class_set: NaN range");
+    TOPO_REQUIRE(!(lo != lo) && !(hi != hi) && frac_share >= 0.0f && frac_share <= 1.0f, "raster_class_set: bad range or share");
     RasterClass c;
     c.large = large != 0;
     c.lo = lo;
     c.hi = hi;
+    c.frac_share = frac_share;
     t_declared = true;
     t_declared_class = c;
     std::lock_guard<std::mutex> lock(g_declared_mu);
@@ -1073,23 +1112,25 @@ int topo_amd_raster_class_set(int large, float lo, float hi) {
     return TOPO_AMD_OK;
 }
 
-int topo_amd_raster_class_from_scan(const uint64_t counts[2], const float range[2]) {
+int topo_amd_raster_class_from_scan(const uint64_t counts[3], const float range[2]) {
     TOPO_REQUIRE(counts && range, "raster_class_from_scan: NULL argument");
     Scan s;
     s.taken = counts[0];
     s.large = counts[1];
+    s.frac = counts[2];
     s.lo = range[0];
     s.hi = range[1];
     const RasterClass c = class_of(s);
-    return topo_amd_raster_class_set(c.large ? 1 : 0, c.lo, c.hi);
+    return topo_amd_raster_class_set(c.large ? 1 : 0, c.lo, c.hi, c.frac_share);
 }
 
-int topo_amd_raster_class_get(int* large, float* lo, float* hi) {
-    TOPO_REQUIRE(large && lo && hi, "raster_class_get: NULL output");
+int topo_amd_raster_class_get(int* large, float* lo, float* hi, float* frac_share) {
+    TOPO_REQUIRE(large && lo && hi && frac_share, "raster_class_get: NULL output");
     const RasterClass c = declared_class();
     *large = c.large ? 1 : 0;
     *lo = c.lo;
     *hi = c.hi;
+    *frac_share = c.frac_share;
     return TOPO_AMD_OK;
 }
 
@@ -1693,23 +1734,24 @@ int topo_amd_shard_classify(const float* owned, int rows_local, int row0, int gn
         void* d = nullptr;
         TOPO_TRY(workspace(0, 64, &d));
         struct Wire {
-            unsigned long long counts[2];
+            unsigned long long counts[3];
             float lo, hi;
-        } w{{s.taken, s.large}, s.lo, s.hi};
+        } w{{s.taken, s.large, s.frac}, s.lo, s.hi};
         TOPO_HIP(hipMemcpyAsync(d, &w, sizeof(w), hipMemcpyHostToDevice, c.compute));
         char* base = (char*)d;
-        TOPO_NCCL(ncclAllReduce(base, base, 2, ncclUint64, ncclSum, g_comm.comm, c.compute));
-        TOPO_NCCL(ncclAllReduce(base + 16, base + 16, 1, ncclFloat, ncclMin, g_comm.comm, c.compute));
-        TOPO_NCCL(ncclAllReduce(base + 20, base + 20, 1, ncclFloat, ncclMax, g_comm.comm, c.compute));
+        TOPO_NCCL(ncclAllReduce(base, base, 3, ncclUint64, ncclSum, g_comm.comm, c.compute));
+        TOPO_NCCL(ncclAllReduce(base + 24, base + 24, 1, ncclFloat, ncclMin, g_comm.comm, c.compute));
+        TOPO_NCCL(ncclAllReduce(base + 28, base + 28, 1, ncclFloat, ncclMax, g_comm.comm, c.compute));
         TOPO_HIP(hipMemcpyAsync(&w, d, sizeof(w), hipMemcpyDeviceToHost, c.compute));
         TOPO_HIP(hipStreamSynchronize(c.compute));
         s.taken = w.counts[0];
         s.large = w.counts[1];
+        s.frac = w.counts[2];
         s.lo = w.lo;
         s.hi = w.hi;
     }
     const RasterClass cls = class_of(s);
-    return topo_amd_raster_class_set(cls.large ? 1 : 0, cls.lo, cls.hi);
+    return topo_amd_raster_class_set(cls.large ? 1 : 0, cls.lo, cls.hi, cls.frac_share);
 }
 
 int topo_amd_halo_wait(void) {

@@ -109,6 +109,11 @@ struct Context {
     size_t lds_per_block = 65536;
     hipStream_t compute = nullptr;   // every kernel goes here
     hipStream_t comm = nullptr;      // RCCL ghost-row traffic
+    // device planes of the host-buffer entry points: grow-only, handed out in the order a call asks for them and kept for
+    // the next call (a hipMalloc / hipFree pair per GiB plane and call cost milliseconds, and copies out of freshly
+    // mapped memory ran at half the link's rate: profiles/r05_host_pipeline.txt).  topo_amd_release_host_planes frees them.
+    std::vector<void*> host_planes;
+    std::vector<size_t> host_plane_bytes;
     hipStream_t up = nullptr, down = nullptr;  // the copies of a pipelined host-buffer call (capi.hip, run_pipelined; created on first use)
     std::vector<hipEvent_t> pipe_events;        // its events: uploaded chunk k, computed chunk k
     hipStream_t aux = nullptr;       // bandwidth-bound epilogues running next to matrix-core kernels (created on first use)
@@ -201,6 +206,7 @@ int gaussian_radius(double sigma);
 struct RasterClass {
     bool large = false;   // more than a quarter of the lattice samples are finite and beyond +-1e5
     float lo = 0.0f, hi = 4096.0f;  // smallest / largest ordinary lattice sample (finite, within +-2^18); lo > hi: none seen
+    float frac_share = 0.0f;        // share of the lattice samples with a fractional part (TIME only: which disc kernels go first)
 };
 RasterClass current_class();  // of the call in flight on this thread (capi.hip sets it around the launchers)
 

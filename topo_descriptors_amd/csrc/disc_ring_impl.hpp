@@ -991,8 +991,9 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                     const bool rows_inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1;
                     if (BORDER) {
                         // (a tile the main launch has not left for this one - it found it fractional, or too wide - stays as it is)
+                        // (read by every wave here, written back only at the tile's last phase - behind the barriers of the phases
+                        // in between - so that no wave reads what another has already changed)
                         tmode = p.defer[tile] == kTileBorder ? kTileDone : kTileGeneral;
-                        if (threadIdx.x == 0 && tmode == kTileDone) p.defer[tile] = (uint8_t)kTileDone;
                     } else {
                         tmode = !rows_inside || !cols_inside ? (p.border_later ? kTileBorder : kTileGeneral) : kTileDone;
                         if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
@@ -1102,6 +1103,7 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                 }
             }
             if (BOTH && ph % PPT == PPT - 1 && tmode == kNeedsFraction && threadIdx.x == 0) p.defer[tile] = kTileDone;
+            if (BORDER && ph % PPT == PPT - 1 && tmode == kTileDone && threadIdx.x == 0) p.defer[tile] = kTileDone;
             if (!BOTH && ph % PPT == PPT - 1 && tmode == kTileGeneral) ++seen_general;
             const Seen seen = convert_batch(C::PRO + ph * B, va, nq, nq2, nqf);
             s0 += B;
@@ -1132,8 +1134,10 @@ __global__ __launch_bounds__(768) void std_ring_kernel_parts(WaveParts ps, int t
     TOPO_RUN_PARTS((std_ring_kernel_body<SIZE, WANT_TPI, MODE>));
 }
 
+constexpr bool std_ring_border_pass(int size) { return size <= 17; }
+
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
-int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
+int launch_std_ring(const Block& b, float* tpi_out, float* std_out, bool border_later = false) {
     using G = RGeo<SIZE, 4>;
     using C = StdRingCfg<SIZE>;
     constexpr size_t kLds = C::LDS + (MODE == kStdBoth ? (size_t)C::R * G::W * sizeof(uint32_t) : 0);
@@ -1154,7 +1158,7 @@ int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
     int tiles_x = 0;
     long ntiles = 0;
     a.report = MODE == kStdMain ? dem_memo_report(b) : nullptr;
-    a.border_later = MODE == kStdMain && c.seams.n == 0 ? 1 : 0;  // (an ordinary call: launch_std_ring_border follows)
+    a.border_later = MODE == kStdMain && border_later ? 1 : 0;  // (launch_std_ring_border follows)
     TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);

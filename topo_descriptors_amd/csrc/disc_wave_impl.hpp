@@ -63,6 +63,8 @@ struct WaveArgs {
     uint32_t* report;   // pinned host words {tiles, tiles with fractional samples} of ONE block's run (dem_memo), or nullptr
     float unit;         // the scaled route: samples are summed as rint(unit x), unit = 2^8 ... 2^16 (scaled_unit)
     uint64_t* rowmask;  // per tile of state kTileGeneralRows: the rows (bit = row of the tile) the general kernel is to write
+    uint32_t* sums2;    // fractional STD by three marching passes: sum of (trunc(x) - c)^2 per pixel, laid out like the outputs ...
+    int32_t* tile_c;    // ... and the offset c of every tile that has them
     const int32_t* border_list;  // std_ring_kernel<kStdBorder>: the tiles at the DEM's border (indices of the main launch's tile list)
     int border_later;            // std_ring_kernel<kStdMain>: 1 = leave those tiles to that launch (kTileBorder), 0 = to the general kernel
 };
@@ -194,17 +196,22 @@ inline int make_parts(const Block& b, const WaveArgs& a0, int tile_h, int strip_
     }
     if (want_defer) {
         void* defer = nullptr;  // the same sizes in every launch of a group, so the same slices of one allocation
-        const size_t masks_at = (defer_off[n] + 15) & ~(size_t)15;  // one uint64 per tile behind the state bytes
-        TOPO_TRY(workspace(8, masks_at + defer_off[n] * sizeof(uint64_t), &defer));
+        const size_t masks_at = (defer_off[n] + 15) & ~(size_t)15;  // one uint64 per tile behind the state bytes, then one int32
+        const size_t cs_at = masks_at + defer_off[n] * sizeof(uint64_t);
+        TOPO_TRY(workspace(8, cs_at + defer_off[n] * sizeof(int32_t), &defer));
         for (int k = 0; k < n; ++k) {
             ps->a[k].defer = (uint8_t*)defer + defer_off[k];
             ps->a[k].rowmask = (uint64_t*)((uint8_t*)defer + masks_at) + defer_off[k];
+            ps->a[k].tile_c = (int32_t*)((uint8_t*)defer + cs_at) + defer_off[k];
         }
     }
     if (want_sums) {
         void* sums = nullptr;
-        TOPO_TRY(workspace(9, sums_off[n] * sizeof(int32_t), &sums));
-        for (int k = 0; k < n; ++k) ps->a[k].sums = (int32_t*)sums + sums_off[k];
+        TOPO_TRY(workspace(9, 2 * sums_off[n] * sizeof(int32_t), &sums));  // (the second half: WaveArgs::sums2)
+        for (int k = 0; k < n; ++k) {
+            ps->a[k].sums = (int32_t*)sums + sums_off[k];
+            ps->a[k].sums2 = (uint32_t*)sums + sums_off[n] + sums_off[k];
+        }
     }
     ps->n = n;
     ps->gate = Gate{nullptr, 0, nullptr, 0, nullptr, nullptr};
@@ -481,7 +488,10 @@ __device__ __forceinline__ float std_from_exact_sums(int64_t T, __int128 S2, int
     if (var < 0.0) var = 0.0;
     return sqrtf((float)var);
 }
-enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4 };
+// kTileFloat (the name is round 1's): samples beyond 2^18 or more relief than the 32-bit chains hold - the limb passes.
+// kTileMissing: a missing sample (non-finite, beyond +-2^24) - staged as u = 0 by every pass and counted by one more (kStInd),
+// the pixels whose discs hold one are NaN; the tile's other passes are the ordinary ones unless kTileFloat is up as well.
+enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4, kTileMissing = 8 };
 // The per-tile byte map (WaveArgs::defer).  kTileDone: finished; kTileGeneral: left to the general kernel (disc_wave_kernel);
 // kNeedsFraction: its sums of trunc(x) are done, the fraction / scaled pass finishes it.
 // kTileGeneralRows: the general kernel writes only the rows named in WaveArgs::rowmask (the scaled route left them: their
@@ -506,8 +516,9 @@ __device__ __forceinline__ uint32_t stage_value(float x, float c, int ci, int au
     // inside int32, the sums are exact (hence the same for every row block and every kernel that
     // forms them, and a running prefix may be carried from tile to tile), and the quantisation,
     // at most 7.6e-6 m per sample, is two orders below the reference's own float32-FFT floor
-    if (WHAT == kStF) return (uint32_t)(int)rintf((x - t) * 65536.0f);
-    const int u = (int)t - ci;
+    const bool missing = !(fabsf(t) < kMissingLim);  // (a missing sample counts as "no tap" in every sum)
+    if (WHAT == kStF) return missing ? 0u : (uint32_t)(int)rintf((x - t) * 65536.0f);
+    const int u = missing ? 0 : (int)t - ci;
     if (WHAT == kStU) return (uint32_t)u;
     return (uint32_t)u * (uint32_t)u;
 }
@@ -550,7 +561,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     int flags = 0;
     uint32_t umax = 0;  // largest |trunc(x) - c| seen, as float bits (NaN / inf sort above all)
     uint32_t tmax = 0;  // largest |trunc(x)| (the builds with STD: a sample beyond 2^18 sends the tile to the limb path whatever c is)
-    bool frac = false;
+    bool frac = false, any_missing = false;
     int smin = 0x7fffffff, smax = -0x7fffffff - 1;
     Vec4<T> run{{(T)0, (T)0, (T)0, (T)0}};
     if (wave == 0) *reinterpret_cast<Vec4<T>*>(Q + lane * NC) = run;
@@ -568,10 +579,15 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
                     // one pass classifies the tile and yields u: d = trunc(x) - c is exact in float
                     const float t = truncf(x);
                     const float d = t - c;
-                    frac |= ok && (x != t);
-                    umax = max(umax, ok ? (__float_as_uint(ABS_CLASS ? t : d) & 0x7fffffffu) : 0u);
-                    if (!ABS_CLASS) tmax = max(tmax, ok ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
-                    bits = ok ? (uint32_t)(int)d : 0u;
+                    // (the marching builds - TAKE / ABS_CLASS with p.defer - leave a tile with a missing sample to the general
+                    // kernel through kTileFloat, as before; the general kernel tells the two apart)
+                    const bool missing = ok && !(fabsf(t) < kMissingLim);
+                    const bool counts = ok && !missing;
+                    any_missing |= missing;
+                    frac |= counts && (x != t);
+                    umax = max(umax, counts ? (__float_as_uint(ABS_CLASS ? t : d) & 0x7fffffffu) : 0u);
+                    if (!ABS_CLASS) tmax = max(tmax, counts ? (__float_as_uint(t) & 0x7fffffffu) : 0u);
+                    bits = counts ? (uint32_t)(int)d : 0u;
                 } else {
                     bits = ok ? stage_value<WHAT>(x, c, ci, aux) : 0u;
                     if (WHAT == kStS && ABS_CLASS) {  // the take-all scaled build classifies the window itself
@@ -595,7 +611,8 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     if (kClassify) {
         if (frac) flags |= kTileFrac;
         if (!ABS_CLASS && umax > __float_as_uint(lim32)) flags |= kTileWide;
-        if (umax > __float_as_uint(ABS_CLASS ? kAbsLim : limcv) || tmax > __float_as_uint(kAbsLim)) flags |= kTileFloat;  // also NaN / inf
+        if (umax > __float_as_uint(ABS_CLASS ? kAbsLim : limcv) || tmax > __float_as_uint(kAbsLim)) flags |= kTileFloat;
+        if (any_missing) flags |= kTileMissing;
     }
     *reinterpret_cast<Vec4<T>*>(TOT + wave * ROWW + lane * NC) = run;
     // tile flags: one ballot per bit inside the wave, one LDS atomic per wave, and the barrier the
@@ -605,6 +622,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
         if (__builtin_amdgcn_ballot_w64(flags & kTileFrac)) wf |= kTileFrac;
         if (__builtin_amdgcn_ballot_w64(flags & kTileWide)) wf |= kTileWide;
         if (__builtin_amdgcn_ballot_w64(flags & kTileFloat)) wf |= kTileFloat;
+        if (__builtin_amdgcn_ballot_w64(flags & kTileMissing)) wf |= kTileMissing;
         if (lane == 0 && wf) atomicOr(flag_word, wf);
     }
     if (WHAT == kStS) block_range(flag_word, smin, smax);
@@ -730,18 +748,21 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
         };
 
         const int flags = stage_prefix<SIZE, TH, NWAVES, kStU, int, ABS_CLASS>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
-        const bool use_float = (flags & kTileFloat) != 0;
+        const bool use_float = (flags & kTileFloat) != 0;      // the limb passes
+        const bool has_missing = (flags & kTileMissing) != 0;  // one more pass counts the missing samples per disc
         const bool wide = (flags & kTileWide) != 0;
         const bool frac = (flags & kTileFrac) != 0;
         // TPI alone on an integer-valued tile needs one pass: its rows are finalised straight from
         // the chain, without the round trip through the scratch planes
-        const bool direct = !WANT_STD && !use_float && !frac;
+        const bool direct = !WANT_STD && !use_float && !frac && !has_missing;
         const int ocol = ox0 + lane * NC;
         const bool lane_ok = lane < G::NVL && ocol < p.nx;
         auto finalise_row = [&](int jj, const Vec4<uint32_t>& q0, const Vec4<uint32_t>& q1,
                                 const Vec4<uint32_t>& q2, const Vec4<uint32_t>& q3) {
             const int oy = oy0 + jj;
             if (!lane_ok || oy < p.out_row0 || oy >= p.out_row0 + p.out_rows || !((rows_wanted >> jj) & 1)) return;
+            Vec4<uint32_t> ind{{0u, 0u, 0u, 0u}};
+            if (has_missing) ind = get(5, jj);  // (kStInd: missing samples in the disc, in the upper half)
             Vec4<float> xs{{0.f, 0.f, 0.f, 0.f}};
             if (WANT_TPI) xs = *reinterpret_cast<const Vec4<float>*>(p.in + (size_t)(oy - p.in_row0) * p.nx + ocol);
             Vec4<float> out_t, out_s;
@@ -785,6 +806,12 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                         x_ctr = in ? (double)p.in[(size_t)(cy2 - p.in_row0) * p.nx + cx2] : 0.0;
                     }
                     out_t.v[t] = (float)((double)xs.v[t] - (s1 - x_ctr) * inv_nm1);
+                }
+            }
+            if (has_missing) {
+#pragma unroll
+                for (int t = 0; t < NC; ++t) {
+                    if ((ind.v[t] >> 16) != 0) out_s.v[t] = out_t.v[t] = __uint_as_float(0x7fc00000u);  // a missing sample in the disc: no value
                 }
             }
             const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
@@ -902,6 +929,18 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                     put(2, wave + k * NWAVES, hi);
                 }
             }
+            }
+            if (has_missing) {
+                // missing samples (staged as u = 0 by the passes above): their count per disc, so that exactly the pixels
+                // whose discs hold one come out as NaN
+                __syncthreads();
+                stage_prefix<SIZE, TH, NWAVES, kStInd, uint32_t>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
+#pragma unroll 1
+                for (int k = 0; k < RW; ++k) {
+                    uint32_t acc[NC];
+                    wave_disc_sum<SIZE, uint32_t, 0, kPipe>(lds_u, wave + k * NWAVES, lane, acc);
+                    put(5, wave + k * NWAVES, acc);
+                }
             }
         } else {
             // the limb path (Stage, above): counts of the samples that are not ordinary / missing, then u and u^2 limb by limb
@@ -1139,7 +1178,9 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
 // are, go to p.sums instead of TPI, and the tile is marked kNeedsFraction for
 // tpi_fraction_march_kernel, which adds the sum of the fractional parts and finalises.
 
-template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
+// SUMS_ALL (with ALLOW_FRAC): the sums go to p.sums for EVERY tile - the first of the three marching passes of STD on a DEM with
+// fractional elevations (launch_wave_any): std_march_kernel needs them for the whole-metre tiles, the fraction pass for the others.
+template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false, bool SUMS_ALL = false>
 __device__ __forceinline__ void tpi_march_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = Geo<SIZE>;
     static_assert(OUT_TPI || OUT_SUM, "nothing to write");
@@ -1206,7 +1247,7 @@ __device__ __forceinline__ void tpi_march_kernel_body(const WaveArgs& p, int til
             tlast = __builtin_amdgcn_s_memtime();  // full stagings (run starts) are not in the sums
 #endif
         }
-        const bool leave = (flags & (ALLOW_FRAC ? kTileFloat : (kTileFloat | kTileFrac))) != 0;
+        const bool leave = (flags & (ALLOW_FRAC ? (kTileFloat | kTileMissing) : (kTileFloat | kTileMissing | kTileFrac))) != 0;
         if (ALLOW_FRAC) {
             const unsigned now = (flags & kTileFrac) ? 1u : 0u;
             // a full staging pass classified the whole window: it stands for every row carried on
@@ -1251,7 +1292,7 @@ __device__ __forceinline__ void tpi_march_kernel_body(const WaveArgs& p, int til
                 wave_disc_sum<SIZE, uint32_t, 0, (SIZE >= 41)>(Q, jj, lane, acc);
                 if (!lane_ok) continue;
                 const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
-                if (OUT_SUM && (!ALLOW_FRAC || SUMS_ONLY)) {
+                if (OUT_SUM && (!ALLOW_FRAC || SUMS_ONLY || SUMS_ALL)) {
                     const Vec4<int> sv{{(int)acc[0], (int)acc[1], (int)acc[2], (int)acc[3]}};
                     *reinterpret_cast<Vec4<int>*>(p.sums + o) = sv;
                 }
@@ -1300,6 +1341,10 @@ __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel(WaveArgs p, int 
 template <int SIZE, int TH, int NWAVES, bool OUT_TPI, bool OUT_SUM, bool ALLOW_FRAC = false>
 __global__ __launch_bounds__(NWAVES * 64) void tpi_march_kernel_parts(WaveParts ps, int tiles_x) {
     TOPO_RUN_PARTS((tpi_march_kernel_body<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>));
+}
+template <int SIZE, int TH, int NWAVES, bool OUT_TPI>
+__global__ __launch_bounds__(NWAVES * 64) void tpi_march_sums_kernel(WaveParts ps, int tiles_x) {  // (SUMS_ALL: one form for every call)
+    TOPO_RUN_PARTS_LOOP((tpi_march_kernel_body<SIZE, TH, NWAVES, OUT_TPI, true, true, true>));
 }
 
 // Grid of the marching launches: persistent blocks, whole XCD rounds, never more blocks than tiles.
@@ -1372,6 +1417,31 @@ int launch_march(const Block& b, float* tpi_out, bool scaled = false) {
     return launch_parts(tpi_march_kernel<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>, tpi_march_kernel_parts<SIZE, TH, NWAVES, OUT_TPI, OUT_SUM, ALLOW_FRAC>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
+// the first of the three marching passes of STD on fractional elevations: sums of trunc(x) for every tile, TPI of the whole-metre ones
+template <int SIZE, int TH, int NWAVES, bool OUT_TPI>
+int launch_march_sums(const Block& b, float* tpi_out) {
+    using G = Geo<SIZE>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0};
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16;
+    static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_march_sums_kernel<SIZE, TH, NWAVES, OUT_TPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)tpi_march_sums_kernel<SIZE, TH, NWAVES, OUT_TPI>, NWAVES * 64, lds));
+        blocks_per_cu = nblk < 1 ? 1 : nblk;
+    }
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, true, &ps, &tiles_x, &ntiles));
+    const long grid = march_grid(c, blocks_per_cu, ntiles);
+    deal_parts(&ps, tiles_x, grid, blocks_per_cu);
+    return launch_parts(nullptr, tpi_march_sums_kernel<SIZE, TH, NWAVES, OUT_TPI>, grid, NWAVES * 64, lds, ps, tiles_x);
+}
+
 // ---- TPI on tiles with fractional elevations: the fraction pass ---------------------------------
 // For the tiles tpi_march_kernel<.., ALLOW_FRAC> marked kNeedsFraction, p.sums holds the exact sum of
 // trunc(x) over the disc.  This kernel marches the prefix sums of the fractional parts (integers in
@@ -1382,7 +1452,11 @@ int launch_march(const Block& b, float* tpi_out, bool scaled = false) {
 // window is carried only from a tile this kernel processed itself; otherwise it is staged in full.
 // Each row's sum of trunc(x) arrives by an LDS-DMA load into the wave's idle slot of the segment
 // totals, in flight during the chain; the pixel's own x is an ordinary load issued before the chain.
-template <int SIZE, int TH, int NWAVES>
+// WANT_STD (the third marching pass of STD on fractional elevations): p.sums2 / p.tile_c hold sum (trunc(x) - c)^2 and c of the
+// tiles std_march_kernel<.., FRAC_STORE> went through; the pixel is finalised with the general kernel's choice and expressions
+// (the integer form when the window's fractional sum is exactly 0, else s1 = sum trunc(x) + 2^-16 sum g and
+// s2 = Su2 + 2 c Su + c^2 n in float64: exact integers whatever c is), hence with its bits.  TPI is written when p.tpi is set.
+template <int SIZE, int TH, int NWAVES, bool WANT_STD = false>
 __device__ __forceinline__ void tpi_fraction_march_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = Geo<SIZE>;
     static_assert(G::T.centre == 0, "odd disc sizes only: the zeroed tap is the pixel itself");
@@ -1393,6 +1467,7 @@ __device__ __forceinline__ void tpi_fraction_march_kernel_body(const WaveArgs& p
     uint32_t* Q = lds_u;
     uint32_t* TOT = Q + (NROWS + 1) * ROWW;
     int* flag_word = reinterpret_cast<int*>(Q + (NROWS + 1 + NWAVES) * ROWW);
+    uint32_t* TOT2 = reinterpret_cast<uint32_t*>(flag_word + 4);  // WANT_STD: a second landing row per wave (the sums of u^2)
     if (threadIdx.x == 0) *flag_word = 0;
     __syncthreads();
 
@@ -1404,6 +1479,7 @@ __device__ __forceinline__ void tpi_fraction_march_kernel_body(const WaveArgs& p
     const int first = deal.first(vb);
     const int last = min(first + deal.count(vb), ntiles);
     const double inv_nm1 = 1.0 / ((double)G::T.taps - 1.0);
+    const double nd = (double)G::T.taps, inv_n = 1.0 / nd, inv_nn1 = 1.0 / (nd * (nd - 1.0));
 
     // Nothing to do on a DEM of whole metres: find that out with one flag per lane (64 tiles per
     // load) instead of walking the run with a dependent byte load per tile.
@@ -1438,6 +1514,7 @@ __device__ __forceinline__ void tpi_fraction_march_kernel_body(const WaveArgs& p
         }
         if (threadIdx.x == 0) p.defer[tile] = kTileDone;
         carry = true;
+        const int ci = WANT_STD ? __builtin_amdgcn_readfirstlane(p.tile_c[tile]) : 0;
 
 #pragma unroll 1
         for (int k = 0; k < RW; ++k) {
@@ -1449,47 +1526,64 @@ __device__ __forceinline__ void tpi_fraction_march_kernel_body(const WaveArgs& p
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.sums + o),
                                              (__attribute__((address_space(3))) void*)(TOT + wave * ROWW + lane * NC), 16,
                                              0, 0);
+            if (WANT_STD)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.sums2 + o),
+                                                 (__attribute__((address_space(3))) void*)(TOT2 + wave * ROWW + lane * NC), 16, 0, 0);
             const size_t xi = live ? (size_t)(oy - p.in_row0) * p.nx + ocol : 0;
-            const Vec4<float> xs = *reinterpret_cast<const Vec4<float>*>(p.in + xi);
+            Vec4<float> xs{{0.f, 0.f, 0.f, 0.f}};
+            if (!WANT_STD || p.tpi != nullptr) xs = *reinterpret_cast<const Vec4<float>*>(p.in + xi);
             uint32_t acc[NC];  // sum of the fractional parts in units of 2^-16 m (fits int32)
             wave_disc_sum<SIZE, uint32_t, 0, (SIZE >= 41)>(Q, jj, lane, acc);
             int lcol = lane * NC;
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(lcol) : : "memory");  // the DMA has landed
             const Vec4<int> sv = *reinterpret_cast<const Vec4<int>*>(TOT + wave * ROWW + lcol);
+            Vec4<uint32_t> s2v{{0u, 0u, 0u, 0u}};
+            if (WANT_STD) s2v = *reinterpret_cast<const Vec4<uint32_t>*>(TOT2 + wave * ROWW + lcol);
             if (!live) continue;
-            Vec4<float> out_t;
+            Vec4<float> out_t, out_s;
 #pragma unroll
             for (int t = 0; t < NC; ++t) {
                 const double sf = (double)(int)acc[t] * (1.0 / 65536.0);
                 const double s1 = (double)sv.v[t] + sf;
                 const double x_ctr = (double)xs.v[t];
                 out_t.v[t] = (float)((double)xs.v[t] - (s1 - x_ctr) * inv_nm1);
+                if (WANT_STD) {
+                    const int su = sv.v[t] - ci * G::T.taps;  // sum of u: what the general kernel's first chain yields
+                    if ((int)acc[t] == 0) {
+                        out_s.v[t] = std_from_int_sums(su, (uint64_t)s2v.v[t], (uint32_t)G::T.taps, (float)inv_nn1);
+                    } else {
+                        const double cd = (double)ci;
+                        const double s2 = (double)s2v.v[t] + 2.0 * cd * (double)su + cd * cd * nd;
+                        out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
+                    }
+                }
             }
-            *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+            if (!WANT_STD || p.tpi != nullptr) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+            if (WANT_STD) *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
         }
     }
 }
 
-template <int SIZE, int TH, int NWAVES>
+template <int SIZE, int TH, int NWAVES, bool WANT_STD = false>
 __global__ __launch_bounds__(NWAVES * 64) void tpi_fraction_march_kernel(WaveParts ps, int tiles_x) {
-    TOPO_RUN_PARTS_LOOP((tpi_fraction_march_kernel_body<SIZE, TH, NWAVES>));
+    TOPO_RUN_PARTS_LOOP((tpi_fraction_march_kernel_body<SIZE, TH, NWAVES, WANT_STD>));
 }
 
-template <int SIZE, int TH, int NWAVES>
-int launch_fraction_march(const Block& b, float* tpi_out) {
+template <int SIZE, int TH, int NWAVES, bool WANT_STD = false>
+int launch_fraction_march(const Block& b, float* tpi_out, float* std_out = nullptr) {
     using G = Geo<SIZE>;
     Context& c = ctx();
-    WaveArgs a{b.in, tpi_out, nullptr, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
                nullptr, nullptr, nullptr, 0, 0};
-    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16;
+    constexpr size_t lds = (size_t)((TH + SIZE) + NWAVES) * ROWW * sizeof(int) + 16 + (WANT_STD ? (size_t)NWAVES * ROWW * sizeof(int) : 0);
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_fraction_march_kernel<SIZE, TH, NWAVES>,
+        TOPO_HIP(hipFuncSetAttribute((const void*)tpi_fraction_march_kernel<SIZE, TH, NWAVES, WANT_STD>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nblk = 0;
         TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nblk, (const void*)tpi_fraction_march_kernel<SIZE, TH, NWAVES>, NWAVES * 64, lds));
+            &nblk, (const void*)tpi_fraction_march_kernel<SIZE, TH, NWAVES, WANT_STD>, NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
     WaveParts ps;
@@ -1498,7 +1592,7 @@ int launch_fraction_march(const Block& b, float* tpi_out) {
     TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, true, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
-    return launch_parts(nullptr, tpi_fraction_march_kernel<SIZE, TH, NWAVES>, grid, NWAVES * 64, lds, ps, tiles_x);
+    return launch_parts(nullptr, tpi_fraction_march_kernel<SIZE, TH, NWAVES, WANT_STD>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 // ---- TPI on tiles with fractional elevations: the scaled one-chain route (round 4) -----------------------------------
@@ -1862,7 +1956,11 @@ __device__ __forceinline__ int stage_u2(const WaveArgs& p, uint32_t* Q, int* fla
     return all;
 }
 
-template <int SIZE, int TH, int NWAVES>
+// FRAC_STORE (the second of the three marching passes of STD on fractional elevations): a tile the first pass marked
+// kNeedsFraction is gone through as well - the sums of u^2 do not care about the fractional parts - but not finalised: its sums
+// go to p.sums2 and its offset to p.tile_c, for the fraction pass (tpi_fraction_march_kernel<.., WANT_STD>).  Such a tile at the
+// DEM's border (the in-domain tap counts enter there) is left to the general kernel.
+template <int SIZE, int TH, int NWAVES, bool FRAC_STORE = false>
 __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = Geo<SIZE>;
     static_assert(TH % NWAVES == 0, "rows must split evenly over the waves");
@@ -1896,7 +1994,9 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
     int deferred_in_a_row = 0;
 #pragma unroll 1
     for (int tile = first; tile < last; ++tile) {
-        if (p.defer[tile] != 0) {  // left by the first kernel (fractional / non-finite / absurd samples)
+        const int state = __builtin_amdgcn_readfirstlane((int)p.defer[tile]);
+        const bool fractional = FRAC_STORE && state == kNeedsFraction;
+        if (state != 0 && !fractional) {  // left by the first kernel (fractional / non-finite / absurd samples)
             carry = false;
             continue;
         }
@@ -1911,9 +2011,15 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
         const int gy0 = oy0 + G::T.off_min;
         const bool border = gy0 < 0 || gy0 + NROWS > p.gny || ox0 - G::X0 < 0 || ox0 - G::X0 + ROWW > p.nx;
         if (ty == 0) carry = false;
+        if (fractional && border) {
+            if (threadIdx.x == 0) p.defer[tile] = 1;
+            carry = false;
+            continue;
+        }
+        constexpr int kFlagMask = FRAC_STORE ? ~(int)kTileFrac : ~0;  // (fractional samples are what this pass is there for)
         int flags = kTileWide;
         if (carry) {
-            flags = stage_u2<SIZE, TH, NWAVES, false>(p, Q, flag_word, gy0, gx, c, ci, lim32);
+            flags = stage_u2<SIZE, TH, NWAVES, false>(p, Q, flag_word, gy0, gx, c, ci, lim32) & kFlagMask;
             if (threadIdx.x == 0) *flag_word = 0;  // read by every thread; the next atomicOr is behind a barrier
         }
         if (flags & kTileWide) {
@@ -1927,7 +2033,7 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
             c = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(c)));
             ci = (int)c;
             __syncthreads();  // the image and the flag word are free
-            flags = stage_u2<SIZE, TH, NWAVES, true>(p, Q, flag_word, gy0, gx, c, ci, lim32);
+            flags = stage_u2<SIZE, TH, NWAVES, true>(p, Q, flag_word, gy0, gx, c, ci, lim32) & kFlagMask;
             if (threadIdx.x == 0) *flag_word = 0;
         }
         if (flags != 0) {  // wide even around its own centre (or a class the first kernel would have caught)
@@ -1938,6 +2044,22 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
         }
         deferred_in_a_row = 0;
         carry = true;
+        if (fractional) {
+            // the sums of u^2 and the offset they were taken with: the fraction pass finalises the tile
+            if (threadIdx.x == 0) p.tile_c[tile] = ci;
+#pragma unroll 1
+            for (int k = 0; k < RW; ++k) {
+                const int jj = wave + k * NWAVES;
+                const int oy = oy0 + jj;
+                if (oy < p.out_row0 || oy >= p.out_row0 + p.out_rows) continue;
+                uint32_t acc[NC];
+                wave_disc_sum<SIZE, uint32_t, 0, true>(Q, jj, lane, acc);
+                const int ocol = ox0 + lane * NC;
+                if (lane < G::NVL && ocol < p.nx)
+                    *reinterpret_cast<Vec4<uint32_t>*>(p.sums2 + (size_t)(oy - p.out_row0) * p.nx + ocol) = Vec4<uint32_t>{{acc[0], acc[1], acc[2], acc[3]}};
+            }
+            continue;
+        }
 
         if (border) {
             if (threadIdx.x < TH) {
@@ -2021,12 +2143,12 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
     }
 }
 
-template <int SIZE, int TH, int NWAVES>
+template <int SIZE, int TH, int NWAVES, bool FRAC_STORE = false>
 __global__ __launch_bounds__(NWAVES * 64) void std_march_kernel(WaveParts ps, int tiles_x) {
-    TOPO_RUN_PARTS_LOOP((std_march_kernel_body<SIZE, TH, NWAVES>));
+    TOPO_RUN_PARTS_LOOP((std_march_kernel_body<SIZE, TH, NWAVES, FRAC_STORE>));
 }
 
-template <int SIZE, int TH, int NWAVES>
+template <int SIZE, int TH, int NWAVES, bool FRAC_STORE = false>
 int launch_std_march(const Block& b, float* std_out) {
     using G = Geo<SIZE>;
     Context& c = ctx();
@@ -2037,10 +2159,10 @@ int launch_std_march(const Block& b, float* std_out) {
     static_assert(lds <= 160 * 1024, "tile does not fit LDS");
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)std_march_kernel<SIZE, TH, NWAVES>,
+        TOPO_HIP(hipFuncSetAttribute((const void*)std_march_kernel<SIZE, TH, NWAVES, FRAC_STORE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nblk = 0;
-        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_march_kernel<SIZE, TH, NWAVES>,
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_march_kernel<SIZE, TH, NWAVES, FRAC_STORE>,
                                                               NWAVES * 64, lds));
         blocks_per_cu = nblk < 1 ? 1 : nblk;
     }
@@ -2050,7 +2172,7 @@ int launch_std_march(const Block& b, float* std_out) {
     TOPO_TRY(make_parts(b, a, TH, G::TILE_W, true, true, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);  // the same grid, hence the same runs, as launch_march
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
-    return launch_parts(nullptr, std_march_kernel<SIZE, TH, NWAVES>, grid, NWAVES * 64, lds, ps, tiles_x);
+    return launch_parts(nullptr, std_march_kernel<SIZE, TH, NWAVES, FRAC_STORE>, grid, NWAVES * 64, lds, ps, tiles_x);
 }
 
 // only_deferred: process the tiles a preceding launch_march of the same geometry marked.
@@ -2150,16 +2272,39 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
     // The marching kernels take the tiles of whole metres, the general kernel the tiles they left
     // (none on a DEM of whole metres; all of them on one with fractional elevations).
     constexpr bool kFullTile = TH12 == 60;  // LDS holds the tile height the marching kernels were tuned for
+    if constexpr (std_ring_fits(SIZE) && !std_ring_both_fits(SIZE) && kFullTile) {
+        // STD (and TPI + STD) on a raster of mostly fractional elevations, discs of 43 ... 67 px (below, the ring kernel has
+        // a three-image second pass; here three images do not fit LDS and every tile used to end with the general kernel's
+        // three staging passes: 20 ms at 67 px on 32768^2).  Three marching passes instead, each carrying its window down
+        // the strips: the sums of trunc(x) (and TPI of the whole-metre tiles), the sums of (trunc(x) - c)^2 (and STD of the
+        // whole-metre tiles), the sums of the fractional parts with the finalisation of the rest.  Exact sums and the
+        // general kernel's expressions: the same bits.  Which route runs first is a matter of time only; it is taken from
+        // the share of fractional samples in the raster class.
+        if (std_out && current_class().frac_share > 0.5f) {
+            if (tpi_out) TOPO_TRY((launch_march_sums<SIZE, TH12, 12, true>(b, tpi_out)));
+            else TOPO_TRY((launch_march_sums<SIZE, TH12, 12, false>(b, nullptr)));
+            TOPO_TRY((launch_std_march<SIZE, TH12, 12, true>(b, std_out)));
+            TOPO_TRY((launch_fraction_march<SIZE, TH12, 12, true>(b, tpi_out, std_out)));
+            if (tpi_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out, true, TH12);
+            return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out, true, TH12);
+        }
+    }
     if constexpr (std_ring_fits(SIZE)) {
         if (std_out && SIZE >= std_ring_min_size()) {
             // one staging pass: u and u^2 rings side by side (disc_ring_impl.hpp), then the general kernel over
             // the tiles it marked (its map has this kernel's strips and rows of 60)
-            const bool border_pass = ctx().seams.n == 0;  // (a sharded call leaves the tiles at the DEM's border to the general kernel)
-            if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out)));
-            else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out)));
-            if (border_pass) {
-                if (tpi_out) TOPO_TRY((launch_std_ring_border<SIZE, true>(b, tpi_out, std_out)));
-                else TOPO_TRY((launch_std_ring_border<SIZE, false>(b, nullptr, std_out)));
+            // The tiles at the DEM's border: a second launch of the ring kernel over the list of them up to 17 px (8192^2, 7 px:
+            // STD 0.240 -> 0.228 ms, TPI + STD 0.282 -> 0.262; 32768^2: 2.78 -> 2.67 and 3.81 -> 3.52), the general kernel beyond
+            // (65 px: an isolated border tile stages 139 rows for its 60, and 0.599 ms became 0.696; profiles/r05_border_pass.txt).
+            // A sharded call leaves them to the general kernel at every size.
+            const bool border_pass = std_ring_border_pass(SIZE) && ctx().seams.n == 0;
+            if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out, border_pass)));
+            else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out, border_pass)));
+            if constexpr (std_ring_border_pass(SIZE)) {
+                if (border_pass) {
+                    if (tpi_out) TOPO_TRY((launch_std_ring_border<SIZE, true>(b, tpi_out, std_out)));
+                    else TOPO_TRY((launch_std_ring_border<SIZE, false>(b, nullptr, std_out)));
+                }
             }
             if constexpr (std_ring_both_fits(SIZE)) {
                 // tiles with fractional elevations: one more pass of the ring kernel with a third image (the

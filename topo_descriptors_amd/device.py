@@ -65,7 +65,7 @@ class RasterScan:
     kernels the whole raster takes.  (A block that is the whole raster needs none of this.)"""
 
     def __init__(self):
-        self.counts = (C.c_uint64 * 2)(0, 0)
+        self.counts = (C.c_uint64 * 3)(0, 0, 0)
         self.range = (C.c_float * 2)(np.inf, -np.inf)
 
     def add(self, block, own_row0=None, own_rows=None):
@@ -82,7 +82,7 @@ class RasterScan:
 
 def forget_raster_class():
     """Withdraw what :meth:`RasterScan.declare` (or ``ShardedDEM``) declared: partial row blocks are ordinary DEMs again."""
-    _lib.check(_lib.load().topo_amd_raster_class_set(-1, 0.0, 0.0), "raster_class_set")
+    _lib.check(_lib.load().topo_amd_raster_class_set(-1, 0.0, 0.0, 0.0), "raster_class_set")
 
 
 def dem_changed(array):
