@@ -8,8 +8,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtopo_amd.so")
-SOURCES = [f"disc_wave_g{g}.hip" for g in range(10)] + ["disc.hip", "disc_wave.hip", "disc_pair.hip", "disc_big.hip", "gauss.hip",
-                                                           "sx.hip", "valley.hip", "valley_fft.hip", "capi.hip"]
+NGROUPS = 16  # the per-size disc kernels: one source (disc_wave_group.hip), compiled once per group of sizes
+# (source, extra flags, object name); the long units first, so that the pool's last jobs are short ones
+UNITS = [("sx.hip", [], "sx.o"), ("gauss.hip", [], "gauss.o")] + \
+        [("disc_wave_group.hip", [f"-DTOPO_GROUP={g}", f"-DTOPO_NGROUPS={NGROUPS}"], f"disc_wave_group{g}.o") for g in range(NGROUPS)] + \
+        [(s, [], s.replace(".hip", ".o")) for s in ("disc_pair.hip", "disc.hip", "disc_wave.hip", "disc_big.hip", "valley.hip",
+                                                    "valley_fft.hip", "capi.hip")]
+SOURCES = sorted({u[0] for u in UNITS})
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -53,18 +58,19 @@ def build_library(force=False, verbose=True):
                         deps(os.path.join(base, name), seen)
         return seen
 
-    def compile_one(src):
-        obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
+    def compile_one(unit):
+        src, extra, name = os.path.join(CSRC, unit[0]), unit[1], unit[2]
+        obj = os.path.join(objdir, name)
         if not force and _newer(obj, sorted(deps(src, set())) + [__file__]):
             return obj  # object newer than its source and every header it includes
-        cmd = [cc, f"--offload-arch={ARCH}", *FLAGS, "-c", src, "-o", obj]
+        cmd = [cc, f"--offload-arch={ARCH}", *FLAGS, *extra, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=8) as pool:
-        objs = list(pool.map(compile_one, srcs))
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 8) as pool:
+        objs = list(pool.map(compile_one, UNITS))
     cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs,
            "-L/opt/rocm/lib", "-lrccl", "-lhipfft", "-pthread"]
     if verbose:

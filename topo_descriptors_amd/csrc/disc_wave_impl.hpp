@@ -414,7 +414,10 @@ __device__ __forceinline__ Vec4<float> load_row4(const WaveArgs& p, int gy, int 
 // fractional parts in integer units of 2^-16 m (exact as well) and exists only on fractional DEMs.  Tiles holding non-finite or absurd samples (|u| so
 // large that one 67-row column sum of u^2 passes 2^32, e.g. -9999 nodata next to real terrain)
 // run float chains on a = x - c and (trunc(x) - c)^2 instead, so NaN propagates and nothing wraps.
-enum Stage { kStU = 0, kStU2 = 1, kStF = 2, kStS = 5, kStInd = 6, kStUL = 7, kStU2L = 8 };
+// kStLimb: one of the three kinds below, picked at run time by aux bits 4-5 (0 kStInd, 1 kStUL, 2 kStU2L) - the limb path runs its
+// six passes through ONE copy of the staging and chain code (it is the slow path; six inlined copies per general kernel and disc
+// size were a fifth of the library's code and of its build time)
+enum Stage { kStU = 0, kStU2 = 1, kStF = 2, kStS = 5, kStInd = 6, kStUL = 7, kStU2L = 8, kStLimb = 9 };
 // The general kernel on tiles the 32-bit integer chains cannot hold - samples beyond +-2^18 (a raster in millimetres), more
 // relief than the chains of u^2 take (nodata next to terrain), non-finite samples.  Still exact integers, in LIMBS:
 //   kStInd  per sample (not ordinary: non-finite or |trunc(x)| > 2^18) + 2^16 (missing: non-finite or |trunc(x)| >= 2^24): the
@@ -504,11 +507,12 @@ template <int WHAT>
 __device__ __forceinline__ uint32_t stage_value(float x, float c, int ci, int aux = 0) {
     if (WHAT == kStS) return (uint32_t)(int)rintf(x * c);
     const float t = truncf(x);
-    if (WHAT == kStInd || WHAT == kStUL || WHAT == kStU2L) {
+    if (WHAT == kStInd || WHAT == kStUL || WHAT == kStU2L || WHAT == kStLimb) {
+        const int kind = WHAT == kStLimb ? ((aux >> 4) & 3) : (WHAT == kStInd ? 0 : (WHAT == kStUL ? 1 : 2));
         const bool missing = !(fabsf(t) < kMissingLim);  // (NaN: missing)
-        if (WHAT == kStInd) return (missing ? 65536u : 0u) | ((missing || fabsf(t) > 262144.0f) ? 1u : 0u);
+        if (kind == 0) return (missing ? 65536u : 0u) | ((missing || fabsf(t) > 262144.0f) ? 1u : 0u);
         const int u = missing ? 0 : (int)t - ci;  // |u| < 2^25
-        if (WHAT == kStUL) return aux == 0 ? ((uint32_t)u & 0xffffu) : (uint32_t)(u >> 16);
+        if (kind == 1) return (aux & 3) == 0 ? ((uint32_t)u & 0xffffu) : (uint32_t)(u >> 16);
         const uint64_t w = (uint64_t)((int64_t)u * (int64_t)u) >> (16 * (aux & 3));
         return (aux & 4) ? (uint32_t)w : ((uint32_t)w & 0xffffu);
     }
@@ -934,7 +938,7 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                 // missing samples (staged as u = 0 by the passes above): their count per disc, so that exactly the pixels
                 // whose discs hold one come out as NaN
                 __syncthreads();
-                stage_prefix<SIZE, TH, NWAVES, kStInd, uint32_t>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv);
+                stage_prefix<SIZE, TH, NWAVES, kStLimb, uint32_t>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv, nullptr, 0);
 #pragma unroll 1
                 for (int k = 0; k < RW; ++k) {
                     uint32_t acc[NC];
@@ -944,10 +948,17 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
             }
         } else {
             // the limb path (Stage, above): counts of the samples that are not ordinary / missing, then u and u^2 limb by limb
-            auto limb_pass = [&](auto what_tag, int aux, int plo, int phi, int shift, bool is_signed, bool first) {
-                constexpr int WHAT = decltype(what_tag)::value;
+            // one copy of the staging and chain code, six passes: {aux (kind << 4 | limb | last << 2), planes, shift, signed, first}
+            const int npass = WANT_STD ? 6 : 3;
+#pragma unroll 1
+            for (int pass = 0; pass < npass; ++pass) {
+                // pass:      0 ind   1 u lo   2 u hi   3 u^2 [0,16)   4 u^2 [16,32)   5 u^2 [32, ...)
+                const int aux = pass == 0 ? 0 : (pass <= 2 ? (1 << 4) | (pass - 1) : (2 << 4) | (pass - 3) | (pass == 5 ? 4 : 0));
+                const int plo = pass == 0 ? 5 : (pass <= 2 ? 0 : 1), phi = pass == 0 ? -1 : (pass <= 2 ? 4 : 2);
+                const int shift = pass == 0 ? 0 : (pass <= 2 ? 16 * (pass - 1) : 16 * (pass - 3));
+                const bool is_signed = pass == 2, first = pass == 1 || pass == 3;
                 __syncthreads();
-                stage_prefix<SIZE, TH, NWAVES, WHAT, uint32_t>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv, nullptr, aux);
+                stage_prefix<SIZE, TH, NWAVES, kStLimb, uint32_t>(p, lds_u, flag_word, gy0, gx, c, ci, lim32, limcv, nullptr, aux);
 #pragma unroll 1
                 for (int k = 0; k < RW; ++k) {
                     const int jj = wave + k * NWAVES;
@@ -973,14 +984,6 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                     put(plo, jj, nlo);
                     put(phi, jj, nhi);
                 }
-            };
-            limb_pass(std::integral_constant<int, kStInd>{}, 0, 5, -1, 0, false, true);
-            limb_pass(std::integral_constant<int, kStUL>{}, 0, 0, 4, 0, false, true);
-            limb_pass(std::integral_constant<int, kStUL>{}, 1, 0, 4, 16, true, false);
-            if (WANT_STD) {
-                limb_pass(std::integral_constant<int, kStU2L>{}, 0, 1, 2, 0, false, true);
-                limb_pass(std::integral_constant<int, kStU2L>{}, 1, 1, 2, 16, false, false);
-                limb_pass(std::integral_constant<int, kStU2L>{}, 2 | 4, 1, 2, 32, false, false);
             }
         }
         if (frac) {
@@ -2359,7 +2362,9 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
     }
     if (tpi_fraction_scaled()) {
         // fractional tiles: one chain on x in units of 2^-8 m (tpi_scaled_march_kernel: <= 1.95 mm, see there)
-        if (dem_memo_mostly_fractional(b)) {  // what the last call on this DEM reported: the scaled build takes every tile
+        // (what the last call on this block reported, or - a block seen for the first time, a host-buffer call - what the
+        // raster class says: the scaled build takes every tile)
+        if (dem_memo_mostly_fractional(b) || current_class().frac_share > 0.5f) {
             TOPO_TRY((launch_scaled_march<SIZE, TH12, 12, true>(b, tpi_out)));
             return launch_wave<SIZE, TH12, 12, true, false>(b, tpi_out, std_out, true);
         }
