@@ -417,6 +417,33 @@ def test_every_disc_size_against_exact(size):
         assert np.array_equal(topo.std(dem, size), s)
 
 
+@pytest.mark.parametrize("size,level", [(7, 0.0), (7, 9000.0), (17, 0.0), (17, 3300.0), (31, -1400.0), (45, -1500.0), (67, -1500.0),
+                                        (67, -1900.0), (67, -2800.0)])
+def test_std_tiles_at_the_dem_border(size, level):
+    """The ring kernel takes the tiles whose discs reach over the DEM's edge itself when the offset c = 0 fits their windows
+    (n x^2 < 2^32: the zero padding then needs no tap counts) and leaves them to the general kernel otherwise.  Levels: every
+    border tile fits / none does / some do (elevations around +-lim32).  Same exact integers either way, so row blocks - whose
+    border tiles are other tiles - keep the bits."""
+    from topo_descriptors_amd import topo
+    dem = (orc.synthetic_dem(430, 640, seed=size) + np.float32(level)).astype(np.float32)
+    t, s = topo.tpi_std(dem, size)
+    e = orc.std_exact(dem, size)
+    assert np.max(np.abs(s - e)) <= 1e-4 * np.max(e)
+    assert np.max(np.abs(t - orc.tpi_exact(dem, size))) <= 2.5e-4
+    assert np.array_equal(topo.std(dem, size), s)
+    up, down = halo(_lib.DESC_TPI, size)
+    nx = dem.shape[1]
+
+    def call(blk, row0, rows):
+        tt, ss = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+        blk.tpi_std(size, tpi=tt, std=ss, out_row0=row0, out_rows=rows)
+        return [tt, ss]
+
+    for nblocks in (2, 3):
+        tb, sb = run_blocks(dem, nblocks, up, down, call)
+        assert np.array_equal(tb, t) and np.array_equal(sb, s), (size, level, nblocks)
+
+
 def test_nodata_and_nan_tiles_do_not_wrap():
     """-9999 nodata next to terrain exceeds the exact integer range of a tile: the float chains
     take over (no silent wrap-around); NaN poisons only windows that contain it."""

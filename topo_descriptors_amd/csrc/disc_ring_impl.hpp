@@ -709,20 +709,22 @@ constexpr bool std_ring_both_fits(int size) {
 // marked for the general kernel.  One read of the DEM instead of the general kernel's three staging passes:
 // 32768^2 with fractional elevations, STD 7 px 6.97 -> 4.10 ms, 17 px 8.34 -> 5.18, 31 px 10.88 -> 7.99, 41 px
 // 12.56 -> 10.81 (profiles/r03_std_ring_both.txt).
-// kStdBorder (round 5): the tiles at the DEM's border, which kStdMain leaves out (their discs reach outside the DEM: the
-// in-domain tap count m enters the finalisation).  They were the general kernel's - a trailing launch over 3 % of the pixels
-// at an eighth of this kernel's rate on an under-filled grid, 20 % of an 8192^2 step at 7 px - and are now a second launch of
-// THIS kernel over the list of those tiles (built by the host: global geometry), with the finalisation for m < n.  A launch of
-// its own, not a branch in kStdMain: kStdMain sits at the register limit, and everything added to its phase loop showed up
-// as spills in the chains.
-enum StdRingMode { kStdMain = 0, kStdBorder = 1, kStdBoth = 2 };
+// The tiles at the DEM's border (round 5).  Samples outside the DEM are staged as u = 0; with the offset c = 0 that IS the
+// reference's zero padding - sum u = sum trunc(x) and sum u^2 = sum trunc(x)^2 over the taps inside the DEM, and the
+// finalisation is the interior one, n S2 - T^2 with the full tap count n (the exact integer std_from_border_sums forms from
+// any c and the in-domain count m: the same bits).  So at a tile whose discs reach over the DEM's edge the ring is re-based
+// to c = 0 when the window's elevations allow it (n x^2 < 2^32: 9362 m at 7 px, 4369 m at 17 px, 1122 m at 67 px) and the
+// tile is computed like every other; otherwise it is the general kernel's, as before.  (Earlier in the round such tiles were
+// a second launch of this kernel over a host-built list with the tap counts in the finalisation - std_ring_kernel<kStdBorder> -
+// 43 us of a 269 us step on 8192^2 at 7 px: two tiles per CU one after the other; rounds 2 - 4 left them to the general
+// kernel.  In the phase loop a finalisation with m cost the main kernel 50 - 60 spilled registers; this form adds none.)
+enum StdRingMode { kStdMain = 0, kStdBoth = 2 };
 
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
 __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = RGeo<SIZE, 4>;
     using C = StdRingCfg<SIZE>;
     constexpr bool BOTH = MODE == kStdBoth;
-    constexpr bool BORDER = MODE == kStdBorder;
     constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW, HIST = C::HIST;
     constexpr int PITCH = (BOTH ? 3 : 2) * G::W;  // dwords per ring row: the u image, the u^2 image (and the image of the fractional parts)
     constexpr int DL = G::DL;
@@ -769,15 +771,9 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
 
 #pragma unroll 1
     for (int pos = first; pos < last;) {
-        // a run: consecutive tiles of one strip (kStdBorder: consecutive entries of the list that are)
-        int tile0 = pos, run_tiles;
-        if (BORDER) {
-            tile0 = p.border_list[pos];
-            run_tiles = 1;
-            while (pos + run_tiles < last && p.border_list[pos + run_tiles] == tile0 + run_tiles && (tile0 + run_tiles) % tiles_y != 0) ++run_tiles;
-        } else {
-            run_tiles = min(last - tile0, tiles_y - tile0 % tiles_y);
-        }
+        // a run: consecutive tiles of one strip
+        const int tile0 = pos;
+        const int run_tiles = min(last - tile0, tiles_y - tile0 % tiles_y);
         const int ty0 = tile0 % tiles_y;
         const int strip = tile0 / tiles_y;
         const int nphase = run_tiles * PPT;
@@ -791,6 +787,10 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
         const int cx = min(ox0 + G::TILE_W / 2, p.nx - 1);
         float cf = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
         if (!(fabsf(cf) <= kAbsLim)) cf = 0.0f;
+        // every disc of the strip's pixels stays inside the DEM's columns
+        const bool cols_inside = ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= p.nx - 1;
+        // a run that starts at the DEM's border starts at c = 0 (see "The tiles at the DEM's border" above)
+        if (!BOTH && (!cols_inside || oyS - G::M < 0 || oyS + C::TH - 1 + G::M > p.gny - 1) && fabsf(cf) <= (float)lim32) cf = 0.0f;
         int ci = __builtin_amdgcn_readfirstlane((int)cf);
         const int gcol = gx0 + scol;
         const bool col_ok = stager && gcol >= 0 && gcol < p.nx;
@@ -944,8 +944,6 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
 
         const int ocol = gx0 + lane * 4;
         const bool lane_ok = lane >= DL && lane < 64 - DL;
-        // every disc of the strip's pixels stays inside the DEM's columns
-        const bool cols_inside = ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= p.nx - 1;
         int s0 = C::PAD - 1 + wave;
         int tmode = kTileDone;  // what the map says about the current tile
 #pragma unroll 1
@@ -955,9 +953,13 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
 #pragma unroll
             for (int k = 0; k < HIST; ++k) wlo = min(wlo, hlo[k]), whi = max(whi, hhi[k]);
             if (ph % PPT == 0) {
-                // a new tile: re-base the ring when c has drifted from the middle of the range
-                const int mid = wlo + (whi - wlo) / 2;
-                if (wlo <= whi && abs(mid - ci) > lim32 / 4) {
+                // a new tile: re-base the ring when c has drifted from the middle of the range - or, at the DEM's border, to
+                // c = 0 when the window takes it (the zero padding then needs no tap counts)
+                const int oy0 = oyS + (ph / PPT) * C::TH;
+                const bool at_border = !cols_inside || oy0 - G::M < 0 || oy0 + C::TH - 1 + G::M > p.gny - 1;
+                const bool zero = !BOTH && at_border && wlo <= whi && whi <= lim32 && -wlo <= lim32;
+                const int mid = zero ? 0 : wlo + (whi - wlo) / 2;
+                if (wlo <= whi && (zero ? ci != 0 : abs(mid - ci) > lim32 / 4)) {
                     const uint32_t delta = (uint32_t)(mid - ci);
                     const uint32_t d2 = delta * delta;
                     // k: how many of a column's rows up to this one hold a SAMPLE (any constant added to it cancels in the
@@ -987,17 +989,8 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                 if (BOTH) {
                     tmode = candidate(tile) ? kNeedsFraction : kTileDone;  // (kTileDone here: not this pass's)
                 } else {
-                    const int oy0 = oyS + (ph / PPT) * C::TH;
-                    const bool rows_inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1;
-                    if (BORDER) {
-                        // (a tile the main launch has not left for this one - it found it fractional, or too wide - stays as it is)
-                        // (read by every wave here, written back only at the tile's last phase - behind the barriers of the phases
-                        // in between - so that no wave reads what another has already changed)
-                        tmode = p.defer[tile] == kTileBorder ? kTileDone : kTileGeneral;
-                    } else {
-                        tmode = !rows_inside || !cols_inside ? (p.border_later ? kTileBorder : kTileGeneral) : kTileDone;
-                        if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
-                    }
+                    tmode = at_border && !zero ? kTileGeneral : kTileDone;
+                    if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
                 }
             }
             // the windows of this phase hold only finite samples within lim32 of c (kStdMain: and whole ones)?
@@ -1044,48 +1037,6 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                         *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
                         if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
                     }
-                } else if (BORDER) {
-                    // The samples outside the DEM were staged as u = 0, so with m = the taps of the pixel's disc inside it,
-                    // sum trunc(x) = Su + c m and sum trunc(x)^2 = Su2 + 2 c Su + c^2 m: 64-bit integers, then the float tail
-                    // of every kernel (std_from_border_sums).  m: one count for the row where only the top / bottom edge cuts
-                    // the discs (scalar), a difference of the table of column heights where only the left / right edge does,
-                    // the loop over the columns in the four corners.
-                    const bool rows_cut = oy - G::M < 0 || oy + G::M > p.gny - 1;
-                    int m_rows = G::T.taps;
-                    if (rows_cut) {
-                        m_rows = 0;
-#pragma unroll 1
-                        for (int k = 0; k < SIZE; ++k) m_rows += max(min(oy + G::T.hi[k], p.gny - 1) - max(oy + G::T.lo[k], 0) + 1, 0);
-                    }
-                    if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
-                        const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
-                        Vec4<float> out_s, out_t;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int ox = ocol + t;
-                            const int k0 = max(0, G::M - ox), k1 = min(SIZE - 1, p.nx - 1 - ox + G::M);  // column offsets inside the DEM
-                            int m = m_rows;
-                            if (k0 != 0 || k1 != SIZE - 1) {
-                                if (!rows_cut) {
-                                    m = k1 >= k0 ? G::T.colpre[k1 + 1] - G::T.colpre[k0] : 0;
-                                } else {
-                                    m = 0;
-#pragma unroll 1
-                                    for (int k = k0; k <= k1; ++k) m += max(min(oy + G::T.hi[k], p.gny - 1) - max(oy + G::T.lo[k], 0) + 1, 0);
-                                }
-                            }
-                            out_s.v[t] = m == G::T.taps ? std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1)
-                                                        : std_from_border_sums((int64_t)(int)su[t], (uint64_t)su2[t], ci, m, (uint32_t)G::T.taps,
-                                                                               (float)inv_nn1);
-                            if (WANT_TPI) {
-                                const int xi = (int)ctr[t] + ci;
-                                // sum of trunc(x) over the taps inside the DEM = su + c m: exact, fits int32
-                                out_t.v[t] = (float)((double)xi - (double)((int)su[t] + ci * m - xi) * inv_nm1);
-                            }
-                        }
-                        *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
-                        if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
-                    }
                 } else if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
                     const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
                     Vec4<float> out_s, out_t;
@@ -1103,7 +1054,6 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                 }
             }
             if (BOTH && ph % PPT == PPT - 1 && tmode == kNeedsFraction && threadIdx.x == 0) p.defer[tile] = kTileDone;
-            if (BORDER && ph % PPT == PPT - 1 && tmode == kTileDone && threadIdx.x == 0) p.defer[tile] = kTileDone;
             if (!BOTH && ph % PPT == PPT - 1 && tmode == kTileGeneral) ++seen_general;
             const Seen seen = convert_batch(C::PRO + ph * B, va, nq, nq2, nqf);
             s0 += B;
@@ -1119,7 +1069,7 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
     }
     // what this block's run looked like, for the next call on this DEM (dem_memo, common.hpp): tiles, and tiles it left to
     // the general kernel (fractional elevations, mostly)
-    if (!BOTH && !BORDER && p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
+    if (!BOTH && p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
         __hip_atomic_store(p.report + 1, (uint32_t)seen_general, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(p.report, (uint32_t)(last > first ? last - first : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1134,10 +1084,8 @@ __global__ __launch_bounds__(768) void std_ring_kernel_parts(WaveParts ps, int t
     TOPO_RUN_PARTS((std_ring_kernel_body<SIZE, WANT_TPI, MODE>));
 }
 
-constexpr bool std_ring_border_pass(int size) { return size <= 17; }
-
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
-int launch_std_ring(const Block& b, float* tpi_out, float* std_out, bool border_later = false) {
+int launch_std_ring(const Block& b, float* tpi_out, float* std_out) {
     using G = RGeo<SIZE, 4>;
     using C = StdRingCfg<SIZE>;
     constexpr size_t kLds = C::LDS + (MODE == kStdBoth ? (size_t)C::R * G::W * sizeof(uint32_t) : 0);
@@ -1158,57 +1106,10 @@ int launch_std_ring(const Block& b, float* tpi_out, float* std_out, bool border_
     int tiles_x = 0;
     long ntiles = 0;
     a.report = MODE == kStdMain ? dem_memo_report(b) : nullptr;
-    a.border_later = MODE == kStdMain && border_later ? 1 : 0;  // (launch_std_ring_border follows)
     TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
     TOPO_TRY(launch_parts(std_ring_kernel<SIZE, WANT_TPI, MODE>, std_ring_kernel_parts<SIZE, WANT_TPI, MODE>, grid, C::NW * 64, kLds, ps, tiles_x));
-    return TOPO_AMD_OK;
-}
-
-// The tiles at the DEM's border of an ordinary (not sharded) call: std_ring_kernel<kStdBorder> over the list of them.
-template <int SIZE, bool WANT_TPI>
-int launch_std_ring_border(const Block& b, float* tpi_out, float* std_out) {
-    using G = RGeo<SIZE, 4>;
-    using C = StdRingCfg<SIZE>;
-    Context& c = ctx();
-    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
-               nullptr, nullptr, nullptr, 0, 0, 0};
-    static int blocks_per_cu = 0;
-    if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_kernel<SIZE, WANT_TPI, kStdBorder>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)C::LDS));
-        int nblk = 0;
-        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_kernel<SIZE, WANT_TPI, kStdBorder>, C::NW * 64,
-                                                              C::LDS));
-        blocks_per_cu = nblk < 1 ? 1 : (nblk > 2 ? 2 : nblk);
-    }
-    WaveParts ps;
-    int tiles_x = 0;
-    long ntiles = 0;
-    TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));  // (the main launch's slices of the tile map)
-    const int tiles_y = ps.tiles_y[0];
-    // the kernel's own test (std_ring_kernel_body), on the global grid
-    std::vector<int32_t> list;
-    for (int strip = 0; strip < tiles_x; ++strip) {
-        const int ox0 = strip * G::TILE_W;
-        const bool cols_inside = ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= b.nx - 1;
-        for (int ty = 0; ty < tiles_y; ++ty) {
-            const int oy0 = (b.out_row0 / C::TH + ty) * C::TH;
-            const bool rows_inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= b.gny - 1;
-            if (!rows_inside || !cols_inside) list.push_back(strip * tiles_y + ty);
-        }
-    }
-    if (list.empty()) return TOPO_AMD_OK;
-    void* d_list = nullptr;
-    TOPO_TRY(upload_table(0, list.data(), list.size() * sizeof(int32_t), &d_list));
-    ps.a[0].border_list = (const int32_t*)d_list;
-    const long n = (long)list.size();
-    const long grid = march_grid(c, blocks_per_cu, n);
-    const PartRun deal{0, (int)(n / grid), 0, (int)(n % grid), 1};
-    hipLaunchKernelGGL((std_ring_kernel<SIZE, WANT_TPI, kStdBorder>), dim3((unsigned)grid), dim3(C::NW * 64), C::LDS, c.compute, ps.a[0], tiles_x,
-                       tiles_y, deal);
-    TOPO_HIP(hipGetLastError());
     return TOPO_AMD_OK;
 }
 

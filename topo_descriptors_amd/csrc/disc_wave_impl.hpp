@@ -65,8 +65,6 @@ struct WaveArgs {
     uint64_t* rowmask;  // per tile of state kTileGeneralRows: the rows (bit = row of the tile) the general kernel is to write
     uint32_t* sums2;    // fractional STD by three marching passes: sum of (trunc(x) - c)^2 per pixel, laid out like the outputs ...
     int32_t* tile_c;    // ... and the offset c of every tile that has them
-    const int32_t* border_list;  // std_ring_kernel<kStdBorder>: the tiles at the DEM's border (indices of the main launch's tile list)
-    int border_later;            // std_ring_kernel<kStdMain>: 1 = leave those tiles to that launch (kTileBorder), 0 = to the general kernel
 };
 
 // One launch, several row blocks ("parts").  An ordinary call has one part.  A sharded call (capi.hip, run_fused)
@@ -499,8 +497,7 @@ enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4, kTileMissing = 8 
 // kNeedsFraction: its sums of trunc(x) are done, the fraction / scaled pass finishes it.
 // kTileGeneralRows: the general kernel writes only the rows named in WaveArgs::rowmask (the scaled route left them: their
 // own windows hold more relief than its unwrapping takes; the other rows of the tile are done)
-// kTileBorder: a tile at the DEM's border, waiting for std_ring_kernel<kStdBorder> (even: the general kernel passes it by)
-enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2, kTileGeneralRows = 3, kTileBorder = 4 };
+enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2, kTileGeneralRows = 3 };
 
 // aux: kStUL the limb (0 / 1); kStU2L the limb (bits 0-1) and "the last limb: all the bits that are left" (bit 2)
 template <int WHAT>
@@ -2296,19 +2293,10 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
         if (std_out && SIZE >= std_ring_min_size()) {
             // one staging pass: u and u^2 rings side by side (disc_ring_impl.hpp), then the general kernel over
             // the tiles it marked (its map has this kernel's strips and rows of 60)
-            // The tiles at the DEM's border: a second launch of the ring kernel over the list of them up to 17 px (8192^2, 7 px:
-            // STD 0.240 -> 0.228 ms, TPI + STD 0.282 -> 0.262; 32768^2: 2.78 -> 2.67 and 3.81 -> 3.52), the general kernel beyond
-            // (65 px: an isolated border tile stages 139 rows for its 60, and 0.599 ms became 0.696; profiles/r05_border_pass.txt).
-            // A sharded call leaves them to the general kernel at every size.
-            const bool border_pass = std_ring_border_pass(SIZE) && ctx().seams.n == 0;
-            if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out, border_pass)));
-            else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out, border_pass)));
-            if constexpr (std_ring_border_pass(SIZE)) {
-                if (border_pass) {
-                    if (tpi_out) TOPO_TRY((launch_std_ring_border<SIZE, true>(b, tpi_out, std_out)));
-                    else TOPO_TRY((launch_std_ring_border<SIZE, false>(b, nullptr, std_out)));
-                }
-            }
+            // (the tiles at the DEM's border are the ring kernel's own where c = 0 fits their windows - every tile of an ordinary
+            // DEM up to 17 px - and the general kernel's otherwise: disc_ring_impl.hpp)
+            if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out)));
+            else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out)));
             if constexpr (std_ring_both_fits(SIZE)) {
                 // tiles with fractional elevations: one more pass of the ring kernel with a third image (the
                 // fractional parts) instead of the general kernel's three staging passes
