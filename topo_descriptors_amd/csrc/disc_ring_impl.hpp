@@ -701,7 +701,7 @@ constexpr bool std_ring_both_fits(int size) {
 
 // kStdMain: what the comment above describes (tiles with fractional samples are left to what follows).
 // kStdBoth, the second pass for DEMs with fractional elevations (discs up to 41 px): it takes the tiles kStdMain left
-// that lie inside the DEM (the border tiles need the in-domain tap counts: general kernel) with a THIRD image in the
+// (those at the DEM's border too: the padding's zeros are samples, below) with a THIRD image in the
 // ring, the prefix rows of the fractional parts in units of 2^-16 m, runs the three chains and finalises every pixel
 // with the general kernel's choice and expressions (the integer form when the window's fractional sum is exactly 0,
 // else s1 = (sum u + c n) + 2^-16 sum g, s2 = sum u^2 + 2 c sum u + c^2 n in float64: exact integers whatever c is),
@@ -709,15 +709,18 @@ constexpr bool std_ring_both_fits(int size) {
 // marked for the general kernel.  One read of the DEM instead of the general kernel's three staging passes:
 // 32768^2 with fractional elevations, STD 7 px 6.97 -> 4.10 ms, 17 px 8.34 -> 5.18, 31 px 10.88 -> 7.99, 41 px
 // 12.56 -> 10.81 (profiles/r03_std_ring_both.txt).
-// The tiles at the DEM's border (round 5).  Samples outside the DEM are staged as u = 0; with the offset c = 0 that IS the
-// reference's zero padding - sum u = sum trunc(x) and sum u^2 = sum trunc(x)^2 over the taps inside the DEM, and the
-// finalisation is the interior one, n S2 - T^2 with the full tap count n (the exact integer std_from_border_sums forms from
-// any c and the in-domain count m: the same bits).  So at a tile whose discs reach over the DEM's edge the ring is re-based
-// to c = 0 when the window's elevations allow it (n x^2 < 2^32: 9362 m at 7 px, 4369 m at 17 px, 1122 m at 67 px) and the
-// tile is computed like every other; otherwise it is the general kernel's, as before.  (Earlier in the round such tiles were
-// a second launch of this kernel over a host-built list with the tap counts in the finalisation - std_ring_kernel<kStdBorder> -
-// 43 us of a 269 us step on 8192^2 at 7 px: two tiles per CU one after the other; rounds 2 - 4 left them to the general
-// kernel.  In the phase loop a finalisation with m cost the main kernel 50 - 60 spilled registers; this form adds none.)
+// The tiles at the DEM's border (round 5).  A tap outside the DEM reads 0 in the reference (zero padding, mode="same"), so
+// it is staged as what it is - a SAMPLE of elevation 0, u = -c - and not as "no tap": then sum u and sum u^2 run over all n
+// taps, T = Su + c n and S2 = Su2 + 2 c Su + c^2 n like anywhere else, and the finalisation is the interior one (n S2 - T^2:
+// the exact integer std_from_border_sums forms from the in-domain sums and the in-domain count m, hence the same bits).  No tap
+// counts, no second finalisation, nothing added to the phase loop; the zeros simply belong to the window's range, so the offset
+// follows to about half the terrain's height and a border window fits while its highest sample stays below 2 lim32 (18.7 km at
+// 7 px, 4.9 km at 31 px, 2.3 km at 65 px); a tile that does not fit is the general kernel's, like a window with too much relief
+// anywhere.  Before: rounds 2 - 4 left every border tile to the general kernel (a trailing launch over 3 % of the pixels at an
+// eighth of the rate on an under-filled grid: 20 % of an 8192^2 step at 7 px); earlier in round 5 they were a second launch of
+// this kernel over a host-built list with the tap counts in the finalisation (43 us of a 269 us step: two tiles per CU one
+// after the other; inside the phase loop that finalisation cost 50 - 60 spilled registers).  Rows outside the block's VIEW
+// (a row block's missing neighbours) are not samples: they are staged at u = 0, keep the range as it is and reach no output.
 enum StdRingMode { kStdMain = 0, kStdBoth = 2 };
 
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
@@ -725,6 +728,11 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
     using G = RGeo<SIZE, 4>;
     using C = StdRingCfg<SIZE>;
     constexpr bool BOTH = MODE == kStdBoth;
+    // the tiles at the DEM's border are computed here (above) up to 39 px: beyond, the windows of Alpine terrain are too wide
+    // with the padding's zeros in them (2 lim32 = 3.6 km at 41 px - where the bench DEM's border tiles fail half way down - 2.3 km at 65 px), and the kernels of the large discs sit at
+    // the register limit - whatever their phase loop gains in scalar work it pays in spills (same box, 32768^2, STD 65 px:
+    // 7.91 ms with the border tiles left to the general kernel at once, 8.33 - 8.68 ms with the test per tile)
+    constexpr bool kBorderHere = SIZE <= 39;
     constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW, HIST = C::HIST;
     constexpr int PITCH = (BOTH ? 3 : 2) * G::W;  // dwords per ring row: the u image, the u^2 image (and the image of the fractional parts)
     constexpr int DL = G::DL;
@@ -749,13 +757,14 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
     const int lim32 = (int)floorf(sqrtf(4294967295.0f / (float)G::T.taps));
     const int rmin = max(0, p.in_row0), rmax = min(p.gny, p.in_row0 + p.in_rows);
     const bool stager = wave < C::SW;
-    // kStdBoth: a tile the first pass left, with every disc of its pixels inside the DEM
+    // kStdBoth: a tile the first pass left for its fractional samples (41 px: with every disc of its pixels inside the DEM)
     auto candidate = [&](int t) {
-        const int ty = t % tiles_y, strip = t / tiles_y;
-        const int oy0 = (p.out_row0 / C::TH + ty) * C::TH, ox0 = strip * G::TILE_W;
-        const bool inside = oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1 && ox0 - G::M >= 0 &&
-                            ox0 + G::TILE_W - 1 + G::M <= p.nx - 1;
-        return inside && p.defer[t] == kTileGeneral;
+        if (!kBorderHere) {
+            const int ty = t % tiles_y, strip = t / tiles_y;
+            const int oy0 = (p.out_row0 / C::TH + ty) * C::TH, ox0 = strip * G::TILE_W;
+            if (!(oy0 - G::M >= 0 && oy0 + C::TH - 1 + G::M <= p.gny - 1 && ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= p.nx - 1)) return false;
+        }
+        return p.defer[t] == kTileGeneral;
     };
     if (BOTH) {
         // nothing to do on a DEM of whole metres: one tile per lane, 64 tiles per ballot
@@ -787,10 +796,11 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
         const int cx = min(ox0 + G::TILE_W / 2, p.nx - 1);
         float cf = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
         if (!(fabsf(cf) <= kAbsLim)) cf = 0.0f;
-        // every disc of the strip's pixels stays inside the DEM's columns
+        // (a run that starts at the DEM's border has the padding's zeros in its first windows: half way)
+        if (kBorderHere && (ox0 - G::M < 0 || ox0 + G::TILE_W - 1 + G::M > p.nx - 1 || oyS - G::M < 0 || oyS + C::TH - 1 + G::M > p.gny - 1))
+            cf = truncf(0.5f * cf);
+        // (the large discs: every disc of the strip's pixels stays inside the DEM's columns?)
         const bool cols_inside = ox0 - G::M >= 0 && ox0 + G::TILE_W - 1 + G::M <= p.nx - 1;
-        // a run that starts at the DEM's border starts at c = 0 (see "The tiles at the DEM's border" above)
-        if (!BOTH && (!cols_inside || oyS - G::M < 0 || oyS + C::TH - 1 + G::M > p.gny - 1) && fabsf(cf) <= (float)lim32) cf = 0.0f;
         int ci = __builtin_amdgcn_readfirstlane((int)cf);
         const int gcol = gx0 + scol;
         const bool col_ok = stager && gcol >= 0 && gcol < p.nx;
@@ -846,28 +856,43 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
             uint32_t amax = 0;  // largest |x| as float bits (NaN / inf sort above all)
             bool frac = false;
             int lo = kBig, hi = -kBig;
+            // outside the DEM: a sample of elevation 0, the reference's padding; outside the block's view: nothing (u = 0).
+            // Two copies of the loop, chosen by the batch (the same for the whole block): rows inside the view need one select
+            // per sample - the four stagers are what a phase of the small discs waits for.
+            auto rows = [&](auto inside_tag) {
+                constexpr bool INSIDE = decltype(inside_tag)::value;  // every row of the batch is inside the block's view
 #pragma unroll
-            for (int r = 0; r < B; ++r) {
-                const int gy = gy0 + n0 + r;
-                const bool ok = col_ok && gy >= rmin && gy < rmax;
-                const float x = ok ? v[r] : (float)ci;  // outside: u = 0 (only tiles inside the DEM are computed)
-                const int t = (int)x;                  // truncation towards zero; NaN -> 0, caught by amax
-                frac |= x != (float)t;
-                amax = max(amax, __float_as_uint(x) & 0x7fffffffu);
-                lo = min(lo, t);
-                hi = max(hi, t);
-                const uint32_t u = (uint32_t)(t - ci);
-                run_u += u;
-                // (24-bit multiply, full rate: a sample that passes the classification has |trunc(x)| <= 2^18 and the
-                // offset follows the data, so |u| < 2^23; what a flagged sample leaves in the ring is never used)
-                run_u2 += (uint32_t)__mul24((int)u, (int)u);
-                q[r] = run_u;
-                q2[r] = run_u2;
-                if (BOTH) {
-                    run_f += stage_value<kStF>(ok ? x : 0.0f, 0.0f, 0);
-                    qf[r] = run_f;
+                for (int r = 0; r < B; ++r) {
+                    const int gy = gy0 + n0 + r;
+                    const bool ok = INSIDE ? col_ok : (col_ok && gy >= rmin && gy < rmax);
+                    float x;
+                    if (INSIDE) {
+                        x = ok ? v[r] : 0.0f;
+                    } else {
+                        // (the large discs leave the border tiles alone: whatever is staged outside the DEM reaches no output)
+                        const bool pad = kBorderHere && (!col_ok || gy < 0 || gy >= p.gny);
+                        x = ok ? v[r] : (pad ? 0.0f : (float)ci);
+                    }
+                    const int t = (int)x;                  // truncation towards zero; NaN -> 0, caught by amax
+                    frac |= x != (float)t;
+                    amax = max(amax, __float_as_uint(x) & 0x7fffffffu);
+                    lo = min(lo, t);
+                    hi = max(hi, t);
+                    const uint32_t u = (uint32_t)(t - ci);
+                    run_u += u;
+                    // (24-bit multiply, full rate: a sample that passes the classification has |trunc(x)| <= 2^18 and the
+                    // offset follows the data, so |u| < 2^23; what a flagged sample leaves in the ring is never used)
+                    run_u2 += (uint32_t)__mul24((int)u, (int)u);
+                    q[r] = run_u;
+                    q2[r] = run_u2;
+                    if (BOTH) {
+                        run_f += stage_value<kStF>(ok ? x : 0.0f, 0.0f, 0);
+                        qf[r] = run_f;
+                    }
                 }
-            }
+            };
+            if (kBorderHere && gy0 + n0 >= rmin && gy0 + n0 + B <= rmax) rows(std::true_type{});
+            else rows(std::false_type{});
             // wave-wide min / max: four rotations inside the rows of 16 lanes (DPP), then the four rows through the
             // scalar unit.  (Twelve __shfl_xor, i.e. LDS round trips one after the other, sat on the staging waves'
             // path to the barrier every phase.)
@@ -953,35 +978,47 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
 #pragma unroll
             for (int k = 0; k < HIST; ++k) wlo = min(wlo, hlo[k]), whi = max(whi, hhi[k]);
             if (ph % PPT == 0) {
-                // a new tile: re-base the ring when c has drifted from the middle of the range - or, at the DEM's border, to
-                // c = 0 when the window takes it (the zero padding then needs no tap counts)
+                // a new tile: re-base the ring when c has drifted from the middle of the range
+                // (or when the window does not fit around c where it is and would around its middle: the border windows, whose
+                // range starts at the padding's 0, are often close to the 2 lim32 the chain of squares takes).  A tile at the
+                // DEM's border has the padding's zeros in its windows, now or a few phases on: they belong to its range from
+                // the start, and when that range is too wide (Alpine terrain under a 65-px disc) the tile is the general
+                // kernel's at once, as every border tile was before - not after some of its rows have been computed for nothing.
                 const int oy0 = oyS + (ph / PPT) * C::TH;
-                const bool at_border = !cols_inside || oy0 - G::M < 0 || oy0 + C::TH - 1 + G::M > p.gny - 1;
-                const bool zero = !BOTH && at_border && wlo <= whi && whi <= lim32 && -wlo <= lim32;
-                const int mid = zero ? 0 : wlo + (whi - wlo) / 2;
-                if (wlo <= whi && (zero ? ci != 0 : abs(mid - ci) > lim32 / 4)) {
+                bool at_border, too_wide, rebase;
+                int mid;
+                if (kBorderHere) {
+                    at_border = ox0 - G::M < 0 || ox0 + G::TILE_W - 1 + G::M > p.nx - 1 || oy0 - G::M < 0 || oy0 + C::TH - 1 + G::M > p.gny - 1;
+                    const int tlo = at_border ? min(wlo, 0) : wlo, thi = at_border ? max(whi, 0) : whi;
+                    too_wide = at_border && tlo <= thi && thi - tlo > 2 * lim32;
+                    mid = tlo + (thi - tlo) / 2;
+                    const bool fits_now = thi - ci <= lim32 && ci - tlo <= lim32;
+                    rebase = tlo <= thi && !too_wide && (abs(mid - ci) > lim32 / 4 || (!fits_now && thi - tlo <= 2 * lim32));
+                } else {
+                    at_border = !cols_inside || oy0 - G::M < 0 || oy0 + C::TH - 1 + G::M > p.gny - 1;
+                    too_wide = at_border;  // (the general kernel's)
+                    mid = wlo + (whi - wlo) / 2;
+                    rebase = wlo <= whi && abs(mid - ci) > lim32 / 4;
+                }
+                if (rebase) {
                     const uint32_t delta = (uint32_t)(mid - ci);
                     const uint32_t d2 = delta * delta;
-                    // k: how many of a column's rows up to this one hold a SAMPLE (any constant added to it cancels in the
-                    // differences the chains take).  A row or column outside the DEM (or the block's view) was staged as u = 0
-                    // and stays so - it stands for "no tap", not for a sample at the old offset - so it must not move with c
-                    // (round 5: the tiles at the DEM's border are computed here now).
-                    const int n_old = C::PRO + ph * B - R;  // stream row of the oldest row in the ring
+                    // k: the rows of the column up to this one, counted from the oldest row in the ring (any constant added to
+                    // it cancels in the differences the chains take).  Every row moves with c - the padding's zeros are samples
+                    // like the others; what the rows outside a block's view hold reaches no output.
                     for (int idx = threadIdx.x; idx < R * G::W; idx += NW * 64) {
                         const int sl = idx / G::W, col = idx - sl * G::W;
                         int since = sl - wslot;  // rows since the oldest one in the ring
                         since = since < 0 ? since + R : since;
-                        const int gcol_r = gx0 + col;
-                        const int k = (gcol_r >= 0 && gcol_r < p.nx) ? min(max(gy0 + n_old + since + 1, rmin), rmax) : 0;
+                        const uint32_t k = (uint32_t)since + 1u;
                         uint32_t* q = Q + sl * PITCH + col;
                         const uint32_t q1 = q[0];
-                        q[G::W] = q[G::W] - 2u * delta * q1 + d2 * (uint32_t)k;
-                        q[0] = q1 - delta * (uint32_t)k;  // (the fractional parts do not depend on c)
+                        q[G::W] = q[G::W] - 2u * delta * q1 + d2 * k;
+                        q[0] = q1 - delta * k;  // (the fractional parts do not depend on c)
                     }
-                    if (stager) {
-                        const int k = col_ok ? min(max(gy0 + n_old + R, rmin), rmax) : 0;  // through the newest row
-                        run_u2 = run_u2 - 2u * delta * run_u + d2 * (uint32_t)k;
-                        run_u = run_u - delta * (uint32_t)k;
+                    if (stager) {  // (through the newest row: k = R)
+                        run_u2 = run_u2 - 2u * delta * run_u + d2 * (uint32_t)R;
+                        run_u = run_u - delta * (uint32_t)R;
                     }
                     ci = mid;
                     __syncthreads();
@@ -989,7 +1026,7 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
                 if (BOTH) {
                     tmode = candidate(tile) ? kNeedsFraction : kTileDone;  // (kTileDone here: not this pass's)
                 } else {
-                    tmode = at_border && !zero ? kTileGeneral : kTileDone;
+                    tmode = too_wide ? kTileGeneralWide : kTileDone;
                     if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
                 }
             }
@@ -997,9 +1034,9 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
             const bool fits = hist == 0 && whi - ci <= lim32 && ci - wlo <= lim32;
             if (BOTH) {
                 if (tmode == kNeedsFraction && !fits) tmode = kTileGeneral;  // the mark stays: general kernel
-            } else if (tmode != kTileGeneral && !fits) {
-                tmode = kTileGeneral;
-                if (threadIdx.x == 0) p.defer[tile] = kTileGeneral;
+            } else if ((tmode & 1) == 0 && !fits) {
+                tmode = hist != 0 ? kTileGeneral : kTileGeneralWide;  // (fractional samples: the second pass may take it)
+                if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
             }
             const bool compute = BOTH ? tmode == kNeedsFraction : tmode == kTileDone;
             uint32_t nq[B], nq2[B], nqf[BOTH ? B : 1];

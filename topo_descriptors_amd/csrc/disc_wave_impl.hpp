@@ -497,7 +497,9 @@ enum TileFlags { kTileFrac = 1, kTileWide = 2, kTileFloat = 4, kTileMissing = 8 
 // kNeedsFraction: its sums of trunc(x) are done, the fraction / scaled pass finishes it.
 // kTileGeneralRows: the general kernel writes only the rows named in WaveArgs::rowmask (the scaled route left them: their
 // own windows hold more relief than its unwrapping takes; the other rows of the tile are done)
-enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2, kTileGeneralRows = 3 };
+// kTileGeneralWide: the general kernel's like kTileGeneral (odd), left by std_ring_kernel for its RANGE (more relief than the chain
+// of squares takes) and not for fractional samples: nothing for that kernel's second pass (kStdBoth), which has the same limit
+enum TileState : uint8_t { kTileDone = 0, kTileGeneral = 1, kNeedsFraction = 2, kTileGeneralRows = 3, kTileGeneralWide = 5 };
 
 // aux: kStUL the limb (0 / 1); kStU2L the limb (bits 0-1) and "the last limb: all the bits that are left" (bit 2)
 template <int WHAT>
@@ -712,7 +714,7 @@ __device__ __forceinline__ void disc_wave_kernel_body(const WaveArgs& p, int til
                 const int mx1 = p.map_tw ? (min(tx * G::TILE_W + G::TILE_W, p.nx) - 1) / p.map_tw : tx;
                 for (int mx = mx0; mx <= mx1; ++mx)
                     for (int my = r0 / p.map_th; my <= r1 / p.map_th; ++my)
-                        marked = marked || p.defer[mx * p.map_tiles_y + (my - base)] == 1;
+                        marked = marked || (p.defer[mx * p.map_tiles_y + (my - base)] & 1) != 0;
             }
         }
         take = marked;
@@ -2293,8 +2295,8 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
         if (std_out && SIZE >= std_ring_min_size()) {
             // one staging pass: u and u^2 rings side by side (disc_ring_impl.hpp), then the general kernel over
             // the tiles it marked (its map has this kernel's strips and rows of 60)
-            // (the tiles at the DEM's border are the ring kernel's own where c = 0 fits their windows - every tile of an ordinary
-            // DEM up to 17 px - and the general kernel's otherwise: disc_ring_impl.hpp)
+            // (the tiles at the DEM's border are the ring kernel's own: the padding's zeros are staged as samples, and such a
+            // window is the general kernel's only when its highest sample passes 2 lim32 - disc_ring_impl.hpp)
             if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out)));
             else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out)));
             if constexpr (std_ring_both_fits(SIZE)) {
