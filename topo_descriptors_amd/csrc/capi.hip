@@ -2013,8 +2013,8 @@ int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int 
     ClassScope cls(s.owned);  // (one rank: the shard is the raster; otherwise what topo_amd_shard_classify / _raster_class_set declared)
     forget_plane(tpi_out, rows_local, nx);
     forget_plane(std_out, rows_local, nx);
-    // (tile rows of the first kernel: 60 for the ring kernels of STD and the marching TPI kernels, 64 for the TPI rings)
-    const int tile_rows = std_out ? 60 : (size <= 17 ? 64 : 60);
+    // (tile rows of the first kernel: 48 / 60 for the ring kernels of STD, 60 for the marching TPI kernels, 64 for the TPI rings)
+    const int tile_rows = std_out ? std_tile_rows(size) : (size <= 17 ? 64 : 60);
     return run_fused(block, s, above, below, tile_rows, [&](const Block& view, int o0, int on) {
         Block b = view;
         b.out_row0 = o0;

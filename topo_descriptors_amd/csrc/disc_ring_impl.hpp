@@ -132,7 +132,9 @@ __device__ __forceinline__ int ring_dword_of_column(int c) {
 // i + LEAD are fetched before the column sums of run i are formed.
 // P0 / P1 (CHAIN_PRIO, disc_wave_impl.hpp): issue priority of the wave for the first and the second half of the
 // chain's steps (-1: leave it alone), so that the waves sharing a SIMD advance together instead of one after the other.
-template <int SIZE, int NCR, int R, int LEAD, int PITCH = 64 * NCR, int P0 = -1, int P1 = -1>
+// SB: scheduling fences around the column sums of a run (the large discs: they keep the reads of run i + LEAD ahead of the
+// subtractions of run i); the small discs' build leaves the scheduler free to interleave the chains of its rows.
+template <int SIZE, int NCR, int R, int LEAD, int PITCH = 64 * NCR, int P0 = -1, int P1 = -1, bool SB = true>
 __device__ __forceinline__ void ring_disc_sum(const uint32_t* ring, int s0, int lane, uint32_t (&acc)[NCR],
                                               uint32_t (&ctr)[NCR], bool young) {
     using G = RGeo<SIZE, NCR>;
@@ -181,12 +183,12 @@ __device__ __forceinline__ void ring_disc_sum(const uint32_t* ring, int s0, int 
             if (G::S.first_step[G::S.order[j]] == D) {
                 const int r = G::S.order[j];
                 if (j + LEAD < NR) fetch(j + LEAD);
-                RING_SB();
+                if (SB) RING_SB();
 #pragma unroll
                 for (int P = 0; P < G::PARTS; ++P)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) cv[r][4 * P + s] = top[r][P][s] - bot[r][P][s];
-                RING_SB();
+                if (SB) RING_SB();
             }
         }
 #pragma unroll
@@ -228,7 +230,7 @@ __device__ __forceinline__ void ring_disc_sum(const uint32_t* ring, int s0, int 
                 }
             }
         }
-        RING_SB();
+        if (SB) RING_SB();
     }
 #pragma unroll
     for (int t = 0; t < NCR; ++t) {
@@ -670,12 +672,18 @@ int launch_ring(const Block& b, float* tpi_out, float* tpi2_out = nullptr) {
 // A window whose relief exceeds 2 lim32 (2244 m at 67 px) cannot be centred: its tile goes to the general
 // kernel through the map (rows of 60, this kernel's own strips), like the tiles with fractional or non-finite
 // samples and the tiles whose discs leave the DEM (their in-domain tap counts differ from n).
+// The small discs take the build with staging waves apart from chain waves (std_ring_spec_kernel, below): its batches are 16
+// rows, so the map tiles of those sizes - this kernel's second pass (kStdBoth) works on the same map - are 48 rows.
+// (kStdSpecMax, std_tile_rows: common.hpp - the shard launcher aligns its seams to these tile rows)
+constexpr bool std_ring_spec(int size) { return size >= 5 && size % 2 == 1 && size <= kStdSpecMax; }
+constexpr int std_ring_tile_rows(int size) { return std_tile_rows(size); }
+
 template <int SIZE>
 struct StdRingCfg {
     using G = RGeo<SIZE, 4>;
     static constexpr int NW = 12;
     static constexpr int B = NW;
-    static constexpr int TH = 60;
+    static constexpr int TH = std_ring_tile_rows(SIZE);
     static constexpr int PPT = TH / B;
     static constexpr int R = SIZE + B;
     static constexpr int PITCH = 2 * G::W;  // dwords per ring row: the u image, then the u^2 image
@@ -971,6 +979,13 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
         const bool lane_ok = lane >= DL && lane < 64 - DL;
         int s0 = C::PAD - 1 + wave;
         int tmode = kTileDone;  // what the map says about the current tile
+#ifdef STD_STAMPS  // (lab build, tools/ubench/tpi_lab.hip: s_memtime around the parts of a phase, summed per wave)
+        long long tsum[6] = {0, 0, 0, 0, 0, 0};
+#define STD_STAMP(i) { const long long now_ = __builtin_amdgcn_s_memtime(); tsum[i] += now_ - tlast; tlast = now_; }
+        long long tlast = __builtin_amdgcn_s_memtime();
+#else
+#define STD_STAMP(i)
+#endif
 #pragma unroll 1
         for (int ph = 0; ph < nphase; ++ph) {
             const int tile = tile0 + ph / PPT;
@@ -1092,16 +1107,27 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
             }
             if (BOTH && ph % PPT == PPT - 1 && tmode == kNeedsFraction && threadIdx.x == 0) p.defer[tile] = kTileDone;
             if (!BOTH && ph % PPT == PPT - 1 && tmode == kTileGeneral) ++seen_general;
+            STD_STAMP(0)
             const Seen seen = convert_batch(C::PRO + ph * B, va, nq, nq2, nqf);
             s0 += B;
             s0 = s0 >= R ? s0 - R : s0;
+            STD_STAMP(1)
             __syncthreads();
+            STD_STAMP(2)
             write_batch(nq, nq2, nqf);
             load_batch(C::PRO + (ph + 1) * B, va);
             publish((ph + 1) & 1, seen);
+            STD_STAMP(3)
             __syncthreads();
+            STD_STAMP(4)
             fold((ph + 1) & 1);
+            STD_STAMP(5)
         }
+#ifdef STD_STAMPS
+        if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 131) && (wave == 0 || wave == 5 || wave == 11) && pos == first)
+            printf("blk %3d wave %2d phases %d: chain+finalise %lld | convert %lld | barrier %lld | write+loads %lld | barrier %lld | fold %lld   (memtime ticks, 100 MHz)\n",
+                   (int)blockIdx.x, wave, nphase, tsum[0], tsum[1], tsum[2], tsum[3], tsum[4], tsum[5]);
+#endif
         pos += run_tiles;
     }
     // what this block's run looked like, for the next call on this DEM (dem_memo, common.hpp): tiles, and tiles it left to
@@ -1119,6 +1145,379 @@ __global__ __launch_bounds__(768) void std_ring_kernel(WaveArgs p, int tiles_x, 
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>
 __global__ __launch_bounds__(768) void std_ring_kernel_parts(WaveParts ps, int tiles_x) {
     TOPO_RUN_PARTS((std_ring_kernel_body<SIZE, WANT_TPI, MODE>));
+}
+
+
+// ---- The small discs: staging waves apart from chain waves (round 5) ------------------------------------------------
+// s_memtime stamps of std_ring_kernel<7> (profiles/r05_std7_stamps.txt): a phase - 12 rows - takes 4900 cycles of which the
+// chip's vector ALUs have work for 1500.  The rest is the order of things: the four staging waves run their chains, THEN
+// convert the next batch (1400 cycles alone on their SIMDs: one wave issues an instruction every 4 - 5 cycles) while the other
+// eight wait at the barrier, then write it and issue the loads (1200 cycles) behind a second barrier.  Here the two jobs
+// run side by side: waves 0-3 only stage (convert batch ph + 1, write it into ring slots nobody reads yet, issue the loads of
+// batch ph + 2), waves 4-11 only run chains (two output rows each per phase, 16 rows per phase), ONE barrier per phase.
+// The ring has 16 more slots for that (R = SIZE + 32); everything else - the offset c and its re-basing, the classification
+// per batch, the border's zeros as samples, the finalisation - is std_ring_kernel's, expression for expression, so the bits are.
+// Used for 5 ... 13 px, where staging and chains weigh about the same; beyond, the chains are what a phase waits for.
+template <int SIZE>
+struct StdSpecCfg {
+    using G = RGeo<SIZE, 4>;
+    static constexpr int NW = 12, SW = G::W / 64, CW = NW - SW, RPW = 2;
+    static constexpr int B = CW * RPW;  // rows per phase and per batch: 16
+    static constexpr int TH = std_ring_tile_rows(SIZE);
+    static constexpr int PPT = TH / B;
+    static constexpr int R = SIZE + 2 * B;
+    static constexpr int PITCH = 2 * G::W;
+    static constexpr int HALO = SIZE - 1;
+    static constexpr int PAD = 1 + (B - (1 + HALO + B) % B) % B;
+    static constexpr int PRO = PAD + HALO + B;
+    static constexpr int NB_PRO = PRO / B;
+    static constexpr int HIST = (SIZE + 2 * B - 1) / B + 1;
+    static constexpr size_t LDS = (size_t)R * PITCH * sizeof(uint32_t) + 2 * NW * 4 * sizeof(int) + 16;
+    // 5 and 7 px: two rings fit a CU's LDS, and the kernel is short of waves (every wave runs a serial stream of dependent
+    // instructions): two blocks per CU, 6 waves per SIMD, 84 registers
+    static constexpr bool kTwoBlocks = 2 * LDS <= 160 * 1024;
+    static constexpr int kWavesPerSimd = kTwoBlocks ? 6 : 3;
+    static_assert(SW == 4 && B == 16, "four staging waves, eight chain waves with two rows each");
+    static_assert(TH % B == 0 && PRO % B == 0, "whole batches");
+    static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
+    static_assert(HIST <= 16, "flag history");
+};
+
+template <int SIZE, bool WANT_TPI>
+__device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
+    using G = RGeo<SIZE, 4>;
+    using C = StdSpecCfg<SIZE>;
+    constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW, HIST = C::HIST, PITCH = C::PITCH;
+    constexpr int DL = G::DL;
+    constexpr int kBig = 0x3fffffff;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+    uint32_t* Q = lds_u;
+    int* wflags = reinterpret_cast<int*>(Q + R * PITCH);  // [2 parities][NW][4]: flags, min, max of the batch a wave staged
+    // more than 128 registers: the block's 12 waves then cannot sit 4 + 4 + 2 + 2 on the SIMDs (the two-blocks-per-CU build of
+    // the smallest discs: 84 at most)
+    if (!C::kTwoBlocks) asm volatile("" ::: "v140");
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ntiles = tiles_x * tiles_y;
+    const int vb = (vb0 + deal.shift) % nb;
+    const int first = deal.first(vb);
+    const int last = min(first + deal.count(vb), ntiles);
+    const double n = (double)G::T.taps;
+    const double inv_nm1 = 1.0 / (n - 1.0);
+    const double inv_nn1 = 1.0 / (n * (n - 1.0));
+    const int lim32 = (int)floorf(sqrtf(4294967295.0f / (float)G::T.taps));
+    const int rmin = max(0, p.in_row0), rmax = min(p.gny, p.in_row0 + p.in_rows);
+    const bool stager = wave < C::SW;
+    const int scol = 64 * wave + lane;  // staged column of a staging lane
+    int seen_general = 0;
+
+#pragma unroll 1
+    for (int pos = first; pos < last;) {
+        const int tile0 = pos;
+        const int run_tiles = min(last - tile0, tiles_y - tile0 % tiles_y);
+        const int ty0 = tile0 % tiles_y;
+        const int strip = tile0 / tiles_y;
+        const int nphase = run_tiles * PPT;
+        const int ox0 = strip * G::TILE_W;
+        const int oyS = (p.out_row0 / C::TH + ty0) * C::TH;
+        const int gx0 = ox0 - G::X0;
+        const int gy0 = oyS - G::M - C::PAD;
+        int cy = min(max(oyS + C::TH / 2, 0), p.gny - 1);
+        cy = min(max(cy, p.in_row0), p.in_row0 + p.in_rows - 1);
+        const int cx = min(ox0 + G::TILE_W / 2, p.nx - 1);
+        float cf = truncf(p.in[(size_t)(cy - p.in_row0) * p.nx + cx]);
+        if (!(fabsf(cf) <= kAbsLim)) cf = 0.0f;
+        const bool cols_border = ox0 - G::M < 0 || ox0 + G::TILE_W - 1 + G::M > p.nx - 1;
+        if (cols_border || oyS - G::M < 0 || oyS + C::TH - 1 + G::M > p.gny - 1) cf = truncf(0.5f * cf);
+        int ci = __builtin_amdgcn_readfirstlane((int)cf);
+        const int gcol = gx0 + scol;
+        const bool col_ok = stager && gcol >= 0 && gcol < p.nx;
+        const float* src = p.in + (col_ok ? gcol : 0);
+        auto load_batch = [&](int n0, float (&v)[B]) {
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                int gy = gy0 + n0 + r;
+                gy = min(max(gy, rmin), rmax - 1);
+                v[r] = src[(size_t)(gy - p.in_row0) * p.nx];
+            }
+        };
+        {
+            // a run of fractional elevations is handed over unstaged (std_ring_kernel)
+            int odd = 0;
+            const int pc = min(max(ox0 + 4 * lane, 0), p.nx - 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int gy = oyS + ((2 * u + 1) * run_tiles * C::TH) / 8;
+                gy = min(max(gy, rmin), rmax - 1);
+                const float x = p.in[(size_t)(gy - p.in_row0) * p.nx + pc];
+                odd += __builtin_amdgcn_ballot_w64(!(x == truncf(x))) != 0 ? 1 : 0;
+            }
+            if (odd == 4) {
+                for (int t = tile0 + (int)threadIdx.x; t < tile0 + run_tiles; t += NW * 64) p.defer[t] = kTileGeneral;
+                pos += run_tiles;
+                continue;
+            }
+        }
+        uint32_t run_u = 0, run_u2 = 0;
+        int wslot = 0;  // ring slot of the next row to stage
+        struct Seen { int flags, lo, hi; };
+        // (stagers only) one batch: classify, convert, prefix, write into the ring, publish what was seen
+        auto stage_batch = [&](int n0, const float (&v)[B], int parity) {
+            // classification on the float samples: min / max of x (trunc is monotonic, so the smallest and largest trunc(x) are
+            // those of the smallest and largest x; v_min / v_max skip a NaN, which the whole-metre test catches: NaN != anything)
+            bool frac = false;
+            float xlo = INFINITY, xhi = -INFINITY;
+            uint32_t q[B], q2[B];
+            auto rows = [&](auto inside_tag) {
+                constexpr bool INSIDE = decltype(inside_tag)::value;  // every row of the batch is inside the block's view
+#pragma unroll
+                for (int r = 0; r < B; ++r) {
+                    const int gy = gy0 + n0 + r;
+                    const bool ok = INSIDE ? col_ok : (col_ok && gy >= rmin && gy < rmax);
+                    float x;
+                    if (INSIDE) {
+                        x = ok ? v[r] : 0.0f;
+                    } else {
+                        const bool pad = !col_ok || gy < 0 || gy >= p.gny;  // outside the DEM: a sample of elevation 0
+                        x = ok ? v[r] : (pad ? 0.0f : (float)ci);
+                    }
+                    const int t = (int)x;
+                    frac |= x != (float)t;
+                    xlo = fminf(xlo, x);
+                    xhi = fmaxf(xhi, x);
+                    const uint32_t u = (uint32_t)(t - ci);
+                    run_u += u;
+                    run_u2 += (uint32_t)__mul24((int)u, (int)u);
+                    q[r] = run_u;
+                    q2[r] = run_u2;
+                }
+            };
+            if (gy0 + n0 >= rmin && gy0 + n0 + B <= rmax) rows(std::true_type{});
+            else rows(std::false_type{});
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                int sl = wslot + r;
+                sl = sl >= R ? sl - R : sl;
+                Q[sl * PITCH + scol] = q[r];
+                Q[sl * PITCH + G::W + scol] = q2[r];
+            }
+            // (a lane that saw NaN only keeps +-inf here: its flag is up through frac; the clamps keep the range arithmetic in int32)
+            const bool absurd = !(fmaxf(fabsf(xlo), fabsf(xhi)) < kAbsLim + 1.0f);
+            int lo = (int)fminf(fmaxf(xlo, -(float)kBig), (float)kBig), hi = (int)fminf(fmaxf(xhi, -(float)kBig), (float)kBig);
+            lo = wave_min_max<false>(lo);
+            hi = wave_min_max<true>(hi);
+            int fl = 0;
+            if (__builtin_amdgcn_ballot_w64(frac)) fl |= kTileFrac;
+            if (__builtin_amdgcn_ballot_w64(absurd)) fl |= kTileFloat;
+            if (lane == 0) {
+                int* w = wflags + (parity * NW + wave) * 4;
+                w[0] = fl;
+                w[1] = lo;
+                w[2] = hi;
+            }
+        };
+        auto advance_wslot = [&]() {
+            wslot += B;
+            wslot = wslot >= R ? wslot - R : wslot;
+        };
+        unsigned hist = 0;
+        int hlo[HIST], hhi[HIST];
+#pragma unroll
+        for (int k = 0; k < HIST; ++k) hlo[k] = kBig, hhi[k] = -kBig;
+        auto fold = [&](int parity, int nbatches) {
+            // (the prologue publishes the range of all its batches at once: nbatches entries of the history)
+            int fl = 0, lo = kBig, hi = -kBig;
+#pragma unroll
+            for (int w = 0; w < C::SW; ++w) {
+                const int* q = wflags + (parity * NW + w) * 4;
+                fl |= q[0];
+                lo = min(lo, q[1]);
+                hi = max(hi, q[2]);
+            }
+            fl = __builtin_amdgcn_readfirstlane(fl);
+            hist = ((hist << 1) | ((fl & (kTileFrac | kTileFloat)) ? 1u : 0u)) & ((1u << HIST) - 1u);
+#pragma unroll
+            for (int k = HIST - 1; k > 0; --k) hlo[k] = hlo[k - 1], hhi[k] = hhi[k - 1];
+            hlo[0] = __builtin_amdgcn_readfirstlane(lo);
+            hhi[0] = __builtin_amdgcn_readfirstlane(hi);
+            (void)nbatches;
+        };
+
+        // prologue: the window of phase 0, one batch at a time; the stagers fold what they saw into one entry
+        // (two batches of loads in flight - a second buffer, the phases unrolled in pairs - changed nothing: 2.27 -> 2.35 ms at
+        // 7 px; the kernel does not wait for its loads)
+        float va[B];
+        __syncthreads();  // (the previous run's chain waves are done with the ring and the flag words)
+        if (stager) {
+            int fl = 0, lo = kBig, hi = -kBig;
+#pragma unroll 1
+            for (int k = 0; k < C::NB_PRO; ++k) {
+                load_batch(k * B, va);
+                stage_batch(k * B, va, 1);
+                advance_wslot();
+                if (lane == 0) {  // (own words: read back what stage_batch just published)
+                    const int* w = wflags + (1 * NW + wave) * 4;
+                    fl |= w[0];
+                    lo = min(lo, w[1]);
+                    hi = max(hi, w[2]);
+                }
+            }
+            if (lane == 0) {
+                int* w = wflags + (0 * NW + wave) * 4;
+                w[0] = fl;
+                w[1] = lo;
+                w[2] = hi;
+            }
+            load_batch(C::PRO, va);
+        } else {
+            for (int k = 0; k < C::NB_PRO; ++k) advance_wslot();
+        }
+        __syncthreads();
+        fold(0, C::NB_PRO);
+
+        const int ocol = gx0 + lane * 4;
+        const bool lane_ok = lane >= DL && lane < 64 - DL;
+        int tmode = kTileDone;
+#ifdef STD_STAMPS
+        long long ssum[6] = {0, 0, 0, 0, 0, 0};
+#define SPEC_STAMP(i) { const long long now_ = __builtin_amdgcn_s_memtime(); ssum[i] += now_ - slast; slast = now_; }
+        long long slast = __builtin_amdgcn_s_memtime();
+#else
+#define SPEC_STAMP(i)
+#endif
+        auto phase = [&](const int ph, float (&vbuf)[B]) {
+            const int tile = tile0 + ph / PPT;
+            int wlo = kBig, whi = -kBig;
+#pragma unroll
+            for (int k = 0; k < HIST; ++k) wlo = min(wlo, hlo[k]), whi = max(whi, hhi[k]);
+            if (ph % PPT == 0) {
+                // a new tile: the offset follows the range (std_ring_kernel; the padding's zeros belong to a border tile's range)
+                const int oy0 = oyS + (ph / PPT) * C::TH;
+                const bool at_border = cols_border || oy0 - G::M < 0 || oy0 + C::TH - 1 + G::M > p.gny - 1;
+                const int tlo = at_border ? min(wlo, 0) : wlo, thi = at_border ? max(whi, 0) : whi;
+                const bool too_wide = at_border && tlo <= thi && thi - tlo > 2 * lim32;
+                const int mid = tlo + (thi - tlo) / 2;
+                const bool fits_now = thi - ci <= lim32 && ci - tlo <= lim32;
+                if (tlo <= thi && !too_wide && (abs(mid - ci) > lim32 / 4 || (!fits_now && thi - tlo <= 2 * lim32))) {
+                    // (nobody writes the ring here: the stagers are in this branch too)
+                    const uint32_t delta = (uint32_t)(mid - ci);
+                    const uint32_t d2 = delta * delta;
+                    for (int idx = threadIdx.x; idx < R * G::W; idx += NW * 64) {
+                        const int sl = idx / G::W, col = idx - sl * G::W;
+                        int since = sl - wslot;
+                        since = since < 0 ? since + R : since;
+                        const uint32_t k = (uint32_t)since + 1u;
+                        uint32_t* q = Q + sl * PITCH + col;
+                        const uint32_t q1 = q[0];
+                        q[G::W] = q[G::W] - 2u * delta * q1 + d2 * k;
+                        q[0] = q1 - delta * k;
+                    }
+                    if (stager) {
+                        run_u2 = run_u2 - 2u * delta * run_u + d2 * (uint32_t)R;
+                        run_u = run_u - delta * (uint32_t)R;
+                    }
+                    ci = mid;
+                    __syncthreads();
+                }
+                tmode = too_wide ? kTileGeneralWide : kTileDone;
+                if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
+            }
+            const bool fits = hist == 0 && whi - ci <= lim32 && ci - wlo <= lim32;
+            if ((tmode & 1) == 0 && !fits) {
+                tmode = hist != 0 ? kTileGeneral : kTileGeneralWide;
+                if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
+            }
+            if (ph % PPT == PPT - 1 && tmode == kTileGeneral) ++seen_general;
+            if (stager) {
+                // the batch phase ph + 1 needs, into the slots behind this phase's window; then the loads of the one after
+                SPEC_STAMP(0)
+                stage_batch(C::PRO + ph * B, vbuf, (ph + 1) & 1);
+                SPEC_STAMP(1)
+                load_batch(C::PRO + (ph + 1) * B, vbuf);
+                SPEC_STAMP(2)
+            } else if (tmode == kTileDone) {
+                SPEC_STAMP(0)
+#pragma unroll 1
+                for (int k = 0; k < C::RPW; ++k) {
+                    const int j = (wave - C::SW) * C::RPW + k;  // row of the phase
+                    int s0 = C::PAD - 1 + ph * B + j;           // stream row of Q index 0 of the output row's window
+                    s0 = s0 % R;
+                    uint32_t su[4], ctr[4], su2[4], dummy[4];
+                    // (unrolling the two rows and dropping the scheduling fences, so that their chains interleave, changed nothing
+                    // at 5 - 9 px and cost 4 - 9 % at 11 - 13 px)
+                    ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q, s0, lane, su, ctr, false);
+                    ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q + G::W, s0, lane, su2, dummy, false);
+                    const int oy = oyS + ph * B + j;
+                    if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
+                        const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+                        Vec4<float> out_s, out_t;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            out_s.v[t] = std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1);
+                            if (WANT_TPI) {
+                                const int xi = (int)ctr[t] + ci;
+                                out_t.v[t] = (float)((double)xi - (double)((int)su[t] + ci * G::T.taps - xi) * inv_nm1);
+                            }
+                        }
+                        *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+                        if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+                    }
+                }
+            }
+            SPEC_STAMP(3)
+            advance_wslot();
+            __syncthreads();
+            SPEC_STAMP(4)
+            fold((ph + 1) & 1, 1);
+            SPEC_STAMP(5)
+        };
+#pragma unroll 1
+        for (int ph = 0; ph < nphase; ++ph) phase(ph, va);
+#ifdef STD_STAMPS
+        if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 131) && (wave == 0 || wave == 5 || wave == 11) && pos == first)
+            printf("blk %3d wave %2d phases %d: top of phase %lld | stage / - %lld | loads / - %lld | (chains) %lld | barrier %lld | fold %lld  (memtime ticks)\n",
+                   (int)blockIdx.x, wave, nphase, ssum[0], ssum[1], ssum[2], ssum[3], ssum[4], ssum[5]);
+#endif
+        pos += run_tiles;
+    }
+    if (p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
+        __hip_atomic_store(p.report + 1, (uint32_t)seen_general, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.report, (uint32_t)(last > first ? last - first : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int SIZE, bool WANT_TPI>
+__global__ __launch_bounds__(768, StdSpecCfg<SIZE>::kWavesPerSimd) void std_ring_spec_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((std_ring_spec_body<SIZE, WANT_TPI>));
+}
+template <int SIZE, bool WANT_TPI>
+__global__ __launch_bounds__(768, StdSpecCfg<SIZE>::kWavesPerSimd) void std_ring_spec_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((std_ring_spec_body<SIZE, WANT_TPI>));
+}
+
+template <int SIZE, bool WANT_TPI>
+int launch_std_ring_spec(const Block& b, float* tpi_out, float* std_out) {
+    using G = RGeo<SIZE, 4>;
+    using C = StdSpecCfg<SIZE>;
+    Context& c = ctx();
+    WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
+               nullptr, nullptr, nullptr, 0, 0, 0};
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_spec_kernel<SIZE, WANT_TPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        int nblk = 0;
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_spec_kernel<SIZE, WANT_TPI>, C::NW * 64, C::LDS));
+        blocks_per_cu = nblk < 1 ? 1 : (nblk > 2 ? 2 : nblk);
+    }
+    WaveParts ps;
+    int tiles_x = 0;
+    long ntiles = 0;
+    a.report = dem_memo_report(b);
+    TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
+    const long grid = march_grid(c, blocks_per_cu, ntiles);
+    deal_parts(&ps, tiles_x, grid, blocks_per_cu);
+    return launch_parts(std_ring_spec_kernel<SIZE, WANT_TPI>, std_ring_spec_kernel_parts<SIZE, WANT_TPI>, grid, C::NW * 64, C::LDS, ps, tiles_x);
 }
 
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>

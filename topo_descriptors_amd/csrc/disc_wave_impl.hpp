@@ -2297,8 +2297,13 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
             // the tiles it marked (its map has this kernel's strips and rows of 60)
             // (the tiles at the DEM's border are the ring kernel's own: the padding's zeros are staged as samples, and such a
             // window is the general kernel's only when its highest sample passes 2 lim32 - disc_ring_impl.hpp)
-            if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out)));
-            else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out)));
+            if constexpr (std_ring_spec(SIZE)) {  // the small discs: staging waves apart from chain waves
+                if (tpi_out) TOPO_TRY((launch_std_ring_spec<SIZE, true>(b, tpi_out, std_out)));
+                else TOPO_TRY((launch_std_ring_spec<SIZE, false>(b, nullptr, std_out)));
+            } else {
+                if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true>(b, tpi_out, std_out)));
+                else TOPO_TRY((launch_std_ring<SIZE, false>(b, nullptr, std_out)));
+            }
             if constexpr (std_ring_both_fits(SIZE)) {
                 // tiles with fractional elevations: one more pass of the ring kernel with a third image (the
                 // fractional parts) instead of the general kernel's three staging passes
