@@ -163,8 +163,8 @@ int launch_tpi_std(const Block& b, const DiscRuns& disc, float* tpi_out, float* 
 int launch_disc_wave(const Block& b, int size, float* tpi_out, float* std_out);
 bool disc_wave_covers(int size);  // a specialisation exists for this disc size
 // Tile rows of the STD / TPI + STD ring kernels: the small discs take the build with staging waves apart from chain waves
-// (disc_ring_impl.hpp, std_ring_spec_kernel: batches of 16 rows, map tiles of 48), the others std_ring_kernel (12 and 60).
-constexpr int kStdSpecMax = 13;
+// (disc_ring_impl.hpp, std_ring_spec_kernel: batches of 16 rows, map tiles of 48) up to 41 px, the others std_ring_kernel (12 and 60).
+constexpr int kStdSpecMax = 41;
 constexpr int std_tile_rows(int size) { return size >= 5 && size % 2 == 1 && size <= kStdSpecMax ? 48 : 60; }
 // TPI of two small disc sizes from one pass over the DEM (disc_pair.hip); TOPO_AMD_EUNSUP = pair not covered
 int launch_tpi_pair(const Block& b, int size_a, float* out_a, int size_b, float* out_b);

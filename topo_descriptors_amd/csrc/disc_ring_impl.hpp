@@ -1157,7 +1157,9 @@ __global__ __launch_bounds__(768) void std_ring_kernel_parts(WaveParts ps, int t
 // batch ph + 2), waves 4-11 only run chains (two output rows each per phase, 16 rows per phase), ONE barrier per phase.
 // The ring has 16 more slots for that (R = SIZE + 32); everything else - the offset c and its re-basing, the classification
 // per batch, the border's zeros as samples, the finalisation - is std_ring_kernel's, expression for expression, so the bits are.
-// Used for 5 ... 13 px, where staging and chains weigh about the same; beyond, the chains are what a phase waits for.
+// Used for 5 ... 41 px (kStdSpecMax): same-box A/B on the 32768^2 bench DEM (tools/std_time.py, profiles/r05_std_spec_ab.txt), STD
+// 7 px 2.67 -> 2.33 ms, 17 px 3.35 -> 2.91, 25 px 4.20 -> 3.83, 31 px 4.58 -> 4.43, 41 px 5.98 -> 5.40; level at 43 - 47 px (where
+// eight chain waves carry what twelve did), and from 49 px the ring has no room for the second batch.
 template <int SIZE>
 struct StdSpecCfg {
     using G = RGeo<SIZE, 4>;
