@@ -230,7 +230,11 @@ def disc_kernels(what, size):
     if what == "tpi":
         return ("tpi_ring_kernel<%d, 8, .>" % size if 5 <= size <= 11 else "tpi_march_kernel<%d, 60, 12, ..>" % size) + \
             " (+ fraction pass and general kernel over marked tiles: none on whole metres)"
-    if 5 <= size <= 67:
+    if 5 <= size <= 41:
+        return "std_ring_spec_kernel<%d, %s> (u and u^2 rings, one staging pass; four staging waves beside eight chain waves, one " \
+               "barrier per 16 rows; the DEM's border tiles included: padding staged as samples of elevation 0) + disc_wave_kernel " \
+               "over the marked tiles (windows with more than 2 lim32 of relief: none here)" % (size, "true" if what == "tpi_std" else "false")
+    if size <= 67:
         return "std_ring_kernel<%d, %s> (u and u^2 rings, one staging pass) + disc_wave_kernel over the marked tiles " \
                "(DEM border, windows with more than 2 lim32 of relief)" % (size, "true" if what == "tpi_std" else "false")
     return "tpi_march_kernel<%d, 60, 12, OUT_SUM> + std_march_kernel<%d, 60, 12> + disc_wave_kernel over marked tiles" % (size, size)
@@ -329,8 +333,8 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
               "tpi_ring_kernel<., kRingMark> (whole-metre tiles, marks) + tpi_ring_kernel<., kRingBoth> (second image: the "
               "fractional parts in 2^-16 m)")
         entry(f"std_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, std=o2), REPS, d), 8,
-              "std_ring_kernel<., kStdMain> + std_ring_kernel<., kStdBoth> (third image: the fractional parts)" if size <= 41 else
-              "disc_wave_kernel (general, three staging passes)")
+              "std_ring_spec_kernel<.> + std_ring_kernel<., kStdBoth> (third image: the fractional parts)" if size <= 41 else
+              "tpi_march_sums_kernel + std_march_kernel<FRAC_STORE> + tpi_fraction_march_kernel<WANT_STD> (three marching passes)")
     frac.free()
     for a in (o1, o2, o3, o4):
         a.free()
