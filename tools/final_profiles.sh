@@ -25,6 +25,11 @@ cp gpurun_out/final/pmc_std67/summary.txt $F/r05_std67_pmc_summary.txt
 cp gpurun_out/final/pmc_std67/summary.txt profiles/r05_std67_pmc_summary.txt
 python3 tools/valu_bound.py std > profiles/r05_std67_valu_bound.json 2> $F/valu_bound_std.err
 cp profiles/r05_std67_valu_bound.json $F/
+# the small discs' kernel with staging waves apart from chain waves (std_ring_spec_kernel<7, .>)
+PMC_SCRIPT=tools/std_trace.py tools/pmc_passes.sh final/pmc_std7 32768 7 > /dev/null 2>&1
+cp gpurun_out/final/pmc_std7/summary.txt $F/r05_std7_pmc_summary.txt
+cp gpurun_out/final/pmc_std7/summary.txt profiles/r05_std7_pmc_summary.txt
+python3 tools/traffic_from_pmc.py gpurun_out/final/pmc_std7 "std_ring_spec_kernel<7, false" $F/r05_std7_traffic.json $HEAD > $F/traffic_std7.log 2>&1
 # the gradient at both sigmas of config 3 (round 3: f16 matrix pipe, fused short filters)
 PMC_SCRIPT=tools/grad_trace.py tools/pmc_passes.sh final/pmc_grad325 32768 3.25 > /dev/null 2>&1
 cp gpurun_out/final/pmc_grad325/summary.txt $F/r05_grad325_pmc_summary.txt
