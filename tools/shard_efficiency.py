@@ -18,7 +18,7 @@ from topo_descriptors_amd import _lib, device as d, shard as shard_mod  # noqa: 
 NY = NX = int(os.environ.get("SHARD_EFF_N", "32768"))
 PARTS = 8
 REPS = int(os.environ.get("SHARD_EFF_REPS", "12"))
-KEYS = ("tpi_s67", "std_s67", "tpi_std_s67", "gradient_sigma3.25", "gradient_sigma30.25", "sx_az0_r500")
+KEYS = ("tpi_s67", "std_s67", "tpi_std_s67", "std_s7", "tpi_std_s7", "gradient_sigma3.25", "gradient_sigma30.25", "sx_az0_r500")
 
 
 def median(v):
@@ -33,6 +33,8 @@ def steps(target, outs):
         "tpi_s67": lambda: target.tpi_std(67, tpi=outs[0]),
         "std_s67": lambda: target.tpi_std(67, std=outs[1]),
         "tpi_std_s67": lambda: target.tpi_std(67, tpi=outs[0], std=outs[1]),
+        "std_s7": lambda: target.tpi_std(7, std=outs[1]),
+        "tpi_std_s7": lambda: target.tpi_std(7, tpi=outs[0], std=outs[1]),
         "gradient_sigma3.25": lambda: target.gradient(3.25, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3]),
         "gradient_sigma30.25": lambda: target.gradient(30.25, [30.0], [-30.0], dx=outs[0], dy=outs[1], slope=outs[2], aspect=outs[3]),
         "sx_az0_r500": lambda: target.sx(dj, di, dist, window, 10.0, outs[0]),
