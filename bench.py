@@ -333,7 +333,7 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
               "tpi_ring_kernel<., kRingMark> (whole-metre tiles, marks) + tpi_ring_kernel<., kRingBoth> (second image: the "
               "fractional parts in 2^-16 m)")
         entry(f"std_s{size}_fractional_dem", time_kernel(lambda: fblk.tpi_std(size, std=o2), REPS, d), 8,
-              "std_ring_spec_kernel<.> + std_ring_kernel<., kStdBoth> (third image: the fractional parts)" if size <= 41 else
+              "std_ring_spec_kernel<.> (probe: hands the runs over) + std_ring_spec_kernel<., ., true> (second pass with a third image: the fractional parts)" if size <= 21 else
               "tpi_march_sums_kernel + std_march_kernel<FRAC_STORE> + tpi_fraction_march_kernel<WANT_STD> (three marching passes)")
     frac.free()
     for a in (o1, o2, o3, o4):

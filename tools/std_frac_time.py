@@ -1,0 +1,32 @@
+"""STD and TPI + STD on the 32768^2 bench DEM WITH fractional elevations (median of 6 launches, HIP events) and CRCs of the
+outputs at 8192^2; with TOPO_AMD_LIBRARY=<other .so> the same-box A/B of two builds.  usage: std_frac_time.py [sizes...]"""
+import json
+import os
+import sys
+import zlib
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from topo_descriptors_amd import device as d  # noqa: E402
+
+sizes = [int(a) for a in sys.argv[1:]] or [7, 17, 21, 31]
+out = {}
+n = 8192
+dem = d.synth_dem(n, n, seed=0, integer=False)
+blk = d.Block(dem)
+t, s = d.DeviceArray(n, n), d.DeviceArray(n, n)
+for size in sizes:
+    blk.tpi_std(size, tpi=t, std=s)
+    d.sync()
+    out[f"crc_{size}"] = [zlib.crc32(t.to_host().tobytes()), zlib.crc32(s.to_host().tobytes())]
+for a in (t, s, dem):
+    a.free()
+n = 32768
+dem = d.synth_dem(n, n, seed=0, integer=False)
+blk = d.Block(dem)
+t, s = d.DeviceArray(n, n), d.DeviceArray(n, n)
+for size in sizes:
+    ms = sorted(d.time_launches(lambda: blk.tpi_std(size, std=s), 6))
+    out[f"std_{size}"] = round(ms[len(ms) // 2], 3)
+    ms = sorted(d.time_launches(lambda: blk.tpi_std(size, tpi=t, std=s), 6))
+    out[f"tpi_std_{size}"] = round(ms[len(ms) // 2], 3)
+print(json.dumps(out))

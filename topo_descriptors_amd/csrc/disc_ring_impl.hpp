@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(768) void std_ring_kernel_parts(WaveParts ps, int t
 // Used for 5 ... 41 px (kStdSpecMax): same-box A/B on the 32768^2 bench DEM (tools/std_time.py, profiles/r05_std_spec_ab.txt), STD
 // 7 px 2.67 -> 2.33 ms, 17 px 3.35 -> 2.91, 25 px 4.20 -> 3.83, 31 px 4.58 -> 4.43, 41 px 5.98 -> 5.40; level at 43 - 47 px (where
 // eight chain waves carry what twelve did), and from 49 px the ring has no room for the second batch.
-template <int SIZE>
+template <int SIZE, bool BOTH = false>
 struct StdSpecCfg {
     using G = RGeo<SIZE, 4>;
     static constexpr int NW = 12, SW = G::W / 64, CW = NW - SW, RPW = 2;
@@ -1168,7 +1168,7 @@ struct StdSpecCfg {
     static constexpr int TH = std_ring_tile_rows(SIZE);
     static constexpr int PPT = TH / B;
     static constexpr int R = SIZE + 2 * B;
-    static constexpr int PITCH = 2 * G::W;
+    static constexpr int PITCH = (BOTH ? 3 : 2) * G::W;  // the u image, the u^2 image (and the image of the fractional parts)
     static constexpr int HALO = SIZE - 1;
     static constexpr int PAD = 1 + (B - (1 + HALO + B) % B) % B;
     static constexpr int PRO = PAD + HALO + B;
@@ -1184,11 +1184,14 @@ struct StdSpecCfg {
     static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
     static_assert(HIST <= 16, "flag history");
 };
+// the second pass for fractional elevations (std_ring_kernel's kStdBoth: a third image, the three chains, the general
+// kernel's expressions) in this form: the three images of SIZE + 32 rows fit up to 21 px
+constexpr bool std_spec_both_fits(int size) { return std_ring_spec(size) && (size_t)(size + 32) * 768 * 4 + 512 <= 160 * 1024; }
 
-template <int SIZE, bool WANT_TPI>
+template <int SIZE, bool WANT_TPI, bool BOTH = false>
 __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
     using G = RGeo<SIZE, 4>;
-    using C = StdSpecCfg<SIZE>;
+    using C = StdSpecCfg<SIZE, BOTH>;
     constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW, HIST = C::HIST, PITCH = C::PITCH;
     constexpr int DL = G::DL;
     constexpr int kBig = 0x3fffffff;
@@ -1206,6 +1209,7 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
     const int first = deal.first(vb);
     const int last = min(first + deal.count(vb), ntiles);
     const double n = (double)G::T.taps;
+    const double inv_n = 1.0 / n;
     const double inv_nm1 = 1.0 / (n - 1.0);
     const double inv_nn1 = 1.0 / (n * (n - 1.0));
     const int lim32 = (int)floorf(sqrtf(4294967295.0f / (float)G::T.taps));
@@ -1213,6 +1217,17 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
     const bool stager = wave < C::SW;
     const int scol = 64 * wave + lane;  // staged column of a staging lane
     int seen_general = 0;
+    // BOTH: a tile the first pass left for its fractional samples
+    auto candidate = [&](int t) { return p.defer[t] == kTileGeneral; };
+    if (BOTH) {
+        // nothing to do on a DEM of whole metres: one tile per lane, 64 tiles per ballot
+        bool any = false;
+        for (int base = first; base < last; base += 64) {
+            const int mine = base + lane;
+            any = any || __builtin_amdgcn_ballot_w64(mine < last && candidate(mine < last ? mine : first)) != 0;
+        }
+        if (!any) return;  // the same for every thread of the block
+    }
 
 #pragma unroll 1
     for (int pos = first; pos < last;) {
@@ -1244,7 +1259,17 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                 v[r] = src[(size_t)(gy - p.in_row0) * p.nx];
             }
         };
-        {
+        if (BOTH) {
+            bool any = false;
+            for (int base = tile0; base < tile0 + run_tiles; base += 64) {
+                const int mine = base + lane;
+                any = any || __builtin_amdgcn_ballot_w64(mine < tile0 + run_tiles && candidate(mine < tile0 + run_tiles ? mine : tile0)) != 0;
+            }
+            if (!any) {  // a run without a tile for this pass is not staged
+                pos += run_tiles;
+                continue;
+            }
+        } else {
             // a run of fractional elevations is handed over unstaged (std_ring_kernel)
             int odd = 0;
             const int pc = min(max(ox0 + 4 * lane, 0), p.nx - 1);
@@ -1261,16 +1286,16 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                 continue;
             }
         }
-        uint32_t run_u = 0, run_u2 = 0;
+        uint32_t run_u = 0, run_u2 = 0, run_f = 0;
         int wslot = 0;  // ring slot of the next row to stage
         struct Seen { int flags, lo, hi; };
         // (stagers only) one batch: classify, convert, prefix, write into the ring, publish what was seen
         auto stage_batch = [&](int n0, const float (&v)[B], int parity) {
             // classification on the float samples: min / max of x (trunc is monotonic, so the smallest and largest trunc(x) are
-            // those of the smallest and largest x; v_min / v_max skip a NaN, which the whole-metre test catches: NaN != anything)
-            bool frac = false;
+            // those of the smallest and largest x; v_min / v_max skip a NaN: the magnitude test is written so that it catches it)
+            bool frac = false, absurd = false;
             float xlo = INFINITY, xhi = -INFINITY;
-            uint32_t q[B], q2[B];
+            uint32_t q[B], q2[B], qf[BOTH ? B : 1];
             auto rows = [&](auto inside_tag) {
                 constexpr bool INSIDE = decltype(inside_tag)::value;  // every row of the batch is inside the block's view
 #pragma unroll
@@ -1286,6 +1311,7 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                     }
                     const int t = (int)x;
                     frac |= x != (float)t;
+                    absurd |= !(fabsf(x) < kAbsLim + 1.0f);  // (NaN too)
                     xlo = fminf(xlo, x);
                     xhi = fmaxf(xhi, x);
                     const uint32_t u = (uint32_t)(t - ci);
@@ -1293,6 +1319,10 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                     run_u2 += (uint32_t)__mul24((int)u, (int)u);
                     q[r] = run_u;
                     q2[r] = run_u2;
+                    if (BOTH) {
+                        run_f += stage_value<kStF>(ok ? x : 0.0f, 0.0f, 0);
+                        qf[r] = run_f;
+                    }
                 }
             };
             if (gy0 + n0 >= rmin && gy0 + n0 + B <= rmax) rows(std::true_type{});
@@ -1303,9 +1333,9 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                 sl = sl >= R ? sl - R : sl;
                 Q[sl * PITCH + scol] = q[r];
                 Q[sl * PITCH + G::W + scol] = q2[r];
+                if (BOTH) Q[sl * PITCH + 2 * G::W + scol] = qf[r];
             }
-            // (a lane that saw NaN only keeps +-inf here: its flag is up through frac; the clamps keep the range arithmetic in int32)
-            const bool absurd = !(fmaxf(fabsf(xlo), fabsf(xhi)) < kAbsLim + 1.0f);
+            // (a lane that saw NaN only keeps +-inf here: its flag is up; the clamps keep the range arithmetic in int32)
             int lo = (int)fminf(fmaxf(xlo, -(float)kBig), (float)kBig), hi = (int)fminf(fmaxf(xhi, -(float)kBig), (float)kBig);
             lo = wave_min_max<false>(lo);
             hi = wave_min_max<true>(hi);
@@ -1338,7 +1368,8 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                 hi = max(hi, q[2]);
             }
             fl = __builtin_amdgcn_readfirstlane(fl);
-            hist = ((hist << 1) | ((fl & (kTileFrac | kTileFloat)) ? 1u : 0u)) & ((1u << HIST) - 1u);
+            constexpr int kStops = BOTH ? kTileFloat : (kTileFrac | kTileFloat);
+            hist = ((hist << 1) | ((fl & kStops) ? 1u : 0u)) & ((1u << HIST) - 1u);
 #pragma unroll
             for (int k = HIST - 1; k > 0; --k) hlo[k] = hlo[k - 1], hhi[k] = hhi[k - 1];
             hlo[0] = __builtin_amdgcn_readfirstlane(lo);
@@ -1422,15 +1453,22 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                     ci = mid;
                     __syncthreads();
                 }
-                tmode = too_wide ? kTileGeneralWide : kTileDone;
-                if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
+                if (BOTH) {
+                    tmode = candidate(tile) && !too_wide ? kNeedsFraction : kTileDone;  // (kTileDone here: not this pass's; the mark stays)
+                } else {
+                    tmode = too_wide ? kTileGeneralWide : kTileDone;
+                    if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
+                }
             }
             const bool fits = hist == 0 && whi - ci <= lim32 && ci - wlo <= lim32;
-            if ((tmode & 1) == 0 && !fits) {
+            if (BOTH) {
+                if (tmode == kNeedsFraction && !fits) tmode = kTileGeneral;  // the mark stays: general kernel
+            } else if ((tmode & 1) == 0 && !fits) {
                 tmode = hist != 0 ? kTileGeneral : kTileGeneralWide;
                 if (threadIdx.x == 0) p.defer[tile] = (uint8_t)tmode;
             }
-            if (ph % PPT == PPT - 1 && tmode == kTileGeneral) ++seen_general;
+            if (!BOTH && ph % PPT == PPT - 1 && tmode == kTileGeneral) ++seen_general;
+            if (BOTH && ph % PPT == PPT - 1 && tmode == kNeedsFraction && threadIdx.x == 0) p.defer[tile] = kTileDone;
             if (stager) {
                 // the batch phase ph + 1 needs, into the slots behind this phase's window; then the loads of the one after
                 SPEC_STAMP(0)
@@ -1438,7 +1476,7 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                 SPEC_STAMP(1)
                 load_batch(C::PRO + (ph + 1) * B, vbuf);
                 SPEC_STAMP(2)
-            } else if (tmode == kTileDone) {
+            } else if (BOTH ? tmode == kNeedsFraction : tmode == kTileDone) {
                 SPEC_STAMP(0)
 #pragma unroll 1
                 for (int k = 0; k < C::RPW; ++k) {
@@ -1451,7 +1489,33 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                     ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q, s0, lane, su, ctr, false);
                     ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q + G::W, s0, lane, su2, dummy, false);
                     const int oy = oyS + ph * B + j;
-                    if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
+                    if (BOTH) {
+                        uint32_t sfi[4];
+                        ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q + 2 * G::W, s0, lane, sfi, dummy, false);
+                        if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
+                            const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
+                            Vec4<float> xs{{0.f, 0.f, 0.f, 0.f}};
+                            if (WANT_TPI) xs = *reinterpret_cast<const Vec4<float>*>(p.in + (size_t)(oy - p.in_row0) * p.nx + ocol);
+                            Vec4<float> out_s, out_t;
+                            const double cd = (double)ci;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                // the general kernel's expressions (disc_wave_kernel, finalise_row) on the same exact sums
+                                const double dsu = (double)(int)su[t], dsu2 = (double)su2[t];
+                                const double sf = (double)(int)sfi[t] * (1.0 / 65536.0);
+                                const double s1 = (dsu + cd * n) + sf;
+                                if (sfi[t] == 0) {
+                                    out_s.v[t] = std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1);
+                                } else {
+                                    const double s2 = dsu2 + 2.0 * cd * dsu + cd * cd * n;
+                                    out_s.v[t] = std_from_sums(s1, s2, inv_n, inv_nm1);
+                                }
+                                if (WANT_TPI) out_t.v[t] = (float)((double)xs.v[t] - (s1 - (double)xs.v[t]) * inv_nm1);
+                            }
+                            *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+                            if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
+                        }
+                    } else if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
                         const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
                         Vec4<float> out_s, out_t;
 #pragma unroll
@@ -1483,43 +1547,43 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
 #endif
         pos += run_tiles;
     }
-    if (p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
+    if (!BOTH && p.report != nullptr && vb == nb / 2 && threadIdx.x == 0) {
         __hip_atomic_store(p.report + 1, (uint32_t)seen_general, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(p.report, (uint32_t)(last > first ? last - first : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-template <int SIZE, bool WANT_TPI>
-__global__ __launch_bounds__(768, StdSpecCfg<SIZE>::kWavesPerSimd) void std_ring_spec_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
-    TOPO_RUN_ONE((std_ring_spec_body<SIZE, WANT_TPI>));
+template <int SIZE, bool WANT_TPI, bool BOTH = false>
+__global__ __launch_bounds__(768, (StdSpecCfg<SIZE, BOTH>::kWavesPerSimd)) void std_ring_spec_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((std_ring_spec_body<SIZE, WANT_TPI, BOTH>));
 }
-template <int SIZE, bool WANT_TPI>
-__global__ __launch_bounds__(768, StdSpecCfg<SIZE>::kWavesPerSimd) void std_ring_spec_kernel_parts(WaveParts ps, int tiles_x) {
-    TOPO_RUN_PARTS((std_ring_spec_body<SIZE, WANT_TPI>));
+template <int SIZE, bool WANT_TPI, bool BOTH = false>
+__global__ __launch_bounds__(768, (StdSpecCfg<SIZE, BOTH>::kWavesPerSimd)) void std_ring_spec_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((std_ring_spec_body<SIZE, WANT_TPI, BOTH>));
 }
 
-template <int SIZE, bool WANT_TPI>
+template <int SIZE, bool WANT_TPI, bool BOTH = false>
 int launch_std_ring_spec(const Block& b, float* tpi_out, float* std_out) {
     using G = RGeo<SIZE, 4>;
-    using C = StdSpecCfg<SIZE>;
+    using C = StdSpecCfg<SIZE, BOTH>;
     Context& c = ctx();
     WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
                nullptr, nullptr, nullptr, 0, 0, 0};
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_spec_kernel<SIZE, WANT_TPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_spec_kernel<SIZE, WANT_TPI, BOTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         int nblk = 0;
-        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_spec_kernel<SIZE, WANT_TPI>, C::NW * 64, C::LDS));
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_spec_kernel<SIZE, WANT_TPI, BOTH>, C::NW * 64, C::LDS));
         blocks_per_cu = nblk < 1 ? 1 : (nblk > 2 ? 2 : nblk);
     }
     WaveParts ps;
     int tiles_x = 0;
     long ntiles = 0;
-    a.report = dem_memo_report(b);
+    a.report = BOTH ? nullptr : dem_memo_report(b);
     TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
-    return launch_parts(std_ring_spec_kernel<SIZE, WANT_TPI>, std_ring_spec_kernel_parts<SIZE, WANT_TPI>, grid, C::NW * 64, C::LDS, ps, tiles_x);
+    return launch_parts(std_ring_spec_kernel<SIZE, WANT_TPI, BOTH>, std_ring_spec_kernel_parts<SIZE, WANT_TPI, BOTH>, grid, C::NW * 64, C::LDS, ps, tiles_x);
 }
 
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>

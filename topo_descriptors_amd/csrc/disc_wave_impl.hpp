@@ -2307,8 +2307,13 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
             if constexpr (std_ring_both_fits(SIZE)) {
                 // tiles with fractional elevations: one more pass of the ring kernel with a third image (the
                 // fractional parts) instead of the general kernel's three staging passes
-                if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true, kStdBoth>(b, tpi_out, std_out)));
-                else TOPO_TRY((launch_std_ring<SIZE, false, kStdBoth>(b, nullptr, std_out)));
+                if constexpr (std_spec_both_fits(SIZE)) {  // (up to 21 px: in the form with staging waves apart from chain waves)
+                    if (tpi_out) TOPO_TRY((launch_std_ring_spec<SIZE, true, true>(b, tpi_out, std_out)));
+                    else TOPO_TRY((launch_std_ring_spec<SIZE, false, true>(b, nullptr, std_out)));
+                } else {
+                    if (tpi_out) TOPO_TRY((launch_std_ring<SIZE, true, kStdBoth>(b, tpi_out, std_out)));
+                    else TOPO_TRY((launch_std_ring<SIZE, false, kStdBoth>(b, nullptr, std_out)));
+                }
             }
             if (tpi_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH);
             return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH);
