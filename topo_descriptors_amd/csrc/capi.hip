@@ -876,7 +876,8 @@ int topo_amd_device_name(char* buf, int buflen) {
     TOPO_TRY(require_ready());
     hipDeviceProp_t prop;
     TOPO_HIP(hipGetDeviceProperties(&prop, ctx().device));
-    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    // (the runtime of this image reports an empty marketing name for the MI355X)
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName, prop.multiProcessorCount);
     return TOPO_AMD_OK;
 }
 
