@@ -1535,7 +1535,9 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
             advance_wslot();
             __syncthreads();
             SPEC_STAMP(4)
+#ifndef SPEC_LAB_NOFOLD  // (lab: what the per-phase bookkeeping costs - tools/ubench/tpi_lab.hip -DSPEC_LAB_NOFOLD)
             fold((ph + 1) & 1, 1);
+#endif
             SPEC_STAMP(5)
         };
 #pragma unroll 1
