@@ -59,11 +59,22 @@ struct RGeo {
     static constexpr int M = T.off_max;
     static constexpr int PARTS = NCR / 4;           // 16-byte pieces per lane and row
     static constexpr int DL = (M + NCR - 1) / NCR;  // lane hops per side
-    static constexpr int NVL = 64 - 2 * DL;         // lanes that end up with full sums
+    static constexpr int NVL_ALL = 64 - 2 * DL;     // lanes that end up with full sums
+    // Strips whose width is a whole number of 128-byte lines (32 columns): every row segment a wave stores is then made of
+    // full, aligned lines - with the widest strip (496 columns = 1984 bytes at 7 px) every other strip starts and ends inside a
+    // line that a neighbour strip, on another CU at another time, completes.  For the TPI rings (8 columns per lane) up to
+    // 11 px, which wait for memory: 32768^2, 7 px 2.00 -> 1.81 ms, 11 px 2.01 -> 1.83, level from 13 px (profiles/r05_aligned_strips.txt); the STD
+    // kernels (4 columns per lane) wait for their chains and lose the lanes given up (17 px 2.91 -> 3.20 ms), so they keep the
+    // widest strips.  (-DRING_ALIGN_STRIPS=0: the widest strips everywhere, for the A/B.)
+#ifndef RING_ALIGN_STRIPS
+#define RING_ALIGN_STRIPS 1
+#endif
+    static constexpr int NVL_LINES = NCR * NVL_ALL / 32 * 32 / NCR;
+    static constexpr int NVL = RING_ALIGN_STRIPS && NCR == 8 && SIZE <= 11 ? NVL_LINES : NVL_ALL;  // lanes whose sums are stored
     static constexpr int TILE_W = NCR * NVL;        // valid output columns per strip
     static constexpr int X0 = NCR * DL;             // staged column of the first valid output
     static constexpr int W = 64 * NCR;              // staged columns = dwords per ring row
-    static_assert(NVL >= 16, "disc too wide for one wavefront");
+    static_assert(NVL >= 16 && NVL <= NVL_ALL, "disc too wide for one wavefront");
     static constexpr int NR = T.num_runs;
     // The two-sided chain: step D (lane distance, DL .. 0) adds, for output sub-column t, the lane's own
     // columns s at offsets di = NCR D + s - t >= 0 (right chain) and -NCR D + s - t < 0 (left chain).
@@ -472,7 +483,7 @@ __device__ __forceinline__ void tpi_ring_kernel_body(const WaveArgs& p, int tile
         fold_flags(0);
 
         const int ocol = gx0 + lane * NCR;  // the lane's own columns
-        const bool lane_ok = lane >= DL && lane < 64 - DL;
+        const bool lane_ok = lane >= DL && lane < DL + G::NVL;
         int s0 = C::PAD - 1 + wave;  // slot of Q index 0 of this wave's row in phase 0
         int mode = kTileDone;
 #ifdef RING_STAMPS
@@ -976,7 +987,7 @@ __device__ __forceinline__ void std_ring_kernel_body(const WaveArgs& p, int tile
         fold(0);
 
         const int ocol = gx0 + lane * 4;
-        const bool lane_ok = lane >= DL && lane < 64 - DL;
+        const bool lane_ok = lane >= DL && lane < DL + G::NVL;
         int s0 = C::PAD - 1 + wave;
         int tmode = kTileDone;  // what the map says about the current tile
 #ifdef STD_STAMPS  // (lab build, tools/ubench/tpi_lab.hip: s_memtime around the parts of a phase, summed per wave)
@@ -1410,7 +1421,7 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
         fold(0, C::NB_PRO);
 
         const int ocol = gx0 + lane * 4;
-        const bool lane_ok = lane >= DL && lane < 64 - DL;
+        const bool lane_ok = lane >= DL && lane < DL + G::NVL;
         int tmode = kTileDone;
 #ifdef STD_STAMPS
         long long ssum[6] = {0, 0, 0, 0, 0, 0};
