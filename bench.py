@@ -230,6 +230,10 @@ def disc_kernels(what, size):
     if what == "tpi":
         return ("tpi_ring_kernel<%d, 8, .>" % size if 5 <= size <= 11 else "tpi_march_kernel<%d, 60, 12, ..>" % size) + \
             " (+ fraction pass and general kernel over marked tiles: none on whole metres)"
+    if 5 <= size <= 7 or (what == "tpi_std" and size <= 13):
+        return "std_ring_spec_kernel<%d, %s, false, 8> (u and u^2 rings, one staging pass; 512-column strips: eight staging waves beside " \
+               "eight chain waves of 8 columns per lane, one barrier per phase; the DEM's border tiles included) + disc_wave_kernel over " \
+               "the marked tiles (none here)" % (size, "true" if what == "tpi_std" else "false")
     if 5 <= size <= 41:
         return "std_ring_spec_kernel<%d, %s> (u and u^2 rings, one staging pass; four staging waves beside eight chain waves, one " \
                "barrier per 16 rows; the DEM's border tiles included: padding staged as samples of elevation 0) + disc_wave_kernel " \

@@ -1171,10 +1171,14 @@ __global__ __launch_bounds__(768) void std_ring_kernel_parts(WaveParts ps, int t
 // Used for 5 ... 41 px (kStdSpecMax): same-box A/B on the 32768^2 bench DEM (tools/std_time.py, profiles/r05_std_spec_ab.txt), STD
 // 7 px 2.67 -> 2.33 ms, 17 px 3.35 -> 2.91, 25 px 4.20 -> 3.83, 31 px 4.58 -> 4.43, 41 px 5.98 -> 5.40; level at 43 - 47 px (where
 // eight chain waves carry what twelve did), and from 49 px the ring has no room for the second batch.
-template <int SIZE, bool BOTH = false>
+// NCR = 8 (the whole-metre pass of the smallest discs): 512-column strips like the TPI rings' - eight staging waves, eight chain
+// waves with two rows of 8 columns per lane each, a block of 16 waves
+template <int SIZE, bool BOTH = false, int NCR = 4>
 struct StdSpecCfg {
-    using G = RGeo<SIZE, 4>;
-    static constexpr int NW = 12, SW = G::W / 64, CW = NW - SW, RPW = 2;
+    using G = RGeo<SIZE, NCR>;
+    // (512-column strips: two rows per chain wave while two images of SIZE + 32 rows of 2 KiB fit - 5 and 7 px - one beyond)
+    static constexpr int SW = G::W / 64, CW = 8, NW = SW + CW;
+    static constexpr int RPW = NCR == 8 && (size_t)(SIZE + 32) * 1024 * 4 + 1024 > 160 * 1024 ? 1 : 2;
     static constexpr int B = CW * RPW;  // rows per phase and per batch: 16
     static constexpr int TH = std_ring_tile_rows(SIZE);
     static constexpr int PPT = TH / B;
@@ -1188,21 +1192,25 @@ struct StdSpecCfg {
     static constexpr size_t LDS = (size_t)R * PITCH * sizeof(uint32_t) + 2 * NW * 4 * sizeof(int) + 16;
     // 5 and 7 px: two rings fit a CU's LDS, and the kernel is short of waves (every wave runs a serial stream of dependent
     // instructions): two blocks per CU, 6 waves per SIMD, 84 registers
-    static constexpr bool kTwoBlocks = 2 * LDS <= 160 * 1024;
-    static constexpr int kWavesPerSimd = kTwoBlocks ? 6 : 3;
-    static_assert(SW == 4 && B == 16, "four staging waves, eight chain waves with two rows each");
+    static constexpr bool kTwoBlocks = NCR == 4 && 2 * LDS <= 160 * 1024;
+    static constexpr int kWavesPerSimd = NCR == 8 ? 4 : (kTwoBlocks ? 6 : 3);
+    static_assert((SW == 4 || SW == 8) && (B == 16 || B == 8), "four or eight staging waves, eight chain waves with one or two rows each");
+    static_assert(NCR == 4 || !BOTH, "three images of 512 columns do not fit");
     static_assert(TH % B == 0 && PRO % B == 0, "whole batches");
     static_assert(LDS <= 160 * 1024, "ring does not fit LDS");
     static_assert(HIST <= 16, "flag history");
 };
 // the second pass for fractional elevations (std_ring_kernel's kStdBoth: a third image, the three chains, the general
 // kernel's expressions) in this form: the three images of SIZE + 32 rows fit up to 21 px
+// the 512-column build: two images of SIZE + 32 rows of 2 KiB
+// (used for 5 and 7 px, and for TPI + STD up to 13 px: launch_wave_any)
+constexpr bool std_spec_wide_fits(int size) { return std_ring_spec(size) && size <= 13; }
 constexpr bool std_spec_both_fits(int size) { return std_ring_spec(size) && (size_t)(size + 32) * 768 * 4 + 512 <= 160 * 1024; }
 
-template <int SIZE, bool WANT_TPI, bool BOTH = false>
+template <int SIZE, bool WANT_TPI, bool BOTH = false, int NCR = 4>
 __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_x, int tiles_y, const PartRun deal, const int vb0, const int nb) {
-    using G = RGeo<SIZE, 4>;
-    using C = StdSpecCfg<SIZE, BOTH>;
+    using G = RGeo<SIZE, NCR>;
+    using C = StdSpecCfg<SIZE, BOTH, NCR>;
     constexpr int B = C::B, R = C::R, PPT = C::PPT, NW = C::NW, HIST = C::HIST, PITCH = C::PITCH;
     constexpr int DL = G::DL;
     constexpr int kBig = 0x3fffffff;
@@ -1211,7 +1219,7 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
     int* wflags = reinterpret_cast<int*>(Q + R * PITCH);  // [2 parities][NW][4]: flags, min, max of the batch a wave staged
     // more than 128 registers: the block's 12 waves then cannot sit 4 + 4 + 2 + 2 on the SIMDs (the two-blocks-per-CU build of
     // the smallest discs: 84 at most)
-    if (!C::kTwoBlocks) asm volatile("" ::: "v140");
+    if (!C::kTwoBlocks && NCR == 4) asm volatile("" ::: "v140");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1227,6 +1235,7 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
     const int rmin = max(0, p.in_row0), rmax = min(p.gny, p.in_row0 + p.in_rows);
     const bool stager = wave < C::SW;
     const int scol = 64 * wave + lane;  // staged column of a staging lane
+    const int sdw = ring_dword_of_column<NCR>(scol);  // ... and its dword in a ring row (RGeo: 16-byte pieces per lane)
     int seen_general = 0;
     // BOTH: a tile the first pass left for its fractional samples
     auto candidate = [&](int t) { return p.defer[t] == kTileGeneral; };
@@ -1342,9 +1351,9 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
             for (int r = 0; r < B; ++r) {
                 int sl = wslot + r;
                 sl = sl >= R ? sl - R : sl;
-                Q[sl * PITCH + scol] = q[r];
-                Q[sl * PITCH + G::W + scol] = q2[r];
-                if (BOTH) Q[sl * PITCH + 2 * G::W + scol] = qf[r];
+                Q[sl * PITCH + sdw] = q[r];
+                Q[sl * PITCH + G::W + sdw] = q2[r];
+                if (BOTH) Q[sl * PITCH + 2 * G::W + sdw] = qf[r];
             }
             // (a lane that saw NaN only keeps +-inf here: its flag is up; the clamps keep the range arithmetic in int32)
             int lo = (int)fminf(fmaxf(xlo, -(float)kBig), (float)kBig), hi = (int)fminf(fmaxf(xhi, -(float)kBig), (float)kBig);
@@ -1420,7 +1429,7 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
         __syncthreads();
         fold(0, C::NB_PRO);
 
-        const int ocol = gx0 + lane * 4;
+        const int ocol = gx0 + lane * NCR;
         const bool lane_ok = lane >= DL && lane < DL + G::NVL;
         int tmode = kTileDone;
 #ifdef STD_STAMPS
@@ -1494,15 +1503,15 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                     const int j = (wave - C::SW) * C::RPW + k;  // row of the phase
                     int s0 = C::PAD - 1 + ph * B + j;           // stream row of Q index 0 of the output row's window
                     s0 = s0 % R;
-                    uint32_t su[4], ctr[4], su2[4], dummy[4];
+                    uint32_t su[NCR], ctr[NCR], su2[NCR], dummy[NCR];
                     // (unrolling the two rows and dropping the scheduling fences, so that their chains interleave, changed nothing
                     // at 5 - 9 px and cost 4 - 9 % at 11 - 13 px)
-                    ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q, s0, lane, su, ctr, false);
-                    ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q + G::W, s0, lane, su2, dummy, false);
+                    ring_disc_sum<SIZE, NCR, R, 2, PITCH>(Q, s0, lane, su, ctr, false);
+                    ring_disc_sum<SIZE, NCR, R, 2, PITCH>(Q + G::W, s0, lane, su2, dummy, false);
                     const int oy = oyS + ph * B + j;
-                    if (BOTH) {
+                    if constexpr (BOTH) {
                         uint32_t sfi[4];
-                        ring_disc_sum<SIZE, 4, R, 2, PITCH>(Q + 2 * G::W, s0, lane, sfi, dummy, false);
+                        ring_disc_sum<SIZE, NCR, R, 2, PITCH>(Q + 2 * G::W, s0, lane, sfi, dummy, false);
                         if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
                             const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
                             Vec4<float> xs{{0.f, 0.f, 0.f, 0.f}};
@@ -1526,19 +1535,25 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
                             *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
                             if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
                         }
-                    } else if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows && ocol < p.nx) {
-                        const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol;
-                        Vec4<float> out_s, out_t;
+                    } else if (lane_ok && oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            out_s.v[t] = std_from_int_sums((int)su[t], (uint64_t)su2[t], (uint32_t)G::T.taps, (float)inv_nn1);
-                            if (WANT_TPI) {
-                                const int xi = (int)ctr[t] + ci;
-                                out_t.v[t] = (float)((double)xi - (double)((int)su[t] + ci * G::T.taps - xi) * inv_nm1);
+                        for (int P = 0; P < NCR / 4; ++P) {  // 16-byte pieces of the lane's columns (nx % 4 == 0: a piece is inside or outside)
+                            if (ocol + 4 * P < p.nx) {
+                                const size_t o = (size_t)(oy - p.out_row0) * p.nx + ocol + 4 * P;
+                                Vec4<float> out_s, out_t;
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    const int c = 4 * P + t;
+                                    out_s.v[t] = std_from_int_sums((int)su[c], (uint64_t)su2[c], (uint32_t)G::T.taps, (float)inv_nn1);
+                                    if (WANT_TPI) {
+                                        const int xi = (int)ctr[c] + ci;
+                                        out_t.v[t] = (float)((double)xi - (double)((int)su[c] + ci * G::T.taps - xi) * inv_nm1);
+                                    }
+                                }
+                                *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
+                                if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
                             }
                         }
-                        *reinterpret_cast<Vec4<float>*>(p.sd + o) = out_s;
-                        if (WANT_TPI) *reinterpret_cast<Vec4<float>*>(p.tpi + o) = out_t;
                     }
                 }
             }
@@ -1566,27 +1581,27 @@ __device__ __forceinline__ void std_ring_spec_body(const WaveArgs& p, int tiles_
     }
 }
 
-template <int SIZE, bool WANT_TPI, bool BOTH = false>
-__global__ __launch_bounds__(768, (StdSpecCfg<SIZE, BOTH>::kWavesPerSimd)) void std_ring_spec_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
-    TOPO_RUN_ONE((std_ring_spec_body<SIZE, WANT_TPI, BOTH>));
+template <int SIZE, bool WANT_TPI, bool BOTH = false, int NCR = 4>
+__global__ __launch_bounds__((StdSpecCfg<SIZE, BOTH, NCR>::NW * 64), (StdSpecCfg<SIZE, BOTH, NCR>::kWavesPerSimd)) void std_ring_spec_kernel(WaveArgs p, int tiles_x, int tiles_y, PartRun deal) {
+    TOPO_RUN_ONE((std_ring_spec_body<SIZE, WANT_TPI, BOTH, NCR>));
 }
-template <int SIZE, bool WANT_TPI, bool BOTH = false>
-__global__ __launch_bounds__(768, (StdSpecCfg<SIZE, BOTH>::kWavesPerSimd)) void std_ring_spec_kernel_parts(WaveParts ps, int tiles_x) {
-    TOPO_RUN_PARTS((std_ring_spec_body<SIZE, WANT_TPI, BOTH>));
+template <int SIZE, bool WANT_TPI, bool BOTH = false, int NCR = 4>
+__global__ __launch_bounds__((StdSpecCfg<SIZE, BOTH, NCR>::NW * 64), (StdSpecCfg<SIZE, BOTH, NCR>::kWavesPerSimd)) void std_ring_spec_kernel_parts(WaveParts ps, int tiles_x) {
+    TOPO_RUN_PARTS((std_ring_spec_body<SIZE, WANT_TPI, BOTH, NCR>));
 }
 
-template <int SIZE, bool WANT_TPI, bool BOTH = false>
+template <int SIZE, bool WANT_TPI, bool BOTH = false, int NCR = 4>
 int launch_std_ring_spec(const Block& b, float* tpi_out, float* std_out) {
-    using G = RGeo<SIZE, 4>;
-    using C = StdSpecCfg<SIZE, BOTH>;
+    using G = RGeo<SIZE, NCR>;
+    using C = StdSpecCfg<SIZE, BOTH, NCR>;
     Context& c = ctx();
     WaveArgs a{b.in, tpi_out, std_out, b.in_rows, b.in_row0, b.gny, b.nx, b.out_row0, b.out_rows,
                nullptr, nullptr, nullptr, 0, 0, 0};
     static int blocks_per_cu = 0;
     if (blocks_per_cu == 0) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_spec_kernel<SIZE, WANT_TPI, BOTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
+        TOPO_HIP(hipFuncSetAttribute((const void*)std_ring_spec_kernel<SIZE, WANT_TPI, BOTH, NCR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         int nblk = 0;
-        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_spec_kernel<SIZE, WANT_TPI, BOTH>, C::NW * 64, C::LDS));
+        TOPO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, (const void*)std_ring_spec_kernel<SIZE, WANT_TPI, BOTH, NCR>, C::NW * 64, C::LDS));
         blocks_per_cu = nblk < 1 ? 1 : (nblk > 2 ? 2 : nblk);
     }
     WaveParts ps;
@@ -1596,7 +1611,7 @@ int launch_std_ring_spec(const Block& b, float* tpi_out, float* std_out) {
     TOPO_TRY(make_parts(b, a, C::TH, G::TILE_W, true, false, &ps, &tiles_x, &ntiles));
     const long grid = march_grid(c, blocks_per_cu, ntiles);
     deal_parts(&ps, tiles_x, grid, blocks_per_cu);
-    return launch_parts(std_ring_spec_kernel<SIZE, WANT_TPI, BOTH>, std_ring_spec_kernel_parts<SIZE, WANT_TPI, BOTH>, grid, C::NW * 64, C::LDS, ps, tiles_x);
+    return launch_parts(std_ring_spec_kernel<SIZE, WANT_TPI, BOTH, NCR>, std_ring_spec_kernel_parts<SIZE, WANT_TPI, BOTH, NCR>, grid, C::NW * 64, C::LDS, ps, tiles_x);
 }
 
 template <int SIZE, bool WANT_TPI, int MODE = kStdMain>

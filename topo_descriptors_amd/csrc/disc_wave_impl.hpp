@@ -2267,6 +2267,11 @@ inline bool tpi_fraction_scaled() {
     return v == 0;
 }
 constexpr int tpi_fraction_min_size() { return 17; }
+// (lab switch: TOPO_AMD_STD_SPEC_WIDE=0 keeps the 256-column strips at 5 and 7 px)
+inline bool std_spec_wide() {
+    static const int v = env_int("TOPO_AMD_STD_SPEC_WIDE", 1);
+    return v != 0;
+}
 
 template <int SIZE>
 int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
@@ -2297,6 +2302,21 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
             // the tiles it marked (its map has this kernel's strips and rows of 60)
             // (the tiles at the DEM's border are the ring kernel's own: the padding's zeros are staged as samples, and such a
             // window is the general kernel's only when its highest sample passes 2 lim32 - disc_ring_impl.hpp)
+            if constexpr (std_spec_wide_fits(SIZE)) {
+                // A raster of whole metres (the raster class: TIME only - every route is exact): 512-column strips, 8 columns per
+                // lane; a tile with fractional samples is the general kernel's then (no second pass on this map).  With row
+                // segments of 2 KiB the two-plane call has no slow mode (tools/two_plane_pairs.py: 2.84 - 3.12 ms for all 30 pairs
+                // of six planes at 7 px, where the 256-column strips run at 2.98 with one plane and 3.85 with the others), and
+                // STD alone gains 2 - 6 % at 5 and 7 px.  From 9 px the ring holds one row per chain wave only and STD alone
+                // loses (9 px 2.37 -> 3.11 ms) while TPI + STD still wins over its usual slow mode up to 13 px (3.60 -> 3.06,
+                // 3.57 -> 3.23): profiles/r05_std_wide_ab.txt.
+                if (current_class().frac_share == 0.0f && std_spec_wide() && (SIZE <= 7 || tpi_out != nullptr)) {
+                    if (tpi_out) TOPO_TRY((launch_std_ring_spec<SIZE, true, false, 8>(b, tpi_out, std_out)));
+                    else TOPO_TRY((launch_std_ring_spec<SIZE, false, false, 8>(b, nullptr, std_out)));
+                    if (tpi_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH, RGeo<SIZE, 8>::TILE_W);
+                    return launch_wave<SIZE, TH8, 8, false, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH, RGeo<SIZE, 8>::TILE_W);
+                }
+            }
             if constexpr (std_ring_spec(SIZE)) {  // the small discs: staging waves apart from chain waves
                 if (tpi_out) TOPO_TRY((launch_std_ring_spec<SIZE, true>(b, tpi_out, std_out)));
                 else TOPO_TRY((launch_std_ring_spec<SIZE, false>(b, nullptr, std_out)));
