@@ -2310,7 +2310,10 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
                 // STD alone gains 2 - 6 % at 5 and 7 px.  From 9 px the ring holds one row per chain wave only and STD alone
                 // loses (9 px 2.37 -> 3.11 ms) while TPI + STD still wins over its usual slow mode up to 13 px (3.60 -> 3.06,
                 // 3.57 -> 3.23): profiles/r05_std_wide_ab.txt.
-                if (current_class().frac_share == 0.0f && std_spec_wide() && (SIZE <= 7 || tpi_out != nullptr)) {
+                // (STD alone on a small raster keeps the 256-column strips: 8192^2 has 18 strips of 480 columns for 17.07 and 12 tiles
+                // per block where the narrow form, two blocks per CU, has 17.7: 0.148 against 0.161 ms)
+                const bool big = (long)b.nx * b.out_rows >= (1L << 28);
+                if (current_class().frac_share == 0.0f && std_spec_wide() && (tpi_out != nullptr || (SIZE <= 7 && big))) {
                     if (tpi_out) TOPO_TRY((launch_std_ring_spec<SIZE, true, false, 8>(b, tpi_out, std_out)));
                     else TOPO_TRY((launch_std_ring_spec<SIZE, false, false, 8>(b, nullptr, std_out)));
                     if (tpi_out) return launch_wave<SIZE, TH8, 8, true, true>(b, tpi_out, std_out, true, StdRingCfg<SIZE>::TH, RGeo<SIZE, 8>::TILE_W);
