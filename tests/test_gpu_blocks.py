@@ -839,3 +839,43 @@ def test_scaled_fraction_route_against_the_exact_one(tmp_path):
     assert np.sqrt(np.mean(err ** 2)) <= 1e-4   # (uniform fractional parts: 2^-8 / sqrt(12 n) = 1.9e-5 m)
     inner = (slice(300 + 33, 420 - 33), slice(900 + 33, 1300 - 33))
     assert np.array_equal(planes["scaled"][inner], planes["exact"][inner])
+
+
+# ---- the 512-column form of the small discs' STD kernel (round 5): the same bits as the 256-column form ------------------------
+_WIDE_CHILD = r"""
+import sys, zlib, json
+sys.path.insert(0, %r)
+from topo_descriptors_amd import device as d
+out = {}
+for ny, nx in ((16384, 16384), (2000, 1500)):   # STD alone takes the wide form on big rasters only; TPI + STD on both
+    dem = d.synth_dem(ny, nx, seed=5)
+    blk = d.Block(dem)
+    t, s = d.DeviceArray(ny, nx), d.DeviceArray(ny, nx)
+    for size in (5, 7, 9, 13):
+        blk.tpi_std(size, std=s)
+        d.sync()
+        a = zlib.crc32(s.to_host().tobytes())
+        blk.tpi_std(size, tpi=t, std=s)
+        d.sync()
+        out["%%d_%%d_%%d" %% (ny, nx, size)] = [a, zlib.crc32(t.to_host().tobytes()), zlib.crc32(s.to_host().tobytes())]
+    for x in (t, s, dem):
+        x.free()
+print(json.dumps(out))
+"""
+
+
+def test_std_512_column_strips_keep_the_bits():
+    """STD / TPI + STD at 5 and 7 px (TPI + STD up to 13 px) on rasters of whole metres take 512-column strips
+    (std_ring_spec_kernel<., ., false, 8>); TOPO_AMD_STD_SPEC_WIDE=0 keeps the 256-column form.  Exact integer sums and one
+    finalisation: identical planes, on a raster large enough for STD alone to take the wide form and on a small one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for wide in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", _WIDE_CHILD % root], cwd=root, env=dict(os.environ, TOPO_AMD_STD_SPEC_WIDE=wide),
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got[wide] = json.loads([line for line in out.stdout.splitlines() if line.startswith("{")][-1])
+    assert got["1"] == got["0"]
