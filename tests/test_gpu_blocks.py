@@ -847,7 +847,7 @@ import sys, zlib, json
 sys.path.insert(0, %r)
 from topo_descriptors_amd import device as d
 out = {}
-for ny, nx in ((16384, 16384), (2000, 1500)):   # STD alone takes the wide form on big rasters only; TPI + STD on both
+for ny, nx in ((8192, 16384), (2000, 1500)):   # STD alone takes the wide form on big rasters only; TPI + STD on both
     dem = d.synth_dem(ny, nx, seed=5)
     blk = d.Block(dem)
     t, s = d.DeviceArray(ny, nx), d.DeviceArray(ny, nx)

@@ -2312,7 +2312,7 @@ int launch_wave_any(const Block& b, float* tpi_out, float* std_out) {
                 // 3.57 -> 3.23): profiles/r05_std_wide_ab.txt.
                 // (STD alone on a small raster keeps the 256-column strips: 8192^2 has 18 strips of 480 columns for 17.07 and 12 tiles
                 // per block where the narrow form, two blocks per CU, has 17.7: 0.148 against 0.161 ms)
-                const bool big = (long)b.nx * b.out_rows >= (1L << 28);
+                const bool big = (long)b.nx * b.out_rows >= (1L << 27);  // (a 4096-row shard of a 32768-column DEM included)
                 if (current_class().frac_share == 0.0f && std_spec_wide() && (tpi_out != nullptr || (SIZE <= 7 && big))) {
                     if (tpi_out) TOPO_TRY((launch_std_ring_spec<SIZE, true, false, 8>(b, tpi_out, std_out)));
                     else TOPO_TRY((launch_std_ring_spec<SIZE, false, false, 8>(b, nullptr, std_out)));
