@@ -587,8 +587,8 @@ def main():
     d.synth_dem(rows_local, nx, row0=row0, seed=0, out=block, out_row=first_row)
     out = d.DeviceArray(rows_local, nx)
     d.sync()
-    if sharded:
-        sd.classify()  # collective: the class of the whole raster (every shard takes the kernels the single GPU takes)
+    # (sharded: the first topo_amd_shard_* call on the freshly written shard classifies the whole raster itself - collective,
+    # in the warm-up - so every shard takes the kernels the single GPU takes)
 
     if not sharded:
         blk = d.Block(block)

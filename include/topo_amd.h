@@ -25,6 +25,19 @@
  *     must contain every row the requested output rows depend on (see topo_amd_halo_rows).
  *   - one process drives one GPU (topo_amd_init(device)); entry points are serialised on
  *     that device's compute stream.
+ *
+ * Threading
+ *   Every entry point may be called from any thread at any time.  The context (workspaces, the device planes of the
+ *   host-buffer entry points, the streams and events of their pipeline, the gate of a sharded call) is guarded by ONE
+ *   mutex that every entry point touching it holds from its first to its last line, so concurrent calls run one after
+ *   the other, each exactly as if it were alone - same bits as a serial run.  A host-buffer call (*_f32) holds it until its
+ *   result is in the caller's array; a device call (*_dev, topo_amd_shard_*) only while it enqueues, so the GPU work of
+ *   several threads queues up back to back on the compute stream (in the order the threads took the mutex).
+ *   topo_amd_sync() waits for everything enqueued so far, by whichever thread.  The calling thread is bound to the
+ *   context's device on entry (hipSetDevice).  topo_amd_last_error() and topo_amd_shard_layout are per thread; the
+ *   stopwatch (topo_amd_timer_*, topo_amd_mark*) is one per process and means what it says only when one thread launches
+ *   between its two ends.  Collective calls (topo_amd_shard_*, topo_amd_comm_*) must be issued in the same order on
+ *   every rank: drive them from one thread per process.
  */
 #ifndef TOPO_AMD_H
 #define TOPO_AMD_H
@@ -92,21 +105,36 @@ int topo_amd_sync(void);
  *     needs the class and remembered with the buffer until the library writes or frees the buffer - or the caller, having
  *     written it with kernels of its own, says so with topo_amd_dem_changed;
  *   - the host-buffer entry points scan the caller's array;
- *   - a PARTIAL row block uses the class the calling thread declared: topo_amd_raster_scan_dev adds up the lattice points
- *     of the rows each block owns (counts += {samples, samples finite and beyond 1e5, samples with a fractional part};
- *     range = {min, max} of the samples within +-2^18; start from 0, 0, 0 and +inf, -inf),
- *     topo_amd_raster_class_from_scan declares the sum (the share of fractional samples only picks which exact disc
- *     kernels run first: time, never bits);
- *     topo_amd_shard_classify does both for a row shard, with an all-reduce over the communicator (collective).  A thread
- *     that has declared nothing sees the last declaration of any thread; with none at all the raster is taken for an
- *     ordinary DEM in whole metres (large = 0, range 0 ... 4096, no fractional samples).  large < 0 withdraws the
- *     declarations.                                                                                                      */
+ *   - a PARTIAL row block uses the class that was declared FOR ITS MEMORY: topo_amd_raster_scan_dev adds up the lattice
+ *     points of the rows each block owns (counts += {samples, samples finite and beyond 1e5, samples with a fractional
+ *     part}; range = {min, max} of the samples within +-2^18; start from 0, 0, 0 and +inf, -inf), then
+ *     topo_amd_raster_class_from_scan(block, in_rows, gny, nx, counts, range) declares the sum for the device rows
+ *     [block, block + in_rows * nx) of a gny x nx raster - once per block the application holds (the share of fractional
+ *     samples only picks which exact disc kernels run first: time, never bits).  A later call whose `in` pointer lies
+ *     inside declared rows of a raster of the same shape takes that class.  A declaration lives exactly as long as the
+ *     data it describes: it is dropped when the library writes or frees memory overlapping the rows (uploads, copies,
+ *     memset, an output plane, topo_amd_free), by topo_amd_dem_changed, or by topo_amd_raster_class_set(..., large = -1,
+ *     ...) (block == NULL: every declaration).  It is not a property of a thread or of the process: two rasters held in
+ *     one process never see each other's class.
+ *   - the topo_amd_shard_* calls declare the class of their shard THEMSELVES at the first call on a buffer nothing is
+ *     declared for (topo_amd_shard_classify: the scans of all ranks, added up by an all-reduce - collective like the
+ *     calls themselves), so every shard takes the single GPU's kernels without the application doing anything.
+ *   - a partial row block of the *_dev entry points that nothing was declared for is taken for an ordinary DEM in whole
+ *     metres (large = 0, range 0 ... 4096, no fractional samples): a fixed rule, not a memory of earlier calls.  On such
+ *     a raster the blocks give the whole raster's bits; on a raster of another class (fractional elevations within a
+ *     few hundred metres, millimetres) they stay inside the tolerances below but may differ from the whole raster in
+ *     the last bits of TPI / the Gaussian - declare the class to get its bits.                                           */
 int topo_amd_dem_changed(const void* dptr, size_t bytes); /* bytes == 0: the whole allocation dptr lies in */
 int topo_amd_raster_scan_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int own_row0, int own_rows,
                              uint64_t counts[3], float range[2]);
-int topo_amd_raster_class_from_scan(const uint64_t counts[3], const float range[2]);
-int topo_amd_raster_class_set(int large, float lo, float hi, float frac_share);
-int topo_amd_raster_class_get(int* large, float* lo, float* hi, float* frac_share);
+int topo_amd_raster_class_from_scan(const float* block, int in_rows, int gny, int nx, const uint64_t counts[3],
+                                    const float range[2]);
+int topo_amd_raster_class_set(const float* block, int in_rows, int gny, int nx, int large, float lo, float hi,
+                              float frac_share);
+/* The class a call on a block starting at `block` (any row of declared rows) of a gny x nx raster would take; *declared = 0:
+ * nothing is declared there (the values are then the ordinary DEM's).                                                     */
+int topo_amd_raster_class_get(const float* block, int gny, int nx, int* declared, int* large, float* lo, float* hi,
+                              float* frac_share);
 
 /* HIP-event stopwatch on the compute stream (what bench.py times kernels with). */
 int topo_amd_timer_start(void);
@@ -239,6 +267,12 @@ int topo_amd_mean_std_dev(const float* in, size_t count, double* mean, double* s
  * single block's bits), page-locked arrays (topo_amd_host_alloc) and pageable ones alike.  The device planes a call needs
  * are kept for the next call (grow-only); topo_amd_release_host_planes() gives them back to the device.                  */
 int topo_amd_release_host_planes(void);
+/* Row chunks the calling thread's last host-buffer call ran in (1: upload, kernels, download one after the other - arrays
+ * of fewer than three chunks, or TOPO_AMD_HOST_PIPELINE=0; a multi-scale call: the most any scale ran in).  For tests and
+ * diagnostics: which branch of the pipeline a call took.  Environment, read at every call: TOPO_AMD_HOST_CHUNK_MB (64; a
+ * chunk is whole multiples of 960 rows, at least 960), TOPO_AMD_HOST_PIPELINE=0 (off), TOPO_AMD_HOST_DOWNLOADS=thread|inline
+ * (who issues the downloads; default: the calling thread when every array is page-locked, a second thread otherwise).    */
+int topo_amd_host_chunks(int* chunks);
 int topo_amd_tpi_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
 int topo_amd_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
 int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigma,
@@ -291,8 +325,12 @@ int topo_amd_comm_destroy(void);
 int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_above,
                                  int halo_below);
 int topo_amd_halo_wait(void);
-/* Collective: the class of the WHOLE sharded raster (above) for the calling thread's later topo_amd_shard_* calls.  owned:
- * the first row this rank owns (device pointer), rows_local of them starting at global row row0.                       */
+/* Collective: the class of the WHOLE sharded raster (above), declared for this rank's owned rows.  owned: the first row this
+ * rank owns (device pointer), rows_local of them starting at global row row0.  The topo_amd_shard_* calls run it themselves
+ * when nothing is declared for the shard (first call, or after the shard's rows were rewritten through the library); calling
+ * it is only needed after the application rewrote the rows with kernels of its own (or use topo_amd_dem_changed).  Refused
+ * when the shard is part of a raster and no communicator exists.  In loop-back mode the rank's rows are scanned at every
+ * placement of the periodic stack they stand for.                                                                        */
 int topo_amd_shard_classify(const float* owned, int rows_local, int row0, int gny, int nx);
 /* Round 4: a sharded call is ONE launch per kernel - the interior rows, then, behind a device-side gate the
  * communication stream opens when the ghost rows have landed, the seam rows - with a clean-up launch behind the

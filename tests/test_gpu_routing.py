@@ -23,31 +23,32 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GNY, NX = 400, 512
 
 
-def run_blocks(dem, nblocks, above, below, call):
+def run_blocks(dem, nblocks, above, below, call, declare=True):
     """Like tests/test_gpu_blocks.py, plus what an application that holds a raster in pieces does once: the class of the
-    WHOLE raster, added up from the blocks (include/topo_amd.h, "what kernel routing may know about a raster")."""
+    WHOLE raster, added up from the rows each block owns and declared for the memory of every block the descriptors are
+    called on (include/topo_amd.h, "what kernel routing may know about a raster")."""
     gny, nx = dem.shape
-    if nblocks > 1:
+    scan = None
+    if nblocks > 1 and declare:
         scan = d.RasterScan()
         for row0, rows in shard.split_rows(gny, nblocks):
             dev = d.DeviceArray.from_host(dem[row0:row0 + rows])
             scan.add(d.Block(dev, row0=row0, gny=gny))
             dev.free()
-        scan.declare()
     pieces = None
-    try:
-        for row0, rows in shard.split_rows(gny, nblocks):
-            lo, hi = max(0, row0 - above), min(gny, row0 + rows + below)
-            dev = d.DeviceArray.from_host(dem[lo:hi])
-            outs = call(d.Block(dev, row0=lo, gny=gny), row0, rows)
-            d.sync()
-            host = [o.to_host() for o in outs]
-            pieces = [[h] for h in host] if pieces is None else [p + [h] for p, h in zip(pieces, host)]
-            for o in outs:
-                o.free()
-            dev.free()
-    finally:
-        d.forget_raster_class()
+    for row0, rows in shard.split_rows(gny, nblocks):
+        lo, hi = max(0, row0 - above), min(gny, row0 + rows + below)
+        dev = d.DeviceArray.from_host(dem[lo:hi])
+        blk = d.Block(dev, row0=lo, gny=gny)
+        if scan is not None:
+            scan.declare(blk)
+        outs = call(blk, row0, rows)
+        d.sync()
+        host = [o.to_host() for o in outs]
+        pieces = [[h] for h in host] if pieces is None else [p + [h] for p, h in zip(pieces, host)]
+        for o in outs:
+            o.free()
+        dev.free()  # (the declaration goes with the memory)
     return [np.concatenate(p, axis=0) for p in pieces]
 
 
@@ -285,8 +286,7 @@ def test_std_on_fractional_elevations_by_three_marching_passes(size):
     assert np.max(np.abs(s - es)) <= 1e-4 * np.max(es), size
     assert np.array_equal(topo.std(dem, size), s.astype(np.float64))
     up, down = shard.halo_rows(_lib.DESC_TPI, size)
-    d.forget_raster_class()
-    for nb in (2, 3):
+    for nb in (2, 3):  # (nothing is declared for these blocks: ordinary DEMs in whole metres)
         pieces_t, pieces_s = [], []
         for row0, rows in shard.split_rows(gny, nb):
             lo, hi = max(0, row0 - up), min(gny, row0 + rows + down)

@@ -72,7 +72,6 @@ SIZES = ([66, 68, 70, 84, 100, 101, 103, 121, 151, 200, 255] if len(sys.argv) > 
          else [1, 2, 3, 4, 5, 6, 7, 9, 11, 15, 17, 19, 25, 31, 33, 41, 67])
 if os.environ.get("FUZZ_SIZES"):  # (lab: a comma-separated list)
     SIZES = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")]
-DECLARE = os.environ.get("FUZZ_DECLARE", "1") != "0"  # 0: the row blocks run without a declared raster class
 while time.time() < t_end:
     ny = int(rng.choice([1, 2, 3, 7, 33, 59, 60, 61, 120, 127, 200, 333, int(rng.integers(1, 400))]))
     nx = int(rng.choice([1, 3, 4, 5, 64, 189, 190, 191, 192, 250, 256, 380, int(rng.integers(1, 500))]))
@@ -121,17 +120,16 @@ while time.time() < t_end:
         # what an application that holds a raster in pieces does once: the class of the WHOLE raster, added up from the
         # rows each block owns (round 5: the unit of the scaled TPI route follows the raster's value range - a window of a
         # few hundred metres of relief takes 2^-13 m where an undeclared block would assume an ordinary DEM's 2^-8)
-        if DECLARE:
-            scan = d.RasterScan()
-            for row0, rows in shard.split_rows(ny, nb):
-                dev = d.DeviceArray.from_host(dem[row0:row0 + rows])
-                scan.add(d.Block(dev, row0=row0, gny=ny))
-                dev.free()
-            scan.declare()
+        scan = d.RasterScan()
+        for row0, rows in shard.split_rows(ny, nb):
+            dev = d.DeviceArray.from_host(dem[row0:row0 + rows])
+            scan.add(d.Block(dev, row0=row0, gny=ny))
+            dev.free()
         for row0, rows in shard.split_rows(ny, nb):
             lo, hi = max(0, row0 - up), min(ny, row0 + rows + down)
             dev = d.DeviceArray.from_host(dem[lo:hi])
             blk = d.Block(dev, row0=lo, gny=ny)
+            scan.declare(blk)  # for this block's memory; it goes with dev.free()
             a, b, c = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
             blk.tpi_std(size, tpi=a, std=b, out_row0=row0, out_rows=rows)
             blk.tpi_std(size, tpi=c, out_row0=row0, out_rows=rows)
@@ -139,7 +137,6 @@ while time.time() < t_end:
             tp.append(a.to_host()); sp.append(b.to_host()); tq.append(c.to_host())
             for x in (a, b, c, dev):
                 x.free()
-        d.forget_raster_class()
         if not np.array_equal(np.concatenate(tp), t_f, equal_nan=True):
             fails.append(f"row blocks tpi(fused) {ctx} nb={nb}")
         if not np.array_equal(np.concatenate(sp).astype(np.float64), s_f.astype(np.float64), equal_nan=True):

@@ -19,22 +19,23 @@ for seed in range(40):
     up, down = shard.halo_rows(_lib.DESC_TPI, size)
     out = {}
     for declared in (False, True):
+        scan = d.RasterScan()
         if declared:
-            scan = d.RasterScan()
             for row0, rows in shard.split_rows(ny, nb):
                 dev = d.DeviceArray.from_host(dem[row0:row0 + rows])
                 scan.add(d.Block(dev, row0=row0, gny=ny))
                 dev.free()
-            scan.declare()
         parts = []
         for row0, rows in shard.split_rows(ny, nb):
             lo, hi = max(0, row0 - up), min(ny, row0 + rows + down)
             dev = d.DeviceArray.from_host(dem[lo:hi])
+            blk = d.Block(dev, row0=lo, gny=ny)
+            if declared:
+                scan.declare(blk)
             c = d.DeviceArray(rows, nx)
-            d.Block(dev, row0=lo, gny=ny).tpi_std(size, tpi=c, out_row0=row0, out_rows=rows)
+            blk.tpi_std(size, tpi=c, out_row0=row0, out_rows=rows)
             d.sync()
             parts.append(c.to_host())
             c.free(), dev.free()
-        d.forget_raster_class()
         out[declared] = int((np.concatenate(parts) != whole).sum())
     print(f"seed {seed}: range {float(dem.max() - dem.min()):7.1f} m   pixels differing from the whole raster: undeclared blocks {out[False]}, declared blocks {out[True]}")

@@ -21,17 +21,19 @@ from topo_descriptors_amd import _lib, device as d, shard  # noqa: E402
 def run_blocks(dem, nblocks, above, below, call):
     gny, nx = dem.shape
     pieces = None
+    scan = None
     if nblocks > 1:  # what an application holding the raster in pieces does once: the class of the whole raster
         scan = d.RasterScan()
         for row0, rows in shard.split_rows(gny, nblocks):
             dev = d.DeviceArray.from_host(dem[row0:row0 + rows])
             scan.add(d.Block(dev, row0=row0, gny=gny))
             dev.free()
-        scan.declare()
     for row0, rows in shard.split_rows(gny, nblocks):
         lo, hi = max(0, row0 - above), min(gny, row0 + rows + below)
         dev = d.DeviceArray.from_host(dem[lo:hi])
         blk = d.Block(dev, row0=lo, gny=gny)
+        if scan is not None:
+            scan.declare(blk)  # (keyed by the block's memory: gone with dev.free())
         outs = call(blk, row0, rows)
         d.sync()
         host = [o.to_host() for o in outs]

@@ -20,3 +20,10 @@ class _Config:
 CFG = _Config()
 
 from . import helpers, topo  # noqa: E402,F401
+
+
+def release_host_planes():
+    """Free the device planes that ``topo.tpi(ndarray)`` and the other host-buffer calls keep between calls (grow-only; a
+    32768 x 32768 gradient leaves about 20 GiB on the GPU).  ``topo_amd_release_host_planes`` of the C ABI."""
+    from . import device  # noqa: PLC0415
+    device.release_host_planes()

@@ -32,12 +32,13 @@ SIGNATURES = {
     "topo_amd_memset": (C.c_int, [_vp, C.c_int, C.c_size_t]),
     "topo_amd_sync": (C.c_int, []),
     "topo_amd_release_host_planes": (C.c_int, []),
+    "topo_amd_host_chunks": (C.c_int, [_i32p]),
     "topo_amd_dem_changed": (C.c_int, [_vp, C.c_size_t]),
     "topo_amd_raster_scan_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_uint64), _f32p]),
-    "topo_amd_raster_class_from_scan": (C.c_int, [C.POINTER(C.c_uint64), _f32p]),
-    "topo_amd_raster_class_set": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_float]),
-    "topo_amd_raster_class_get": (C.c_int, [_i32p, _f32p, _f32p, _f32p]),
+    "topo_amd_raster_class_from_scan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), _f32p]),
+    "topo_amd_raster_class_set": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]),
+    "topo_amd_raster_class_get": (C.c_int, [_vp, C.c_int, C.c_int, _i32p, _i32p, _f32p, _f32p, _f32p]),
     "topo_amd_shard_classify": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "topo_amd_timer_start": (C.c_int, []),
     "topo_amd_timer_stop": (C.c_int, [_f32p]),

@@ -37,6 +37,20 @@ Context& ctx() {
     return c;
 }
 
+std::recursive_mutex& call_mutex() {
+    static std::recursive_mutex mu;
+    return mu;
+}
+namespace {
+thread_local int t_bound_device = -1;  // the device this thread's HIP calls go to, as far as the library has set it
+}
+CallGuard::CallGuard() : lock(call_mutex()) {
+    const Context& c = ctx();
+    if (c.ready && t_bound_device != c.device) {
+        if (hipSetDevice(c.device) == hipSuccess) t_bound_device = c.device;
+    }
+}
+
 int require_ready() {
     if (!ctx().ready) {
         set_error("libtopo_amd: call topo_amd_init(device) first");
@@ -100,6 +114,59 @@ int memo_slot(const Block& b, bool create) {
     for (int w = 0; w < kMemoWords; ++w) g_memo_words[kMemoWords * oldest + w] = 0;
     return oldest;
 }
+// What was declared for partial row blocks (topo_amd_raster_class_set / _from_scan / topo_amd_shard_classify): keyed by the
+// device rows the declaration was made for and the shape of the raster they belong to.  A call's block finds its class
+// when its first row lies inside a declared range of a raster of the same shape.  Dropped like the memo: whenever the
+// library writes or frees memory that overlaps the range, by topo_amd_dem_changed, and by a withdrawal.  Nothing here
+// belongs to a thread or outlives its memory: two rasters in one process cannot inherit each other's class.
+struct Declared {
+    uintptr_t lo = 0, hi = 0;  // [lo, hi): the device rows
+    int gny = 0, nx = 0;
+    unsigned long used = 0;
+    RasterClass cls;
+};
+constexpr size_t kMaxDeclared = 256;
+std::vector<Declared> g_declared;  // g_memo_mu held
+// g_memo_mu held
+const Declared* find_declared(const Block& b) {
+    const uintptr_t p = (uintptr_t)b.in;
+    for (Declared& e : g_declared)
+        if (p >= e.lo && p < e.hi && e.gny == b.gny && e.nx == b.nx) {
+            e.used = ++g_memo_clock;
+            return &e;
+        }
+    return nullptr;
+}
+bool declared_class(const Block& b, RasterClass* out) {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    const Declared* e = find_declared(b);
+    if (e && out) *out = e->cls;
+    return e != nullptr;
+}
+void declare_class(const float* block, int in_rows, int gny, int nx, const RasterClass& cls) {
+    std::lock_guard<std::mutex> lock(g_memo_mu);
+    const uintptr_t lo = (uintptr_t)block, hi = lo + (size_t)in_rows * nx * sizeof(float);
+    // a declaration replaces whatever was declared for overlapping memory
+    g_declared.erase(std::remove_if(g_declared.begin(), g_declared.end(), [&](const Declared& e) { return e.lo < hi && lo < e.hi; }),
+                     g_declared.end());
+    if (g_declared.size() >= kMaxDeclared) {
+        auto oldest = std::min_element(g_declared.begin(), g_declared.end(), [](const Declared& x, const Declared& y) { return x.used < y.used; });
+        g_declared.erase(oldest);
+    }
+    Declared e;
+    e.lo = lo;
+    e.hi = hi;
+    e.gny = gny;
+    e.nx = nx;
+    e.used = ++g_memo_clock;
+    e.cls = cls;
+    g_declared.push_back(e);
+}
+// g_memo_mu held
+void forget_declared(uintptr_t lo, uintptr_t hi) {
+    g_declared.erase(std::remove_if(g_declared.begin(), g_declared.end(), [&](const Declared& e) { return e.lo < hi && lo < e.hi; }),
+                     g_declared.end());
+}
 }  // namespace
 
 uint32_t* dem_memo_report(const Block& b) {
@@ -136,6 +203,7 @@ void dem_memo_forget(const void* p, size_t bytes) {
     if (!p) return;
     std::lock_guard<std::mutex> lock(g_memo_mu);
     const uintptr_t lo = (uintptr_t)p, hi = lo + (bytes ? bytes : 1);
+    forget_declared(lo, hi);
     for (int k = 0; k < kMemos; ++k) {
         DemMemo& m = g_memo[k];
         if (!m.in) continue;
@@ -251,19 +319,6 @@ RasterClass scan_host(const float* dem, int ny, int nx) {
     return class_of(s);
 }
 
-// what the calling thread declared for its partial row blocks (topo_amd_raster_class_set); a thread that has declared
-// nothing sees the last declaration of any thread (set up once, drive from worker threads: like topo_amd_shard_layout)
-thread_local bool t_declared = false;
-thread_local RasterClass t_declared_class;
-std::mutex g_declared_mu;
-bool g_declared = false;
-RasterClass g_declared_class;
-RasterClass declared_class() {
-    if (t_declared) return t_declared_class;
-    std::lock_guard<std::mutex> lock(g_declared_mu);
-    return g_declared ? g_declared_class : RasterClass();
-}
-
 // The class of the call in flight on this thread: set by the outermost entry point, resolved when a launcher first asks.
 thread_local const Block* t_call_block = nullptr;  // the block the outermost entry point was given
 thread_local bool t_class_known = false;
@@ -272,8 +327,9 @@ thread_local RasterClass t_class;
 
 RasterClass current_class() {
     if (t_class_known) return t_class;
-    RasterClass c = declared_class();
+    RasterClass c;  // nothing declared: an ordinary DEM in whole metres
     const Block* b = t_call_block;
+    if (b != nullptr && !(b->in_row0 == 0 && b->in_rows == b->gny)) (void)declared_class(*b, &c);
     if (b != nullptr && b->in_row0 == 0 && b->in_rows == b->gny) {
         // the block IS the raster: its own scan, remembered with the block
         bool have = false;
@@ -476,9 +532,13 @@ int gradient_shard_halo(double sigma, double sig_ratio) {
 // host-buffer call spends most of its time on (tools/ubench/page_touch.cpp: 92 ms per GiB against 19 ms
 // for the copy itself).  prefault() asks for huge pages and touches the array from a few threads
 // while the upload and the kernels run; ready() joins them before the first download.
+thread_local int t_host_chunks = 0;  // row chunks of the calling thread's last host-buffer call (topo_amd_host_chunks)
 struct HostRun {
     std::vector<void*> bufs;
     std::vector<std::thread> touchers;
+    explicit HostRun(bool entry_point = true) {
+        if (entry_point) t_host_chunks = 0;
+    }
     ~HostRun() {
         ready();
         for (size_t k = 0; k < bufs.size(); ++k) dem_memo_forget(bufs[k], sizes[k]);  // (the planes stay; what was known about their content goes)
@@ -559,20 +619,17 @@ int download(void* host, const void* dev, size_t bytes) {
 // "the rows uploaded so far") on the compute stream; a second host thread downloads the output rows of every finished
 // chunk on a third stream (its own thread because copies to and from pageable memory block the caller).
 // TOPO_AMD_HOST_PIPELINE=0: one chunk (the old order).  TOPO_AMD_HOST_CHUNK_MB: size of a chunk of the DEM (default 64).
+// TOPO_AMD_HOST_DOWNLOADS=thread / inline: who issues the downloads (default: by the arrays, below).  All three are read at
+// every call (a getenv each), so a test can walk through them in one process.
 struct HostPlane {
     float* host;
     float* dev;
 };
 int pipeline_chunk_rows(int ny, int nx) {
-    static const bool on = [] {
-        const char* e = std::getenv("TOPO_AMD_HOST_PIPELINE");
-        return !(e && *e == '0');
-    }();
-    static const double chunk_mb = [] {
-        const char* e = std::getenv("TOPO_AMD_HOST_CHUNK_MB");
-        return e && *e ? std::max(1.0, std::atof(e)) : 64.0;
-    }();
-    if (!on) return ny;
+    const char* e = std::getenv("TOPO_AMD_HOST_PIPELINE");
+    if (e && *e == '0') return ny;
+    e = std::getenv("TOPO_AMD_HOST_CHUNK_MB");
+    const double chunk_mb = e && *e ? std::max(1.0, std::atof(e)) : 64.0;
     // whole tile rows of every kernel (60 and 64: 960), at least 960 rows
     long rows = (long)(chunk_mb * 1048576.0 / ((double)nx * sizeof(float)));
     rows = std::max(960L, rows / 960 * 960);
@@ -589,6 +646,7 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
     const int nchunks = (ny + chunk - 1) / chunk;
     const size_t row_bytes = (size_t)nx * sizeof(float);
     (void)above;
+    t_host_chunks = std::max(t_host_chunks, nchunks < 3 ? 1 : nchunks);  // (a multi-scale call: the most any of its scales ran in)
     if (nchunks < 3) {
         if (upload) TOPO_HIP(hipMemcpyAsync(d_in, dem, (size_t)ny * row_bytes, hipMemcpyHostToDevice, c.compute));
         const int rc = compute(ny, 0, ny);
@@ -612,9 +670,9 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
     // Page-locked arrays (topo_amd_host_alloc, hipHostRegister): every copy is asynchronous, and the calling thread issues the
     // downloads itself, behind each chunk's kernels.  Pageable arrays: copies block their caller, so the downloads go to a
     // second thread (tools/ubench/pipe_paths.hip: 23.4 / 23.9 ms for 2 x 1 GiB against 38 - 39 ms one after the other).
-    // TOPO_AMD_HOST_PIPELINE=thread / inline forces one or the other.
-    static const int forced_mode = [] {
-        const char* e = std::getenv("TOPO_AMD_HOST_PIPELINE");
+    // TOPO_AMD_HOST_DOWNLOADS=thread / inline forces one or the other.
+    const int forced_mode = [] {
+        const char* e = std::getenv("TOPO_AMD_HOST_DOWNLOADS");
         return e && *e == 't' ? 1 : (e && *e == 'i' ? 2 : 0);
     }();
     auto page_locked = [](const void* p) {
@@ -761,6 +819,7 @@ int topo_amd_device_count(void) {
 }
 
 int topo_amd_init(int device) {
+    TOPO_ENTER();
     Context& c = ctx();
     if (c.ready && c.device == device) return TOPO_AMD_OK;
     if (c.ready) {
@@ -822,12 +881,17 @@ hipEvent_t g_marks[kMarks] = {};
 }  // namespace
 
 int topo_amd_shutdown(void) {
+    TOPO_ENTER();
     Context& c = ctx();
     if (!c.ready) return TOPO_AMD_OK;
     (void)hipDeviceSynchronize();
     if (g_comm.comm) {
         (void)ncclCommDestroy(g_comm.comm);
         g_comm = Comm();
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_memo_mu);
+        g_declared.clear();
     }
     valley_fft_release();  // FFT plans hold the stream that goes away below
     for (int i = 0; i < 12; ++i)
@@ -873,6 +937,7 @@ int topo_amd_shutdown(void) {
 }
 
 int topo_amd_device_name(char* buf, int buflen) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     hipDeviceProp_t prop;
     TOPO_HIP(hipGetDeviceProperties(&prop, ctx().device));
@@ -882,11 +947,13 @@ int topo_amd_device_name(char* buf, int buflen) {
 }
 
 int topo_amd_cu_count(void) {
+    TOPO_ENTER();
     if (require_ready() != TOPO_AMD_OK) return TOPO_AMD_ENODEV;
     return ctx().num_cu;
 }
 
 int topo_amd_malloc(void** dptr, size_t bytes) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dptr != nullptr, "topo_amd_malloc: NULL result pointer");
     TOPO_HIP(hipMalloc(dptr, bytes ? bytes : 4));
@@ -895,6 +962,7 @@ int topo_amd_malloc(void** dptr, size_t bytes) {
 }
 
 int topo_amd_free(void* dptr) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     if (dptr) {
         TOPO_HIP(hipStreamSynchronize(ctx().compute));
@@ -911,18 +979,21 @@ int topo_amd_free(void* dptr) {
 // Page-locked host memory for the arrays handed to the host-buffer entry points (topo_amd_*_f32): the copies then run
 // at the link's rate without the driver staging them (bench.py, end_to_end: pinned against pageable).
 int topo_amd_host_alloc(void** hptr, size_t bytes) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(hptr != nullptr && bytes > 0, "host_alloc: bad arguments");
     TOPO_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
     return TOPO_AMD_OK;
 }
 int topo_amd_host_free(void* hptr) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     if (hptr) TOPO_HIP(hipHostFree(hptr));
     return TOPO_AMD_OK;
 }
 
 int topo_amd_release_host_planes(void) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     Context& c = ctx();
     TOPO_HIP(hipStreamSynchronize(c.compute));
@@ -937,7 +1008,14 @@ int topo_amd_release_host_planes(void) {
     return TOPO_AMD_OK;
 }
 
+int topo_amd_host_chunks(int* chunks) {
+    TOPO_REQUIRE(chunks != nullptr, "host_chunks: NULL output");
+    *chunks = t_host_chunks;
+    return TOPO_AMD_OK;
+}
+
 int topo_amd_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     dem_memo_forget(dst, bytes);
     TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().compute));
@@ -946,11 +1024,12 @@ int topo_amd_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 }
 
 int topo_amd_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     {
         // a destination fresh from the allocator has no pages yet: fault them in from several
         // threads (the kernels launched before this call are usually still running meanwhile)
-        HostRun pages;
+        HostRun pages(false);
         pages.prefault(dst, bytes);
     }
     TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().compute));
@@ -959,6 +1038,7 @@ int topo_amd_memcpy_d2h(void* dst, const void* src, size_t bytes) {
 }
 
 int topo_amd_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     dem_memo_forget(dst, bytes);
     TOPO_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().compute));
@@ -966,6 +1046,7 @@ int topo_amd_memcpy_d2d(void* dst, const void* src, size_t bytes) {
 }
 
 int topo_amd_memset(void* dst, int value, size_t bytes) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     dem_memo_forget(dst, bytes);
     TOPO_HIP(hipMemsetAsync(dst, value, bytes, ctx().compute));
@@ -1003,6 +1084,7 @@ int check_gate_errors() {
 // rows for them.  0 in a healthy run (after the first calls, in which RCCL sets its connections up); a statistic
 // for bench.py and the tests, never an error.
 int topo_amd_gate_giveups(unsigned* count) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(count != nullptr, "gate_giveups: NULL output");
     const uint32_t now = *(volatile uint32_t*)ctx().gate_timeouts;
@@ -1012,6 +1094,7 @@ int topo_amd_gate_giveups(unsigned* count) {
 }
 
 int topo_amd_sync(void) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_HIP(hipStreamSynchronize(ctx().compute));
     TOPO_HIP(hipStreamSynchronize(ctx().comm));
@@ -1019,12 +1102,14 @@ int topo_amd_sync(void) {
 }
 
 int topo_amd_timer_start(void) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_HIP(hipEventRecord(ctx().t0, ctx().compute));
     return TOPO_AMD_OK;
 }
 
 int topo_amd_timer_stop(float* elapsed_ms) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_HIP(hipEventRecord(ctx().t1, ctx().compute));
     TOPO_HIP(hipEventSynchronize(ctx().t1));
@@ -1034,6 +1119,7 @@ int topo_amd_timer_stop(float* elapsed_ms) {
 
 
 int topo_amd_mark(int index) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(index >= 0 && index < kMarks, "mark: index %d outside [0, %d)", index, kMarks);
     if (!g_marks[index]) TOPO_HIP(hipEventCreate(&g_marks[index]));
@@ -1042,6 +1128,7 @@ int topo_amd_mark(int index) {
 }
 
 int topo_amd_mark_elapsed(int from, int to, float* elapsed_ms) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(from >= 0 && from < kMarks && to >= 0 && to < kMarks && g_marks[from] && g_marks[to] && elapsed_ms,
                  "mark_elapsed: marks %d and %d must have been recorded", from, to);
@@ -1051,6 +1138,7 @@ int topo_amd_mark_elapsed(int from, int to, float* elapsed_ms) {
 }
 
 int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed, int integer_valued) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(out && rows >= 1 && nx >= 1, "synth_dem: bad arguments");
     forget_plane(out, rows, nx);
@@ -1059,6 +1147,7 @@ int topo_amd_synth_dem_dev(float* out, int rows, int row0, int nx, uint32_t seed
 
 // ---- the raster class (common.hpp) ----------------------------------------------------------------------------------
 int topo_amd_dem_changed(const void* dptr, size_t bytes) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dptr != nullptr, "dem_changed: NULL pointer");
     if (bytes == 0) {  // the whole allocation
@@ -1073,6 +1162,7 @@ int topo_amd_dem_changed(const void* dptr, size_t bytes) {
 
 int topo_amd_raster_scan_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int own_row0, int own_rows,
                              uint64_t counts[3], float range[2]) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(in && counts && range && gny >= 1 && nx >= 1 && in_rows >= 1 && in_row0 >= 0 && in_row0 + in_rows <= gny,
                  "raster_scan: bad block");
@@ -1092,42 +1182,51 @@ int topo_amd_raster_scan_dev(const float* in, int in_rows, int in_row0, int gny,
     return TOPO_AMD_OK;
 }
 
-int topo_amd_raster_class_set(int large, float lo, float hi, float frac_share) {
-    if (large < 0) {  // forget the declaration (this thread's and the process-wide one)
-        t_declared = false;
-        std::lock_guard<std::mutex> lock(g_declared_mu);
-        g_declared = false;
+namespace {
+int check_declared_rows(const float* block, int in_rows, int gny, int nx, const char* who) {
+    TOPO_REQUIRE(block != nullptr && in_rows >= 1 && gny >= in_rows && nx >= 1,
+                 "%s: the declaration is for device rows: block != NULL, 1 <= in_rows <= gny, nx >= 1 (got %p, %d, %d, %d)", who,
+                 (const void*)block, in_rows, gny, nx);
+    return TOPO_AMD_OK;
+}
+}  // namespace
+
+int topo_amd_raster_class_set(const float* block, int in_rows, int gny, int nx, int large, float lo, float hi, float frac_share) {
+    if (large < 0) {  // withdraw: what was declared for memory overlapping these rows (block == NULL: every declaration)
+        std::lock_guard<std::mutex> lock(g_memo_mu);
+        if (block == nullptr) g_declared.clear();
+        else forget_declared((uintptr_t)block, (uintptr_t)block + (size_t)std::max(1, in_rows) * std::max(1, nx) * sizeof(float));
         return TOPO_AMD_OK;
     }
+    TOPO_TRY(check_declared_rows(block, in_rows, gny, nx, "raster_class_set"));
     TOPO_REQUIRE(!(lo != lo) && !(hi != hi) && frac_share >= 0.0f && frac_share <= 1.0f, "raster_class_set: bad range or share");
     RasterClass c;
     c.large = large != 0;
     c.lo = lo;
     c.hi = hi;
     c.frac_share = frac_share;
-    t_declared = true;
-    t_declared_class = c;
-    std::lock_guard<std::mutex> lock(g_declared_mu);
-    g_declared = true;
-    g_declared_class = c;
+    declare_class(block, in_rows, gny, nx, c);
     return TOPO_AMD_OK;
 }
 
-int topo_amd_raster_class_from_scan(const uint64_t counts[3], const float range[2]) {
+int topo_amd_raster_class_from_scan(const float* block, int in_rows, int gny, int nx, const uint64_t counts[3], const float range[2]) {
     TOPO_REQUIRE(counts && range, "raster_class_from_scan: NULL argument");
+    TOPO_TRY(check_declared_rows(block, in_rows, gny, nx, "raster_class_from_scan"));
     Scan s;
     s.taken = counts[0];
     s.large = counts[1];
     s.frac = counts[2];
     s.lo = range[0];
     s.hi = range[1];
-    const RasterClass c = class_of(s);
-    return topo_amd_raster_class_set(c.large ? 1 : 0, c.lo, c.hi, c.frac_share);
+    declare_class(block, in_rows, gny, nx, class_of(s));
+    return TOPO_AMD_OK;
 }
 
-int topo_amd_raster_class_get(int* large, float* lo, float* hi, float* frac_share) {
-    TOPO_REQUIRE(large && lo && hi && frac_share, "raster_class_get: NULL output");
-    const RasterClass c = declared_class();
+int topo_amd_raster_class_get(const float* block, int gny, int nx, int* declared, int* large, float* lo, float* hi, float* frac_share) {
+    TOPO_REQUIRE(block && declared && large && lo && hi && frac_share, "raster_class_get: NULL argument");
+    RasterClass c;  // (nothing declared: what a partial block is then taken for)
+    Block b{block, 1, 0, gny, nx, 0, 1};
+    *declared = declared_class(b, &c) ? 1 : 0;
     *large = c.large ? 1 : 0;
     *lo = c.lo;
     *hi = c.hi;
@@ -1202,6 +1301,7 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
 // ---- device row-block entry points ------------------------------------------------------------
 int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int size,
                          int out_row0, int out_rows, float* tpi_out, float* std_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     ClassScope cls(b);
@@ -1212,6 +1312,7 @@ int topo_amd_tpi_std_dev(const float* in, int in_rows, int in_row0, int gny, int
 
 int topo_amd_tpi_multi_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int n_sizes, const int32_t* sizes,
                            int out_row0, int out_rows, float* const* tpi_outs) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(n_sizes >= 1 && sizes && tpi_outs, "tpi_multi: no sizes");
     for (int k = 0; k < n_sizes; ++k) TOPO_REQUIRE(tpi_outs[k], "tpi_multi: NULL output plane %d", k);
@@ -1245,6 +1346,7 @@ int topo_amd_tpi_multi_dev(const float* in, int in_rows, int in_row0, int gny, i
 
 int topo_amd_gaussian_dev(const float* in, int in_rows, int in_row0, int gny, int nx,
                           double sigma_y, double sigma_x, int out_row0, int out_rows, float* out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(out != nullptr, "gaussian: NULL output");
     TOPO_REQUIRE(sigma_y >= 0.0 && sigma_x >= 0.0, "gaussian: negative sigma");
@@ -1258,6 +1360,7 @@ int topo_amd_gaussian_dev(const float* in, int in_rows, int in_row0, int gny, in
 
 int topo_amd_sobel_dev(const float* in, int in_rows, int in_row0, int gny, int nx, int out_row0,
                        int out_rows, float* dx_out, float* dy_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     TOPO_TRY(check_block(b, 1, 1, "sobel"));
@@ -1270,6 +1373,7 @@ int topo_amd_gradient_dev(const float* in, int in_rows, int in_row0, int gny, in
                           double sig_ratio, int res_mode, const void* res_x, const void* res_y,
                           int out_row0, int out_rows, float* dx_out, float* dy_out,
                           float* slope_out, float* aspect_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     Block b{in, in_rows, in_row0, gny, nx, out_row0, out_rows};
     const int h = gradient_halo(sigma, sig_ratio);
@@ -1283,8 +1387,9 @@ int topo_amd_gradient_dev(const float* in, int in_rows, int in_row0, int gny, in
 int topo_amd_sx_dev(const float* in, int in_rows, int in_row0, int gny, int nx, const int32_t* dj,
                     const int32_t* di, const double* dist, int n_off, int window, double height,
                     int out_row0, int out_rows, float* out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
-    TOPO_REQUIRE(out && dj && di && dist && n_off >= 0, "sx: NULL argument");
+    TOPO_REQUIRE(out && n_off >= 0 && (n_off == 0 || (dj && di && dist)), "sx: NULL argument");
     int up = 0, down = 0;
     for (int n = 0; n < n_off; ++n) {
         if (std::isnan(dist[n])) continue;
@@ -1314,6 +1419,7 @@ int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, in
                           const int32_t* first, const int32_t* dj, const int32_t* di, const double* dist,
                           const int32_t* window, double height, int out_row0, int out_rows,
                           float* const* outs) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(n_az >= 1 && first && dj && di && dist && window && outs, "sx_multi: NULL argument");
     for (int k = 0; k < n_az; ++k) TOPO_REQUIRE(outs[k], "sx_multi: NULL output plane %d", k);
@@ -1328,6 +1434,7 @@ int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, in
 int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny, int nx, const float* taps,
                               const int32_t* ksize, const float* angles, int n_angles, int n_planes, double mean,
                               double stdev, int out_row0, int out_rows, float* norm_out, float* dir_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(taps && ksize && angles && norm_out && dir_out && n_angles >= 1, "valley_ridge: NULL argument");
     int up = 0, down = 0;
@@ -1340,6 +1447,7 @@ int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny
 }
 
 int topo_amd_mean_std_dev(const float* in, size_t count, double* mean, double* stdev) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(in && mean && stdev && count >= 1, "mean_std: bad arguments");
     return launch_mean_std(in, count, mean, stdev);
@@ -1348,6 +1456,7 @@ int topo_amd_mean_std_dev(const float* in, size_t count, double* mean, double* s
 // ---- host-buffer entry points ----------------------------------------------------------------
 int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* tpi_out,
                          float* std_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && ny >= 1 && nx >= 1, "tpi_std: bad DEM");
     TOPO_REQUIRE(tpi_out || std_out, "tpi_std: both outputs are NULL");
@@ -1371,6 +1480,7 @@ int topo_amd_tpi_std_f32(const float* dem, int ny, int nx, int size, double sigm
 
 int topo_amd_tpi_std_multi_f32(const float* dem, int ny, int nx, int n_scales, const int32_t* sizes,
                                const double* sigmas, float* const* tpi_outs, float* const* std_outs) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && ny >= 1 && nx >= 1, "tpi_std_multi: bad DEM");
     TOPO_REQUIRE(n_scales >= 1 && sizes, "tpi_std_multi: no scales");
@@ -1410,16 +1520,19 @@ int topo_amd_tpi_std_multi_f32(const float* dem, int ny, int nx, int n_scales, c
 }
 
 int topo_amd_tpi_f32(const float* dem, int ny, int nx, int size, double sigma, float* out) {
+    TOPO_ENTER();
     TOPO_REQUIRE(out != nullptr, "tpi: NULL output");
     return topo_amd_tpi_std_f32(dem, ny, nx, size, sigma, out, nullptr);
 }
 
 int topo_amd_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* out) {
+    TOPO_ENTER();
     TOPO_REQUIRE(out != nullptr, "std: NULL output");
     return topo_amd_tpi_std_f32(dem, ny, nx, size, sigma, nullptr, out);
 }
 
 int topo_amd_gauss_f32(const float* dem, int ny, int nx, double sigma_y, double sigma_x, float* out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && out && ny >= 1 && nx >= 1, "gauss: bad arguments");
     TOPO_REQUIRE(sigma_y >= 0.0 && sigma_x >= 0.0, "gaussian: negative sigma");
@@ -1438,6 +1551,7 @@ int topo_amd_gauss_f32(const float* dem, int ny, int nx, double sigma_y, double 
 }
 
 int topo_amd_sobel_f32(const float* dem, int ny, int nx, float* dx_out, float* dy_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && dx_out && dy_out && ny >= 1 && nx >= 1, "sobel: bad arguments");
     const size_t bytes = (size_t)ny * nx * sizeof(float);
@@ -1458,6 +1572,7 @@ int topo_amd_sobel_f32(const float* dem, int ny, int nx, float* dx_out, float* d
 int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double sig_ratio,
                           int res_mode, const void* res_x, const void* res_y, float* dx_out,
                           float* dy_out, float* slope_out, float* aspect_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && ny >= 1 && nx >= 1, "gradient: bad DEM");
     const size_t bytes = (size_t)ny * nx * sizeof(float);
@@ -1497,9 +1612,12 @@ int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double
 
 int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const int32_t* di,
                     const double* dist, int n_off, int window, double height, float* out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && out && ny >= 1 && nx >= 1, "sx: bad arguments");
-    TOPO_REQUIRE(dj && di && dist && n_off >= 0, "sx: NULL argument");
+    // (no ray pixel at all: the tables may be NULL; the plane is zero-filled and the call answers TOPO_AMD_EEMPTY, like
+    // a sector whose pixels are all NaN)
+    TOPO_REQUIRE(n_off >= 0 && (n_off == 0 || (dj && di && dist)), "sx: NULL argument");
     const size_t bytes = (size_t)ny * nx * sizeof(float);
     int up = 0, down = 0;
     for (int n = 0; n < n_off; ++n) {
@@ -1521,8 +1639,11 @@ int topo_amd_sx_f32(const float* dem, int ny, int nx, const int32_t* dj, const i
 int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int32_t* first,
                           const int32_t* dj, const int32_t* di, const double* dist, const int32_t* window,
                           double height, float* const* outs) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && outs && n_az >= 1 && ny >= 1 && nx >= 1, "sx_multi: bad arguments");
+    TOPO_REQUIRE(first && dj && di && dist && window, "sx_multi: NULL argument");
+    for (int k = 0; k < n_az; ++k) TOPO_REQUIRE(outs[k], "sx_multi: NULL output plane %d", k);
     const size_t bytes = (size_t)ny * nx * sizeof(float);
     HostRun run;
     void* d_in = nullptr;
@@ -1530,7 +1651,6 @@ int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int3
     TOPO_TRY(run.alloc(&d_in, bytes));
     for (int k = 0; k < n_az; ++k) TOPO_TRY(run.alloc((void**)&d_out[k], bytes));
     for (int k = 0; k < n_az; ++k) run.prefault(outs[k], bytes);
-    TOPO_REQUIRE(first && dj && di && dist && window, "sx_multi: NULL argument");
     int up = 0, down = 0;
     sx_multi_reach(n_az, first, dj, dist, &up, &down);
     std::vector<HostPlane> planes;
@@ -1546,6 +1666,7 @@ int topo_amd_sx_multi_f32(const float* dem, int ny, int nx, int n_az, const int3
 int topo_amd_valley_ridge_f32(const float* dem, int ny, int nx, const float* taps, const int32_t* ksize,
                               const float* angles, int n_angles, int n_planes, double mean, double stdev,
                               float* norm_out, float* dir_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(dem && ny >= 1 && nx >= 1 && norm_out && dir_out, "valley_ridge: bad arguments");
     const size_t bytes = (size_t)ny * nx * sizeof(float);
@@ -1556,6 +1677,9 @@ int topo_amd_valley_ridge_f32(const float* dem, int ny, int nx, const float* tap
     TOPO_TRY(run.alloc(&d_dir, bytes));
     run.prefault(norm_out, bytes);
     run.prefault(dir_out, bytes);
+    // (not pipelined: half a second of kernels per 20 ms of copies at full size, and the FFT route of the large kernels is
+    // not cut-invariant)
+    t_host_chunks = 1;
     TOPO_HIP(hipMemcpyAsync(d_in, dem, bytes, hipMemcpyHostToDevice, ctx().compute));
     TOPO_TRY(topo_amd_valley_ridge_dev((const float*)d_in, ny, 0, ny, nx, taps, ksize, angles, n_angles, n_planes,
                                        mean, stdev, 0, ny, (float*)d_norm, (float*)d_dir));
@@ -1591,6 +1715,7 @@ void cap_rccl_channels() {
 }  // namespace
 
 int topo_amd_comm_unique_id(char id[TOPO_AMD_UNIQUE_ID_BYTES]) {
+    TOPO_ENTER();
     static_assert(sizeof(ncclUniqueId) <= TOPO_AMD_UNIQUE_ID_BYTES, "unique id size");
     cap_rccl_channels();
     ncclUniqueId uid;
@@ -1601,6 +1726,7 @@ int topo_amd_comm_unique_id(char id[TOPO_AMD_UNIQUE_ID_BYTES]) {
 }
 
 int topo_amd_comm_init(int rank, int nranks, const char id[TOPO_AMD_UNIQUE_ID_BYTES]) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "comm_init: rank %d of %d", rank, nranks);
     TOPO_REQUIRE(g_comm.comm == nullptr, "comm_init: communicator already exists");
@@ -1617,6 +1743,7 @@ int topo_amd_comm_rank(void) { return g_comm.rank; }
 int topo_amd_comm_size(void) { return g_comm.size; }
 
 int topo_amd_comm_destroy(void) {
+    TOPO_ENTER();
     if (g_comm.comm) {
         (void)hipDeviceSynchronize();
         TOPO_NCCL(ncclCommDestroy(g_comm.comm));
@@ -1646,6 +1773,7 @@ int stamp_gate(Context& c) {
 
 int topo_amd_halo_exchange_start(float* block, int rows_local, int nx, int halo_above,
                                  int halo_below) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     Context& c = ctx();
     TOPO_REQUIRE(block && rows_local >= 1 && nx >= 1 && halo_above >= 0 && halo_below >= 0,
@@ -1724,11 +1852,28 @@ int topo_amd_shard_layout_get(int* halo_above, int* halo_below) {
 // bytes, once per DEM), and the class of the WHOLE raster is declared for the calling thread's later topo_amd_shard_* calls -
 // so every shard takes the kernels the single-GPU run of the raster takes.  `owned`: the first row the rank owns.
 int topo_amd_shard_classify(const float* owned, int rows_local, int row0, int gny, int nx) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(owned && rows_local >= 1 && row0 >= 0 && row0 + rows_local <= gny && nx >= 1, "shard_classify: bad arguments");
-    Block b{owned, rows_local, row0, gny, nx, row0, rows_local};
+    // (a shard that is not the whole raster needs its neighbours' samples: without a communicator - a ShardedDEM built
+    // before topo_amd_comm_init - the class of the rows at hand would pass for the raster's.  Loop-back: the rank is its
+    // own neighbour, its rows are all there is.)
+    TOPO_REQUIRE(rows_local == gny || g_comm.size > 1 || halo_loopback(),
+                 "shard_classify: rows [%d, %d) of a raster of %d rows, but no communicator exists (topo_amd_comm_init) - the other "
+                 "shards' samples cannot be added", row0, row0 + rows_local, gny);
     Scan s;
-    TOPO_TRY(scan_block(b, row0, rows_local, &s));
+    if (halo_loopback() && rows_local < gny) {
+        // the rank is every rank: the raster is its rows stacked periodically, so they are scanned at every placement
+        for (long place = (long)row0 - ((long)row0 + rows_local - 1) / rows_local * rows_local; place < gny; place += rows_local) {
+            const int o0 = (int)std::max(0L, place), o1 = (int)std::min((long)gny, place + rows_local);
+            if (o1 <= o0) continue;
+            Block b{owned, rows_local, (int)place, gny, nx, o0, o1 - o0};
+            TOPO_TRY(scan_block(b, o0, o1 - o0, &s));
+        }
+    } else {
+        Block b{owned, rows_local, row0, gny, nx, row0, rows_local};
+        TOPO_TRY(scan_block(b, row0, rows_local, &s));
+    }
     if (g_comm.size > 1) {
         TOPO_REQUIRE(g_comm.comm != nullptr, "shard_classify: call topo_amd_comm_init first");
         Context& c = ctx();
@@ -1751,11 +1896,12 @@ int topo_amd_shard_classify(const float* owned, int rows_local, int row0, int gn
         s.lo = w.lo;
         s.hi = w.hi;
     }
-    const RasterClass cls = class_of(s);
-    return topo_amd_raster_class_set(cls.large ? 1 : 0, cls.lo, cls.hi, cls.frac_share);
+    declare_class(owned, rows_local, gny, nx, class_of(s));
+    return TOPO_AMD_OK;
 }
 
 int topo_amd_halo_wait(void) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     if (g_comm.halo_pending) {
         TOPO_HIP(hipStreamWaitEvent(ctx().compute, ctx().halo_done, 0));
@@ -2000,10 +2146,22 @@ int run_gated(float* block, const Shard& s, int above, int below, bool device_ga
 }  // namespace
 }  // namespace topo
 
+namespace {
+// The class of the raster a shard belongs to, before the first launcher asks: a shard that is the whole raster is scanned
+// like any whole block; a partial one uses what was declared for its owned rows, and declares it itself - collectively,
+// every rank being in the same call on a buffer nobody has declared anything for since it was last written - when
+// nothing was (a C caller that never heard of topo_amd_shard_classify gets the single GPU's bits too).
+int ensure_shard_class(const Shard& s) {
+    if (s.rows_local == s.owned.gny || declared_class(s.owned, nullptr)) return TOPO_AMD_OK;
+    return topo_amd_shard_classify(s.owned.in, s.rows_local, s.row0, s.owned.gny, s.owned.nx);
+}
+}  // namespace
+
 extern "C" {
 
 int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int nx, int size,
                            float* tpi_out, float* std_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     DiscRuns disc;
     TOPO_TRY(build_disc(size, &disc));
@@ -2011,7 +2169,8 @@ int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int 
     TOPO_TRY(shard_view(&block, above, below, "shard_tpi_std"));
     block += shard_view_offset(above, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, above, below);
-    ClassScope cls(s.owned);  // (one rank: the shard is the raster; otherwise what topo_amd_shard_classify / _raster_class_set declared)
+    TOPO_TRY(ensure_shard_class(s));
+    ClassScope cls(s.owned);  // (the shard is the raster, or what ensure_shard_class found declared for its owned rows)
     forget_plane(tpi_out, rows_local, nx);
     forget_plane(std_out, rows_local, nx);
     // (tile rows of the first kernel: 48 / 60 for the ring kernels of STD, 60 for the marching TPI kernels, 64 for the TPI rings)
@@ -2028,11 +2187,13 @@ int topo_amd_shard_tpi_std(float* block, int rows_local, int row0, int gny, int 
 int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int nx, double sigma,
                             double sig_ratio, int res_mode, const void* res_x, const void* res_y,
                             float* dx_out, float* dy_out, float* slope_out, float* aspect_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     const int h = gradient_shard_halo(sigma, sig_ratio);  // == topo_amd_halo_rows(GRADIENT, sigma, sig_ratio)
     TOPO_TRY(shard_view(&block, h, h, "shard_gradient"));
     block += shard_view_offset(h, nx);
     Shard s = make_shard(block, rows_local, row0, gny, nx, h, h);
+    TOPO_TRY(ensure_shard_class(s));
     ClassScope cls(s.owned);
     for (float* o : {dx_out, dy_out, slope_out, aspect_out}) forget_plane(o, rows_local, nx);
     return run_gated(block, s, h, h, false, [&](const Block& view, int o0, int on) {
@@ -2054,6 +2215,7 @@ int topo_amd_shard_gradient(float* block, int rows_local, int row0, int gny, int
 int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx, const int32_t* dj,
                       const int32_t* di, const double* dist, int n_off, int window, double height,
                       float* out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     int up = 0, down = 0;
     for (int n = 0; n < n_off; ++n) {
@@ -2076,6 +2238,7 @@ int topo_amd_shard_sx(float* block, int rows_local, int row0, int gny, int nx, c
 int topo_amd_shard_sx_multi(float* block, int rows_local, int row0, int gny, int nx, int n_az,
                             const int32_t* first, const int32_t* dj, const int32_t* di, const double* dist,
                             const int32_t* window, double height, float* const* outs) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(n_az >= 1 && first && dj && di && dist && window && outs, "shard_sx_multi: NULL argument");
     int up = 0, down = 0;
@@ -2097,6 +2260,7 @@ int topo_amd_shard_sx_multi(float* block, int rows_local, int row0, int gny, int
 int topo_amd_shard_valley_ridge(float* block, int rows_local, int row0, int gny, int nx, const float* taps,
                                 const int32_t* ksize, const float* angles, int n_angles, int n_planes,
                                 float* norm_out, float* dir_out) {
+    TOPO_ENTER();
     TOPO_TRY(require_ready());
     TOPO_REQUIRE(block && taps && ksize && angles && norm_out && dir_out && n_angles >= 1,
                  "shard_valley_ridge: NULL argument");

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -132,6 +133,23 @@ struct Context {
 
 Context& ctx();
 int require_ready();
+
+// ---- threading: one call at a time per context (SURVEY 8b "re-entrant per device context") -------------------------------
+// The context owns things a call uses from its first to its last line - the grow-only workspaces `ws`, the device planes
+// of the host-buffer entry points, the events and streams of their pipeline, the seam / gate state of a sharded call, the
+// parameter-table staging - so every extern "C" entry point that touches the context holds the context's mutex for its
+// whole duration (recursive: the host-buffer entry points call the device ones).  Calls of several threads therefore run
+// one after the other, in the order they take the mutex; a device (`*_dev`, `topo_amd_shard_*`) call only ENQUEUES, so the
+// mutex is held for microseconds there and the GPU work of the threads still queues up back to back on the compute
+// stream.  The guard also binds the calling thread to the context's device (HIP's current device is per thread).
+std::recursive_mutex& call_mutex();
+struct CallGuard {
+    std::lock_guard<std::recursive_mutex> lock;
+    CallGuard();
+    CallGuard(const CallGuard&) = delete;
+    CallGuard& operator=(const CallGuard&) = delete;
+};
+#define TOPO_ENTER() ::topo::CallGuard call_guard_
 int workspace(int slot, size_t bytes, void** out);       // device scratch, grow-only
 int upload_table(int slot, const void* host, size_t bytes, void** out);  // async on compute
 
@@ -205,8 +223,10 @@ int gaussian_radius(double sigma);
 // sample of the WHOLE raster on a lattice of the GLOBAL grid (topo_amd_raster_scan_dev), never from the block of one call:
 // a block that is the whole raster is scanned by the library (remembered per buffer until the library writes the buffer
 // or topo_amd_dem_changed names it); the host-buffer entry points scan the caller's array; a partial row block uses what
-// the application declared for its thread (topo_amd_raster_class_set; shard.py all-reduces the scans of the shards), an
-// ordinary DEM in metres if nothing was declared.  So every row block of a raster takes the whole raster's kernels.
+// was declared FOR ITS MEMORY (topo_amd_raster_class_set / _from_scan: keyed by the block's device rows and the raster's
+// shape, dropped when the library writes or frees them - never a property of a thread or of the process); the
+// topo_amd_shard_* calls declare it themselves on first use (topo_amd_shard_classify, collective); a partial block nobody
+// declared anything for is an ordinary DEM in whole metres.  So every row block of a raster takes the whole raster's kernels.
 struct RasterClass {
     bool large = false;   // more than a quarter of the lattice samples are finite and beyond +-1e5
     float lo = 0.0f, hi = 4096.0f;  // smallest / largest ordinary lattice sample (finite, within +-2^18); lo > hi: none seen

@@ -533,6 +533,11 @@ __device__ __forceinline__ uint32_t stage_value(float x, float c, int ci, int au
 // not needed, and a criterion that does not look at c can be evaluated by the marching build on
 // the rows it adds to a carried window.
 constexpr float kAbsLim = 262144.0f;
+// The scaled route stages (int)rint(x unit): beyond 2^30 / unit the conversion saturates, and a window made of such samples
+// alone would have range 0 and pass the unwrapping test (a band of 65535 between the lattice rows of a raster
+// whose class said unit = 2^16).  A sample is the scaled chain's only below this limit (2^18 for units up to 2^12, 2^14 at
+// 2^16): the others are "bad" like non-finite ones, whatever class the raster was declared with.
+__device__ __forceinline__ float scaled_abs_lim(float unit) { return fminf(kAbsLim, 1073741824.0f / unit); }
 
 // Block-wide minimum / maximum of per-lane values through two LDS words (flag_word[2], flag_word[3]; the caller keeps
 // them at INT_MAX / INT_MIN between tiles): one butterfly per wave, one atomic pair per wave.
@@ -614,7 +619,7 @@ __device__ __forceinline__ int stage_prefix(const WaveArgs& p, uint32_t* lds, in
     if (kClassify) {
         if (frac) flags |= kTileFrac;
         if (!ABS_CLASS && umax > __float_as_uint(lim32)) flags |= kTileWide;
-        if (umax > __float_as_uint(ABS_CLASS ? kAbsLim : limcv) || tmax > __float_as_uint(kAbsLim)) flags |= kTileFloat;
+        if (umax > __float_as_uint(ABS_CLASS ? (WHAT == kStS ? scaled_abs_lim(c) : kAbsLim) : limcv) || tmax > __float_as_uint(kAbsLim)) flags |= kTileFloat;
         if (any_missing) flags |= kTileMissing;
     }
     *reinterpret_cast<Vec4<T>*>(TOT + wave * ROWW + lane * NC) = run;
@@ -1141,7 +1146,7 @@ __device__ __forceinline__ int stage_march(const WaveArgs& p, uint32_t* Q, int* 
     if (!FRACTION) {
         int wf = 0;
         if (__builtin_amdgcn_ballot_w64(frac)) wf |= kTileFrac;
-        if (__builtin_amdgcn_ballot_w64(amax > __float_as_uint(kAbsLim))) wf |= kTileFloat;
+        if (__builtin_amdgcn_ballot_w64(amax > __float_as_uint(SCALED ? scaled_abs_lim(p.unit) : kAbsLim))) wf |= kTileFloat;
         if (lane == 0 && wf) atomicOr(flag_word, wf);
     }
     if (SCALED) block_range(flag_word, smin, smax);
@@ -1623,7 +1628,8 @@ int launch_fraction_march(const Block& b, float* tpi_out, float* std_out = nullp
 // unit below 2^30 and |x| unit below 2^28 - from the raster class (common.hpp: a lattice sample of the WHOLE raster, the same
 // for every row block of it).  An ordinary DEM in metres gets 2^8 (error <= 2^-9 m per sample); a raster of small values -
 // kilometres, a normalised surface - gets finer units, so that the error stays below 4e-6 of its value range whatever the
-// range is.  (The tile-by-tile test in the kernel guards the exactness of the unwrapping; this only sets the precision.)
+// range is.  (The tile-by-tile test in the kernel guards the exactness of the unwrapping and - scaled_abs_lim - the float to
+// integer conversion of every staged sample; this only sets the precision.)
 inline float scaled_unit(int taps) {
     const RasterClass c = current_class();
     int k = 8;
@@ -1744,8 +1750,9 @@ __device__ __forceinline__ void tpi_scaled_march_kernel_body(const WaveArgs& p, 
 #pragma unroll
                 for (int s2 = 0; s2 < NC; ++s2) {
                     const int q = (int)stage_value<kStS>(v.v[s2], p.unit, 0);
-                    // (a sample the integer chain cannot take - non-finite, beyond 2^18 - counts as the widest range)
-                    const bool bad = !(fabsf(truncf(v.v[s2])) <= kAbsLim);
+                    // (a sample the integer chain cannot take - non-finite, beyond 2^18 or what the unit leaves of 2^30 - counts
+                    // as the widest range)
+                    const bool bad = !(fabsf(truncf(v.v[s2])) <= scaled_abs_lim(p.unit));
                     lo = ok ? (bad ? -0x7fffffff - 1 : min(lo, q)) : lo;
                     hi = ok ? (bad ? 0x7fffffff : max(hi, q)) : hi;
                 }
@@ -1985,8 +1992,6 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
     const int first = deal.first(vb);
     const int last = min(first + deal.count(vb), ntiles);
     const double n = (double)G::T.taps;
-    const double inv_n = 1.0 / n;
-    const double inv_nm1 = 1.0 / (n - 1.0);
     const double inv_nn1 = 1.0 / (n * (n - 1.0));
     const float lim32 = floorf(sqrtf(4294967295.0f / (float)G::T.taps));
 
@@ -2080,7 +2085,6 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
             }
             __syncthreads();
         }
-        const double cd = (double)c;
         // one copy of the row loop per kind of tile: away from the DEM border every pixel has all n
         // taps, so m is a constant and only the short formula is compiled in
         auto rows = [&](auto border_tag) {
@@ -2118,7 +2122,6 @@ __device__ __forceinline__ void std_march_kernel_body(const WaveArgs& p, int til
                 Vec4<float> out_s;
 #pragma unroll
                 for (int t = 0; t < NC; ++t) {
-                    const double su2 = (double)acc[t];
                     double m = n;
                     if (BORDER) {
                         const int d_lo = max(G::T.off_min, -(ocol + t));

@@ -61,8 +61,10 @@ def sync():
 
 class RasterScan:
     """The class of a raster that is held as several row blocks (include/topo_amd.h, "what kernel routing may know about
-    a raster"): ``add`` the rows each block owns, then ``declare`` - the calling thread's partial row blocks then take the
-    kernels the whole raster takes.  (A block that is the whole raster needs none of this.)"""
+    a raster"): ``add`` the rows each block owns, then ``declare`` it for every block the descriptors will be called on -
+    those blocks then take the kernels the whole raster takes.  A declaration belongs to the block's MEMORY (it goes when
+    the library writes or frees it), not to a thread.  (A block that is the whole raster needs none of this, and
+    ``ShardedDEM`` does it by itself.)"""
 
     def __init__(self):
         self.counts = (C.c_uint64 * 3)(0, 0, 0)
@@ -76,13 +78,48 @@ class RasterScan:
                    "raster_scan_dev")
         return self
 
-    def declare(self):
-        _lib.check(_lib.lib().topo_amd_raster_class_from_scan(self.counts, self.range), "raster_class_from_scan")
+    def declare(self, *blocks):
+        """Declare the class added up so far for the device rows of each :class:`Block` in ``blocks``."""
+        if not blocks:
+            raise ValueError("RasterScan.declare: name the blocks the class is declared for (it is keyed by their memory)")
+        for blk in blocks:
+            _lib.check(_lib.lib().topo_amd_raster_class_from_scan(blk.data.row_ptr(blk.first), blk.rows, blk.gny, blk.nx,
+                                                                  self.counts, self.range), "raster_class_from_scan")
+        return self
 
 
-def forget_raster_class():
-    """Withdraw what :meth:`RasterScan.declare` (or ``ShardedDEM``) declared: partial row blocks are ordinary DEMs again."""
-    _lib.check(_lib.load().topo_amd_raster_class_set(-1, 0.0, 0.0, 0.0), "raster_class_set")
+def forget_raster_class(block=None):
+    """Withdraw what was declared for ``block``'s rows (``None``: every declaration): undeclared partial row blocks are
+    ordinary DEMs in whole metres."""
+    if block is None:
+        _lib.check(_lib.load().topo_amd_raster_class_set(None, 0, 0, 0, -1, 0.0, 0.0, 0.0), "raster_class_set")
+    else:
+        _lib.check(_lib.load().topo_amd_raster_class_set(block.data.row_ptr(block.first), block.rows, block.gny, block.nx,
+                                                         -1, 0.0, 0.0, 0.0), "raster_class_set")
+
+
+def raster_class(block):
+    """``(declared, large, lo, hi, frac_share)`` a call on ``block`` would take (``declared`` False: the ordinary DEM's)."""
+    dec, large = C.c_int32(), C.c_int32()
+    lo, hi, share = C.c_float(), C.c_float(), C.c_float()
+    _lib.check(_lib.lib().topo_amd_raster_class_get(block.data.row_ptr(block.first), block.gny, block.nx, C.byref(dec),
+                                                    C.byref(large), C.byref(lo), C.byref(hi), C.byref(share)),
+               "raster_class_get")
+    return bool(dec.value), bool(large.value), lo.value, hi.value, share.value
+
+
+def release_host_planes():
+    """Give the device planes the host-buffer calls (``topo.tpi(ndarray)`` ...) keep between calls back to the GPU: a
+    32768 x 32768 gradient leaves about 20 GiB behind (they are kept because copies out of freshly mapped device memory run
+    at half the link's rate)."""
+    _lib.check(_lib.lib().topo_amd_release_host_planes(), "release_host_planes")
+
+
+def host_chunks():
+    """Row chunks the calling thread's last host-buffer call ran in (1: the serial order)."""
+    n = C.c_int32()
+    _lib.check(_lib.lib().topo_amd_host_chunks(C.byref(n)), "host_chunks")
+    return n.value
 
 
 def dem_changed(array):

@@ -130,12 +130,12 @@ class ShardedDEM:
         _lib.check(_lib.lib().topo_amd_memset(self.block.ptr, 0, self.block.nbytes), "topo_amd_memset")
         if local_rows is not None:
             self.block.upload_rows(local_rows, plan.halo_above)
-            self.classify()
 
     def classify(self):
-        """Collective (every rank, after its rows are in place - called by the constructor when it uploads them): the
-        class of the WHOLE raster from the lattice samples of all shards (``topo_amd_shard_classify``), so that every
-        shard takes the kernels the single-GPU run takes."""
+        """Collective: the class of the WHOLE raster from the lattice samples of all shards
+        (``topo_amd_shard_classify``), so that every shard takes the kernels the single-GPU run takes.  The descriptor
+        calls do this themselves at the first call after the shard's rows were written through the library; calling it
+        is only needed when the rows were rewritten behind the library's back."""
         from . import _lib
         p = self.plan
         _lib.check(_lib.lib().topo_amd_shard_classify(self.block.row_ptr(p.halo_above), p.rows_local, p.row0, p.gny, p.nx),

@@ -68,13 +68,14 @@ def tpi(dem, size, sigma=None):
     diameter ``size`` pixels, centre excluded; optional Gaussian pre-smoothing ``sigma``
     (reference topo.py:145-181).  float32 in, float32 out; DataArray in, DataArray out.
 
-    With ``sigma`` the pre-smoothing is :func:`dem`'s: see there for how far a non-finite sample reaches.  Without it a NaN reaches the windows that contain it and
-    some more pixels of its tile (it travels down the column prefix sums); the reference's FFT convolution makes the
-    whole array NaN.
+    With ``sigma`` the pre-smoothing is :func:`dem`'s: see there for how far a non-finite sample reaches.  Without it a
+    sample that is not finite (or beyond +-2**24) is MISSING, and exactly the pixels whose disc holds one are NaN - the
+    footprint of the disc, whatever the tiles or row blocks; the reference's FFT convolution makes the whole array NaN.
 
     Accuracy.  On a DEM of whole metres the result is the float64 evaluation of the reference's formula, rounded to
     float32.  Where a disc of 19 pixels or more holds fractional elevations, the neighbourhood sum is taken on ``x``
-    in units of 2**-8 m (one integer chain instead of two): each sample is off by at most 2**-9 m = 1.95 mm, hence so are
+    in units of 2**-k m (one integer chain instead of two; k = 8 for an ordinary DEM, up to 16 for a raster whose whole
+    value range is small): each sample is off by at most 2**-9 m = 1.95 mm, hence so are
     the mean and TPI (about 0.02 mm rms at 67 pixels when the fractional parts are spread evenly) - the order of the
     1.4 - 1.7 mm the reference's own float32 FFT is off by, and far inside 1e-4 of the range.  Smaller discs, and
     :func:`tpi_std`, are exact to 2**-16 m; ``TOPO_AMD_TPI_FRACTION_EXACT=1`` makes this function so as well, at about
