@@ -521,10 +521,9 @@ int gradient_halo(double sigma, double sig_ratio) {
 int gradient_shard_halo(double sigma, double sig_ratio) {
     if (sigma <= 1.0) return 1;
     if (sig_ratio == 0.0) sig_ratio = 1.0;
-    if (sig_ratio != 1.0) return gaussian_reach(gaussian_radius(std::max(sigma, sigma * sig_ratio))) + 1;  // (gradient_halo, + the reach)
+    if (sig_ratio != 1.0) return gradient_halo(sigma, sig_ratio);
     const int R = gaussian_radius(sigma);
-    // (radius 49 ... 121: + 32 rows, the slab references of the split-once axis-0 kernel: gauss.hip, s1_rows_ok)
-    return (R >= mfma_min_radius(true) && R < 16) ? 17 : gaussian_reach(R) + 1;
+    return (R >= mfma_min_radius(true) && R < 16) ? 17 : R + 1;
 }
 
 // RAII-less helper for the host-buffer entry points
@@ -1266,7 +1265,6 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
             TOPO_TRY(build_disc((int)p0, &d));
             int R = p1 > 0.0 ? gaussian_radius(p1) : 0;
             if (R >= mfma_min_radius(false) && R < 16) R = 16;  // pre-smoothing on the matrix cores: see DESC_GAUSS
-            R = R > 0 ? gaussian_reach(R) : 0;
             *above = -d.dj_min + R;
             *below = d.dj_max + R;
             return TOPO_AMD_OK;
@@ -1275,8 +1273,7 @@ int topo_amd_halo_rows(int descriptor, double p0, double p1, int* above, int* be
             // (radius mfma_min_radius .. 15: the matrix-core kernels want the accumulation-offset row of every
             // 32-row tile inside the block, 16 rows from the tile's first row: gauss.hip, mfma_rows_ok)
             const int R = gaussian_radius(p0);
-            // (radius 49 ... 121: R + 32, the reference rows of the split-once axis-0 kernel: gauss.hip, s1_rows_ok)
-            *above = *below = (R >= mfma_min_radius(false) && R < 16) ? 16 : gaussian_reach(R);
+            *above = *below = (R >= mfma_min_radius(false) && R < 16) ? 16 : R;
             return TOPO_AMD_OK;
         }
         case TOPO_AMD_DESC_GRADIENT:
@@ -1598,9 +1595,7 @@ int topo_amd_gradient_f32(const float* dem, int ny, int nx, double sigma, double
         rx = d_rx;
         ry = d_ry;
     }
-    // (the depth with which a row block has the whole raster's bits - gradient_shard_halo - not the bare reach: a chunk is
-    // computed when that many rows below it are on the device)
-    const int h = gradient_shard_halo(sigma, sig_ratio);
+    const int h = gradient_halo(sigma, sig_ratio == 0.0 ? 1.0 : sig_ratio);
     std::vector<HostPlane> outs;
     for (int k = 0; k < 4; ++k) outs.push_back({host_out[k], (float*)d_o[k]});
     return run_pipelined(run, dem, (float*)d_in, ny, nx, h, h, true, outs, [&](int view_rows, int r0, int rows) {

@@ -215,7 +215,6 @@ int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize,
                         int n_planes, double mean, double stdev, float* norm_out, float* dir_out);
 
 int gaussian_radius(double sigma);
-int gaussian_reach(int radius);  // ghost rows for whole-DEM bits: the radius, + 32 where axis 0 runs split once (gauss.hip)
 
 // ---- the raster class: what kernel routing may know about the WHOLE raster -------------------------------------------
 // Two kernel choices change the last bits of a result (never its correctness): the Gaussian / gradient of a raster whose

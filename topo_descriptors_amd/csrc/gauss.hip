@@ -1167,7 +1167,10 @@ __global__ __launch_bounds__(64 * NW) void gauss_axis1_f16_kernel(GaussArgs p, i
 // on row 32 of each 64-row slab, R + 32 ghost rows for whole-DEM bits - and gives the tile kernel's time, 2.51 against
 // 2.56 ms at sigma 30.25: 16 columns are 64-byte halves of lines shared with the neighbour wave, 1.56 x the plane
 // fetched unless a block barrier per tile keeps the waves together, which takes the overlap away again; it is not in the
-// library: profiles/r04_gauss_split_once.txt.)
+// library: profiles/r04_gauss_split_once.txt.  Round 6 built it again with staging waves loading whole 512-byte row
+// segments for the block, and once more with every wave for itself at one wave per SIMD: correct, 5 - 8 % on axis 0 alone at
+// radius 97 ... 121, nothing on the gradient, R + 32 ghost rows for every caller - left out again: profiles/r06_gauss_axis0_s1.txt,
+// commit d700ebd.)
 __device__ __forceinline__ int floor_div64(int a) { return a >> 6; }  // arithmetic shift: floor for negative a
 // The ring's row pitch is the window + kS1Pad halves.  An A operand is one ds_read_b128 per plane: lane (n = lane & 15, kg =
 // lane >> 4) reads 16 bytes of row n from position 8 kg.  The instruction is served in four groups of 16 lanes that are NOT
@@ -1176,7 +1179,8 @@ __device__ __forceinline__ int floor_div64(int a) { return a >> 6; }  // arithme
 // 121) row n starts 5 n sixteen-byte slots into the 256-byte bank row, and three of the eight rows of the second set land
 // on slots of the first: every group two LDS cycles instead of one (SQ_LDS_BANK_CONFLICT 40 % of SQ_LDS_IDX_ACTIVE, rounds
 // 4 and 5).  A pitch of 4 p dwords with p = 2 (mod 4) puts rows {0-3, 12-15} on the even slots and rows {4-11}, one slot
-// further, on the odd ones: window + 16 halves for every window of 32 NK columns, NK odd.
+// further, on the odd ones: window + 16 halves for every window of 32 NK columns, NK odd.  (The time did not move - the
+// conflicts were not what the kernel waits for: profiles/r06_gauss_axis0_s1.txt, section 4.)
 constexpr int kS1Pad = 16;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1473,594 +1477,6 @@ __global__ __launch_bounds__(512) void gauss_axis1_s1_kernel(GaussArgs p, int ro
         tile(t, pre_a, pre_b);
         if (t + 1 < t_last) tile(t + 1, pre_b, pre_a);
     }
-    }
-}
-
-
-// r[k] of lane i (i = lane & 3, inside a quad of lanes) <- r[i] of lane k: a 4 x 4 transpose across the four lanes of a quad.
-// Two butterfly stages (lane bit 0 against register bit 0, then bit 1 against bit 1); each element that moves comes through
-// one DPP quad permutation and one select.
-__device__ __forceinline__ void quad_transpose(float (&r)[4], int lane) {
-    const bool odd = (lane & 1) != 0, upper = (lane & 2) != 0;
-    auto swap1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false)); };
-    auto swap2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false)); };
-#pragma unroll
-    for (int k = 0; k < 4; k += 2) {  // even lane: r[k + 1] <- partner's r[k]; odd lane: r[k] <- partner's r[k + 1]
-        const float a = swap1(r[k]), b = swap1(r[k + 1]);
-        const float n0 = odd ? b : r[k], n1 = odd ? r[k + 1] : a;
-        r[k] = n0;
-        r[k + 1] = n1;
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {  // lower pair of lanes: r[k + 2] <- partner's r[k]; upper pair: r[k] <- partner's r[k + 2]
-        const float a = swap2(r[k]), b = swap2(r[k + 2]);
-        const float n0 = upper ? b : r[k], n1 = upper ? r[k + 2] : a;
-        r[k] = n0;
-        r[k + 2] = n1;
-    }
-}
-
-// ---- split once: axis 0, radius 49 ... 121 (round 6) -----------------------------------------------------------------------
-// The tile kernel of axis 0 (gauss_axis0_f16_kernel) runs one wave per SIMD - its float32 ring takes the LDS - and that
-// wave splits every sample of its window again for every tile: per 16-row step 24 vector instructions and 8 LDS reads in
-// front of 3 MFMAs, none of it overlapped (a wave alone does not overlap its own vector work with its own MFMAs:
-// profiles/r03_gauss_f16.txt, 384 cycles per step of which 192 are the MFMAs').  Round 4 built the split-once scheme for
-// this axis with every wave loading, splitting and chaining its own 16 columns: 64-byte halves of lines, 1.56 x the plane
-// fetched, the tile kernel's time (profiles/r04_gauss_split_once.txt).  Here the block is cooperative, like the STD kernel of
-// the small discs (std_ring_spec_kernel): a block owns 128 columns - 512-byte row segments, whole 128-byte lines - and
-//   * waves 4 ... 7 only STAGE: staging wave w takes rows 8 w ... 8 w + 7 of every group of 32 rows the march adds, all 128
-//     columns (lane -> columns lane and lane + 64: every load instruction is 256 contiguous bytes), splits each sample ONCE
-//     into its f16 pair against the reference of its 64-row slab, and writes the pair into the block's ring - hi[128
-//     columns][PITCH rows], lo[...], column-major, so that the 8 window rows of a B operand are one 16-byte read;
-//   * waves 0 ... 3 only CHAIN: chain wave w owns columns 32 w ... 32 w + 31 and 32-row tiles; a step is two 16-byte LDS
-//     reads and three v_mfma_f32_32x32x16_f16 - the tap blocks of the tile kernel (build_tap_blocks) - and nothing else;
-//     the result gets sum_s (c_s - c_b) W_s back in float32 (the slab table W of the axis-1 kernel: upload_weights).
-// A wave that issues nothing but MFMAs gets one through every 32 cycles: 54 per 32 x 32 tile, the staging wave on the same
-// SIMD working underneath.  ONE barrier per tile: the chain reads a window top to bottom, so the 32 rows the next group
-// overwrites (steps 0 and 1) are in registers when a chain wave meets the barrier at the start of its tile, and the
-// staging waves meet it when the group for that tile is written - they have a whole tile's time for 16 loads, two splits
-// and four 16-byte writes per lane, loaded one tile ahead.
-// Slabs: 64 rows on the global grid; the reference of a slab is its row 32 (reflected at the DEM's edges like any sample),
-// per column.  A row block therefore has the whole DEM's bits when it carries R + 32 ghost rows (s1_rows_ok;
-// topo_amd_halo_rows asks for them): the reference row of every slab that a wanted output's window touches is then in the
-// block.  A block that comes with less (but at least R rows) takes the tile kernel: correct, other last bits.
-// Flags: one byte per 32 x 32 unit, the tile kernel's layout (the repair pass is shared).
-template <int S, int NP>
-__global__ __launch_bounds__(512) void gauss_axis0_s1_kernel(GaussArgs p, int tile_first, int ntiles, int tiles_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float L[];
-    constexpr int Rp = 8 * (S - 2), RR = 16 * S, PITCH = RR + 8, NSIDE = (Rp + 63) / 64;
-    constexpr int NG = RR / 32;  // groups of 32 rows in a window = tiles a group stays for
-    static_assert(Rp % 32 == 0 && RR % 32 == 0 && NSIDE <= 2, "groups of 32 rows inside one slab, at most 5 slabs per window");
-    // (PITCH = 4 p dwords, p odd: the 16 lanes of a ds_read_b128 group - 16 different columns - fall on 16 different slots;
-    // the 8 lanes of a ds_write_b128 group - columns 1 apart, PITCH / 2 = 20 (mod 32) dwords - on 8 different ones)
-    static_assert((PITCH / 8) % 2 == 1, "odd number of 16-byte slots per ring column");
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    _Float16* const hi = reinterpret_cast<_Float16*>(L);
-    _Float16* const lo = hi + 128 * PITCH;
-    float* const ctab = L + 128 * PITCH;   // [8 slabs][128 columns]
-    float* const wlds = ctab + 8 * 128;    // W[5][64]
-    int* const lastw = reinterpret_cast<int*>(wlds + 5 * 64);  // [4]: last tile whose window holds a sample (or a reference) that is not a plain finite one, per 32 columns
-    // the low parts of the last kTapLds tap blocks: the same for the four chain waves, read back a step ahead of their use
-    // (144 registers of tap blocks + accumulator + operands + correction do not fit a wave's 256 at 18 steps)
-    constexpr int kTapLds = S >= 18 ? 5 : 0;
-    f16x8* const tapl = reinterpret_cast<f16x8*>(wlds + 5 * 64 + 16);  // [kTapLds][64 lanes]
-    const int R = p.radius;
-    const int dbg = p.nchunks;  // LAB: 1 no stores, 2 no tile barriers, 4 no correction
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = blockIdx.x * 128;
-    const int tb = blockIdx.y * tiles_per_block, te = min(tb + tiles_per_block, ntiles);
-    if (tb >= te) return;
-    if (p.run_if && *p.run_if == 0) return;
-    for (int k = threadIdx.x; k < 5 * 64; k += 512) wlds[k] = p.wtab[k];
-    for (int k = threadIdx.x; k < 8 * 128; k += 512) ctab[k] = 0.0f;
-    if (threadIdx.x < 4) lastw[threadIdx.x] = kNoWild;
-    __syncthreads();
-    const int y_start = (tile_first + tb) * 32 - Rp;  // first row of the first window
-
-    if (wave >= 4) {
-        // ---------------------------------------------------------------- staging waves
-        const int sw = wave - 4;
-        const int ca = lane, cb = lane + 64;  // the lane's two columns of the block
-        const int gxa = min(x0 + ca, p.nx - 1), gxb = min(x0 + cb, p.nx - 1);
-        const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
-        auto row_ptr = [&](int gy) {
-            gy = reflect_index(gy, p.gny);
-            gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
-            return p.in + (size_t)(gy - p.in_row0) * p.nx;
-        };
-        struct Pre {
-            float a[8], b[8];  // rows n0 + 8 sw ... + 7 of the lane's two columns
-            float ra, rb;      // the reference row of the slab the NEXT group lies in (used when that group starts a slab)
-        };
-        // Every group is 18 loads, whatever it is (a reference row comes with every group, rows beyond the block clamp): the
-        // compiler's s_waitcnt then knows how many loads stand between a group's issue and its use, and three groups stay in
-        // flight (a conditional load in here and it waits for all of them at every tile).  The reference is that of the slab
-        // the NEXT group lies in: the table entry of a slab is written one tile before its first group is staged, so a chain
-        // wave may read the table anywhere in its tile (the chain waves meet the tile's barrier at different steps, below).
-        auto load = [&](int n0, Pre& v) {
-            const int r0 = n0 + 8 * sw, rr = ((n0 + 32) & ~63) + 32;
-            // (the branches are around the addresses only - wave-uniform scalar arithmetic - never around a load)
-            const float* q0 = r0 >= row_lo && r0 + 8 <= row_hi ? p.in + (size_t)(r0 - p.in_row0) * p.nx : nullptr;
-            const float* qr = rr >= row_lo && rr < row_hi ? p.in + (size_t)(rr - p.in_row0) * p.nx : row_ptr(rr);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float* q = q0 ? q0 + (size_t)e * p.nx : row_ptr(r0 + e);
-                v.a[e] = q[gxa];
-                v.b[e] = q[gxb];
-            }
-            v.ra = qr[gxa];
-            v.rb = qr[gxb];
-        };
-        float c_a = 0.0f, c_b = 0.0f;    // the references of the slab being staged
-        float cn_a = 0.0f, cn_b = 0.0f;  // ... of the slab that starts with the next group (set a tile ahead)
-        // announces the slab that starts at virtual row n1 (a multiple of 64): its references into the table, marks for the
-        // tiles that will hold its samples if a reference cannot serve (`stay`: the last tile holding the slab's second group)
-        auto announce = [&](float ra, float rb, int n1, int stay) {
-            const bool wa = wild(ra), wb = wild(rb);
-            cn_a = wa ? 0.0f : ra;
-            cn_b = wb ? 0.0f : rb;
-            if (sw == 0) {
-                ctab[(floor_div64(n1) & 7) * 128 + ca] = cn_a;
-                ctab[(floor_div64(n1) & 7) * 128 + cb] = cn_b;
-            }
-            const unsigned long long ma = __builtin_amdgcn_ballot_w64(wa), mb = __builtin_amdgcn_ballot_w64(wb);
-            if (lane == 0 && sw == 0) {
-                if (ma & 0xffffffffull) atomicMax(&lastw[0], stay);
-                if (ma >> 32) atomicMax(&lastw[1], stay);
-                if (mb & 0xffffffffull) atomicMax(&lastw[2], stay);
-                if (mb >> 32) atomicMax(&lastw[3], stay);
-            }
-        };
-        // the group from virtual row n0 into ring rows [slot, slot + 32); `stay`: the last tile whose window holds it
-        auto stage = [&](Pre& v, int n0, int slot, int stay) {
-            bool bad_a = false, bad_b = false;
-            if ((n0 & 63) == 0) {  // (wave-uniform) a slab starts: the references announced a tile ago
-                c_a = cn_a;
-                c_b = cn_b;
-            }
-            if (((n0 + 32) & 63) == 0) announce(v.ra, v.rb, n0 + 32, stay + 2);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool wa = wild(v.a[e]), wb = wild(v.b[e]);
-                bad_a |= wa;
-                bad_b |= wb;
-                v.a[e] = wa ? 0.0f : v.a[e];
-                v.b[e] = wb ? 0.0f : v.b[e];
-            }
-            const f32x2 quarter = {0.25f, 0.25f};
-            f16x8 dh, dl;
-            split8(v.a, quarter, f32x2{-0.25f * c_a, -0.25f * c_a}, dh, dl);
-            *reinterpret_cast<f16x8*>(hi + ca * PITCH + slot + 8 * sw) = dh;
-            *reinterpret_cast<f16x8*>(lo + ca * PITCH + slot + 8 * sw) = dl;
-            split8(v.b, quarter, f32x2{-0.25f * c_b, -0.25f * c_b}, dh, dl);
-            *reinterpret_cast<f16x8*>(hi + cb * PITCH + slot + 8 * sw) = dh;
-            *reinterpret_cast<f16x8*>(lo + cb * PITCH + slot + 8 * sw) = dl;
-            const unsigned long long ma = __builtin_amdgcn_ballot_w64(bad_a), mb = __builtin_amdgcn_ballot_w64(bad_b);
-            if (lane == 0 && (ma | mb)) {
-                if (ma & 0xffffffffull) atomicMax(&lastw[0], stay);
-                if (ma >> 32) atomicMax(&lastw[1], stay);
-                if (mb & 0xffffffffull) atomicMax(&lastw[2], stay);
-                if (mb >> 32) atomicMax(&lastw[3], stay);
-            }
-        };
-        // the first window: the reference of the slab its first group lies in comes by itself
-        {
-            const float* q = row_ptr((y_start & ~63) + 32);
-            announce(q[gxa], q[gxb], y_start & ~63, tb + 1);
-            c_a = cn_a;
-            c_b = cn_b;
-            for (int k0 = 0; k0 < NG; k0 += 3) {  // three groups in flight
-                Pre v[3];
-#pragma unroll
-                for (int u = 0; u < 3; ++u)
-                    if (k0 + u < NG) load(y_start + 32 * (k0 + u), v[u]);
-#pragma unroll
-                for (int u = 0; u < 3; ++u)
-                    if (k0 + u < NG) stage(v[u], y_start + 32 * (k0 + u), 32 * (k0 + u), tb + k0 + u);  // group k leaves the window after tile tb + k
-            }
-        }
-        // The group tile t + 1 adds is staged behind barrier X_t; its loads were issued three tiles earlier (three register
-        // sets that take turns: a tile is about a microsecond, HBM's latency under load is more).
-        Pre pre0, pre1, pre2;
-        const int g_first = y_start + RR;  // the group tile tb + 1 adds
-        load(g_first, pre0);
-        load(g_first + 32, pre1);
-        load(g_first + 64, pre2);
-        __syncthreads();  // the first window is staged
-        int base = 0;
-        auto tile = [&](int t, Pre& pre) {
-            if (t < te && !(dbg & 2)) __syncthreads();  // X_t: every chain wave is past steps 0 and 1 of tile t; the group tile t needs was written before
-            const int n0 = g_first + 32 * (t - tb);  // the 32 rows tile t + 1 adds, over the oldest ones
-            if (t + 1 < te) stage(pre, n0, base, t + NG);
-            load(n0 + 96, pre);  // (past the run's end: rows nobody stages - the loads stay regular)
-            base += 32;
-            base = base >= RR ? base - RR : base;
-        };
-#ifdef S1A0_STAMPS
-        const long long st0 = __builtin_amdgcn_s_memtime();
-#endif
-        for (int t = tb; t < te; t += 3) {
-            tile(t, pre0);
-            tile(t + 1, pre1);
-            tile(t + 2, pre2);
-        }
-#ifdef S1A0_STAMPS
-        if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0)
-            printf("staging wave %d: %d tiles, %lld ticks (100 MHz) in the tile loop\n", sw, te - tb, (long long)__builtin_amdgcn_s_memtime() - st0);
-#endif
-        return;
-    }
-
-    // -------------------------------------------------------------------- chain waves
-    f16x8 twh[S], twl[S];
-    build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
-    if (wave == 0) {
-#pragma unroll
-        for (int e = 0; e < kTapLds; ++e) tapl[e * 64 + lane] = twl[S - kTapLds + e];
-    }
-    const int j = lane & 31, g = lane >> 5;
-    const int col = 32 * wave + j;  // the lane's column of the block
-    const _Float16* const bh = hi + col * PITCH + 8 * g;  // B: column `col`, 8 window rows from 8 g of a step
-    const _Float16* const bl = lo + col * PITCH + 8 * g;
-    // the lane's place in a block of 8 rows after the quad transpose: row 4 g + (j & 3), columns 4 (j >> 2) ... + 3 of the wave's 32
-    const unsigned out_quad_off = (unsigned)((4 * g + (j & 3)) * p.nx + 32 * wave + 4 * (j >> 2)) * 4u;
-    const bool wide_stores = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && x0 + 128 <= p.nx;
-    const int ox = x0 + col;
-    __syncthreads();  // the first window is staged
-    int base = 0;
-#ifdef S1A0_STAMPS
-    long long acc_t[5] = {0, 0, 0, 0, 0};
-    const long long ct0 = __builtin_amdgcn_s_memtime();
-#define S1A0_STAMP(i) { const long long now_ = __builtin_amdgcn_s_memtime(); acc_t[i] += now_ - last_; last_ = now_; }
-#else
-#define S1A0_STAMP(i)
-#endif
-    int slot = 0;
-    f16x8 dh[2], dl[2];  // (two sets: a read has the three MFMAs of a step to land; a third set costs the registers of two tap blocks)
-    auto fetch = [&](int k) {
-        dh[k] = *reinterpret_cast<const f16x8*>(bh + slot);
-        dl[k] = *reinterpret_cast<const f16x8*>(bl + slot);
-        slot += 16;
-        slot = slot >= RR ? slot - RR : slot;
-    };
-    // steps 0 and 1 of a tile are read while the tile before it is stored (their rows were staged long before; the rows
-    // that ARE being staged meanwhile are the tile's last two steps)
-    fetch(0);
-    fetch(1);
-    for (int t = tb; t < te; ++t) {
-#ifdef S1A0_STAMPS
-        long long last_ = __builtin_amdgcn_s_memtime();
-#endif
-        const int y0 = (tile_first + t) * 32;
-        S1A0_STAMP(0)
-        // the correction: the other slabs' references against the tile's own (the group tile t added may have brought a
-        // slab along: the table is read behind the barrier), a piece of the table W per step underneath the products
-        const int b = floor_div64(y0), o = (y0 & 63) + 4 * g;
-        const float cbv = ctab[(b & 7) * 128 + col];
-        const float* const crow = ctab + col;
-        float cs = 0.0f;  // the reference of the slab whose pieces of W are on their way (read with the slab's first piece)
-        // (registers: 144 of the wave's 256 hold the tap blocks, so the table W comes in 16-byte pieces - the piece for rows
-        // 8 u ... 8 u + 3 + 4 g of slab q - one or two per step, each used a step later)
-        constexpr int NPAIR = 2 * NSIDE * 4, PER = (NPAIR + S - 3) / (S - 2);
-        constexpr int kSkew = (S - 5) / 3;  // steps between the barriers of two chain waves: 18 steps -> 2, 6, 10, 14; 14 -> 2, 5, 8, 11; 10 -> 2, 3, 4, 5
-        static_assert(2 + 3 * kSkew <= S - 3, "the last wave's barrier stands in front of the first read of step S - 2");
-        float corr[16];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) corr[v] = 0.0f;
-        f4 wpc[PER];
-        f16x8 tl_next;
-        f32x16 acc;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            // X_t.  Behind it the staging waves write over the rows of steps 0 and 1 (read by now: s >= 2) and the group this
-            // tile reads in its last two steps is complete (the barrier stands in front of the first read of step S - 2).
-            // Every chain wave meets it at a step of its own, a quarter of a tile apart: the waves' store phases - 16 stores
-            // of 256 bytes each, 16 cycles of the CU's one memory pipe apiece - then fall into each other's products instead
-            // of on top of each other (four waves storing at once: 1000 cycles per tile with every matrix pipe idle).
-            if (s >= 2 && s <= S - 3 && (s - 2) % kSkew == 0 && (s - 2) / kSkew < 4) {
-                if (wave == (s - 2) / kSkew && !(dbg & 2)) __syncthreads();
-            }
-            if (s >= 1 && s + 1 < S) fetch((s + 1) % 2);
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {  // the pieces read a step ago (pair i = (slab q = i / 4, piece u = i % 4))
-                const int i_old = (s - 2) * PER + e;
-                if (s >= 2 && i_old < NPAIR && !(dbg & 4)) {
-                    const int u = i_old % 4;
-                    const float dq = cs - cbv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) corr[4 * u + r] = fmaf(dq, wpc[e][r], corr[4 * u + r]);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {  // this step's pieces; with the first piece of a slab its reference (PER divides 4: a step's pieces are one slab's)
-                const int i_new = (s - 1) * PER + e;
-                if (s >= 1 && i_new < NPAIR) {
-                    const int q = i_new / 4, u = i_new % 4;
-                    const int d = q < NSIDE ? q - NSIDE : q - NSIDE + 1;
-                    static_assert(PER == 1 || PER == 2, "pieces of one slab stay together: 4 pieces per slab, 1 or 2 per step");
-                    if (u == 0) cs = crow[((b + d) & 7) * 128];
-                    wpc[e] = *reinterpret_cast<const f4*>(wlds + (d + 2) * 64 + o + 8 * u);
-                }
-            }
-            f16x8 tl_now;
-            if (s >= S - kTapLds) tl_now = tl_next;
-            if (s + 1 >= S - kTapLds && s + 1 < S) tl_next = tapl[(s + 1 - (S - kTapLds)) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
-            f16_products<false, NP>(twh[s], s >= S - kTapLds ? tl_now : twl[s], dh[s % 2], dl[s % 2], acc);
-        }
-        static_assert((S - 1) * PER >= NPAIR + PER, "every piece of the table is read and used inside the loop");
-        static_assert(S % 2 == 0, "the operand sets take turns: step 0 of the next tile goes into set 0");
-        S1A0_STAMP(2)
-        // all sixteen values first, then sixteen stores off scalar row bases with the lane's offset in one register (a
-        // store that shares its data or address register with the next one's arithmetic holds that arithmetic up until the
-        // memory pipe has taken the operands: 80 cycles a store, profiles/r06_gauss_axis0_s1.txt)
-        float outv[16];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) outv[v] = fmaf(acc[v], p.out_scale, corr[v]) + cbv;
-#ifdef S1A0_STAMPS
-        asm volatile("" :: "v"(outv[0]), "v"(outv[15]));
-        S1A0_STAMP(1)
-#endif
-        base += 32;
-        base = base >= RR ? base - RR : base;
-        if (t + 1 < te) {  // the next tile's first two steps (the operand registers are free)
-            slot = base;
-            fetch(0);
-            fetch(1);
-        }
-        if (lane == 0 && !(dbg & 8)) p.flags[((size_t)t * gridDim.x + blockIdx.x) * 4 + wave] = lastw[wave] >= t ? 1 : 0;  // LAB 8: no flags
-        if (dbg & 1) {
-        } else if (wide_stores && y0 >= p.out_row0 && y0 + 32 <= p.out_row0 + p.out_rows) {  // (wave-uniform: every lane's column is inside the DEM)
-            {
-                // A store instruction costs the CU's memory pipe about as much whatever it carries (sixteen dword stores: 1200
-                // cycles of a 3700-cycle tile, profiles/r06_gauss_axis0_s1.txt), so the four rows a lane holds of its column
-                // are turned, quad of lanes by quad, into four columns of one row: four 16-byte stores, each instruction
-                // eight whole 128-byte lines.  Buffer stores: the tile's first row is the (wave-uniform) resource, the row
-                // block a scalar offset, the lane's place one register - no vector address arithmetic.
-                float* const rb = p.out + (size_t)((dbg & 16) ? 0 : y0 - p.out_row0) * p.nx + x0;  // LAB 16: every tile into the first rows
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rb, 0, 0x7fffffff, 0x00020000);
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 d[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float r4[4] = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};  // rows 8 q + 4 g + 0 ... 3 of column j
-                    if (!(dbg & 32)) quad_transpose(r4, lane);  // -> row 8 q + 4 g + (j & 3), columns 4 (j >> 2) ... + 3   (LAB 32: not turned)
-                    d[q] = u32x4{__builtin_bit_cast(unsigned, r4[0]), __builtin_bit_cast(unsigned, r4[1]), __builtin_bit_cast(unsigned, r4[2]),
-                                 __builtin_bit_cast(unsigned, r4[3])};
-                }
-                // (the four stores behind all four turns, each from registers of its own: a store holds up the next write of
-                // its data registers until the memory pipe has fetched them)
-                asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
-#pragma unroll
-                for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128(d[q], rsrc, (int)out_quad_off, 8 * q * p.nx * 4, 0);
-            }
-        } else if (ox < p.nx) {
-            {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int oy = y0 + (v & 3) + 8 * (v >> 2) + 4 * g;
-                    if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = outv[v];
-                }
-            }
-        }
-        S1A0_STAMP(3)
-    }
-#ifdef S1A0_STAMPS
-    if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0)
-        printf("chain wave %d: %d tiles, %lld ticks in all | loop top %lld | results (wait for the last product, 32 x fma + add) %lld | products (issue) %lld | next reads, flags, transpose, stores %lld\n", wave,
-               te - tb, (long long)__builtin_amdgcn_s_memtime() - ct0, acc_t[0], acc_t[1], acc_t[2], acc_t[3]);
-#endif
-}
-
-
-// ---- split once, axis 0, every wave for itself (round 6, second form) ------------------------------------------------------------
-// What the cooperative kernel above taught (profiles/r06_gauss_axis0_s1.txt): a SIMD that holds an MFMA wave and a vector
-// wave does not overlap them - per tile 54 x 32 cycles of products PLUS 4.5 cycles for every vector instruction of either
-// wave - while a wave's OWN vector instructions hide under its own MFMAs, about four per MFMA.  So: four waves per CU, one per
-// SIMD (512 registers each: nothing spills, nothing lives in LDS but the ring), a wave owns 32 columns (128-byte lines) and
-// does everything for them - loads the 32 rows its next tile adds (lane -> column lane & 31, rows 16 (lane >> 5) ... + 15:
-// every load instruction is two rows of 128 bytes), splits them ONCE against the slab references, writes the f16 pairs into
-// its own columns of the ring (column-major: a B operand is one 16-byte read) - piece by piece underneath the products of
-// the tile it is computing.  No barrier: nobody else touches a wave's columns.  Per 32 x 32 tile 54 MFMAs and about 300
-// vector instructions instead of the tile kernel's 54 and 500 (the window split again for every tile).
-// Slabs, references, the table W, the R + 32 ghost rows, flags: as above.
-template <int S, int NP>
-__global__ __launch_bounds__(256) void gauss_axis0_s1w_kernel(GaussArgs p, int tile_first, int ntiles, int tiles_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float L[];
-    constexpr int Rp = 8 * (S - 2), RR = 16 * S, PITCH = RR + 8, NSIDE = (Rp + 63) / 64;
-    constexpr int NG = RR / 32;
-    static_assert(Rp % 32 == 0 && RR % 32 == 0 && NSIDE <= 2 && (PITCH / 8) % 2 == 1 && S % 2 == 0, "see gauss_axis0_s1_kernel");
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    _Float16* const hi = reinterpret_cast<_Float16*>(L);
-    _Float16* const lo = hi + 128 * PITCH;
-    float* const ctab = L + 128 * PITCH;  // [8 slabs][128 columns]
-    float* const wlds = ctab + 8 * 128;   // W[5][64]
-    const int R = p.radius;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = blockIdx.x * 128;
-    const int tb = blockIdx.y * tiles_per_block, te = min(tb + tiles_per_block, ntiles);
-    if (tb >= te) return;
-    if (p.run_if && *p.run_if == 0) return;
-    for (int k = threadIdx.x; k < 5 * 64; k += 256) wlds[k] = p.wtab[k];
-    for (int k = threadIdx.x; k < 8 * 128; k += 256) ctab[k] = 0.0f;
-    __syncthreads();  // (the only one: the table W is the block's)
-    const int j = lane & 31, g = lane >> 5;
-    const int col = 32 * wave + j;
-    const int gx = min(x0 + col, p.nx - 1);
-    const int row_lo = max(0, p.in_row0), row_hi = min(p.gny, p.in_row0 + p.in_rows);
-    auto row_ptr = [&](int gy) {
-        gy = reflect_index(gy, p.gny);
-        gy = min(max(gy, p.in_row0), p.in_row0 + p.in_rows - 1);
-        return p.in + (size_t)(gy - p.in_row0) * p.nx;
-    };
-    f16x8 twh[S], twl[S];
-    build_tap_blocks<S>(p.taps, R, p.tap_scale, lane, twh, twl);
-    struct Pre {
-        float x[16];  // rows n0 + 16 g ... + 15 of the lane's column
-        float r;      // the reference row of the slab the NEXT group lies in
-    };
-    // 17 loads, always (clamped rows past the block's end are loaded and never staged): the compiler's s_waitcnt counts stay exact
-    auto load = [&](int n0, Pre& v) {
-        const int r0 = n0 + 16 * g, rr = ((n0 + 32) & ~63) + 32;
-        const bool inside = n0 >= row_lo && n0 + 32 <= row_hi;  // (wave-uniform)
-        const float* q0 = inside ? p.in + (size_t)(r0 - p.in_row0) * p.nx : nullptr;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v.x[e] = (q0 ? q0 + (size_t)e * p.nx : row_ptr(r0 + e))[gx];
-        v.r = row_ptr(rr)[gx];
-    };
-    float c_now = 0.0f, c_next = 0.0f;
-    int last_wild = kNoWild;
-    const int y_start = (tile_first + tb) * 32 - Rp;
-    _Float16* const wh = hi + col * PITCH + 16 * g;  // the lane's 16 rows of a group
-    _Float16* const wl = lo + col * PITCH + 16 * g;
-    // announce the slab that starts at virtual row n1: its reference into the table (stay: last tile that holds its samples)
-    auto announce = [&](float r, int n1, int stay) {
-        const bool w = wild(r);
-        c_next = w ? 0.0f : r;
-        if (g == 0) ctab[(floor_div64(n1) & 7) * 128 + col] = c_next;
-        if (__builtin_amdgcn_ballot_w64(w)) last_wild = max(last_wild, stay);
-    };
-    // half `h` (rows 8 h ... 8 h + 7 of the lane's 16) of a group: zero what is not a plain finite sample, split, write
-    auto stage_half = [&](Pre& v, int h, int slot, bool& bad) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool w = wild(v.x[8 * h + e]);
-            bad |= w;
-            x[e] = w ? 0.0f : v.x[8 * h + e];
-        }
-        f16x8 dh, dl;
-        split8(x, f32x2{0.25f, 0.25f}, f32x2{-0.25f * c_now, -0.25f * c_now}, dh, dl);
-        *reinterpret_cast<f16x8*>(wh + slot + 8 * h) = dh;
-        *reinterpret_cast<f16x8*>(wl + slot + 8 * h) = dl;
-    };
-    // the first window
-    {
-        announce(row_ptr((y_start & ~63) + 32)[gx], y_start & ~63, tb + 1);
-        c_now = c_next;
-        for (int k = 0; k < NG; ++k) {
-            Pre v;
-            const int n0 = y_start + 32 * k;
-            load(n0, v);
-            if ((n0 & 63) == 0) c_now = c_next;
-            if (((n0 + 32) & 63) == 0) announce(v.r, n0 + 32, tb + k + 2);
-            bool bad = false;
-            stage_half(v, 0, 32 * k, bad);
-            stage_half(v, 1, 32 * k, bad);
-            if (__builtin_amdgcn_ballot_w64(bad)) last_wild = max(last_wild, tb + k);
-        }
-    }
-    const _Float16* const bh = hi + col * PITCH + 8 * g;
-    const _Float16* const bl = lo + col * PITCH + 8 * g;
-    const unsigned out_quad_off = (unsigned)((4 * g + (j & 3)) * p.nx + 32 * wave + 4 * (j >> 2)) * 4u;
-    const bool wide_stores = (p.nx & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && x0 + 128 <= p.nx;
-    const int ox = x0 + col;
-    const int g_first = y_start + RR;  // the group tile tb + 1 adds
-    Pre pre_a, pre_b;                  // loaded two tiles ahead of their staging: two sets that take turns
-    load(g_first, pre_a);
-    load(g_first + 32, pre_b);
-    __builtin_amdgcn_wave_barrier();
-    int base = 0, slot = 0;
-    f16x8 dh[3], dl[3];
-    auto fetch = [&](int k) {
-        dh[k] = *reinterpret_cast<const f16x8*>(bh + slot);
-        dl[k] = *reinterpret_cast<const f16x8*>(bl + slot);
-        slot += 16;
-        slot = slot >= RR ? slot - RR : slot;
-    };
-    fetch(0);
-    fetch(1);
-    auto tile = [&](const int t, Pre& pre) {
-        const int y0 = (tile_first + t) * 32;
-        const int n0 = g_first + 32 * (t - tb);  // the group tile t + 1 adds: staged underneath this tile's products, over the rows of steps 0 and 1
-        const bool more = t + 1 < te;
-        const int b = floor_div64(y0), o = (y0 & 63) + 4 * g;
-        const float cbv = ctab[(b & 7) * 128 + col];
-        const float* const crow = ctab + col;
-        constexpr int NPAIR = 2 * NSIDE * 4, PER = (NPAIR + S - 3) / (S - 2);
-        float cs = 0.0f;
-        float corr[16];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) corr[v] = 0.0f;
-        f4 wpc[PER];
-        f32x16 acc;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-        bool bad = false;
-        constexpr int kHalf0 = 3, kHalf1 = S >= 14 ? 8 : 6;  // the steps in front of which the two halves of the group are staged
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (s + 2 < S) fetch((s + 2) % 3);
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                const int i_old = (s - 2) * PER + e;
-                if (s >= 2 && i_old < NPAIR) {
-                    const int u = i_old % 4;
-                    const float dq = cs - cbv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) corr[4 * u + r] = fmaf(dq, wpc[e][r], corr[4 * u + r]);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                const int i_new = (s - 1) * PER + e;
-                if (s >= 1 && i_new < NPAIR) {
-                    const int q = i_new / 4, u = i_new % 4;
-                    const int d = q < NSIDE ? q - NSIDE : q - NSIDE + 1;
-                    if (u == 0) cs = crow[((b + d) & 7) * 128];
-                    wpc[e] = *reinterpret_cast<const f4*>(wlds + (d + 2) * 64 + o + 8 * u);
-                }
-            }
-            if (s == kHalf0 && more) {  // (steps 0 and 1 are in registers: their rows may go)
-                if ((n0 & 63) == 0) c_now = c_next;
-                if (((n0 + 32) & 63) == 0) announce(pre.r, n0 + 32, t + NG + 2);
-                stage_half(pre, 0, base, bad);
-            }
-            if (s == kHalf1 && more) {
-                stage_half(pre, 1, base, bad);
-                if (__builtin_amdgcn_ballot_w64(bad)) last_wild = max(last_wild, t + NG);
-            }
-            if (s == kHalf1 + 1) load(n0 + 64, pre);  // (the set is free again: the group two tiles on)
-            f16_products<false, NP>(twh[s], twl[s], dh[s % 3], dl[s % 3], acc);
-        }
-        float outv[16];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) outv[v] = fmaf(acc[v], p.out_scale, corr[v]) + cbv;
-        base += 32;
-        base = base >= RR ? base - RR : base;
-        if (more) {
-            slot = base;
-            fetch(0);
-            fetch(1);
-        }
-        if (lane == 0) p.flags[((size_t)t * gridDim.x + blockIdx.x) * 4 + wave] = last_wild >= t ? 1 : 0;
-        if (wide_stores && y0 >= p.out_row0 && y0 + 32 <= p.out_row0 + p.out_rows) {
-            float* const rb = p.out + (size_t)(y0 - p.out_row0) * p.nx + x0;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rb, 0, 0x7fffffff, 0x00020000);
-            u32x4 d[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float r4[4] = {outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]};
-                quad_transpose(r4, lane);
-                d[q] = u32x4{__builtin_bit_cast(unsigned, r4[0]), __builtin_bit_cast(unsigned, r4[1]), __builtin_bit_cast(unsigned, r4[2]),
-                             __builtin_bit_cast(unsigned, r4[3])};
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128(d[q], rsrc, (int)out_quad_off, 8 * q * p.nx * 4, 0);
-        } else if (ox < p.nx) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int oy = y0 + (v & 3) + 8 * (v >> 2) + 4 * g;
-                if (oy >= p.out_row0 && oy < p.out_row0 + p.out_rows) p.out[(size_t)(oy - p.out_row0) * p.nx + ox] = outv[v];
-            }
-        }
-    };
-    for (int t = tb; t < te; t += 2) {
-        tile(t, pre_a);
-        if (t + 1 < te) tile(t + 1, pre_b);
     }
 }
 
@@ -2591,46 +2007,6 @@ int launch_s1_axis1_any(int nk, long waves, const GaussArgs& a, int rows, int ns
     set_error("gaussian (split-once matrix-core route): no kernel for this radius");
     return TOPO_AMD_EUNSUP;
 }
-// split-once axis 0 (gauss_axis0_s1_kernel): S steps of 16 rows per 32-row tile, Rp = 8 (S - 2) a multiple of 32
-int s1_axis0_steps(int R) { return 2 + (R + 31) / 32 * 4; }  // radius 49 ... 64: 10, ... 96: 14, ... 121: 18
-constexpr size_t s1_axis0_lds(int S) { return ((size_t)128 * (16 * S + 8) + 8 * 128 + 5 * 64 + 16 + (S >= 18 ? 5 : 0) * 64 * 4) * sizeof(float); }
-template <int S>
-int launch_s1_axis0(dim3 grid, const GaussArgs& a, int tile_first, int ntiles, int per) {
-    Context& c = ctx();
-    static_assert(s1_axis0_lds(S) <= 160 * 1024, "the ring fits LDS");
-    static bool ready = false;
-    if (!ready) {
-        TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis0_s1_kernel<S, TOPO_F16_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ready = true;
-    }
-    static const bool own = [] {  // LAB: TOPO_AMD_S1A0_FORM=coop: the cooperative form (staging waves apart from chain waves)
-        const char* e = std::getenv("TOPO_AMD_S1A0_FORM");
-        return !(e && *e == 'c');
-    }();
-    if (own) {
-        static bool ready_w = false;
-        if (!ready_w) {
-            TOPO_HIP(hipFuncSetAttribute((const void*)gauss_axis0_s1w_kernel<S, TOPO_F16_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            ready_w = true;
-        }
-        const size_t lds = ((size_t)128 * (16 * S + 8) + 8 * 128 + 5 * 64) * sizeof(float);
-        hipLaunchKernelGGL((gauss_axis0_s1w_kernel<S, TOPO_F16_NP>), grid, dim3(256), lds, c.compute, a, tile_first, ntiles, per);
-        TOPO_HIP(hipGetLastError());
-        return TOPO_AMD_OK;
-    }
-    hipLaunchKernelGGL((gauss_axis0_s1_kernel<S, TOPO_F16_NP>), grid, dim3(512), s1_axis0_lds(S), c.compute, a, tile_first, ntiles, per);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
-}
-int launch_s1_axis0_any(int steps, dim3 grid, const GaussArgs& a, int tile_first, int ntiles, int per) {
-    switch (steps) {
-        case 10: return launch_s1_axis0<10>(grid, a, tile_first, ntiles, per);
-        case 14: return launch_s1_axis0<14>(grid, a, tile_first, ntiles, per);
-        case 18: return launch_s1_axis0<18>(grid, a, tile_first, ntiles, per);
-    }
-    set_error("gaussian (split-once matrix-core route, axis 0): no kernel for this radius");
-    return TOPO_AMD_EUNSUP;
-}
 #define TOPO_F16_STEPS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
 int launch_f16_axis0_any(int steps, int mt, dim3 grid, const GaussArgs& a, int tile_first, int ntiles, int per) {
     switch (steps) {
@@ -2657,68 +2033,11 @@ int launch_f16_axis1_any(int steps, int mt, long waves, const GaussArgs& a, int 
 thread_local const int* t_run_if = nullptr;
 
 // axis 0 on the f16 route: tiles of 32 MT rows on the global grid, one flag byte per 32 x 32 unit
-// Split-once axis 0 on a row block: the reference row (row 32) of every 64-row slab that the window of one of the block's
-// output rows touches is inside the block (reflected at the DEM's edges first, like the samples).  True for the whole DEM
-// and for blocks with R + 32 ghost rows (gaussian_reach: what topo_amd_halo_rows answers); a block that comes with less
-// takes the tile kernel, whose results differ in the last bits.  (DEMs of fewer than 512 rows: the tile kernel - a
-// property of the global grid, the same for every row block.)
-bool s1_rows_ok(const Block& b, int R) {
-    if (b.gny < 512) return false;
-    const int lo = b.out_row0 - R, hi = b.out_row0 + b.out_rows - 1 + R;
-    auto fdiv = [](int a) { return a >= 0 ? a / 64 : -((-a + 63) / 64); };
-    for (int s = fdiv(lo); s <= fdiv(hi); ++s) {
-        int y = 64 * s + 32;
-        const int period = 2 * b.gny;
-        y %= period;
-        if (y < 0) y += period;
-        y = y < b.gny ? y : period - 1 - y;
-        if (y < b.in_row0 || y >= b.in_row0 + b.in_rows) return false;
-    }
-    return true;
-}
-// TOPO_AMD_GAUSS_SPLIT_ONCE_AXIS0=0: the tile kernel on axis 0 (A/B)
-bool split_once_axis0(int R) {
-    static const bool on = [] {
-        const char* e = std::getenv("TOPO_AMD_GAUSS_SPLIT_ONCE_AXIS0");
-        return !(e && *e == '0');
-    }();
-    return on && R >= 49 && R <= 121 && split_once(f16_steps(R));
-}
-int run_axis0_s1(const Block& b, GaussArgs a) {
-    Context& c = ctx();
-    const int tile_first = b.out_row0 / 32;
-    const int ntiles = (b.out_row0 + b.out_rows - 1) / 32 - tile_first + 1;
-    const int strips = (b.nx + 127) / 128;
-    // one block of 8 waves per CU marches down its strip of 128 columns; with fewer strips than CUs the march is cut into
-    // runs (each run restages its window: runs of 512 rows or more)
-    int splits = (c.num_cu + strips - 1) / strips;
-    splits = std::max(1, std::min(splits, ntiles / 16 > 0 ? ntiles / 16 : 1));
-    if (strips >= c.num_cu) splits = 1;
-    const int per = (ntiles + splits - 1) / splits;
-    TOPO_TRY(check_grid_rows((ntiles + per - 1) / per, "gaussian (split-once axis 0)"));
-    dim3 grid(strips, (ntiles + per - 1) / per);
-    const long units = (long)ntiles * strips * 4;
-    void* flags = nullptr;
-    TOPO_TRY(workspace(10, (size_t)units, &flags));
-    a.flags = (unsigned char*)flags;
-    a.fine_rows = a.fine_cols = 0;
-    {
-        const char* e = std::getenv("TOPO_AMD_S1A0_DEBUG");  // LAB
-        a.nchunks = e && *e ? std::atoi(e) : 0;
-    }
-    TOPO_TRY(launch_s1_axis0_any(s1_axis0_steps(a.radius), grid, a, tile_first, ntiles, per));
-    hipLaunchKernelGGL(gauss_f16_repair_kernel<false>, dim3((unsigned)std::min<long>(kRepairBlocks, (units + 63) / 64)), dim3(64), 0, c.compute,
-                       a, ntiles, strips * 4, tile_first, 0);
-    TOPO_HIP(hipGetLastError());
-    return TOPO_AMD_OK;
-}
-
 int run_axis0_f16(const Block& b, GaussArgs a, double sigma) {
     Context& c = ctx();
     set_f16_scales(sigma, &a);
     a.run_if = t_run_if;
     a.wild_flag = nullptr;
-    if (split_once_axis0(a.radius) && !t_axis0_one_tile && s1_rows_ok(b, a.radius)) return run_axis0_s1(b, a);
     const int mt = f16_mt(false, a.radius), tile = 32 * mt;
     const int tile_first = b.out_row0 / tile;
     const int ntiles = (b.out_row0 + b.out_rows - 1) / tile - tile_first + 1;
@@ -3242,9 +2561,6 @@ int upload_resolution(int res_mode, const void* res_x, const void* res_y, int nx
 }  // namespace
 
 int gaussian_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
-// ghost rows with which a row block of the Gaussian has the whole DEM's bits: the radius, plus 32 where axis 0 takes the
-// split-once kernel (s1_rows_ok: the reference rows of its slabs)
-int gaussian_reach(int R) { return R + (split_once_axis0(R) ? 32 : 0); }
 
 int mfma_min_radius(bool for_gradient) { return mfma_min_radius_impl(for_gradient); }
 
@@ -3441,8 +2757,7 @@ int launch_gradient(const Block& b, double sigma, double sig_ratio, int res_mode
             if (taper && s1 - c1 < small + 32 && s1 - c1 > 0 && c1 < s1) c1 = std::max(c0 + 32, (s1 - small) / 32 * 32);  // leave the small last chunk
             if (c1 + 32 > s1 || c1 <= c0) c1 = s1;  // no sliver at the end
             // row shard with its exchange in flight: does the filter of these rows reach into the ghost rows?
-            // (the reach: with the split-once axis-0 kernel the slab references lie up to 32 rows beyond the filter)
-            chunks.push_back({c0, c1, gated && (c0 - gaussian_reach(R) < c.ghost.ghost_lo || c1 + gaussian_reach(R) > c.ghost.ghost_hi), false});
+            chunks.push_back({c0, c1, gated && (c0 - R < c.ghost.ghost_lo || c1 + R > c.ghost.ghost_hi), false});
             c0 = c1;
         }
         TOPO_REQUIRE(chunks.size() <= 64, "gradient: %zu row chunks (at most 64)", chunks.size());
