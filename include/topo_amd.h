@@ -270,8 +270,10 @@ int topo_amd_release_host_planes(void);
 /* Row chunks the calling thread's last host-buffer call ran in (1: upload, kernels, download one after the other - arrays
  * of fewer than three chunks, or TOPO_AMD_HOST_PIPELINE=0; a multi-scale call: the most any scale ran in).  For tests and
  * diagnostics: which branch of the pipeline a call took.  Environment, read at every call: TOPO_AMD_HOST_CHUNK_MB (64; a
- * chunk is whole multiples of 960 rows, at least 960), TOPO_AMD_HOST_PIPELINE=0 (off), TOPO_AMD_HOST_DOWNLOADS=thread|inline
- * (who issues the downloads; default: the calling thread when every array is page-locked, a second thread otherwise).    */
+ * chunk is whole multiples of 960 rows, at least 960; the last one takes the rest: half a chunk to a chunk and a half),
+ * TOPO_AMD_HOST_PIPELINE=0 (off), TOPO_AMD_HOST_DOWNLOADS=thread|inline
+ * (who issues the downloads; default: the calling thread when every array is page-locked, a second thread otherwise).
+ * topo_amd_valley_ridge_f32 is not pipelined (always one chunk).                                                         */
 int topo_amd_host_chunks(int* chunks);
 int topo_amd_tpi_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);
 int topo_amd_std_f32(const float* dem, int ny, int nx, int size, double sigma, float* out);

@@ -10,5 +10,5 @@ blk = d.Block(dem)
 o = d.DeviceArray(n, n)
 med = lambda f: round(sorted(d.time_launches(f, 7))[3], 3)
 for s in sigmas:
-    print(json.dumps({"sigma": s, "f16": os.environ.get("TOPO_AMD_GAUSS_F16", "1"), "axis0_ms": med(lambda: blk.gaussian(s, 0.0, o)),
+    print(json.dumps({"sigma": s, "split_once": os.environ.get("TOPO_AMD_GAUSS_SPLIT_ONCE", "1"), "axis0_ms": med(lambda: blk.gaussian(s, 0.0, o)),
                       "axis1_ms": med(lambda: blk.gaussian(0.0, s, o)), "both_ms": med(lambda: blk.gaussian(s, s, o))}))

@@ -1,5 +1,5 @@
 """Error of the Gaussian against the float64 evaluation of the same filter (oracle/topo_oracle.gaussian_exact), for
-the route the library is configured to take (TOPO_AMD_GAUSS_F16=0: float32 matrix-core chain).  Prints max / rms
+the route the library takes (TOPO_AMD_GAUSS_SPLIT_ONCE=0: the tile kernels on axis 1 too).  Prints max / rms
 error, where the maximum sits, and the same figures for a single axis."""
 import os, sys, json
 sys.path.insert(0, os.getcwd())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Host-buffer calls (upload || kernels || download in row chunks, csrc/capi.hip run_pipelined) against the serial order:
 topo_amd_tpi_f32 / topo_amd_gradient_f32 on an n x n DEM, page-locked and pageable arrays, for a few chunk sizes.
-Each configuration runs in a child process (the switches are read once per process).
+Each configuration runs in a child process (a fresh set of device planes; the switches themselves are read at every call).
 
     python tools/host_pipeline_time.py [n=16384]
 """
@@ -62,8 +62,8 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "child":
         child(n)
         return
-    for env in ({"TOPO_AMD_HOST_PIPELINE": "0"}, {}, {"TOPO_AMD_HOST_PIPELINE": "thread"}, {"TOPO_AMD_HOST_PIPELINE": "inline"},
-                {"TOPO_AMD_HOST_CHUNK_MB": "128"}):
+    for env in ({"TOPO_AMD_HOST_PIPELINE": "0"}, {}, {"TOPO_AMD_HOST_DOWNLOADS": "thread"},
+                {"TOPO_AMD_HOST_DOWNLOADS": "inline"}, {"TOPO_AMD_HOST_CHUNK_MB": "128"}, {"TOPO_AMD_HOST_CHUNK_MB": "32"}):
         print(env or "default (64 MB chunks)", flush=True)
         e = dict(os.environ)
         e.update(env)

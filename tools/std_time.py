@@ -1,5 +1,6 @@
 """Time STD and TPI + STD on the 32768^2 bench DEM (median of 6 launches, HIP events) and CRC the outputs at
-8192^2: run with TOPO_AMD_STD_RING_MIN=31 (ring kernel) and =999 (marching pair)."""
+8192^2.  The same-box A/B of two builds of the library: run once as is and once with TOPO_AMD_LIBRARY=<the other .so>
+(the switch TOPO_AMD_STD_RING_MIN this tool once flipped is a constant since round 5)."""
 import json
 import os
 import sys
@@ -9,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from topo_descriptors_amd import device as d  # noqa: E402
 
 sizes = [int(a) for a in sys.argv[1:]] or [31, 45, 65, 67]
-out = {"TOPO_AMD_STD_RING_MIN": os.environ.get("TOPO_AMD_STD_RING_MIN")}
+out = {"library": os.environ.get("TOPO_AMD_LIBRARY", "in-tree")}
 n = 8192
 for integer in (True, False):
     dem = d.synth_dem(n, n, seed=0, integer=integer)

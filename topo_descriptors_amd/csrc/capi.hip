@@ -635,6 +635,17 @@ int pipeline_chunk_rows(int ny, int nx) {
     rows = std::max(960L, rows / 960 * 960);
     return rows * 3 > ny ? ny : (int)rows;  // fewer than three chunks: nothing to overlap
 }
+// The cuts of a pipelined call: chunks of `chunk` rows, the last one half a chunk to a chunk and a half (no sliver at the end).
+// (Round 6 tried a taper - a quarter and a half chunk at both ends, so that less stands in front of the first kernels and
+// behind the last ones: 16384^2 TPI 67 px 26.05 -> 25.93 ms page-locked, 24.97 -> 24.80 pageable, profiles/r06_host_pipeline.txt:
+// the fill and the drain are not what separates the call from the 22.4 ms of 1 GiB each way at 48 GB/s.  Not kept.)
+std::vector<int> pipeline_cuts(int ny, int chunk) {
+    std::vector<int> cut{0};
+    int at = 0;
+    while (ny - at > chunk + chunk / 2) cut.push_back(at += chunk);
+    cut.push_back(ny);
+    return cut;
+}
 // compute(view_rows, out_row0, out_rows): enqueue the kernels that write output rows [out_row0, out_row0 + out_rows) of
 // every plane, reading rows [0, view_rows) of d_in.  above / below: rows of the DEM an output row depends on.
 // upload == false: the DEM is on the device already (later scales of a multi-scale call).
@@ -643,7 +654,8 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
                   const std::vector<HostPlane>& outs, Compute&& compute) {
     Context& c = ctx();
     const int chunk = pipeline_chunk_rows(ny, nx);
-    const int nchunks = (ny + chunk - 1) / chunk;
+    const std::vector<int> cut = chunk >= ny ? std::vector<int>{0, ny} : pipeline_cuts(ny, chunk);
+    const int nchunks = (int)cut.size() - 1;
     const size_t row_bytes = (size_t)nx * sizeof(float);
     (void)above;
     t_host_chunks = std::max(t_host_chunks, nchunks < 3 ? 1 : nchunks);  // (a multi-scale call: the most any of its scales ran in)
@@ -705,7 +717,7 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
                 cv.wait(lock, [&] { return ready_chunks > j || failed; });
                 if (failed) return;
             }
-            const int r0 = j * chunk, r1 = std::min(ny, r0 + chunk);
+            const int r0 = cut[j], r1 = cut[j + 1];
             hipError_t e = hipStreamWaitEvent(c.down, computed[j], 0);
             for (size_t k = 0; k < outs.size() && e == hipSuccess; ++k)
                 if (outs[k].host)
@@ -730,7 +742,7 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
         failed = true;
     };
     for (int k = 0; k < nchunks && rc == TOPO_AMD_OK; ++k) {
-        const int u0 = k * chunk, u1 = std::min(ny, u0 + chunk);
+        const int u0 = cut[k], u1 = cut[k + 1];
         if (upload) {
             hipError_t e = hipMemcpyAsync(d_in + (size_t)u0 * nx, dem + (size_t)u0 * nx, (size_t)(u1 - u0) * row_bytes,
                                           hipMemcpyHostToDevice, c.up);
@@ -742,8 +754,8 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
             }
         }
         const int uploaded = upload ? u1 : ny;
-        while (next < nchunks && std::min(ny, std::min(ny, next * chunk + chunk) + below) <= uploaded) {
-            const int r0 = next * chunk, r1 = std::min(ny, r0 + chunk);
+        while (next < nchunks && std::min(ny, cut[next + 1] + below) <= uploaded) {
+            const int r0 = cut[next], r1 = cut[next + 1];
             if (upload && hipStreamWaitEvent(c.compute, up_done[k], 0) != hipSuccess) {
                 set_error("hipStreamWaitEvent(compute, upload) failed");
                 fail(TOPO_AMD_EHIP);

@@ -2236,11 +2236,10 @@ constexpr int tile_rows(int size, int nwaves, int cap) {
 }
 
 // Which discs take the marching kernels.  Measured on a 32768^2 DEM of whole metres
-// (tools/std_crossover.py, profiles/r01_std_crossover.txt): for STD / TPI+STD the marching pair wins
+// (profiles/r01_std_crossover.txt): for STD / TPI+STD the marching pair wins
 // from 31 px (2 %) to 67 px (11 %) and loses below (three planes of traffic in one general kernel
 // against five) and wherever LDS no longer holds the full 60-row tile (101 px: 36-row tiles, 46 ms
-// against 31 ms).  TOPO_AMD_STD_MARCH_MIN / TOPO_AMD_TPI_MARCH_MIN move the lower bounds (tuning
-// knobs; the results do not depend on them).
+// against 31 ms).  (The lower bounds were environment switches until round 5; constants now.)
 inline int env_int(const char* name, int fallback) {
     const char* e = std::getenv(name);
     return e ? std::atoi(e) : fallback;
@@ -2249,15 +2248,14 @@ constexpr int std_march_min_size() { return 31; }
 constexpr int tpi_march_min_size() { return 1; }
 // Disc size from which TPI on tiles with fractional elevations takes the two marching passes
 // (sum of trunc(x), then sum of the fractional parts) instead of the general kernel.
-// Disc size from which TPI takes the ring build (disc_ring_impl.hpp) instead of tpi_march_kernel
-// (TOPO_AMD_TPI_RING_MIN, a tuning knob: both give the same bits).
-// Measured on the 32768^2 bench DEM (tools/ring_time.py, profiles/r02_tpi_ring.txt): 2.03-2.06 ms against
+// Disc size from which TPI takes the ring build (disc_ring_impl.hpp) instead of tpi_march_kernel (both give the same bits).
+// Measured on the 32768^2 bench DEM (profiles/r02_tpi_ring.txt): 2.03-2.06 ms against
 // 2.31-2.37 ms for 5 ... 11 px, level at 13-17 px, 4.6 ms against 4.4 ms at 67 px.  Round 3: the ring sizes go up
 // to 17 px, because with fractional elevations the two-image pass (kRingBoth) halves the time there (7 px 5.36 ->
 // 2.48 ms, 13 px 5.82 -> 3.60, 17 px 6.00 -> 3.79, profiles/r03_tpi_ring_both.txt) while whole metres cost the
 // same to 15 px and 5 % more at 17 (2.43 against 2.32 ms).
 constexpr int tpi_ring_min_size() { return 5; }
-// Disc size from which STD / TPI + STD take the one-pass ring kernel (TOPO_AMD_STD_RING_MIN; 999 = never).  Same-box
+// Disc size from which STD / TPI + STD take the one-pass ring kernel.  Same-box
 // A/B on the 32768^2 bench DEM (tools/std_time.py, profiles/r02_std_ring.txt), ring kernel against what it replaces:
 // STD 7 px 3.10 / 5.67 ms, 17 px 3.77 / 6.40, 31 px 5.28 / 7.89, 45 px 6.76 / 9.70, 65 px 9.37 / 12.78, 67 px 10.33 /
 // 13.61; TPI + STD 67 px 10.86 / 14.22.  Identical bits (CRC-32 of both planes, whole metres and fractional DEM).
