@@ -118,11 +118,11 @@ def kernel_sources_sha256():
 
 def measured_traffic(ny, nx, size, world):
     """HBM bytes per launch of the TPI kernel from the committed rocprofv3 PMC passes
-    (profiles/r05_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this exact
+    (profiles/r06_tpi67_traffic.json, made by tools/pmc_passes.sh + tools/traffic_from_pmc.py on this exact
     workload), with the git head and the kernel-source hash the profile was taken at.  The number is nulled
     when the workload or the sources differ from the profiled ones."""
-    info = {"traffic": None, "traffic_profile_head": None, "traffic_profile": "profiles/r05_tpi67_traffic.json"}
-    path = os.path.join(REPO, "profiles", "r05_tpi67_traffic.json")
+    info = {"traffic": None, "traffic_profile_head": None, "traffic_profile": "profiles/r06_tpi67_traffic.json"}
+    path = os.path.join(REPO, "profiles", "r06_tpi67_traffic.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -140,13 +140,13 @@ def measured_traffic(ny, nx, size, world):
 
 
 def valu_bound(ny, nx, size, world, kernel_ms):
-    """What bounds the kernel in practice: vector-ALU issue.  profiles/r05_tpi67_valu_bound.json (tools/valu_bound.py)
+    """What bounds the kernel in practice: vector-ALU issue.  profiles/r06_tpi67_valu_bound.json (tools/valu_bound.py)
     prices the kernel's own instruction stream - the row loop's instructions by issue class from the ISA, the rest
     from the launch's SQ_INSTS_VALU counter - with the issue costs measured on the GPU; the fraction is that time
     over the measured one.  Nulled when the workload or the kernel sources differ from the profiled ones."""
-    info = {"valu_bound_ms": None, "frac_of_valu_bound": None, "valu_bound_profile": "profiles/r05_tpi67_valu_bound.json"}
+    info = {"valu_bound_ms": None, "frac_of_valu_bound": None, "valu_bound_profile": "profiles/r06_tpi67_valu_bound.json"}
     try:
-        with open(os.path.join(REPO, "profiles", "r05_tpi67_valu_bound.json")) as fh:
+        with open(os.path.join(REPO, "profiles", "r06_tpi67_valu_bound.json")) as fh:
             prof = json.load(fh)
     except (OSError, ValueError):
         info["valu_bound_note"] = "no committed profile"
@@ -269,12 +269,12 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
             # what bounds STD in practice: vector-ALU issue too (tools/valu_bound.py std: the launch's SQ_INSTS_VALU priced at
             # the phase loop's mix of issue classes)
             try:
-                with open(os.path.join(REPO, "profiles", "r05_std67_valu_bound.json")) as fh:
+                with open(os.path.join(REPO, "profiles", "r06_std67_valu_bound.json")) as fh:
                     prof = json.load(fh)
                 if prof.get("kernel_sources_sha256") == kernel_sources_sha256() and prof.get("valu_bound_ms"):
                     out["std_s67"]["valu_bound_ms"] = prof["valu_bound_ms"]
                     out["std_s67"]["frac_of_valu_bound"] = round(prof["valu_bound_ms"] / out["std_s67"]["ms"], 4)
-                    out["std_s67"]["valu_bound_profile"] = "profiles/r05_std67_valu_bound.json"
+                    out["std_s67"]["valu_bound_profile"] = "profiles/r06_std67_valu_bound.json"
                 else:
                     out["std_s67"]["valu_bound_note"] = "kernel sources changed since tools/valu_bound.py std ran"
             except (OSError, ValueError):
@@ -700,6 +700,29 @@ def main():
                 "algorithmic_bytes_per_pixel": BYTES_PER_PIXEL["tpi"],
             },
         }
+        if not sharded:
+            # what the memory system gives a kernel that does NOTHING but move the same 8 B/pixel (round 6): the runtime's
+            # device-to-device copy of the DEM plane into the output plane, timed like the kernel (HIP events on the compute
+            # stream, behind the timed region).  tools/ubench/strip_copy.hip measures the same with the kernels' own access
+            # pattern - 128-column strips marched down: 1.54 ms = 5.6 TB/s (profiles/r06_gauss_axis0_s1.txt, 3b).
+            try:
+                lib = _lib.lib()
+                nbytes = rows_local * nx * 4
+                copies = []
+                for k in range(4):
+                    d.mark(0)
+                    _lib.check(lib.topo_amd_memcpy_d2d(out.ptr, block.row_ptr(first_row), nbytes), "memcpy_d2d")
+                    d.mark(1)
+                    copies.append(d.mark_elapsed(0, 1))
+                copy_ms = sorted(copies[1:])[1]
+                result["roofline"]["hbm_copy_live"] = {
+                    "what": "hipMemcpyAsync device-to-device of one plane (4 B/pixel read + 4 B/pixel written, like the kernel)",
+                    "ms": round(copy_ms, 4), "GB/s": round(2 * nbytes / (copy_ms * 1e-3) / 1e9, 1),
+                    "kernel_over_copy": round(kernel_ms / copy_ms, 3)}
+                step()  # (the output plane holds the kernel's result again for the parity spot below)
+                d.sync()
+            except Exception as exc:  # noqa: BLE001
+                result["roofline"]["hbm_copy_live"] = {"error": repr(exc)}
         if not args.no_cpu and not sharded:
             rows_s = min(ny, 16384)  # ~4 s of scipy on one core + ~6 s of the C twin on all of them
             cols_s = min(nx, 16384)

@@ -10,8 +10,8 @@ VOP1 / VOP2 integer and float operations, 1.87 ns for every DPP form, v_add3_u32
 converts and float64).  The instructions outside the row loop (staging, tile bookkeeping) come from the launch's
 SQ_INSTS_VALU counter minus the row loop's share and are priced at the kernel's overall mix.
 
-    python tools/valu_bound.py [SQ_INSTS_VALU per launch, default from profiles/r05_tpi67_pmc_summary.txt] > profiles/r05_tpi67_valu_bound.json
-    python tools/valu_bound.py std [SQ_INSTS_VALU per launch, default from profiles/r05_std67_pmc_summary.txt] > profiles/r05_std67_valu_bound.json
+    python tools/valu_bound.py [SQ_INSTS_VALU per launch, default from profiles/r06_tpi67_pmc_summary.txt] > profiles/r06_tpi67_valu_bound.json
+    python tools/valu_bound.py std [SQ_INSTS_VALU per launch, default from profiles/r06_std67_pmc_summary.txt] > profiles/r06_std67_valu_bound.json
 
 std (round 4): the same for std_ring_kernel<67, false> - its phase loop (one output row of 256 pixels per wave and
 phase: two chains, the staging share of the wave, the finalisation) priced by issue class; the scalar instructions of
@@ -99,7 +99,7 @@ def main():
         total_valu = float(sys.argv[1])
     else:
         try:
-            block = open(os.path.join(REPO, "profiles", "r05_std67_pmc_summary.txt" if std else "r05_tpi67_pmc_summary.txt")).read() \
+            block = open(os.path.join(REPO, "profiles", "r06_std67_pmc_summary.txt" if std else "r06_tpi67_pmc_summary.txt")).read() \
                 .split("std_ring_kernel<67, false" if std else "tpi_march_kernel<67")[1]
             total_valu = float(re.search(r"SQ_INSTS_VALU\s+n=\s*\d+\s+mean=([0-9.e+]+)", block).group(1))
         except (OSError, IndexError, AttributeError):
