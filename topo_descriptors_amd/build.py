@@ -33,13 +33,32 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+STAMP = LIB + ".srchash"  # what the library was built from: travels with it (git-ignored, not gpurun-ignored)
+
+
+def sources_hash(paths):
+    """sha256 over the sources, the headers and the build recipe: modification times do not survive a checkout or a
+    snapshot onto another machine, the content does."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(" ".join([ARCH] + FLAGS + [str(NGROUPS)]).encode())
+    for path in sorted(paths):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build_library(force=False, verbose=True):
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
     headers.append(os.path.join(os.path.dirname(HERE), "include", "topo_amd.h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if not force and _newer(LIB, srcs + headers):
-        return LIB
+    want = sources_hash(srcs + headers)
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+        with open(STAMP) as fh:
+            if fh.read().strip() == want:
+                return LIB  # built from exactly these sources (whatever the files' times say)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
@@ -76,6 +95,8 @@ def build_library(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as fh:
+        fh.write(want + "\n")
     return LIB
 
 
