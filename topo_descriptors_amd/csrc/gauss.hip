@@ -2042,7 +2042,12 @@ int run_axis0_f16(const Block& b, GaussArgs a, double sigma) {
     const int tile_first = b.out_row0 / tile;
     const int ntiles = (b.out_row0 + b.out_rows - 1) / tile - tile_first + 1;
     const int strips = (b.nx + kMfmaCols - 1) / kMfmaCols;
-    int splits = (2 * c.num_cu + strips - 1) / strips;
+    // blocks the chip holds at once: the ring of the long filters takes a CU's LDS (one block per CU), two fit up to 80 KB.
+    // (Round 6: this was 2 x the CUs whatever the ring - at radius 49 ... 121 on a 16384-column raster 512 blocks of one per CU:
+    // two rounds, each run restaging its 2 Rp halo rows for half as many tiles.)
+    const size_t ring_bytes = (size_t)(16 * (f16_steps(a.radius) + 2 * (mt - 1))) * kMfmaCols * sizeof(float);
+    const int per_cu = ring_bytes <= 80 * 1024 ? 2 : 1;
+    int splits = (per_cu * c.num_cu + strips - 1) / strips;
     const int min_run = 8 / mt;  // a cut restages 2 Rp rows: runs of 256 rows or more
     splits = std::max(1, std::min(splits, ntiles / min_run > 0 ? ntiles / min_run : 1));
     if (strips >= c.num_cu) splits = 1;
