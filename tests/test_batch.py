@@ -298,3 +298,38 @@ def test_wrappers_against_the_reference_wrappers(golden):
             assert np.mean(out[m] == ref[m]) >= 0.999, key
         else:
             assert np.max(np.abs(out[m] - ref[m])) <= 1e-4 * scale, (key, np.max(np.abs(out[m] - ref[m])), scale)
+
+
+@pytest.mark.gpu
+def test_a_wgs84_dataset_goes_through_the_batch_wrappers():
+    """reference helpers.py:89-97: a DEM on a longitude / latitude grid is reprojected to UTM for its resolution; the `utm`
+    package is absent here and helpers._utm_from_latlon stands in (pinned on CPU in tests/test_host_api.py).  The gradient then
+    divides by per-pixel resolutions (topo.py:688-712).  Checked against the oracle fed the same projected coordinates."""
+    from oracle import topo_oracle as orc
+    from topo_descriptors_amd import helpers as hlp
+    rng = np.random.default_rng(5)
+    ny, nx = 150, 210
+    x = 8.0 + np.arange(nx) / 1200.0                              # 3 arc seconds, 46.5 N: ~64 m x ~93 m
+    y = 46.5 - np.arange(ny) / 1200.0
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    dem = np.round(1500 + 400 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + rng.uniform(0, 20, (ny, nx))).astype(np.float32)
+    ds = FakeDataset(dem, x, y)
+    ds.attrs["crs"] = "EPSG:4326"
+    px, res = hlp.scale_to_pixel([500, 1000], ds)
+    assert res["x"].ndim == 2 and res["y"].ndim == 2 and list(px) == [7, 13]
+    east, north = hlp._wgs84_to_utm(x, y)
+    opx, ores = orc.scale_to_pixel([500, 1000], east, north)
+    assert np.array_equal(px, opx) and np.array_equal(res["x"], ores["x"]) and np.array_equal(res["y"], ores["y"])
+
+    out = batch.compute_gradient(ds, [500, 1000], outdir=None)
+    for scale, p in zip((500, 1000), px):
+        want = orc.gradient_scipy(dem, p / 4, ores)
+        names = batch._gradient_names(scale, 1)
+        for k in range(3):
+            assert np.max(np.abs(out[names[k]] - want[k])) <= 1e-4 * np.max(np.abs(want[k])), names[k]
+        steep = want[2] > 0.1
+        assert np.max(orc.wrapped_angle_diff(out[names[3]], want[3])[steep]) <= 1e-4 * 360.0
+    out = batch.compute_tpi(ds, [500, 1000], outdir=None)
+    for scale, p in zip((500, 1000), px):
+        want = orc.tpi_exact(dem, int(p))
+        assert np.max(np.abs(out[f"TPI_{scale}M"] - want)) <= 1e-4 * np.max(np.abs(want))

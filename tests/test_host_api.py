@@ -101,6 +101,90 @@ def test_scale_to_pixel_and_sigmas_golden(golden):
         assert (s is None and np.isnan(w)) or s == w
 
 
+# ---- WGS84 grids: the built-in UTM projection (reference helpers.py:91-97 calls the `utm` package, absent here) ---------------
+# Known answers of the `utm` package itself: its README's example and the city table of its own test-suite (metres, rounded there).
+UTM_README = ((51.2, 7.5), (395201.3103811303, 5673135.241182375, 32))
+UTM_CITIES = [((50.77535, 6.08389), (294409, 5628898, 32)),       # Aachen
+              ((40.71435, -74.00597), (583960, 4507523, 18)),      # New York
+              ((-41.28646, 174.77624), (313784, 5427057, 60)),     # Wellington
+              ((-33.92487, 18.42406), (261878, 6243186, 34)),      # Capetown
+              ((-32.89018, -68.84405), (514586, 6360877, 19)),     # Mendoza
+              ((64.83778, -147.71639), (466013, 7190568, 6)),      # Fairbanks
+              ((56.79680, -5.00601), (377486, 6296562, 30))]       # Ben Nevis
+
+
+def _kruger_utm(lat, lon, zone):
+    """Independent check: Krueger's n-series (Karney 2011, to n^4), not the Snyder series the package and the product use."""
+    a, f = 6378137.0, 1 / 298.257223563
+    n = f / (2 - f)
+    A = a / (1 + n) * (1 + n ** 2 / 4 + n ** 4 / 64)
+    al = [n / 2 - 2 * n ** 2 / 3 + 5 * n ** 3 / 16 + 41 * n ** 4 / 180, 13 * n ** 2 / 48 - 3 * n ** 3 / 5 + 557 * n ** 4 / 1440,
+          61 * n ** 3 / 240 - 103 * n ** 4 / 140, 49561 * n ** 4 / 161280]
+    phi, lam = np.radians(lat), np.radians(lon - ((zone - 1) * 6 - 180 + 3))
+    e = np.sqrt(f * (2 - f))
+    t = np.sinh(np.arctanh(np.sin(phi)) - e * np.arctanh(e * np.sin(phi)))
+    xi, eta = np.arctan2(t, np.cos(lam)), np.arctanh(np.sin(lam) / np.sqrt(1 + t * t))
+    east = 500000 + 0.9996 * A * (eta + sum(al[j] * np.cos(2 * (j + 1) * xi) * np.sinh(2 * (j + 1) * eta) for j in range(4)))
+    north = 0.9996 * A * (xi + sum(al[j] * np.sin(2 * (j + 1) * xi) * np.cosh(2 * (j + 1) * eta) for j in range(4)))
+    return east, north + (10000000 if np.max(lat) < 0 else 0)
+
+
+def test_utm_known_answers_of_the_package():
+    (lat, lon), (e, n, z) = UTM_README
+    east, north, zone = hlp._utm_from_latlon(np.array([lat]), np.array([lon]))
+    assert zone == z and abs(east[0] - e) < 1e-6 and abs(north[0] - n) < 1e-6
+    for (lat, lon), (e, n, z) in UTM_CITIES:
+        east, north, zone = hlp._utm_from_latlon(np.array([lat]), np.array([lon]))
+        assert zone == z and abs(east[0] - e) <= 0.5 and abs(north[0] - n) <= 0.5, (lat, lon)
+    # the zone exceptions the package lists: Norway (32 V) and Svalbard (31, 33, 35, 37 X)
+    for (lat, lon), z in [((60.0, 4.0), 32), ((56.0, 3.0), 32), ((55.999, 4.0), 31), ((64.0, 4.0), 31), ((72.0, 8.99), 31),
+                          ((72.0, 9.0), 33), ((78.0, 20.99), 33), ((78.0, 21.0), 35), ((78.0, 33.0), 37), ((78.0, 42.0), 38),
+                          ((0.0, -180.0), 1), ((0.0, 179.99), 60), ((46.8, 8.2), 32)]:
+        assert hlp._utm_zone_number(np.array([lat]), np.array([lon])) == z, (lat, lon)
+
+
+def test_utm_against_the_kruger_series_and_one_zone_for_an_array():
+    rng = np.random.default_rng(11)
+    for south in (False, True):
+        lat = rng.uniform(0.5, 83.5, 4000) * (-0.95 if south else 1)
+        zone0 = None
+        lon = rng.uniform(6.0, 12.0, 4000)                        # inside zone 32 (the first element decides)
+        lat[0], lon[0] = (-10.0 if south else 46.0), 9.0
+        east, north, zone = hlp._utm_from_latlon(lat, lon)
+        assert zone == 32
+        ke, kn = _kruger_utm(lat, lon, 32)
+        assert np.max(np.abs(east - ke)) < 5e-3 and np.max(np.abs(north - kn)) < 5e-3   # the package's series: millimetres in-zone
+    # a grid across a zone boundary stays in the FIRST element's zone (eastings keep growing: np.gradient of them is the resolution)
+    lon, lat = np.meshgrid(np.linspace(5.0, 7.0, 41), np.linspace(47.0, 46.0, 21))
+    east, north, zone = hlp._utm_from_latlon(lat, lon)
+    assert zone == 31 and np.all(np.diff(east, axis=1) > 0) and np.all(np.diff(north, axis=0) < 0)
+    ke, kn = _kruger_utm(lat, lon, 31)
+    assert np.max(np.abs(east - ke)) < 0.05 and np.max(np.abs(north - kn)) < 0.05
+    # the package's range errors
+    for lat, lon in [(84.1, 0.0), (-80.1, 0.0), (0.0, 180.1), (0.0, -180.1)]:
+        with pytest.raises(ValueError):
+            hlp._utm_from_latlon(np.array([lat]), np.array([lon]))
+    with pytest.raises(ValueError):
+        hlp._utm_from_latlon(np.array([-1.0, 1.0]), np.array([7.0, 7.0]))   # "latitudes must all have the same sign"
+
+
+def test_scale_to_pixel_of_a_wgs84_grid():
+    """reference helpers.py:89-104: meshgrid, from_latlon, float32, np.gradient along the last axis / axis 0."""
+    x = 7.0 + np.arange(60) / 1200.0                               # 3 arc seconds
+    y = 47.0 - np.arange(45) / 1200.0
+    ds = FakeDataset(np.zeros((45, 60), np.float32), x, y, crs="EPSG:4326")
+    px, res = hlp.scale_to_pixel([2000, 200, 500], ds)
+    assert res["x"].shape == (45, 60) and res["y"].shape == (45, 60) and res["x"].dtype == np.float32
+    lon, lat = np.meshgrid(x, y)
+    ke, kn = _kruger_utm(lat, lon, 32)
+    want_x, want_y = np.gradient(ke.astype(np.float32), axis=1), np.gradient(kn.astype(np.float32), axis=0)
+    assert np.max(np.abs(res["x"] - want_x)) <= 0.07 and np.max(np.abs(res["y"] - want_y)) <= 0.6   # float32 metres: ulp 1/32 and 1/2
+    assert np.all(res["x"] > 0) and np.all(res["y"] < 0)
+    mean_res = np.mean(np.abs([res["x"].mean(), res["y"].mean()]))
+    assert abs(mean_res - (63.3 + 92.65) / 2) < 0.3               # 3" at 47 N: ~63.3 m east-west, ~92.65 m north-south
+    assert np.array_equal(px, hlp.round_up_to_odd(np.array([2000, 200, 500]) / mean_res)) and list(px) == [25, 3, 7]
+
+
 # ---- error behaviour of the boundary ------------------------------------------------------------
 def test_check_dem_errors():
     x, y = np.arange(5.0), np.arange(4.0)

@@ -60,14 +60,90 @@ def round_up_to_odd(f):
     return (np.round((f - 1.0) / 2.0) * 2.0 + 1.0).astype(np.int64)
 
 
+# ---- WGS84 -> UTM without the `utm` wheel ---------------------------------------------------------------------------------------
+# The reference reprojects a WGS84 grid with `utm.from_latlon(lat, lon)` (helpers.py:91-97; PyPI package `utm`, version not
+# pinned by the reference, absent from this image).  What follows restates that function's published algorithm (Turbo87/utm,
+# conversion.py: the Transverse Mercator series of USGS Professional Paper 1395 / Snyder on the WGS84 ellipsoid, scale 0.9996) for
+# array input, including its choice of ONE zone for the whole array from the array's FIRST element (with the Norway / Svalbard
+# exceptions) - that choice is what makes np.gradient of the eastings meaningful across a grid that straddles a zone boundary.
+# Pinned by known answers of the package's own README and test-suite (tests/test_host_api.py); when the package is installed
+# it is used instead.
+_UTM_K0 = 0.9996
+_UTM_E = 0.00669438
+_UTM_E2 = _UTM_E * _UTM_E
+_UTM_E3 = _UTM_E2 * _UTM_E
+_UTM_E_P2 = _UTM_E / (1.0 - _UTM_E)
+_UTM_M1 = 1 - _UTM_E / 4 - 3 * _UTM_E2 / 64 - 5 * _UTM_E3 / 256
+_UTM_M2 = 3 * _UTM_E / 8 + 3 * _UTM_E2 / 32 + 45 * _UTM_E3 / 1024
+_UTM_M3 = 15 * _UTM_E2 / 256 + 45 * _UTM_E3 / 1024
+_UTM_M4 = 35 * _UTM_E3 / 3072
+_UTM_R = 6378137.0
+
+
+def _utm_zone_number(latitude, longitude):
+    """Zone of the array's first element (the package's rule for numpy input), Norway and Svalbard as the package has them."""
+    lat = float(np.asarray(latitude).flat[0])
+    lon = float(np.asarray(longitude).flat[0])
+    if 56 <= lat < 64 and 3 <= lon < 12:
+        return 32
+    if 72 <= lat <= 84 and lon >= 0:
+        if lon < 9:
+            return 31
+        if lon < 21:
+            return 33
+        if lon < 33:
+            return 35
+        if lon < 42:
+            return 37
+    return int((lon + 180) / 6) + 1
+
+
+def _utm_from_latlon(latitude, longitude):
+    """``(easting, northing, zone_number)`` of WGS84 latitudes / longitudes in degrees (arrays of one shape), all in the zone of
+    the first element.  Raises like the package outside 80 S ... 84 N / 180 W ... 180 E and for latitudes of mixed sign."""
+    lat = np.asarray(latitude, dtype=np.float64)
+    lon = np.asarray(longitude, dtype=np.float64)
+    if lat.size == 0:
+        raise ValueError("from_latlon: empty input")
+    if not (np.min(lat) >= -80.0 and np.max(lat) <= 84.0):
+        raise ValueError("latitude out of range (must be between 80 deg S and 84 deg N)")
+    if not (np.min(lon) >= -180.0 and np.max(lon) <= 180.0):
+        raise ValueError("longitude out of range (must be between 180 deg W and 180 deg E)")
+    if np.min(lat) < 0 and np.max(lat) >= 0:
+        raise ValueError("latitudes must all have the same sign")
+    lat_rad = np.radians(lat)
+    lat_sin, lat_cos = np.sin(lat_rad), np.cos(lat_rad)
+    lat_tan = lat_sin / lat_cos
+    lat_tan2 = lat_tan * lat_tan
+    lat_tan4 = lat_tan2 * lat_tan2
+    zone = _utm_zone_number(lat, lon)
+    central_lon_rad = np.radians((zone - 1) * 6 - 180 + 3)
+    n = _UTM_R / np.sqrt(1 - _UTM_E * lat_sin ** 2)
+    c = _UTM_E_P2 * lat_cos ** 2
+    d_lon = (np.radians(lon) - central_lon_rad + np.pi) % (2 * np.pi) - np.pi  # the package's mod_angle
+    a = lat_cos * d_lon
+    a2 = a * a
+    a3 = a2 * a
+    a4 = a3 * a
+    a5 = a4 * a
+    a6 = a5 * a
+    m = _UTM_R * (_UTM_M1 * lat_rad - _UTM_M2 * np.sin(2 * lat_rad) + _UTM_M3 * np.sin(4 * lat_rad) - _UTM_M4 * np.sin(6 * lat_rad))
+    easting = _UTM_K0 * n * (a + a3 / 6 * (1 - lat_tan2 + c) +
+                             a5 / 120 * (5 - 18 * lat_tan2 + lat_tan4 + 72 * c - 58 * _UTM_E_P2)) + 500000
+    northing = _UTM_K0 * (m + n * lat_tan * (a2 / 2 + a4 / 24 * (5 - lat_tan2 + 9 * c + 4 * c ** 2) +
+                                             a6 / 720 * (61 - 58 * lat_tan2 + lat_tan4 + 600 * c - 330 * _UTM_E_P2)))
+    if np.max(lat) < 0:
+        northing = northing + 10000000
+    return easting, northing, zone
+
+
 def _wgs84_to_utm(x_coords, y_coords):
+    lon, lat = np.meshgrid(x_coords, y_coords)
     try:
         import utm  # noqa: PLC0415
-    except Exception as exc:  # noqa: BLE001
-        raise RuntimeError("WGS84 (epsg:4326) grids need the 'utm' package to derive the "
-                           "resolution in metres") from exc
-    lon, lat = np.meshgrid(x_coords, y_coords)
-    east, north, _, _ = utm.from_latlon(lat, lon)
+        east, north, _, _ = utm.from_latlon(lat, lon)
+    except ImportError:
+        east, north, _ = _utm_from_latlon(lat, lon)
     return east.astype(np.float32), north.astype(np.float32)
 
 
