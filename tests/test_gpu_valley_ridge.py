@@ -14,6 +14,21 @@ pytestmark = pytest.mark.gpu
 
 from topo_descriptors_amd import _lib, device as d, shard, topo  # noqa: E402
 
+ROUTES = ["direct", "matrix", "fft"]
+ROUTE_CODE = {"direct": 0, "matrix": 1 + 4, "fft": 2}
+
+
+def _set_route(monkeypatch, route):
+    """The three evaluations of the angle loop: tap by tap in float32 (csrc/valley.hip), the dense product on the matrix pipe
+    that kernels of up to 13 px take by default (csrc/valley_mfma.hip), the FFT that large kernels take.  Both switches are read
+    at every launch."""
+    monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "1" if route == "fft" else "100000")
+    if route == "direct":
+        monkeypatch.setenv("TOPO_AMD_VALLEY_MFMA_MAX_KERNEL", "0")
+    else:
+        monkeypatch.delenv("TOPO_AMD_VALLEY_MFMA_MAX_KERNEL", raising=False)
+
+
 VR_TAGS = ["int_valley_s7", "int_ridge_s7", "int_valley_s5", "int_valley_s17", "int_valley_s9_flat0",
            "int_ridge_s9_flat2", "frac_valley_s7", "frac_valley_s9_sig"]
 
@@ -25,16 +40,16 @@ def _case(g, tag):
     return dem, size, mode, flats, sigma
 
 
-# both evaluations of the angle loop: the direct kernel (what these sizes take by default) and the
-# FFT route that large kernels take (TOPO_AMD_VALLEY_FFT_MIN_KERNEL is read at every launch)
-@pytest.mark.parametrize("route", ["direct", "fft"])
+@pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("tag", VR_TAGS)
 def test_valley_ridge_against_the_reference(golden, tag, route, monkeypatch):
-    monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "1" if route == "fft" else "100000")
+    _set_route(monkeypatch, route)
     g = golden("valley_ridge")
     dem, size, mode, flats, sigma = _case(g, tag)
     norm_ref, dir_ref = g[f"{tag}_norm"], g[f"{tag}_dir"]
     norm, direction = topo.valley_ridge(dem, size, mode, flats, sigma)
+    # the 17 px kernels (24 x 24 canvas, 325 cells with taps) are beyond the matrix-pipe kernel's 240: tap by tap
+    assert d.valley_route() == (0 if route == "matrix" and size == 17 else ROUTE_CODE[route])
     assert norm.dtype == np.float32 and direction.dtype == np.float32 and norm.shape == dem.shape
     scale = float(np.max(np.abs(norm_ref)))
     floor = float(g[f"{tag}_norm_floor"])
@@ -55,9 +70,11 @@ def test_valley_ridge_rejects_unknown_mode_like_the_reference():
         topo.valley_ridge(np.zeros((16, 16), np.float32), 5, "canyon")
 
 
-def test_valley_ridge_row_blocks_are_bit_identical():
+@pytest.mark.parametrize("route", ["direct", "matrix"])
+def test_valley_ridge_row_blocks_are_bit_identical(route, monkeypatch):
     """Row blocks with ghost rows (the reach of the largest rotated kernel) against the single
     block; the standardisation uses the mean / std of the whole DEM in both."""
+    _set_route(monkeypatch, route)
     dem = orc.synthetic_dem(150, 200, seed=9)
     size, flats = 9, [0, 0.15, 0.3]
     kernels = topo._valley_kernels(size, flats)
@@ -83,7 +100,8 @@ def test_valley_ridge_row_blocks_are_bit_identical():
         return np.concatenate(norms), np.concatenate(dirs)
 
     whole = run(1)
-    for nb in (2, 3):
+    assert d.valley_route() == ROUTE_CODE[route]
+    for nb in (2, 3, 7):
         parts = run(nb)
         assert np.array_equal(parts[0], whole[0]) and np.array_equal(parts[1], whole[1]), nb
     # a subset of angles is what the oracle gets too
@@ -100,13 +118,13 @@ def test_device_mean_std_matches_numpy():
     assert abs(stdev - float(np.std(dem, dtype=np.float64))) <= 1e-9 * stdev
 
 
-@pytest.mark.parametrize("route", ["direct", "fft"])
+@pytest.mark.parametrize("route", ROUTES)
 def test_single_rank_shard_valley_ridge(route, monkeypatch):
     """topo_amd_shard_valley_ridge with one rank: moments and standardisation on the device, the
     exchange a no-op, interior / seam split still run.  Against the float64 oracle, and equal to
     the device-block call given the same mean / std (bit for bit on the direct kernel; to rounding by
     FFT, where the interior and the seam strips are transformed separately)."""
-    monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "1" if route == "fft" else "100000")
+    _set_route(monkeypatch, route)
     dem = orc.synthetic_dem(140, 192, seed=21)
     gny, nx = dem.shape
     size, flats = 7, [0, 0.15, 0.3]
@@ -132,7 +150,8 @@ def test_single_rank_shard_valley_ridge(route, monkeypatch):
     n2, a2 = d.DeviceArray(gny, nx), d.DeviceArray(gny, nx)
     d.Block(dev).valley_ridge(taps, ksize, angles, len(flats), mean, stdev, n2, a2)
     d.sync()
-    if route == "direct":
+    assert d.valley_route() == ROUTE_CODE[route]
+    if route != "fft":
         assert np.array_equal(n2.to_host(), norm) and np.array_equal(a2.to_host(), direction)
     else:
         assert np.max(np.abs(n2.to_host() - norm)) <= 1e-5 * scale
@@ -185,6 +204,7 @@ def test_fft_route_equals_the_direct_kernel_to_rounding(monkeypatch):
     dem = orc.synthetic_dem(200, 240, seed=6)
     flats = [0, 0.15, 0.3]
     taps, ksize, ang = topo._valley_ridge_tables(topo._ridge_kernels(33, flats), np.arange(0, 180, 9, dtype=np.float32))
+    monkeypatch.setenv("TOPO_AMD_VALLEY_MFMA_MAX_KERNEL", "0")
     monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "100000")
     norm_d, dir_d = _block_run(dem, taps, ksize, ang, 3, 1)
     monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "1")
@@ -192,3 +212,93 @@ def test_fft_route_equals_the_direct_kernel_to_rounding(monkeypatch):
     scale = float(norm_d.max())
     assert np.max(np.abs(norm_f - norm_d)) <= 2e-5 * scale
     assert np.mean(dir_f == dir_d) >= 0.995
+
+
+@pytest.mark.parametrize("size,planes", [(3, 3), (5, 3), (7, 1), (7, 2), (7, 3), (7, 4), (9, 3), (11, 3), (13, 3)])
+def test_matrix_pipe_against_the_tap_by_tap_kernel_and_float64(size, planes, monkeypatch):
+    """Every kernel size the matrix-pipe route takes, 1 to 4 planes, a partial last filter tile (177 angles): the norm against
+    the float64 oracle and against the float32 chain, the direction through the oracle's per-angle maps.  The split-f16 product
+    is the closer of the two to float64."""
+    flats = [0, 0.1, 0.2, 0.3][:planes]
+    dem = (orc.synthetic_dem(96, 130, seed=size) + np.random.default_rng(size).uniform(0, 1, (96, 130))).astype(np.float32)
+    angles = np.arange(0, 177, 3 if size > 7 else 1, dtype=np.float32)
+    taps, ksize, ang = topo._valley_ridge_tables(topo._valley_kernels(size, flats), angles)
+    _set_route(monkeypatch, "direct")
+    norm_d, dir_d = _block_run(dem, taps, ksize, ang, planes, 1)
+    assert d.valley_route() == 0
+    _set_route(monkeypatch, "matrix")
+    norm_m, dir_m = _block_run(dem, taps, ksize, ang, planes, 1)
+    assert d.valley_route() == 5
+    (norm_ex, _), maps = orc.valley_ridge_exact(dem, size, "valley", flats, angles=angles, return_maps=True)
+    scale = float(np.max(norm_ex))
+    err_m, err_d = float(np.max(np.abs(norm_m - norm_ex))), float(np.max(np.abs(norm_d - norm_ex)))
+    assert err_m <= 2e-6 * scale and err_m <= 1.5 * err_d + 1e-7 * scale, (err_m, err_d, scale)
+    index = np.searchsorted(angles, dir_m)
+    assert np.all(angles[index] == dir_m)
+    assert np.max(np.max(maps, axis=0) - np.take_along_axis(maps, index[None], axis=0)[0]) <= 1e-5 * scale
+    assert np.mean(dir_m == dir_d) >= 0.99
+
+
+def test_matrix_pipe_hands_non_finite_windows_to_the_tap_by_tap_kernel(monkeypatch):
+    """NaN, +-inf and a sample beyond the f16 range after standardising (3e9 m): exactly the pixels whose kernel footprint holds
+    one of them are evaluated tap by tap (their bits are the direct route's), every other pixel by the matrix pipe (its bits are
+    those of the same DEM without the specials), nothing is left marked, and row blocks keep the single block's bits."""
+    size, flats = 7, [0, 0.15, 0.3]
+    clean = (orc.synthetic_dem(150, 210, seed=5) + np.random.default_rng(1).uniform(0, 1, (150, 210))).astype(np.float32)
+    dem = clean.copy()
+    dem[40, 50] = np.nan
+    dem[100:103, 150] = np.inf
+    dem[0, 0] = np.nan
+    dem[149, 209] = -np.inf
+    dem[70, 100] = 3e9
+    dem[31, 64] = np.nan            # on a tile seam of the matrix-pipe kernel (32 rows x 64 columns)
+    special = ~np.isfinite(dem) | (dem > 1e9)
+    angles = np.arange(0, 180, dtype=np.float32)
+    taps, ksize, ang = topo._valley_ridge_tables(topo._valley_kernels(size, flats), angles)
+    mean, stdev = float(clean.mean()), float(clean.std())
+
+    def run(field, nblocks=1):
+        gny, nx = field.shape
+        up, down = shard.halo_rows(_lib.DESC_VALLEY_RIDGE, int(ksize.max()))
+        norms, dirs = [], []
+        for row0, rows in shard.split_rows(gny, nblocks):
+            lo, hi = max(0, row0 - up), min(gny, row0 + rows + down)
+            dev = d.DeviceArray.from_host(field[lo:hi])
+            n, a = d.DeviceArray(rows, nx), d.DeviceArray(rows, nx)
+            d.Block(dev, row0=lo, gny=gny).valley_ridge(taps, ksize, ang, 3, mean, stdev, n, a, out_row0=row0, out_rows=rows)
+            d.sync()
+            norms.append(n.to_host())
+            dirs.append(a.to_host())
+            for x in (dev, n, a):
+                x.free()
+        return np.concatenate(norms), np.concatenate(dirs)
+
+    _set_route(monkeypatch, "direct")
+    norm_d, dir_d = run(dem)
+    _set_route(monkeypatch, "matrix")
+    norm_m, dir_m = run(dem)
+    assert d.valley_route() == 5
+    norm_c, dir_c = run(clean)
+    assert not np.any(norm_m == -1.0)
+    # the footprint: the cells of the 10 x 10 window in which some kernel has a tap, around every special sample
+    kmax = int(ksize.max())
+    live = np.zeros((kmax, kmax), bool)
+    pos = 0
+    for ks in ksize:
+        t = taps[pos:pos + ks * ks * 4].reshape(ks, ks, 4)[:, :, :3]
+        sh = kmax // 2 - ks // 2
+        live[sh:sh + ks, sh:sh + ks] |= np.any(t != 0, axis=2)
+        pos += ks * ks * 4
+    touched = np.zeros(dem.shape, bool)
+    for y, x in zip(*np.nonzero(special)):
+        for ky, kx in zip(*np.nonzero(live)):
+            oy, ox = y - (ky - kmax // 2), x - (kx - kmax // 2)   # the pixel whose window cell (ky, kx) is (y, x)
+            if 0 <= oy < dem.shape[0] and 0 <= ox < dem.shape[1]:
+                touched[oy, ox] = True
+    assert touched.sum() > 200
+    same = lambda a, b: np.array_equal(a, b, equal_nan=True)  # noqa: E731
+    assert same(norm_m[touched], norm_d[touched]) and same(dir_m[touched], dir_d[touched])
+    assert same(norm_m[~touched], norm_c[~touched]) and same(dir_m[~touched], dir_c[~touched])
+    for nb in (2, 5):
+        norm_b, dir_b = run(dem, nb)
+        assert same(norm_b, norm_m) and same(dir_b, dir_m), nb

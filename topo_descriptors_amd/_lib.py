@@ -33,6 +33,7 @@ SIGNATURES = {
     "topo_amd_sync": (C.c_int, []),
     "topo_amd_release_host_planes": (C.c_int, []),
     "topo_amd_host_chunks": (C.c_int, [_i32p]),
+    "topo_amd_valley_route": (C.c_int, [_i32p]),
     "topo_amd_dem_changed": (C.c_int, [_vp, C.c_size_t]),
     "topo_amd_raster_scan_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_uint64), _f32p]),

@@ -13,7 +13,7 @@ NGROUPS = 16  # the per-size disc kernels: one source (disc_wave_group.hip), com
 UNITS = [("sx.hip", [], "sx.o"), ("gauss.hip", [], "gauss.o")] + \
         [("disc_wave_group.hip", [f"-DTOPO_GROUP={g}", f"-DTOPO_NGROUPS={NGROUPS}"], f"disc_wave_group{g}.o") for g in range(NGROUPS)] + \
         [(s, [], s.replace(".hip", ".o")) for s in ("disc_pair.hip", "disc.hip", "disc_wave.hip", "disc_big.hip", "valley.hip",
-                                                    "valley_fft.hip", "capi.hip")]
+                                                    "valley_mfma.hip", "valley_fft.hip", "capi.hip")]
 SOURCES = sorted({u[0] for u in UNITS})
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -532,6 +532,7 @@ int gradient_shard_halo(double sigma, double sig_ratio) {
 // host-buffer call spends most of its time on (tools/ubench/page_touch.cpp: 92 ms per GiB against 19 ms
 // for the copy itself).  prefault() asks for huge pages and touches the array from a few threads
 // while the upload and the kernels run; ready() joins them before the first download.
+thread_local int t_valley_route = 0;  // the evaluation the calling thread's last valley / ridge call took (topo_amd_valley_route)
 thread_local int t_host_chunks = 0;  // row chunks of the calling thread's last host-buffer call (topo_amd_host_chunks)
 struct HostRun {
     std::vector<void*> bufs;
@@ -808,6 +809,9 @@ int run_pipelined(HostRun& run, const float* dem, float* d_in, int ny, int nx, i
 }
 
 }  // namespace
+
+void note_valley_route(int route) { t_valley_route = route; }
+
 }  // namespace topo
 
 using namespace topo;
@@ -1017,6 +1021,12 @@ int topo_amd_release_host_planes(void) {
     }
     c.host_planes.clear();
     c.host_plane_bytes.clear();
+    return TOPO_AMD_OK;
+}
+
+int topo_amd_valley_route(int* route) {
+    TOPO_REQUIRE(route != nullptr, "valley_route: NULL output");
+    *route = t_valley_route;
     return TOPO_AMD_OK;
 }
 

@@ -209,6 +209,15 @@ int launch_valley_ridge_fft(const Block& b, const float* taps, const int32_t* ks
                             float* dir_out);
 void valley_fft_release();  // destroys the cached FFT plans (topo_amd_shutdown)
 int valley_ridge_reach(const int32_t* ksize, int n_angles, int* above, int* below);
+void note_valley_route(int route);  // what topo_amd_valley_route reports for the calling thread (capi.hip)
+// the same on the matrix pipe for rotated kernels of up to kValleyMfmaMaxKernel cells a side with at most 240 cells that hold a
+// tap at any angle (valley_mfma.hip; *done = 0: not such a case, nothing launched); leaves the pixels it cannot do marked
+// norm = -1 and their tiles (kValleyMfmaTileRows x 64, anchored at out_row0) flagged
+constexpr int kValleyMfmaMaxKernel = 25;
+constexpr int kValleyMfmaTileRows = 32;
+int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles,
+                             int n_planes, int kmax, double mean, double stdev, float* norm_out, float* dir_out,
+                             const int** flags_out, int* flag_cols, int* done);
 int launch_mean_std(const float* in, size_t count, double* mean, double* stdev);
 int launch_moments(const float* in, size_t count, double pivot, bool pivot_is_first_sample, double* sum, double* sumsq);
 int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles,

@@ -22,6 +22,7 @@
 // 64 px and more are handed to the FFT route (valley_fft.hip), as are those too large for the LDS tile.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -37,6 +38,7 @@ constexpr int kRows = kTileH / (kThreads / 64);  // output rows per thread
 // side of the largest rotated kernel from which the FFT path takes over (TOPO_AMD_VALLEY_FFT_MIN_KERNEL)
 constexpr int kValleyFftFrom = 64;  // measured: direct 911 ms / FFT 1818 ms at 47 px, 6216 / 1818 at 95 px (8192^2)
 typedef float tap4 __attribute__((ext_vector_type(4)));  // one tap: the weights of up to four planes
+static_assert(kTileW == 64 && kValleyMfmaTileRows % kTileH == 0, "the repair pass maps its tiles onto valley_mfma.hip's");
 
 struct VrArgs {
     const float* in;
@@ -51,6 +53,8 @@ struct VrArgs {
     int out_row0, out_rows;
     int kmax, stride, rows_l, cols_l;
     float mean, stdev;
+    const int* repair;  // not NULL: behind valley_mfma.hip - only the tiles it flagged, and in them only the pixels it marked norm = -1
+    int repair_cols;
 };
 
 template <int NP>
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(kThreads) void valley_ridge_kernel(VrArgs p) {
     const int ox0 = blockIdx.x * kTileW;
     const int oy0 = p.out_row0 + blockIdx.y * kTileH;
     const int reach = p.kmax / 2;  // "same" centring: a kernel of side K starts K / 2 before the pixel
+    if (p.repair != nullptr && p.repair[(blockIdx.y / (kValleyMfmaTileRows / kTileH)) * p.repair_cols + blockIdx.x] == 0) return;
 
     for (int r = wave; r < p.rows_l; r += kThreads / 64) {
         const int gy = oy0 - reach + r;
@@ -130,6 +135,7 @@ __global__ __launch_bounds__(kThreads) void valley_ridge_kernel(VrArgs p) {
         const int oy = oy0 + wave + 4 * r;
         if (oy >= p.out_row0 + p.out_rows) continue;
         const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
+        if (p.repair != nullptr && p.norm[o] != -1.0f) continue;
         p.norm[o] = fmaxf(best[r], 0.0f);  // clip(min=0), topo.py:446
         p.dir[o] = best_angle[r];
     }
@@ -257,9 +263,21 @@ int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize,
     // large kernels: by FFT (valley_fft.hip), whose cost does not depend on the kernel size
     const char* e = std::getenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL");
     const int fft_from = e && *e ? std::atoi(e) : kValleyFftFrom;
+    note_valley_route(kmax >= fft_from || lds > 160 * 1024 ? 2 : 0);
     if (kmax >= fft_from || lds > 160 * 1024)
         return launch_valley_ridge_fft(b, taps, ksize, angles, n_angles, n_planes, kmax, mean, stdev, norm_out,
                                        dir_out);
+    // small kernels: the dense product on the matrix pipe (valley_mfma.hip); this kernel then only visits the tiles in which
+    // that one met a non-finite sample
+    e = std::getenv("TOPO_AMD_VALLEY_MFMA_MAX_KERNEL");
+    const int mfma_upto = e && *e ? std::min(std::atoi(e), kValleyMfmaMaxKernel) : kValleyMfmaMaxKernel;
+    if (kmax <= mfma_upto) {
+        int done = 0;
+        TOPO_TRY(launch_valley_ridge_mfma(b, taps, ksize, angles, n_angles, n_planes, kmax, mean, stdev, norm_out, dir_out,
+                                          &a.repair, &a.repair_cols, &done));
+        if (!done) a.repair = nullptr;
+        if (done) note_valley_route(1 + 4);
+    }
     // compress: the non-zero taps of each angle, with their offset in the LDS tile (smaller kernels
     // sit centred inside the reach staged for the largest one)
     std::vector<int> meta((size_t)2 * n_angles);

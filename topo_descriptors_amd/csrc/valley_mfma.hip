@@ -1,0 +1,411 @@
+// K7m: valley / ridge index on the matrix pipe, for rotated kernels of up to kValleyMfmaMaxKernel cells a side.
+//
+// The same quantity as valley.hip (reference topo.py:431-447; the host's tables are the plane sums of the rotated
+// kernels, flipped: a correlation): per pixel, the largest response over the angles of the maximum over the planes,
+// and the angle it came from.  valley.hip evaluates the non-zero taps one v_fma_f32 each and runs at the rate at which
+// the chip issues that instruction (39.9 T FMA/s: 523 ms for 180 angles x 3 planes of the 7 px kernel on 32768^2).
+// Here the window of a pixel is the K dimension of a product
+//     response[filter, pixel] = sum_k taps[filter, k] * z[pixel, k]
+// with M = 32 filters ((angle, plane) pairs), N = 32 pixels (32 neighbours in a row) and K = 16 cells per
+// v_mfma_f32_32x32x16_f16.  K runs over the LIVE cells only: the cells of the largest rotated canvas in which some
+// filter has a non-zero tap - 53 of the 10 x 10 cells of the 7 px kernel (the reference masks the ring its spline
+// rotation contaminates), 4 K steps.  A filter's own zeros inside the live set are multiplied: 64 slots against 36
+// non-zero taps, on a pipe that is 32 x as fast as the vector ALU.
+//
+// float32 accuracy from f16 operands: z = hi + lo and tap = hi + lo (two f16 each, 22 bits), three products
+// hi*hi + hi*lo + lo*hi accumulated in float32; the dropped lo*lo is 2^-22 of a term (measured: closer to the float64
+// evaluation than valley.hip's float32 chain).  z is the standardised DEM (|z| of a few units), so no reference value is
+// subtracted and a result does not depend on the tile a pixel falls in: row blocks keep the bits of the single block.
+//
+// Operands.  A (taps): laid out by the host as the instruction wants it, 1 KB per (filter tile, K step, part), streamed
+// through LDS in groups of filter tiles (double-buffered global_load ... lds, one barrier per group; the four waves of a
+// block share every fragment).  B (pixels): built ONCE per pixel tile from the f16 image of the block's DEM tile in LDS
+// (ds_read_u16 at the live cells' offsets, which the kernel keeps in LDS: lanes 32-63 supply the second eight cells of a
+// K step) and kept in registers for all the filters: 2 * KS * 4 registers per pixel tile.  The slots behind the last
+// live cell re-read the first one against zero taps, so a non-finite sample reaches exactly the pixels whose live
+// window holds it.  Two blocks of four waves share a CU and drift apart: one's epilogues run under the other's MFMAs.
+//
+// Result layout of the instruction: a lane holds, for pixel column (lane & 31), the 16 filters 8 q + 4 (lane >> 5) + i.
+// The host puts the planes of an angle side by side in those 16 and the angles in rising order down the tiles: the
+// maximum over the planes is one v_max3_f32 in a lane, the running best with its angle two registers per pixel tile,
+// and "the first angle that reaches the maximum keeps it" (topo.py:438) is the strict comparison plus one exchange
+// between the two lane halves at the end.
+//
+// Pixels whose live window holds a non-finite sample (or one beyond the f16 range after standardising: |z| > 65504)
+// come out non-finite for every filter - 0 * inf - and are handed to valley.hip's kernel: this kernel stores norm = -1
+// (the norm proper is clipped at 0) and raises its tile's flag; the launcher then runs the direct kernel over the
+// flagged tiles, which rewrites exactly the marked pixels.  Which pixels those are depends on their own window alone.
+#include "common.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace topo {
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 4;  // one per SIMD
+constexpr int kThreads = 64 * kWaves;
+constexpr int kTW = 64;                   // pixel columns of a block: two pixel tiles of 32
+constexpr int kTH = kValleyMfmaTileRows;  // pixel rows of a block: eight per wave
+constexpr int kPitch = kTW + kValleyMfmaMaxKernel - 1;  // halfs a row of the LDS image (even)
+constexpr int kFragBytes = 1024;          // one operand fragment: 64 lanes x 8 halfs
+constexpr int kMaxSteps = 15;             // K steps the kernel is built for (240 live cells)
+static_assert(kPitch % 2 == 0, "the LDS image's rows start on a dword");
+
+__host__ __device__ constexpr int pixel_tiles(int ks) { return ks <= 8 ? 2 : 1; }  // a wave holds at a time
+__host__ __device__ constexpr int group_tiles(int ks) {                             // per LDS stage: at most 30 KB
+    return ks <= 3 ? 4 : ks <= 5 ? 3 : ks <= 7 ? 2 : 1;
+}
+__host__ __device__ constexpr int image_bytes(int w) {
+    return ((kTH + w - 1) * kPitch * 2 * 2 + kMaxSteps * 16 * 4 + kFragBytes - 1) / kFragBytes * kFragBytes;
+}
+
+struct VmArgs {
+    const float* in;
+    float* norm;
+    float* dir;
+    const unsigned char* atab;  // [group][tile in group][K step][hi, lo][64 lanes x 16 bytes]
+    const int* koff;            // [K step][16]: the LDS distance (halfs) of the step's cells from the window's first cell
+    const float* angles;
+    int* flags;                 // one per block: some pixel left to the direct kernel
+    int n_angles, n_tiles, n_groups;
+    int w;                      // side of the window = of the largest rotated canvas
+    int in_rows, in_row0, gny, nx;
+    int out_row0, out_rows;
+    float mean, stdev;
+};
+
+// the maximum over the planes of an angle.  Plain fmaxf, which returns the other operand for a NaN like valley.hip's: no
+// inline assembly here - the compiler's hazard recogniser does not look into it, and a vector instruction that reads an
+// MFMA result needs up to 11 wait states behind the MFMA (with v_max3_f32 in an asm statement the single-accumulator
+// form of this kernel read results that were not there yet).
+__device__ __forceinline__ float max_planes(const f32x16& acc, int first, int np) {
+    float m = acc[first];
+    for (int q = 1; q < np; ++q) m = __builtin_fmaxf(m, acc[first + q]);
+    return m;
+}
+
+template <int KS, int NP>
+__global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
+    constexpr int P = pixel_tiles(KS);
+    constexpr int GT = group_tiles(KS);
+    constexpr int GROUP_BYTES = GT * KS * 2 * kFragBytes;
+    constexpr int UNITS = (kTH / kWaves) * (2 / P);
+    constexpr int APH = 16 / NP;  // angles in a lane's 16 results
+    constexpr int APT = 2 * APH;  // angles of a filter tile
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int rows_l = kTH + p.w - 1, cols_l = kTW + p.w - 1;
+    const int plane = rows_l * kPitch;  // halfs: the hi plane, then the lo plane, then the cells' offsets
+    _Float16* img = reinterpret_cast<_Float16*>(lds);
+    int* koff = reinterpret_cast<int*>(lds + (size_t)plane * 4);
+    unsigned char* abuf = lds + image_bytes(p.w);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = lane & 31;
+    const int h = lane >> 5;
+    const int ox0 = blockIdx.x * kTW;
+    const int oy0 = p.out_row0 + blockIdx.y * kTH;
+    const int reach = p.w / 2;  // "same" centring: a kernel of side K starts K / 2 before the pixel
+
+    // the stream of tap fragments: group g of the table into buffer `buf`, fragment by fragment over the waves
+    auto issue_group = [&](int g, int buf) {
+        const unsigned char* src = p.atab + (size_t)g * GROUP_BYTES + lane * 16;
+        unsigned char* dst = abuf + buf * GROUP_BYTES;
+#pragma unroll
+        for (int f = wave; f < GT * KS * 2; f += kWaves)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * kFragBytes),
+                                             (__attribute__((address_space(3))) void*)(dst + f * kFragBytes + lane * 16), 16, 0,
+                                             0);
+    };
+    issue_group(0, 0);
+
+    // the block's DEM tile, standardised the way numpy does it ((x - mean) / std in float32), zero outside the DEM
+    // (the reference zero-pads the standardised field), as two f16 planes
+    for (int r = wave; r < rows_l; r += kWaves) {
+        const int gy = oy0 - reach + r;
+        const int by = gy - p.in_row0;
+        const bool row_ok = gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
+        for (int c = lane; c < cols_l; c += 64) {
+            const int gx = ox0 - reach + c;
+            float v = 0.0f;
+            if (row_ok && gx >= 0 && gx < p.nx) v = (p.in[(size_t)by * p.nx + gx] - p.mean) / p.stdev;
+            const _Float16 hi = (_Float16)v;
+            img[r * kPitch + c] = hi;
+            img[plane + r * kPitch + c] = (_Float16)(v - (float)hi);
+        }
+    }
+    for (int i = threadIdx.x; i < KS * 16; i += kThreads) koff[i] = p.koff[i];
+
+    int it = 0;  // position in the stream: buffer it & 1 holds group it % n_groups
+#pragma unroll 1
+    for (int u = 0; u < UNITS; ++u) {
+        const int row = wave + kWaves * (P == 2 ? u : u >> 1);
+        const int col0 = P == 2 ? 0 : 32 * (u & 1);
+        f16x8 bh[P][KS], bl[P][KS];
+        float best[P];
+        int bidx[P];
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            best[pt] = -INFINITY;
+            bidx[pt] = 0;
+        }
+        if (u == 0) __syncthreads();  // the image tile and the offsets are written
+        {
+            const _Float16* src = img + row * kPitch + col0 + n;
+            const int* ko = koff + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const _Float16* at = src + ko[s * 16 + e];
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) {
+                        bh[pt][s][e] = at[32 * pt];
+                        bl[pt][s][e] = at[plane + 32 * pt];
+                    }
+                }
+        }
+#pragma unroll 1
+        for (int g = 0; g < p.n_groups; ++g, ++it) {
+            // my fragments of this group have landed; behind the barrier everybody's have, and nobody reads the other buffer any more
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue_group(g + 1 == p.n_groups ? 0 : g + 1, (it + 1) & 1);
+            const unsigned char* ab = abuf + (it & 1) * GROUP_BYTES + lane * 16;
+            // the fragments of K step j + 1 are on their way while the products of step j issue
+            f16x8 ah = *reinterpret_cast<const f16x8*>(ab);
+            f16x8 al = *reinterpret_cast<const f16x8*>(ab + kFragBytes);
+#pragma unroll
+            for (int tt = 0; tt < GT; ++tt) {
+                const int tile = g * GT + tt;
+                if (tile >= p.n_tiles) break;  // (wave-uniform; the stream's last group is padded with empty tiles)
+                f32x16 acc[P];
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[pt][v] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int j = tt * KS + s;
+                    f16x8 nh = ah, nl = al;
+                    if (j + 1 < GT * KS) {
+                        nh = *reinterpret_cast<const f16x8*>(ab + ((j + 1) * 2) * kFragBytes);
+                        nl = *reinterpret_cast<const f16x8*>(ab + ((j + 1) * 2 + 1) * kFragBytes);
+                    }
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[pt][s], acc[pt], 0, 0, 0);
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[pt][s], acc[pt], 0, 0, 0);
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[pt][s], acc[pt], 0, 0, 0);
+                    ah = nh;
+                    al = nl;
+                }
+                const int first_angle = tile * APT + h * APH;
+                if ((tile + 1) * APT <= p.n_angles) {  // a full tile (wave-uniform)
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                        for (int s = 0; s < APH; ++s) {
+                            const float m = max_planes(acc[pt], s * NP, NP);
+                            const bool better = m > best[pt];  // strict: the first angle that reaches the maximum keeps it
+                            best[pt] = __builtin_fmaxf(best[pt], m);  // (a NaN m leaves it, like the comparison)
+                            bidx[pt] = better ? first_angle + s : bidx[pt];
+                        }
+                } else {
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                        for (int s = 0; s < APH; ++s) {
+                            const float m = max_planes(acc[pt], s * NP, NP);
+                            const bool better = first_angle + s < p.n_angles && m > best[pt];
+                            best[pt] = better ? m : best[pt];
+                            bidx[pt] = better ? first_angle + s : bidx[pt];
+                        }
+                }
+            }
+        }
+        // lanes l and l + 32 hold different angles of the same pixel: the larger one, the earlier angle on a tie
+        bool unfinished = false;
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            const float ob = __shfl_xor(best[pt], 32);
+            const int oi = __shfl_xor(bidx[pt], 32);
+            const bool take = ob > best[pt] || (ob == best[pt] && oi < bidx[pt]);
+            const float b = take ? ob : best[pt];
+            const int bi = take ? oi : bidx[pt];
+            const int ox = ox0 + col0 + 32 * pt + n;
+            const int oy = oy0 + row;
+            if (ox >= p.nx || oy >= p.out_row0 + p.out_rows) continue;
+            const bool finite = fabsf(b) < INFINITY;
+            unfinished = unfinished || !finite;
+            const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
+            if (h == 0)
+                p.norm[o] = finite ? fmaxf(b, 0.0f) : -1.0f;  // clip(min=0), topo.py:446; -1: left to the direct kernel
+            else
+                p.dir[o] = finite ? p.angles[bi] : 0.0f;
+        }
+        if (unfinished) p.flags[blockIdx.y * gridDim.x + blockIdx.x] = 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream's last, unused group: not into the LDS of the next block
+}
+
+// float -> f16 bits, round to nearest even (the host builds the tap operands; no _Float16 arithmetic in host code)
+uint16_t f16_bits(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+    if (x < 0x38800000u) {  // below 2^-14: a subnormal half, in units of 2^-24
+        float a;
+        std::memcpy(&a, &x, 4);
+        return (uint16_t)(sign | (uint16_t)std::nearbyintf(a * 16777216.0f));  // 1024 = the smallest normal, as it should
+    }
+    const uint32_t r = x + 0xfffu + ((x >> 13) & 1u);
+    if (r >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);
+    return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
+}
+
+float f16_value(uint16_t b) {
+    const int e = (b >> 10) & 31, m = b & 1023;
+    float v;
+    if (e == 0)
+        v = std::ldexp((float)m, -24);
+    else if (e == 31)
+        v = m ? NAN : INFINITY;
+    else
+        v = std::ldexp((float)(m | 1024), e - 25);
+    return (b & 0x8000u) ? -v : v;
+}
+
+template <int KS, int NP>
+int launch_ks(const VmArgs& a, dim3 grid) {
+    const int lds = image_bytes(a.w) + 2 * group_tiles(KS) * KS * 2 * kFragBytes;
+    TOPO_HIP(hipFuncSetAttribute((const void*)valley_mfma_kernel<KS, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((valley_mfma_kernel<KS, NP>), grid, dim3(kThreads), lds, ctx().compute, a);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+template <int KS>
+int launch_np(const VmArgs& a, dim3 grid, int n_planes) {
+    switch (n_planes) {
+        case 1: return launch_ks<KS, 1>(a, grid);
+        case 2: return launch_ks<KS, 2>(a, grid);
+        case 3: return launch_ks<KS, 3>(a, grid);
+        default: return launch_ks<KS, 4>(a, grid);
+    }
+}
+
+}  // namespace
+
+// The matrix-pipe evaluation over the block.  *done = 0: not a case for it (no live cell, or more than 240), nothing
+// launched.  Otherwise *flags_out / *flag_cols describe the tiles (kValleyMfmaTileRows rows x 64 columns, anchored at
+// out_row0) in which it left pixels marked norm = -1 for the direct kernel.
+int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles,
+                             int n_planes, int kmax, double mean, double stdev, float* norm_out, float* dir_out,
+                             const int** flags_out, int* flag_cols, int* done) {
+    *done = 0;
+    TOPO_REQUIRE(kmax >= 1 && kmax <= kValleyMfmaMaxKernel, "valley_ridge (matrix pipe): kernel side %d", kmax);
+    const int W = kmax;  // the window = the largest canvas (a smaller one sits inside it: it starts ks / 2 before the pixel)
+    // the canvases of all (angle, plane) filters in the common window, and the cells in which any of them has a tap
+    std::vector<float> canvas((size_t)n_angles * n_planes * W * W, 0.0f);
+    std::vector<char> live_cell((size_t)W * W, 0);
+    const float* src = taps;
+    for (int ang = 0; ang < n_angles; ++ang) {
+        const int ks = ksize[ang];
+        const int shift = W / 2 - ks / 2;
+        for (int ky = 0; ky < ks; ++ky)
+            for (int kx = 0; kx < ks; ++kx)
+                for (int q = 0; q < n_planes; ++q) {
+                    const float t = src[((size_t)ky * ks + kx) * 4 + q];
+                    if (t == 0.0f) continue;
+                    const size_t cell = (size_t)(ky + shift) * W + kx + shift;
+                    canvas[((size_t)ang * n_planes + q) * W * W + cell] = t;
+                    live_cell[cell] = 1;
+                }
+        src += (size_t)ks * ks * 4;
+    }
+    std::vector<int> live;
+    for (int c = 0; c < W * W; ++c)
+        if (live_cell[c]) live.push_back(c);
+    const int KS = ((int)live.size() + 15) / 16;
+    if (KS < 1 || KS > kMaxSteps) return TOPO_AMD_OK;
+    std::vector<int> koff((size_t)KS * 16);
+    for (int k = 0; k < KS * 16; ++k) {
+        const int c = live[k < (int)live.size() ? k : 0];  // behind the last live cell: the first one again, against zero taps
+        koff[k] = (c / W) * kPitch + c % W;
+    }
+    const int aph = 16 / n_planes, apt = 2 * aph;
+    const int n_tiles = (n_angles + apt - 1) / apt;
+    const int gt = group_tiles(KS);
+    const int n_groups = (n_tiles + gt - 1) / gt;
+    const size_t frag_halfs = kFragBytes / 2;
+    std::vector<uint16_t> atab((size_t)n_groups * gt * KS * 2 * frag_halfs, 0);
+    for (int ang = 0; ang < n_angles; ++ang) {
+        const int tile = ang / apt, hrow = (ang % apt) / aph, slot = (ang % apt) % aph;
+        for (int q = 0; q < n_planes; ++q) {
+            const float* cv = canvas.data() + ((size_t)ang * n_planes + q) * W * W;
+            const int v = slot * n_planes + q;             // the result register of the lane half
+            const int m = 8 * (v / 4) + 4 * hrow + v % 4;  // its row of the filter tile
+            for (int k = 0; k < (int)live.size(); ++k) {
+                const float t = cv[live[k]];
+                if (t == 0.0f) continue;
+                const uint16_t hi = f16_bits(t);
+                const uint16_t lo = f16_bits(t - f16_value(hi));
+                const int s = k / 16, kh = (k % 16) / 8, e = k % 8;  // K step, K half = lane half of the A operand, element
+                const size_t frag = ((size_t)tile * KS + s) * 2;
+                const size_t at = (size_t)(m + 32 * kh) * 8 + e;
+                atab[frag * frag_halfs + at] = hi;
+                atab[(frag + 1) * frag_halfs + at] = lo;
+            }
+        }
+    }
+    void *d_atab = nullptr, *d_koff = nullptr, *d_angles = nullptr, *d_flags = nullptr;
+    TOPO_TRY(upload_table(4, atab.data(), atab.size() * sizeof(uint16_t), &d_atab));
+    TOPO_TRY(upload_table(5, koff.data(), koff.size() * sizeof(int), &d_koff));
+    TOPO_TRY(upload_table(2, angles, (size_t)n_angles * sizeof(float), &d_angles));
+    dim3 grid((b.nx + kTW - 1) / kTW, (b.out_rows + kTH - 1) / kTH);
+    const size_t flag_bytes = (size_t)grid.x * grid.y * sizeof(int);
+    TOPO_TRY(workspace(3, flag_bytes, &d_flags));
+    TOPO_HIP(hipMemsetAsync(d_flags, 0, flag_bytes, ctx().compute));
+    VmArgs a{};
+    a.in = b.in;
+    a.norm = norm_out;
+    a.dir = dir_out;
+    a.atab = (const unsigned char*)d_atab;
+    a.koff = (const int*)d_koff;
+    a.angles = (const float*)d_angles;
+    a.flags = (int*)d_flags;
+    a.n_angles = n_angles;
+    a.n_tiles = n_tiles;
+    a.n_groups = n_groups;
+    a.w = W;
+    a.in_rows = b.in_rows;
+    a.in_row0 = b.in_row0;
+    a.gny = b.gny;
+    a.nx = b.nx;
+    a.out_row0 = b.out_row0;
+    a.out_rows = b.out_rows;
+    a.mean = (float)mean;
+    a.stdev = (float)stdev;
+    *flags_out = (const int*)d_flags;
+    *flag_cols = (int)grid.x;
+    *done = 1;
+    switch (KS) {
+#define TOPO_KS(k) case k: return launch_np<k>(a, grid, n_planes);
+        TOPO_KS(1) TOPO_KS(2) TOPO_KS(3) TOPO_KS(4) TOPO_KS(5) TOPO_KS(6) TOPO_KS(7) TOPO_KS(8) TOPO_KS(9) TOPO_KS(10)
+        TOPO_KS(11) TOPO_KS(12) TOPO_KS(13) TOPO_KS(14) TOPO_KS(15)
+#undef TOPO_KS
+    }
+    return TOPO_AMD_OK;
+}
+
+}  // namespace topo

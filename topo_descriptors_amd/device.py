@@ -122,6 +122,14 @@ def host_chunks():
     return n.value
 
 
+def valley_route():
+    """The evaluation the calling thread's last valley / ridge call took: 0 tap by tap (``csrc/valley.hip``), 1 matrix pipe
+    (``csrc/valley_mfma.hip``), 2 FFT; + 4 when the tap-by-tap kernel followed the matrix pipe over its flagged tiles."""
+    n = C.c_int32()
+    _lib.check(_lib.lib().topo_amd_valley_route(C.byref(n)), "valley_route")
+    return n.value
+
+
 def dem_changed(array):
     """Tell the library that ``array`` (a :class:`DeviceArray`) was written by something other than the library."""
     _lib.check(_lib.lib().topo_amd_dem_changed(array.ptr, array.nbytes), "dem_changed")
