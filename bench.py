@@ -316,16 +316,36 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
           "sx_multi_kernel<8>", per=8)
     for a in fan[4:]:
         a.free()
-    # valley index at 200 m (7 px): 180 angles x 3 plane sums of rotated kernels in one pass
-    # (first version, direct float32 evaluation)
+    # valley index at 200 m (7 px): 180 angles x 3 plane sums of rotated kernels in one pass.  Round 6: a dense
+    # product on the matrix pipe over the 53 cells of the 10 x 10 canvas that hold a tap at any angle (csrc/valley_mfma.hip);
+    # the tap-by-tap float32 kernel of rounds 2 - 5 (csrc/valley.hip) is timed beside it
     from topo_descriptors_amd import topo
     mean, stdev = d.mean_std(dem)
     taps, ksize, angles = topo._valley_ridge_tables(topo._valley_kernels(7, [0, 0.15, 0.3]),
                                                     np.arange(0, 180, dtype=np.float32))
     st = time_kernel(lambda: blk.valley_ridge(taps, ksize, angles, 3, mean, stdev, o1, o2), REPS, d)
-    entry("valley_ridge_s7", st, 12, "valley_ridge_kernel<3>")
+    route = d.valley_route()
+    entry("valley_ridge_s7", st, 12, "valley_mfma_kernel<4, 3> (v_mfma_f32_32x32x16_f16, split-f16 operands: 3 products, 4 K steps of 16 "
+          "live cells, 18 tiles of 10 angles x 3 planes) + valley_ridge_kernel<3> over the tiles with non-finite samples (none here)"
+          if route & 1 else "valley_ridge_kernel<3>")
+    out["valley_ridge_s7"]["route"] = route
+    kmax = int(ksize.max())
+    live = np.zeros((kmax, kmax), bool)
+    pos = 0
+    for ks in ksize:
+        sh = kmax // 2 - ks // 2
+        live[sh:sh + ks, sh:sh + ks] |= np.any(taps[pos:pos + ks * ks * 4].reshape(ks, ks, 4)[:, :, :3] != 0, axis=2)
+        pos += ks * ks * 4
+    mfmas = (px / 32) * 18 * ((int(live.sum()) + 15) // 16) * 3          # per launch; 32 x 32 x 16 multiply-adds each
+    out["valley_ridge_s7"]["live_cells"] = int(live.sum())
+    out["valley_ridge_s7"]["mfma_TFLOP_per_s_executed"] = round(mfmas * 32768 / st["median"] / 1e9, 1)
+    out["valley_ridge_s7"]["mfma_frac_of_2500_TFLOP_per_s"] = round(mfmas * 32768 / st["median"] / 1e9 / 2500.0, 3)
+    os.environ["TOPO_AMD_VALLEY_MFMA_MAX_KERNEL"] = "0"   # read at every launch
+    st = time_kernel(lambda: blk.valley_ridge(taps, ksize, angles, 3, mean, stdev, o1, o2), max(2, REPS // 3), d)
+    del os.environ["TOPO_AMD_VALLEY_MFMA_MAX_KERNEL"]
+    entry("valley_ridge_s7_tap_by_tap", st, 12, "valley_ridge_kernel<3> (the float32 chain on the non-zero taps: rounds 2 - 5)")
     nonzero = int(np.any(taps.reshape(-1, 4)[:, :3] != 0, axis=1).sum())  # the taps the kernel evaluates
-    out["valley_ridge_s7"]["GFMA_per_s_executed"] = round(px * nonzero * 3 / st["median"] / 1e6, 0)
+    out["valley_ridge_s7_tap_by_tap"]["GFMA_per_s_executed"] = round(px * nonzero * 3 / st["median"] / 1e6, 0)
 
     # the same TPI on fractional elevations: every tile runs the integer pass plus the float
     # chain on the fractional parts and goes through the per-row scratch planes (two passes)

@@ -35,6 +35,9 @@ PMC_SCRIPT=tools/grad_trace.py tools/pmc_passes.sh final/pmc_grad325 32768 3.25 
 cp gpurun_out/final/pmc_grad325/summary.txt $F/r06_grad325_pmc_summary.txt
 PMC_SCRIPT=tools/grad_trace.py tools/pmc_passes.sh final/pmc_grad30 32768 30.25 > /dev/null 2>&1
 cp gpurun_out/final/pmc_grad30/summary.txt $F/r06_grad30_pmc_summary.txt
+# the valley index on the matrix pipe (round 6): MFMA busy cycles next to the vector ALU's and the LDS's
+PMC_EXTRA="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES" PMC_SCRIPT=tools/valley_trace.py tools/pmc_passes.sh final/pmc_valley 16384 7 > /dev/null 2>&1
+cp gpurun_out/final/pmc_valley/summary.txt $F/r06_valley_pmc_summary.txt
 # (the Sx kernels' counters: profiles/r02_sx_pmc_summary.txt stands for the axis-aligned scans; PMC_SCRIPT=tools/sx_trace.py re-takes them)
 # the sharded step with the real exchange on one GPU: one 4096-row shard of the 8-GPU split, neighbours = itself
 TOPO_AMD_HALO_LOOPBACK=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --ny 4096 > $F/r06_bench_loopback_4096rows.json 2> $F/loopback.err

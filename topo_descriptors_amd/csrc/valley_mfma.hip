@@ -21,9 +21,13 @@
 // through LDS in groups of filter tiles (double-buffered global_load ... lds, one barrier per group; the four waves of a
 // block share every fragment).  B (pixels): built ONCE per pixel tile from the f16 image of the block's DEM tile in LDS
 // (ds_read_u16 at the live cells' offsets, which the kernel keeps in LDS: lanes 32-63 supply the second eight cells of a
-// K step) and kept in registers for all the filters: 2 * KS * 4 registers per pixel tile.  The slots behind the last
+// K step) and kept in registers for all the filters: 2 * KS * 4 registers per pixel tile, four pixel tiles (two, one: by KS) a wave
+// at a time - every tap fragment read from LDS then feeds that many MFMAs.  The slots behind the last
 // live cell re-read the first one against zero taps, so a non-finite sample reaches exactly the pixels whose live
-// window holds it.  Two blocks of four waves share a CU and drift apart: one's epilogues run under the other's MFMAs.
+// window holds it.  Two blocks of four waves share a CU.
+// Measured (profiles/r06_valley_mfma.txt): the chip clocks at 1.9 GHz under this kernel and the matrix pipe is busy 75 - 78 % of
+// the time; taking a tile's maxima under the next tile's MFMAs (two result sets), reading a tile's fragments in one batch, and
+// hand-placed scheduling groups each changed nothing.
 //
 // Result layout of the instruction: a lane holds, for pixel column (lane & 31), the 16 filters 8 q + 4 (lane >> 5) + i.
 // The host puts the planes of an angle side by side in those 16 and the angles in rising order down the tiles: the
@@ -37,6 +41,7 @@
 // flagged tiles, which rewrites exactly the marked pixels.  Which pixels those are depends on their own window alone.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -58,9 +63,9 @@ constexpr int kFragBytes = 1024;          // one operand fragment: 64 lanes x 8 
 constexpr int kMaxSteps = 15;             // K steps the kernel is built for (240 live cells)
 static_assert(kPitch % 2 == 0, "the LDS image's rows start on a dword");
 
-__host__ __device__ constexpr int pixel_tiles(int ks) { return ks <= 8 ? 2 : 1; }  // a wave holds at a time
-__host__ __device__ constexpr int group_tiles(int ks) {                             // per LDS stage: at most 30 KB
-    return ks <= 3 ? 4 : ks <= 5 ? 3 : ks <= 7 ? 2 : 1;
+__host__ __device__ constexpr int pixel_tiles(int ks) { return ks <= 4 ? 4 : ks <= 8 ? 2 : 1; }  // a wave holds at a time
+__host__ __device__ constexpr int group_tiles(int ks) {  // per LDS stage: at most 30 KB; even, or one
+    return ks <= 3 ? 4 : ks <= 7 ? 2 : 1;
 }
 __host__ __device__ constexpr int image_bytes(int w) {
     return ((kTH + w - 1) * kPitch * 2 * 2 + kMaxSteps * 16 * 4 + kFragBytes - 1) / kFragBytes * kFragBytes;
@@ -74,7 +79,7 @@ struct VmArgs {
     const int* koff;            // [K step][16]: the LDS distance (halfs) of the step's cells from the window's first cell
     const float* angles;
     int* flags;                 // one per block: some pixel left to the direct kernel
-    int n_angles, n_tiles, n_groups;
+    int n_angles, n_groups;
     int w;                      // side of the window = of the largest rotated canvas
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
     constexpr int P = pixel_tiles(KS);
     constexpr int GT = group_tiles(KS);
     constexpr int GROUP_BYTES = GT * KS * 2 * kFragBytes;
-    constexpr int UNITS = (kTH / kWaves) * (2 / P);
+    constexpr int UNITS = (kTH / kWaves) * 2 / P;  // a wave's 16 pixel tiles (8 rows x 2 halves of the 64 columns), P at a time
     constexpr int APH = 16 / NP;  // angles in a lane's 16 results
     constexpr int APT = 2 * APH;  // angles of a filter tile
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -145,8 +150,6 @@ __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
     int it = 0;  // position in the stream: buffer it & 1 holds group it % n_groups
 #pragma unroll 1
     for (int u = 0; u < UNITS; ++u) {
-        const int row = wave + kWaves * (P == 2 ? u : u >> 1);
-        const int col0 = P == 2 ? 0 : 32 * (u & 1);
         f16x8 bh[P][KS], bl[P][KS];
         float best[P];
         int bidx[P];
@@ -157,17 +160,18 @@ __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
         }
         if (u == 0) __syncthreads();  // the image tile and the offsets are written
         {
-            const _Float16* src = img + row * kPitch + col0 + n;
             const int* ko = koff + 8 * h;
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const _Float16* at = src + ko[s * 16 + e];
+                    const int off = ko[s * 16 + e];
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt) {
-                        bh[pt][s][e] = at[32 * pt];
-                        bl[pt][s][e] = at[plane + 32 * pt];
+                        const int q = u * P + pt;  // the wave's pixel tile: row wave + 4 (q / 2), columns 32 (q % 2) ...
+                        const _Float16* at = img + (wave + kWaves * (q >> 1)) * kPitch + 32 * (q & 1) + n + off;
+                        bh[pt][s][e] = at[0];
+                        bl[pt][s][e] = at[plane];
                     }
                 }
         }
@@ -178,13 +182,9 @@ __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
             __syncthreads();
             issue_group(g + 1 == p.n_groups ? 0 : g + 1, (it + 1) & 1);
             const unsigned char* ab = abuf + (it & 1) * GROUP_BYTES + lane * 16;
-            // the fragments of K step j + 1 are on their way while the products of step j issue
-            f16x8 ah = *reinterpret_cast<const f16x8*>(ab);
-            f16x8 al = *reinterpret_cast<const f16x8*>(ab + kFragBytes);
 #pragma unroll
             for (int tt = 0; tt < GT; ++tt) {
-                const int tile = g * GT + tt;
-                if (tile >= p.n_tiles) break;  // (wave-uniform; the stream's last group is padded with empty tiles)
+                const int tile = g * GT + tt;  // (the host fills the last group up with copies of the last angle)
                 f32x16 acc[P];
 #pragma unroll
                 for (int pt = 0; pt < P; ++pt)
@@ -192,43 +192,27 @@ __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
                     for (int v = 0; v < 16; ++v) acc[pt][v] = 0.0f;
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const int j = tt * KS + s;
-                    f16x8 nh = ah, nl = al;
-                    if (j + 1 < GT * KS) {
-                        nh = *reinterpret_cast<const f16x8*>(ab + ((j + 1) * 2) * kFragBytes);
-                        nl = *reinterpret_cast<const f16x8*>(ab + ((j + 1) * 2 + 1) * kFragBytes);
-                    }
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(ab + ((tt * KS + s) * 2) * kFragBytes);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(ab + ((tt * KS + s) * 2 + 1) * kFragBytes);
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[pt][s], acc[pt], 0, 0, 0);
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[pt][s], acc[pt], 0, 0, 0);
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[pt][s], acc[pt], 0, 0, 0);
-                    ah = nh;
-                    al = nl;
                 }
-                const int first_angle = tile * APT + h * APH;
-                if ((tile + 1) * APT <= p.n_angles) {  // a full tile (wave-uniform)
+                // maximum over the planes of each of the APH angles a lane holds, then over the angles: strict, so the first angle
+                // that reaches the maximum keeps it (a NaN compares false and leaves the best alone, like valley.hip's)
+                const int first = tile * APT + h * APH;
 #pragma unroll
-                    for (int pt = 0; pt < P; ++pt)
+                for (int pt = 0; pt < P; ++pt)
 #pragma unroll
-                        for (int s = 0; s < APH; ++s) {
-                            const float m = max_planes(acc[pt], s * NP, NP);
-                            const bool better = m > best[pt];  // strict: the first angle that reaches the maximum keeps it
-                            best[pt] = __builtin_fmaxf(best[pt], m);  // (a NaN m leaves it, like the comparison)
-                            bidx[pt] = better ? first_angle + s : bidx[pt];
-                        }
-                } else {
-#pragma unroll
-                    for (int pt = 0; pt < P; ++pt)
-#pragma unroll
-                        for (int s = 0; s < APH; ++s) {
-                            const float m = max_planes(acc[pt], s * NP, NP);
-                            const bool better = first_angle + s < p.n_angles && m > best[pt];
-                            best[pt] = better ? m : best[pt];
-                            bidx[pt] = better ? first_angle + s : bidx[pt];
-                        }
-                }
+                    for (int s = 0; s < APH; ++s) {
+                        const float m = max_planes(acc[pt], s * NP, NP);
+                        const bool better = m > best[pt];
+                        best[pt] = __builtin_fmaxf(best[pt], m);
+                        bidx[pt] = better ? first + s : bidx[pt];
+                    }
             }
         }
         // lanes l and l + 32 hold different angles of the same pixel: the larger one, the earlier angle on a tie
@@ -239,9 +223,10 @@ __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
             const int oi = __shfl_xor(bidx[pt], 32);
             const bool take = ob > best[pt] || (ob == best[pt] && oi < bidx[pt]);
             const float b = take ? ob : best[pt];
-            const int bi = take ? oi : bidx[pt];
-            const int ox = ox0 + col0 + 32 * pt + n;
-            const int oy = oy0 + row;
+            const int bi = min(take ? oi : bidx[pt], p.n_angles - 1);  // (the last tile is filled up with copies of the last angle)
+            const int q = u * P + pt;
+            const int ox = ox0 + 32 * (q & 1) + n;
+            const int oy = oy0 + wave + kWaves * (q >> 1);
             if (ox >= p.nx || oy >= p.out_row0 + p.out_rows) continue;
             const bool finite = fabsf(b) < INFINITY;
             unfinished = unfinished || !finite;
@@ -349,10 +334,11 @@ int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* k
     const int n_groups = (n_tiles + gt - 1) / gt;
     const size_t frag_halfs = kFragBytes / 2;
     std::vector<uint16_t> atab((size_t)n_groups * gt * KS * 2 * frag_halfs, 0);
-    for (int ang = 0; ang < n_angles; ++ang) {
+    // the last group of tiles is filled up with copies of the last angle: a copy never beats the original under the strict comparison
+    for (int ang = 0; ang < n_groups * gt * apt; ++ang) {
         const int tile = ang / apt, hrow = (ang % apt) / aph, slot = (ang % apt) % aph;
         for (int q = 0; q < n_planes; ++q) {
-            const float* cv = canvas.data() + ((size_t)ang * n_planes + q) * W * W;
+            const float* cv = canvas.data() + ((size_t)std::min(ang, n_angles - 1) * n_planes + q) * W * W;
             const int v = slot * n_planes + q;             // the result register of the lane half
             const int m = 8 * (v / 4) + 4 * hrow + v % 4;  // its row of the filter tile
             for (int k = 0; k < (int)live.size(); ++k) {
@@ -385,7 +371,6 @@ int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* k
     a.angles = (const float*)d_angles;
     a.flags = (int*)d_flags;
     a.n_angles = n_angles;
-    a.n_tiles = n_tiles;
     a.n_groups = n_groups;
     a.w = W;
     a.in_rows = b.in_rows;
