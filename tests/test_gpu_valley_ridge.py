@@ -48,7 +48,7 @@ def test_valley_ridge_against_the_reference(golden, tag, route, monkeypatch):
     dem, size, mode, flats, sigma = _case(g, tag)
     norm_ref, dir_ref = g[f"{tag}_norm"], g[f"{tag}_dir"]
     norm, direction = topo.valley_ridge(dem, size, mode, flats, sigma)
-    # the 17 px kernels (24 x 24 canvas, 325 cells with taps) are beyond the matrix-pipe kernel's 240: tap by tap
+    # the 17 px kernels (24 x 24 canvas, 399 cells with taps) are beyond the matrix-pipe kernel's 240: tap by tap
     assert d.valley_route() == (0 if route == "matrix" and size == 17 else ROUTE_CODE[route])
     assert norm.dtype == np.float32 and direction.dtype == np.float32 and norm.shape == dem.shape
     scale = float(np.max(np.abs(norm_ref)))
