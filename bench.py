@@ -325,19 +325,34 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
                                                     np.arange(0, 180, dtype=np.float32))
     st = time_kernel(lambda: blk.valley_ridge(taps, ksize, angles, 3, mean, stdev, o1, o2), REPS, d)
     route = d.valley_route()
-    entry("valley_ridge_s7", st, 12, "valley_mfma_kernel<4, 3> (v_mfma_f32_32x32x16_f16, split-f16 operands: 3 products, 4 K steps of 16 "
-          "live cells, 18 tiles of 10 angles x 3 planes) + valley_ridge_kernel<3> over the tiles with non-finite samples (none here)"
-          if route & 1 else "valley_ridge_kernel<3>")
-    out["valley_ridge_s7"]["route"] = route
+    # what the matrix pipe executes: cells (or, folded, pairs of cells) that hold a tap at any angle -> K steps of 16; filter tiles
+    # of 10 angles x 3 planes, per class of canvas centre when folded, the last group filled up; 3 products
     kmax = int(ksize.max())
-    live = np.zeros((kmax, kmax), bool)
+    cells, members = {}, {}
     pos = 0
     for ks in ksize:
         sh = kmax // 2 - ks // 2
-        live[sh:sh + ks, sh:sh + ks] |= np.any(taps[pos:pos + ks * ks * 4].reshape(ks, ks, 4)[:, :, :3] != 0, axis=2)
+        centre = int(ks) - 1 + 2 * sh if route & 8 else -1
+        live = np.any(taps[pos:pos + ks * ks * 4].reshape(ks, ks, 4)[:, :, :3] != 0, axis=2)
+        for ky, kx in zip(*np.nonzero(live)):
+            cell = (ky + sh) * kmax + kx + sh
+            cells.setdefault(centre, set()).add(min(cell, (centre - ky - sh) * kmax + centre - kx - sh) if route & 8 else cell)
+        members[centre] = members.get(centre, 0) + 1
         pos += ks * ks * 4
-    mfmas = (px / 32) * 18 * ((int(live.sum()) + 15) // 16) * 3          # per launch; 32 x 32 x 16 multiply-adds each
-    out["valley_ridge_s7"]["live_cells"] = int(live.sum())
+    ksteps = max((len(c) + 15) // 16 for c in cells.values())
+    group = 4 if ksteps <= 3 else 2 if ksteps <= 7 else 1
+    tiles = sum(-(-(-(-n // 10)) // group) * group for n in members.values())
+    mfmas = (px / 32) * tiles * ksteps * 3          # per launch; 32 x 32 x 16 multiply-adds each
+    label = (f"valley_fold_kernel<{ksteps}, 3> (v_mfma_f32_32x32x16_f16 over PAIRS of window cells - the kernels are point-symmetric: "
+             f"{' + '.join(str(len(c)) for c in cells.values())} live pairs in the two classes of canvas centre, {ksteps} K steps, {tiles} "
+             "filter tiles of 10 angles x 3 planes, split-f16 operands: 3 products)" if route & 8 else
+             f"valley_mfma_kernel<{ksteps}, 3> (v_mfma_f32_32x32x16_f16 over the {sum(len(c) for c in cells.values())} window cells that hold "
+             f"a tap, {ksteps} K steps, {tiles} filter tiles, split-f16 operands: 3 products)")
+    entry("valley_ridge_s7", st, 12, label + " + valley_ridge_kernel<3> over the tiles with non-finite samples (none here)"
+          if route & 1 else "valley_ridge_kernel<3>")
+    out["valley_ridge_s7"]["route"] = route
+    out["valley_ridge_s7"]["k_steps"] = ksteps
+    out["valley_ridge_s7"]["filter_tiles"] = tiles
     out["valley_ridge_s7"]["mfma_TFLOP_per_s_executed"] = round(mfmas * 32768 / st["median"] / 1e9, 1)
     out["valley_ridge_s7"]["mfma_frac_of_2500_TFLOP_per_s"] = round(mfmas * 32768 / st["median"] / 1e9 / 2500.0, 3)
     os.environ["TOPO_AMD_VALLEY_MFMA_MAX_KERNEL"] = "0"   # read at every launch

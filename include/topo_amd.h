@@ -250,11 +250,13 @@ int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, in
  * mean / stdev: the DEM is normalised as (x - mean) / stdev in float32 while it is read
  * (topo.py:427); topo_amd_mean_std_dev computes them for a device-resident DEM.
  * norm_out = max over angles and planes, clipped at 0; dir_out = first angle reaching it.
- * Three evaluations, chosen by the kernels alone (never by the data or the block): rotated
- * kernels of up to 25 cells a side whose taps fall on at most 240 cells of that canvas (sizes
- * up to 13 px) run as a dense product on the matrix pipe (split-f16 operands, float32
- * accumulation: closer to float64 than the float32 chain; TOPO_AMD_VALLEY_MFMA_MAX_KERNEL,
- * 0 = never); larger ones tap by tap in float32; kernels of 64 px and more
+ * Three evaluations, chosen by the kernel tables alone (never by the data or the block):
+ * rotated kernels of up to 25 cells a side run as a dense product on the matrix pipe
+ * (split-f16 operands, float32 accumulation: closer to float64 than the float32 chain;
+ * TOPO_AMD_VALLEY_MFMA_MAX_KERNEL, 0 = never) - over PAIRS of opposite cells when every
+ * table is point-symmetric bit by bit, as the reference's are (at most 240 pairs with taps:
+ * kernels of up to 17 px; TOPO_AMD_VALLEY_FOLD=0: never), over the cells otherwise (at most
+ * 240 cells with taps: up to 13 px); larger ones tap by tap in float32; kernels of 64 px and more
  * (TOPO_AMD_VALLEY_FFT_MIN_KERNEL), and any too large for that kernel, by FFT like the
  * reference's signal.convolve.  The first two: a pixel whose kernel footprint holds a
  * non-finite sample is evaluated tap by tap in both, row blocks give the single block's bits.
@@ -266,7 +268,8 @@ int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny
                               int out_row0, int out_rows, float* norm_out, float* dir_out);
 /* Which evaluation the calling thread's last valley / ridge call took (for tests and diagnostics): 0 tap by tap,
  * 1 matrix pipe, 2 FFT; + 4: the matrix-pipe pass was followed by the tap-by-tap kernel over the tiles in which it met
- * non-finite samples (launched whenever the matrix pipe is used; it returns at once in tiles that are not flagged).      */
+ * non-finite samples (launched whenever the matrix pipe is used; it returns at once in tiles that are not flagged);
+ * + 8: the matrix pipe ran over pairs of opposite cells (point-symmetric tables).                                        */
 int topo_amd_valley_route(int* route);
 /* Mean and population standard deviation (numpy's default ddof = 0) of count device floats,
  * accumulated in float64.                                                                */

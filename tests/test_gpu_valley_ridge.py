@@ -14,19 +14,23 @@ pytestmark = pytest.mark.gpu
 
 from topo_descriptors_amd import _lib, device as d, shard, topo  # noqa: E402
 
-ROUTES = ["direct", "matrix", "fft"]
-ROUTE_CODE = {"direct": 0, "matrix": 1 + 4, "fft": 2}
+ROUTES = ["direct", "matrix", "folded", "fft"]
+ROUTE_CODE = {"direct": 0, "matrix": 1 + 4, "folded": 1 + 4 + 8, "fft": 2}
 
 
 def _set_route(monkeypatch, route):
-    """The three evaluations of the angle loop: tap by tap in float32 (csrc/valley.hip), the dense product on the matrix pipe
-    that kernels of up to 13 px take by default (csrc/valley_mfma.hip), the FFT that large kernels take.  Both switches are read
-    at every launch."""
+    """The evaluations of the angle loop: tap by tap in float32 (csrc/valley.hip); the dense product on the matrix pipe over the
+    cells that hold a tap (csrc/valley_mfma.hip), and its folded form over PAIRS of cells, which point-symmetric tables - the
+    reference's - take by default up to 17 px; the FFT that large kernels take.  The switches are read at every launch."""
     monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "1" if route == "fft" else "100000")
     if route == "direct":
         monkeypatch.setenv("TOPO_AMD_VALLEY_MFMA_MAX_KERNEL", "0")
     else:
         monkeypatch.delenv("TOPO_AMD_VALLEY_MFMA_MAX_KERNEL", raising=False)
+    if route == "matrix":
+        monkeypatch.setenv("TOPO_AMD_VALLEY_FOLD", "0")
+    else:
+        monkeypatch.delenv("TOPO_AMD_VALLEY_FOLD", raising=False)
 
 
 VR_TAGS = ["int_valley_s7", "int_ridge_s7", "int_valley_s5", "int_valley_s17", "int_valley_s9_flat0",
@@ -48,7 +52,8 @@ def test_valley_ridge_against_the_reference(golden, tag, route, monkeypatch):
     dem, size, mode, flats, sigma = _case(g, tag)
     norm_ref, dir_ref = g[f"{tag}_norm"], g[f"{tag}_dir"]
     norm, direction = topo.valley_ridge(dem, size, mode, flats, sigma)
-    # the 17 px kernels (24 x 24 canvas, 399 cells with taps) are beyond the matrix-pipe kernel's 240: tap by tap
+    # the 17 px kernels (24 x 24 canvas, 399 cells with taps) are beyond the unfolded matrix-pipe kernel's 240 cells: tap by tap;
+    # folded they are 13 K steps of pairs
     assert d.valley_route() == (0 if route == "matrix" and size == 17 else ROUTE_CODE[route])
     assert norm.dtype == np.float32 and direction.dtype == np.float32 and norm.shape == dem.shape
     scale = float(np.max(np.abs(norm_ref)))
@@ -70,7 +75,7 @@ def test_valley_ridge_rejects_unknown_mode_like_the_reference():
         topo.valley_ridge(np.zeros((16, 16), np.float32), 5, "canyon")
 
 
-@pytest.mark.parametrize("route", ["direct", "matrix"])
+@pytest.mark.parametrize("route", ["direct", "matrix", "folded"])
 def test_valley_ridge_row_blocks_are_bit_identical(route, monkeypatch):
     """Row blocks with ghost rows (the reach of the largest rotated kernel) against the single
     block; the standardisation uses the mean / std of the whole DEM in both."""
@@ -214,21 +219,25 @@ def test_fft_route_equals_the_direct_kernel_to_rounding(monkeypatch):
     assert np.mean(dir_f == dir_d) >= 0.995
 
 
-@pytest.mark.parametrize("size,planes", [(3, 3), (5, 3), (7, 1), (7, 2), (7, 3), (7, 4), (9, 3), (11, 3), (13, 3)])
-def test_matrix_pipe_against_the_tap_by_tap_kernel_and_float64(size, planes, monkeypatch):
+@pytest.mark.parametrize("form", ["matrix", "folded"])
+@pytest.mark.parametrize("size,planes", [(3, 3), (5, 3), (7, 1), (7, 2), (7, 3), (7, 4), (9, 3), (11, 3), (13, 3), (15, 3), (17, 3)])
+def test_matrix_pipe_against_the_tap_by_tap_kernel_and_float64(size, planes, form, monkeypatch):
     """Every kernel size the matrix-pipe route takes, 1 to 4 planes, a partial last filter tile (177 angles): the norm against
     the float64 oracle and against the float32 chain, the direction through the oracle's per-angle maps.  The split-f16 product
     is the closer of the two to float64."""
     flats = [0, 0.1, 0.2, 0.3][:planes]
     dem = (orc.synthetic_dem(96, 130, seed=size) + np.random.default_rng(size).uniform(0, 1, (96, 130))).astype(np.float32)
-    angles = np.arange(0, 177, 3 if size > 7 else 1, dtype=np.float32)
+    angles = np.arange(0, 177, 5 if size > 11 else 3 if size > 7 else 1, dtype=np.float32)
     taps, ksize, ang = topo._valley_ridge_tables(topo._valley_kernels(size, flats), angles)
     _set_route(monkeypatch, "direct")
     norm_d, dir_d = _block_run(dem, taps, ksize, ang, planes, 1)
     assert d.valley_route() == 0
-    _set_route(monkeypatch, "matrix")
+    _set_route(monkeypatch, form)
     norm_m, dir_m = _block_run(dem, taps, ksize, ang, planes, 1)
-    assert d.valley_route() == 5
+    if form == "matrix" and size > 13:
+        assert d.valley_route() == 0   # more than 240 cells with taps: the unfolded form hands the whole call to the tap-by-tap kernel
+        return
+    assert d.valley_route() == ROUTE_CODE[form]
     (norm_ex, _), maps = orc.valley_ridge_exact(dem, size, "valley", flats, angles=angles, return_maps=True)
     scale = float(np.max(norm_ex))
     err_m, err_d = float(np.max(np.abs(norm_m - norm_ex))), float(np.max(np.abs(norm_d - norm_ex)))
@@ -239,7 +248,8 @@ def test_matrix_pipe_against_the_tap_by_tap_kernel_and_float64(size, planes, mon
     assert np.mean(dir_m == dir_d) >= 0.99
 
 
-def test_matrix_pipe_hands_non_finite_windows_to_the_tap_by_tap_kernel(monkeypatch):
+@pytest.mark.parametrize("form", ["matrix", "folded"])
+def test_matrix_pipe_hands_non_finite_windows_to_the_tap_by_tap_kernel(form, monkeypatch):
     """NaN, +-inf and a sample beyond the f16 range after standardising (3e9 m): exactly the pixels whose kernel footprint holds
     one of them are evaluated tap by tap (their bits are the direct route's), every other pixel by the matrix pipe (its bits are
     those of the same DEM without the specials), nothing is left marked, and row blocks keep the single block's bits."""
@@ -275,9 +285,9 @@ def test_matrix_pipe_hands_non_finite_windows_to_the_tap_by_tap_kernel(monkeypat
 
     _set_route(monkeypatch, "direct")
     norm_d, dir_d = run(dem)
-    _set_route(monkeypatch, "matrix")
+    _set_route(monkeypatch, form)
     norm_m, dir_m = run(dem)
-    assert d.valley_route() == 5
+    assert d.valley_route() == ROUTE_CODE[form]
     norm_c, dir_c = run(clean)
     assert not np.any(norm_m == -1.0)
     # the footprint: the cells of the 10 x 10 window in which some kernel has a tap, around every special sample
@@ -302,3 +312,24 @@ def test_matrix_pipe_hands_non_finite_windows_to_the_tap_by_tap_kernel(monkeypat
     for nb in (2, 5):
         norm_b, dir_b = run(dem, nb)
         assert same(norm_b, norm_m) and same(dir_b, dir_m), nb
+
+
+def test_tables_that_are_not_point_symmetric_take_the_unfolded_form(monkeypatch):
+    """The folded form is for tables that are point-symmetric bit by bit (the reference's are); one tap changed and the call runs
+    over the cells instead of the pairs - with that tap honoured."""
+    dem = (orc.synthetic_dem(80, 100, seed=2) + np.random.default_rng(2).uniform(0, 1, (80, 100))).astype(np.float32)
+    angles = np.arange(0, 180, 4, dtype=np.float32)
+    taps, ksize, ang = topo._valley_ridge_tables(topo._valley_kernels(7, [0, 0.15, 0.3]), angles)
+    _set_route(monkeypatch, "folded")
+    norm_f, _ = _block_run(dem, taps, ksize, ang, 3, 1)
+    assert d.valley_route() == 13
+    bent = taps.copy()
+    first = np.nonzero(bent)[0][0]
+    bent[first] *= 1.5
+    norm_b, dir_b = _block_run(dem, bent, ksize, ang, 3, 1)
+    assert d.valley_route() == 5
+    _set_route(monkeypatch, "direct")
+    norm_d, dir_d = _block_run(dem, bent, ksize, ang, 3, 1)
+    scale = float(norm_d.max())
+    assert np.max(np.abs(norm_b - norm_d)) <= 1e-5 * scale and np.mean(dir_b == dir_d) >= 0.99
+    assert np.max(np.abs(norm_b - norm_f)) > 1e-4 * scale   # and the changed tap shows

@@ -14,6 +14,7 @@ from topo_descriptors_amd import _lib, device as d, topo  # noqa: E402
 
 def run(dem, size, flats, route, angles=None, mode="valley", moments=None):
     os.environ["TOPO_AMD_VALLEY_MFMA_MAX_KERNEL"] = "0" if route == "direct" else "64"
+    os.environ["TOPO_AMD_VALLEY_FOLD"] = os.environ.get("VM_FOLD", "1")   # the parity sweep: the folded form unless VM_FOLD=0
     kernels = topo._valley_kernels(size, flats) if mode == "valley" else topo._ridge_kernels(size, flats)
     ang = np.arange(0, 180, dtype=np.float32) if angles is None else angles
     taps, ksize, ang = topo._valley_ridge_tables(kernels, ang)
@@ -93,11 +94,12 @@ def timing():
             print(f"lab {lab}: {min(ts[1:]):8.2f} ms", flush=True)
         return
     dem = orc.synthetic_dem(side, side, seed=1)
-    for size in (5, 7, 9, 11, 13):
-        for route in ("direct", "mfma"):
+    for size in (5, 7, 9, 11, 13, 15, 17):
+        for route in ("direct", "mfma", "folded"):
             kernels = topo._valley_kernels(size, [0, 0.15, 0.3])
             taps, ksize, ang = topo._valley_ridge_tables(kernels, np.arange(0, 180, dtype=np.float32))
             os.environ["TOPO_AMD_VALLEY_MFMA_MAX_KERNEL"] = "0" if route == "direct" else "64"
+            os.environ["TOPO_AMD_VALLEY_FOLD"] = "1" if route == "folded" else "0"
             dev = d.DeviceArray.from_host(dem)
             n, a = d.DeviceArray(side, side), d.DeviceArray(side, side)
             blk = d.Block(dev)
@@ -108,7 +110,7 @@ def timing():
                 blk.valley_ridge(taps, ksize, ang, 3, 1500.0, 400.0, n, a)
                 d.sync()
                 ts.append((time.perf_counter() - t0) * 1e3)
-            print(f"{side}^2 size {size:2d} canvas {int(ksize.max()):2d} {route:6s}: {min(ts[1:]):8.2f} ms", flush=True)
+            print(f"{side}^2 size {size:2d} canvas {int(ksize.max()):2d} {route:6s}: {min(ts[1:]):8.2f} ms (route {d.valley_route()})", flush=True)
             for x in (n, a, dev):
                 x.free()
 

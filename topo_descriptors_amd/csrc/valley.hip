@@ -276,7 +276,7 @@ int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize,
         TOPO_TRY(launch_valley_ridge_mfma(b, taps, ksize, angles, n_angles, n_planes, kmax, mean, stdev, norm_out, dir_out,
                                           &a.repair, &a.repair_cols, &done));
         if (!done) a.repair = nullptr;
-        if (done) note_valley_route(1 + 4);
+        if (done) note_valley_route(1 + 4 + (done == 2 ? 8 : 0));
     }
     // compress: the non-zero taps of each angle, with their offset in the LDS tile (smaller kernels
     // sit centred inside the reach staged for the largest one)

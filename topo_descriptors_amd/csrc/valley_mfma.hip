@@ -241,6 +241,196 @@ __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream's last, unused group: not into the LDS of the next block
 }
 
+// ---- the folded form ------------------------------------------------------------------------------------------------
+// The reference's kernels are V / U profiles across one axis, constant along the other, turned about the canvas centre: exactly
+// point-symmetric, K(c) = K(c*) with c* the cell opposite the centre (the launcher checks the tables bit by bit; any other table
+// takes the kernel above).  Then sum_c K(c) z(c) = sum over PAIRS K(c) (z(c) + z(c*)): K runs over the live pairs - 27 for the
+// 7 px kernel, 2 K steps instead of 4.  Canvases of odd and of even side have different centres (half a cell apart in the common
+// window), so there are two classes of angles, each with its own pairs: filter tiles are pure in class, a wave builds its pixel
+// operands once per class (z(c) + z(c*) in float32 from a float32 image of the DEM tile, then the hi / lo split), and runs the
+// class's tiles.  Tiles are then no longer in angle order: the running best is kept per class (rising angles inside a class, the
+// strict comparison as before) and the classes - like the two lane halves - are merged on (value, then the smaller angle index).
+struct VfArgs {
+    const float* in;
+    float* norm;
+    float* dir;
+    const unsigned char* atab;  // [group][tile in group][K step][hi, lo][64 lanes x 16 bytes]; the groups of class 0, then of class 1
+    const int* koff;            // [class][K step][16][2]: the LDS distances (floats) of a pair's two cells from the window's first cell
+    const int* pos_angle;       // [group][tile][row position] -> index of the angle (copies of a class's last angle fill its last group)
+    const float* angles;
+    int* flags;
+    int class_groups[2];
+    int w;
+    int in_rows, in_row0, gny, nx;
+    int out_row0, out_rows;
+    float mean, stdev;
+};
+
+__host__ __device__ constexpr int fold_image_bytes(int w) {
+    return ((kTH + w - 1) * kPitch * 4 + 2 * kMaxSteps * 16 * 2 * 4 + kFragBytes - 1) / kFragBytes * kFragBytes;
+}
+
+template <int KS, int NP>
+__global__ __launch_bounds__(kThreads, 2) void valley_fold_kernel(VfArgs p) {
+    constexpr int P = pixel_tiles(KS);
+    constexpr int GT = group_tiles(KS);
+    constexpr int GROUP_BYTES = GT * KS * 2 * kFragBytes;
+    constexpr int UNITS = (kTH / kWaves) * 2 / P;
+    constexpr int APH = 16 / NP;
+    constexpr int APT = 2 * APH;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int rows_l = kTH + p.w - 1, cols_l = kTW + p.w - 1;
+    float* img = reinterpret_cast<float*>(lds);
+    int* koff = reinterpret_cast<int*>(lds + (size_t)rows_l * kPitch * 4);
+    unsigned char* abuf = lds + fold_image_bytes(p.w);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = lane & 31;
+    const int h = lane >> 5;
+    const int ox0 = blockIdx.x * kTW;
+    const int oy0 = p.out_row0 + blockIdx.y * kTH;
+    const int reach = p.w / 2;
+    const int n_groups = p.class_groups[0] + p.class_groups[1];
+
+    auto issue_group = [&](int g, int buf) {
+        const unsigned char* src = p.atab + (size_t)g * GROUP_BYTES + lane * 16;
+        unsigned char* dst = abuf + buf * GROUP_BYTES;
+#pragma unroll
+        for (int f = wave; f < GT * KS * 2; f += kWaves)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * kFragBytes),
+                                             (__attribute__((address_space(3))) void*)(dst + f * kFragBytes + lane * 16), 16, 0,
+                                             0);
+    };
+    issue_group(0, 0);
+
+    for (int r = wave; r < rows_l; r += kWaves) {
+        const int gy = oy0 - reach + r;
+        const int by = gy - p.in_row0;
+        const bool row_ok = gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
+        for (int c = lane; c < cols_l; c += 64) {
+            const int gx = ox0 - reach + c;
+            float v = 0.0f;
+            if (row_ok && gx >= 0 && gx < p.nx) v = (p.in[(size_t)by * p.nx + gx] - p.mean) / p.stdev;
+            img[r * kPitch + c] = v;
+        }
+    }
+    for (int i = threadIdx.x; i < 2 * KS * 16 * 2; i += kThreads) koff[i] = p.koff[i];
+
+    int it = 0;
+#pragma unroll 1
+    for (int u = 0; u < UNITS; ++u) {
+        float rv[P];  // the best over the classes done so far, and its angle's index
+        int ri[P];
+        bool bad[P];  // a class came out non-finite: a non-finite sample on one of ITS pairs (the other class may not see that cell)
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            rv[pt] = -INFINITY;
+            ri[pt] = 0x7fffffff;
+            bad[pt] = false;
+        }
+        if (u == 0) __syncthreads();
+        int g0 = 0;
+#pragma unroll 1
+        for (int cls = 0; cls < 2; ++cls) {
+            const int ng = p.class_groups[cls];
+            if (ng == 0) continue;  // (wave-uniform)
+            f16x8 bh[P][KS], bl[P][KS];
+            float best[P];
+            int bpos[P];
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                best[pt] = -INFINITY;
+                bpos[pt] = g0 * GT * APT;
+            }
+            {
+                const int* ko = koff + (cls * KS * 16 + 8 * h) * 2;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int o1 = ko[(s * 16 + e) * 2], o2 = ko[(s * 16 + e) * 2 + 1];
+#pragma unroll
+                        for (int pt = 0; pt < P; ++pt) {
+                            const int q = u * P + pt;
+                            const float* at = img + (wave + kWaves * (q >> 1)) * kPitch + 32 * (q & 1) + n;
+                            const float zf = at[o1] + at[o2];
+                            const _Float16 hi = (_Float16)zf;
+                            bh[pt][s][e] = hi;
+                            bl[pt][s][e] = (_Float16)(zf - (float)hi);
+                        }
+                    }
+            }
+#pragma unroll 1
+            for (int g = g0; g < g0 + ng; ++g, ++it) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                issue_group(g + 1 == n_groups ? 0 : g + 1, (it + 1) & 1);
+                const unsigned char* ab = abuf + (it & 1) * GROUP_BYTES + lane * 16;
+#pragma unroll
+                for (int tt = 0; tt < GT; ++tt) {
+                    f32x16 acc[P];
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) acc[pt][v] = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const f16x8 ah = *reinterpret_cast<const f16x8*>(ab + ((tt * KS + s) * 2) * kFragBytes);
+                        const f16x8 al = *reinterpret_cast<const f16x8*>(ab + ((tt * KS + s) * 2 + 1) * kFragBytes);
+#pragma unroll
+                        for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[pt][s], acc[pt], 0, 0, 0);
+#pragma unroll
+                        for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[pt][s], acc[pt], 0, 0, 0);
+#pragma unroll
+                        for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[pt][s], acc[pt], 0, 0, 0);
+                    }
+                    const int first = (g * GT + tt) * APT + h * APH;
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                        for (int s = 0; s < APH; ++s) {
+                            const float m = max_planes(acc[pt], s * NP, NP);
+                            const bool better = m > best[pt];
+                            best[pt] = __builtin_fmaxf(best[pt], m);
+                            bpos[pt] = better ? first + s : bpos[pt];
+                        }
+                }
+            }
+            g0 += ng;
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) {
+                const int ai = p.pos_angle[bpos[pt]];
+                bad[pt] = bad[pt] || !(fabsf(best[pt]) < INFINITY);
+                const bool take = best[pt] > rv[pt] || (best[pt] == rv[pt] && ai < ri[pt]);
+                rv[pt] = take ? best[pt] : rv[pt];
+                ri[pt] = take ? ai : ri[pt];
+            }
+        }
+        bool unfinished = false;
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            const float ob = __shfl_xor(rv[pt], 32);
+            const int oi = __shfl_xor(ri[pt], 32);
+            const bool take = ob > rv[pt] || (ob == rv[pt] && oi < ri[pt]);
+            const float b = take ? ob : rv[pt];
+            const int bi = take ? oi : ri[pt];
+            const int q = u * P + pt;
+            const int ox = ox0 + 32 * (q & 1) + n;
+            const int oy = oy0 + wave + kWaves * (q >> 1);
+            if (ox >= p.nx || oy >= p.out_row0 + p.out_rows) continue;
+            const bool finite = !bad[pt] && fabsf(b) < INFINITY;
+            unfinished = unfinished || !finite;
+            const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
+            if (h == 0)
+                p.norm[o] = finite ? fmaxf(b, 0.0f) : -1.0f;
+            else
+                p.dir[o] = finite ? p.angles[bi] : 0.0f;
+        }
+        if (unfinished) p.flags[blockIdx.y * gridDim.x + blockIdx.x] = 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // float -> f16 bits, round to nearest even (the host builds the tap operands; no _Float16 arithmetic in host code)
 uint16_t f16_bits(float f) {
     uint32_t x;
@@ -289,10 +479,182 @@ int launch_np(const VmArgs& a, dim3 grid, int n_planes) {
     }
 }
 
+template <int KS, int NP>
+int launch_fold_ks(const VfArgs& a, dim3 grid) {
+    const int lds = fold_image_bytes(a.w) + 2 * group_tiles(KS) * KS * 2 * kFragBytes;
+    TOPO_HIP(hipFuncSetAttribute((const void*)valley_fold_kernel<KS, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((valley_fold_kernel<KS, NP>), grid, dim3(kThreads), lds, ctx().compute, a);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+template <int KS>
+int launch_fold_np(const VfArgs& a, dim3 grid, int n_planes) {
+    switch (n_planes) {
+        case 1: return launch_fold_ks<KS, 1>(a, grid);
+        case 2: return launch_fold_ks<KS, 2>(a, grid);
+        case 3: return launch_fold_ks<KS, 3>(a, grid);
+        default: return launch_fold_ks<KS, 4>(a, grid);
+    }
+}
+
+// The folded form, if the tables allow it: every kernel bit for bit point-symmetric, at most two canvas centres in the common
+// window, at most 15 K steps of live pairs (kernels of up to 17 px).  *folded = 0: not such a case, nothing launched.
+int launch_fold(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles, int n_planes, int W,
+                double mean, double stdev, float* norm_out, float* dir_out, const int** flags_out, int* flag_cols, int* folded) {
+    *folded = 0;
+    // symmetry, and the class of every angle: the window cell opposite (wy, wx) is (C - wy, C - wx), C = ks - 1 + 2 (W / 2 - ks / 2)
+    std::vector<int> cls_of(n_angles), centre;
+    const float* src = taps;
+    for (int ang = 0; ang < n_angles; ++ang) {
+        const int ks = ksize[ang];
+        for (int ky = 0; ky < ks; ++ky)
+            for (int kx = 0; kx < ks; ++kx)
+                for (int q = 0; q < n_planes; ++q)
+                    if (src[((size_t)ky * ks + kx) * 4 + q] != src[((size_t)(ks - 1 - ky) * ks + (ks - 1 - kx)) * 4 + q]) return TOPO_AMD_OK;
+        const int C = ks - 1 + 2 * (W / 2 - ks / 2);
+        size_t k = 0;
+        while (k < centre.size() && centre[k] != C) ++k;
+        if (k == centre.size()) centre.push_back(C);
+        if (centre.size() > 2) return TOPO_AMD_OK;
+        cls_of[ang] = (int)k;
+        src += (size_t)ks * ks * 4;
+    }
+    const int n_cls = (int)centre.size();
+    // the live pairs of each class (a pair by its first cell in row-major order), and each angle's taps on its class's pairs
+    std::vector<int> pair_of[2];     // window cell -> pair index of the class, or -1
+    std::vector<int> pair_cell[2];   // pair -> its first cell
+    for (int c = 0; c < n_cls; ++c) pair_of[c].assign((size_t)W * W, -1);
+    src = taps;
+    for (int ang = 0; ang < n_angles; ++ang) {
+        const int ks = ksize[ang], sh = W / 2 - ks / 2, c = cls_of[ang], C = centre[c];
+        for (int ky = 0; ky < ks; ++ky)
+            for (int kx = 0; kx < ks; ++kx) {
+                bool any = false;
+                for (int q = 0; q < n_planes; ++q) any = any || src[((size_t)ky * ks + kx) * 4 + q] != 0.0f;
+                if (!any) continue;
+                const int wy = ky + sh, wx = kx + sh, oy = C - wy, ox = C - wx;
+                if (oy < 0 || oy >= W || ox < 0 || ox >= W) return TOPO_AMD_OK;  // (cannot happen: the partner is a cell of the same canvas)
+                const int cell = std::min(wy * W + wx, oy * W + ox);
+                if (pair_of[c][cell] < 0) pair_of[c][cell] = -2;  // live; numbered below in row-major order
+            }
+        src += (size_t)ks * ks * 4;
+    }
+    int KS = 0;
+    for (int c = 0; c < n_cls; ++c) {
+        for (int cell = 0; cell < W * W; ++cell)
+            if (pair_of[c][cell] == -2) {
+                pair_of[c][cell] = (int)pair_cell[c].size();
+                pair_cell[c].push_back(cell);
+            }
+        KS = std::max(KS, ((int)pair_cell[c].size() + 15) / 16);
+    }
+    if (KS < 1 || KS > kMaxSteps) return TOPO_AMD_OK;
+    const int aph = 16 / n_planes, apt = 2 * aph, gt = group_tiles(KS);
+    // the stream: the tiles of class 0 (its angles in rising order, the last group filled with copies of its last angle), then class 1
+    std::vector<int> pos_angle;
+    int class_groups[2] = {0, 0};
+    for (int c = 0; c < n_cls; ++c) {
+        std::vector<int> mine;
+        for (int ang = 0; ang < n_angles; ++ang)
+            if (cls_of[ang] == c) mine.push_back(ang);
+        const int tiles = ((int)mine.size() + apt - 1) / apt;
+        class_groups[c] = (tiles + gt - 1) / gt;
+        for (int k = 0; k < class_groups[c] * gt * apt; ++k) pos_angle.push_back(mine[std::min(k, (int)mine.size() - 1)]);
+    }
+    const int n_groups = class_groups[0] + class_groups[1];
+    const size_t frag_halfs = kFragBytes / 2;
+    std::vector<uint16_t> atab((size_t)n_groups * gt * KS * 2 * frag_halfs, 0);
+    std::vector<size_t> first_tap((size_t)n_angles);
+    {
+        size_t at = 0;
+        for (int ang = 0; ang < n_angles; ++ang) {
+            first_tap[ang] = at;
+            at += (size_t)ksize[ang] * ksize[ang] * 4;
+        }
+    }
+    for (size_t pos = 0; pos < pos_angle.size(); ++pos) {
+        const int ang = pos_angle[pos], c = cls_of[ang], C = centre[c];
+        const int ks = ksize[ang], sh = W / 2 - ks / 2;
+        const int tile = (int)pos / apt, hrow = ((int)pos % apt) / aph, slot = ((int)pos % apt) % aph;
+        const float* t = taps + first_tap[ang];
+        for (int ky = 0; ky < ks; ++ky)
+            for (int kx = 0; kx < ks; ++kx) {
+                const int wy = ky + sh, wx = kx + sh, cell = wy * W + wx, other = (C - wy) * W + (C - wx);
+                if (cell > other) continue;  // the pair's second cell: the same tap
+                const int k = pair_of[c][cell];
+                if (k < 0) continue;
+                for (int q = 0; q < n_planes; ++q) {
+                    float v = t[((size_t)ky * ks + kx) * 4 + q];
+                    if (v == 0.0f) continue;
+                    if (cell == other) v *= 0.5f;  // the centre cell is its own partner: z + z against half the tap (exact)
+                    const uint16_t hi = f16_bits(v);
+                    const uint16_t lo = f16_bits(v - f16_value(hi));
+                    const int r = slot * n_planes + q, m = 8 * (r / 4) + 4 * hrow + r % 4;
+                    const int s = k / 16, kh = (k % 16) / 8, e = k % 8;
+                    const size_t frag = ((size_t)tile * KS + s) * 2;
+                    const size_t at = (size_t)(m + 32 * kh) * 8 + e;
+                    atab[frag * frag_halfs + at] = hi;
+                    atab[(frag + 1) * frag_halfs + at] = lo;
+                }
+            }
+    }
+    std::vector<int> koff((size_t)2 * KS * 16 * 2, 0);
+    for (int c = 0; c < n_cls; ++c)
+        for (int k = 0; k < KS * 16; ++k) {
+            const int cell = pair_cell[c][k < (int)pair_cell[c].size() ? k : 0];  // behind the last live pair: the first one, zero taps
+            const int wy = cell / W, wx = cell % W;
+            koff[((size_t)c * KS * 16 + k) * 2] = wy * kPitch + wx;
+            koff[((size_t)c * KS * 16 + k) * 2 + 1] = (centre[c] - wy) * kPitch + (centre[c] - wx);
+        }
+    void *d_atab = nullptr, *d_koff = nullptr, *d_angles = nullptr, *d_flags = nullptr, *d_pos = nullptr;
+    // one table: the offsets, then the positions' angles (the table slots are few)
+    std::vector<int> ints(koff);
+    ints.insert(ints.end(), pos_angle.begin(), pos_angle.end());
+    TOPO_TRY(upload_table(4, atab.data(), atab.size() * sizeof(uint16_t), &d_atab));
+    TOPO_TRY(upload_table(5, ints.data(), ints.size() * sizeof(int), &d_koff));
+    d_pos = (char*)d_koff + koff.size() * sizeof(int);
+    TOPO_TRY(upload_table(2, angles, (size_t)n_angles * sizeof(float), &d_angles));
+    dim3 grid((b.nx + kTW - 1) / kTW, (b.out_rows + kTH - 1) / kTH);
+    const size_t flag_bytes = (size_t)grid.x * grid.y * sizeof(int);
+    TOPO_TRY(workspace(3, flag_bytes, &d_flags));
+    TOPO_HIP(hipMemsetAsync(d_flags, 0, flag_bytes, ctx().compute));
+    VfArgs a{};
+    a.in = b.in;
+    a.norm = norm_out;
+    a.dir = dir_out;
+    a.atab = (const unsigned char*)d_atab;
+    a.koff = (const int*)d_koff;
+    a.pos_angle = (const int*)d_pos;
+    a.angles = (const float*)d_angles;
+    a.flags = (int*)d_flags;
+    a.class_groups[0] = class_groups[0];
+    a.class_groups[1] = class_groups[1];
+    a.w = W;
+    a.in_rows = b.in_rows;
+    a.in_row0 = b.in_row0;
+    a.gny = b.gny;
+    a.nx = b.nx;
+    a.out_row0 = b.out_row0;
+    a.out_rows = b.out_rows;
+    a.mean = (float)mean;
+    a.stdev = (float)stdev;
+    *flags_out = (const int*)d_flags;
+    *flag_cols = (int)grid.x;
+    *folded = 1;
+    switch (KS) {
+#define TOPO_KS(k) case k: return launch_fold_np<k>(a, grid, n_planes);
+        TOPO_KS(1) TOPO_KS(2) TOPO_KS(3) TOPO_KS(4) TOPO_KS(5) TOPO_KS(6) TOPO_KS(7) TOPO_KS(8) TOPO_KS(9) TOPO_KS(10)
+        TOPO_KS(11) TOPO_KS(12) TOPO_KS(13) TOPO_KS(14) TOPO_KS(15)
+#undef TOPO_KS
+    }
+    return TOPO_AMD_OK;
+}
+
 }  // namespace
 
 // The matrix-pipe evaluation over the block.  *done = 0: not a case for it (no live cell, or more than 240), nothing
-// launched.  Otherwise *flags_out / *flag_cols describe the tiles (kValleyMfmaTileRows rows x 64 columns, anchored at
+// launched; 1: the kernel over the live cells; 2: the folded form (point-symmetric tables).  Otherwise *flags_out / *flag_cols describe the tiles (kValleyMfmaTileRows rows x 64 columns, anchored at
 // out_row0) in which it left pixels marked norm = -1 for the direct kernel.
 int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles,
                              int n_planes, int kmax, double mean, double stdev, float* norm_out, float* dir_out,
@@ -300,6 +662,18 @@ int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* k
     *done = 0;
     TOPO_REQUIRE(kmax >= 1 && kmax <= kValleyMfmaMaxKernel, "valley_ridge (matrix pipe): kernel side %d", kmax);
     const int W = kmax;  // the window = the largest canvas (a smaller one sits inside it: it starts ks / 2 before the pixel)
+    {
+        const char* e = std::getenv("TOPO_AMD_VALLEY_FOLD");  // 0: never the folded form (read at every launch; tests)
+        if (!(e && *e == '0')) {
+            int folded = 0;
+            TOPO_TRY(launch_fold(b, taps, ksize, angles, n_angles, n_planes, W, mean, stdev, norm_out, dir_out, flags_out, flag_cols,
+                                 &folded));
+            if (folded) {
+                *done = 2;
+                return TOPO_AMD_OK;
+            }
+        }
+    }
     // the canvases of all (angle, plane) filters in the common window, and the cells in which any of them has a tap
     std::vector<float> canvas((size_t)n_angles * n_planes * W * W, 0.0f);
     std::vector<char> live_cell((size_t)W * W, 0);
