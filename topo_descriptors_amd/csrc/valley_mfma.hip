@@ -39,6 +39,9 @@
 // come out non-finite for every filter - 0 * inf - and are handed to valley.hip's kernel: this kernel stores norm = -1
 // (the norm proper is clipped at 0) and raises its tile's flag; the launcher then runs the direct kernel over the
 // flagged tiles, which rewrites exactly the marked pixels.  Which pixels those are depends on their own window alone.
+//
+// Two kernels: valley_mfma_kernel over the live cells (any tables), and valley_fold_kernel over PAIRS of opposite cells, which
+// tables that are point-symmetric bit by bit - the reference's - take: half the K steps (further down, "the folded form").
 #include "common.hpp"
 
 #include <algorithm>
