@@ -341,7 +341,7 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
         pos += ks * ks * 4
     ksteps = max((len(c) + 15) // 16 for c in cells.values())
     group = 4 if ksteps <= 3 else 2 if ksteps <= 7 else 1
-    tiles = sum(-(-(-(-n // 10)) // group) * group for n in members.values())
+    tiles = sum(-(-n // 10) for n in members.values()) if route & 8 else sum(-(-(-(-n // 10)) // group) * group for n in members.values())
     mfmas = (px / 32) * tiles * ksteps * 3          # per launch; 32 x 32 x 16 multiply-adds each
     label = (f"valley_fold_kernel<{ksteps}, 3> (v_mfma_f32_32x32x16_f16 over PAIRS of window cells - the kernels are point-symmetric: "
              f"{' + '.join(str(len(c)) for c in cells.values())} live pairs in the two classes of canvas centre, {ksteps} K steps, {tiles} "

@@ -131,13 +131,16 @@ while time.time() < t_end:
         else:
             if ny < 3 or nx < 3 or ny * nx > 40000:
                 continue
-            size = int(rng.choice([3, 5, 7, 9, 11, 13]))
+            size = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17]))
             flats = [[0, 0.15, 0.3], [0], [0.2, 0.4], [0, 0.1, 0.2, 0.3]][int(rng.integers(4))]
             mode = str(rng.choice(["valley", "ridge"]))
             angles = np.sort(rng.choice(np.arange(180, dtype=np.float32), int(rng.integers(1, 40)), replace=False))
             # the matrix-pipe kernel (what these sizes take) three times out of four, the tap-by-tap kernel otherwise; read at every launch
+            # and of the matrix-pipe calls one in three over the cells instead of the pairs (TOPO_AMD_VALLEY_FOLD=0)
             os.environ["TOPO_AMD_VALLEY_MFMA_MAX_KERNEL"] = "0" if rng.random() < 0.25 else "64"
-            ctx = f"valley ny={ny} nx={nx} size={size} flats={flats} mode={mode} angles={len(angles)} matrix={os.environ['TOPO_AMD_VALLEY_MFMA_MAX_KERNEL']}"
+            os.environ["TOPO_AMD_VALLEY_FOLD"] = "0" if rng.random() < 0.33 else "1"
+            ctx = (f"valley ny={ny} nx={nx} size={size} flats={flats} mode={mode} angles={len(angles)} "
+                   f"matrix={os.environ['TOPO_AMD_VALLEY_MFMA_MAX_KERNEL']} fold={os.environ['TOPO_AMD_VALLEY_FOLD']}")
             counts["valley"] += 1
             kernels = topo._ridge_kernels(size, flats) if mode == "ridge" else topo._valley_kernels(size, flats)
             taps, ksize, ang = topo._valley_ridge_tables(kernels, angles)

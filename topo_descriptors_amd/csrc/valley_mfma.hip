@@ -263,6 +263,7 @@ struct VfArgs {
     const float* angles;
     int* flags;
     int class_groups[2];
+    int class_tiles[2];         // filter tiles of the class (its last group may hold fewer than the stream's stage does)
     int w;
     int in_rows, in_row0, gny, nx;
     int out_row0, out_rows;
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(kThreads, 2) void valley_fold_kernel(VfArgs p) {
                 const unsigned char* ab = abuf + (it & 1) * GROUP_BYTES + lane * 16;
 #pragma unroll
                 for (int tt = 0; tt < GT; ++tt) {
+                    if ((g - g0) * GT + tt >= p.class_tiles[cls]) break;  // (wave-uniform: the class's last stage is not full)
                     f32x16 acc[P];
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt)
@@ -556,12 +558,13 @@ int launch_fold(const Block& b, const float* taps, const int32_t* ksize, const f
     const int aph = 16 / n_planes, apt = 2 * aph, gt = group_tiles(KS);
     // the stream: the tiles of class 0 (its angles in rising order, the last group filled with copies of its last angle), then class 1
     std::vector<int> pos_angle;
-    int class_groups[2] = {0, 0};
+    int class_groups[2] = {0, 0}, class_tiles[2] = {0, 0};
     for (int c = 0; c < n_cls; ++c) {
         std::vector<int> mine;
         for (int ang = 0; ang < n_angles; ++ang)
             if (cls_of[ang] == c) mine.push_back(ang);
         const int tiles = ((int)mine.size() + apt - 1) / apt;
+        class_tiles[c] = tiles;
         class_groups[c] = (tiles + gt - 1) / gt;
         for (int k = 0; k < class_groups[c] * gt * apt; ++k) pos_angle.push_back(mine[std::min(k, (int)mine.size() - 1)]);
     }
@@ -633,6 +636,8 @@ int launch_fold(const Block& b, const float* taps, const int32_t* ksize, const f
     a.flags = (int*)d_flags;
     a.class_groups[0] = class_groups[0];
     a.class_groups[1] = class_groups[1];
+    a.class_tiles[0] = class_tiles[0];
+    a.class_tiles[1] = class_tiles[1];
     a.w = W;
     a.in_rows = b.in_rows;
     a.in_row0 = b.in_row0;
