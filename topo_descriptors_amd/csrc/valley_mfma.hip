@@ -26,8 +26,10 @@
 // live cell re-read the first one against zero taps, so a non-finite sample reaches exactly the pixels whose live
 // window holds it.  Two blocks of four waves share a CU.
 // Measured (profiles/r06_valley_mfma.txt): the chip clocks at 1.9 GHz under this kernel and the matrix pipe is busy 75 - 78 % of
-// the time; taking a tile's maxima under the next tile's MFMAs (two result sets), reading a tile's fragments in one batch, and
-// hand-placed scheduling groups each changed nothing.
+// the time - the kernel's time is the SUM of its MFMA cycles (32 each) and its vector instructions' issue cycles (4 each): the two
+// waves of a SIMD do not overlap one's MFMAs with the other's vector instructions, whatever their priorities.  Taking a tile's
+// maxima under the next tile's MFMAs (two result sets), reading a tile's fragments in one batch, and hand-placed scheduling
+// groups each changed nothing; fewer K steps and more MFMAs per fragment read did.
 //
 // Result layout of the instruction: a lane holds, for pixel column (lane & 31), the 16 filters 8 q + 4 (lane >> 5) + i.
 // The host puts the planes of an angle side by side in those 16 and the angles in rising order down the tiles: the
