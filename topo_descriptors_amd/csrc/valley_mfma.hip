@@ -101,6 +101,58 @@ __device__ __forceinline__ float max_planes(const f32x16& acc, int first, int np
     return m;
 }
 
+// The running best of a pixel tile in a lane: the largest response so far, the tile (its first position in the lane) it came
+// from and - instead of the angle - that tile's maxima over the planes, one per angle: a tile then costs its APH plane maxima, the
+// maximum of those, ONE comparison and APH + 1 selects instead of a comparison and a select per angle (16 vector instructions
+// against 21 at three planes); which angle it was is read off once, at the end (`position`: the first that equals the best, so
+// "the first angle that reaches the maximum keeps it" holds inside a tile as it does across tiles by the strict comparison; a NaN
+// compares false and leaves the best alone, like valley.hip's).  For one plane a lane holds 16 angles: too many registers, the
+// angle is tracked directly.
+template <int NP>
+struct Best {
+    static constexpr int APH = 16 / NP;
+    static constexpr bool kByTile = APH <= 8;
+    float value;
+    int first;                     // position of the winning tile's first angle (kByTile), or of the winning angle
+    float of_tile[kByTile ? APH : 1];
+    __device__ __forceinline__ void reset(int position0) {
+        value = -INFINITY;
+        first = position0;
+#pragma unroll
+        for (int s = 0; s < (kByTile ? APH : 1); ++s) of_tile[s] = -INFINITY;
+    }
+    __device__ __forceinline__ void take(const f32x16& acc, int tile_first) {
+        if (kByTile) {
+            float m[APH];
+#pragma unroll
+            for (int s = 0; s < APH; ++s) m[s] = max_planes(acc, s * NP, NP);
+            float t = m[0];
+#pragma unroll
+            for (int s = 1; s < APH; ++s) t = __builtin_fmaxf(t, m[s]);
+            const bool better = t > value;  // strict: an earlier tile keeps a tie
+            value = __builtin_fmaxf(value, t);
+            first = better ? tile_first : first;
+#pragma unroll
+            for (int s = 0; s < APH; ++s) of_tile[s] = better ? m[s] : of_tile[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < APH; ++s) {
+                const float m = max_planes(acc, s * NP, NP);
+                const bool better = m > value;
+                value = __builtin_fmaxf(value, m);
+                first = better ? tile_first + s : first;
+            }
+        }
+    }
+    __device__ __forceinline__ int position() const {
+        if (!kByTile) return first;
+        int slot = 0;
+#pragma unroll
+        for (int s = APH - 1; s >= 0; --s) slot = of_tile[s] == value ? s : slot;
+        return first + slot;
+    }
+};
+
 template <int KS, int NP>
 __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
     constexpr int P = pixel_tiles(KS);
@@ -156,13 +208,9 @@ __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
 #pragma unroll 1
     for (int u = 0; u < UNITS; ++u) {
         f16x8 bh[P][KS], bl[P][KS];
-        float best[P];
-        int bidx[P];
+        Best<NP> best[P];
 #pragma unroll
-        for (int pt = 0; pt < P; ++pt) {
-            best[pt] = -INFINITY;
-            bidx[pt] = 0;
-        }
+        for (int pt = 0; pt < P; ++pt) best[pt].reset(0);
         if (u == 0) __syncthreads();  // the image tile and the offsets are written
         {
             const int* ko = koff + 8 * h;
@@ -206,29 +254,22 @@ __global__ __launch_bounds__(kThreads, 2) void valley_mfma_kernel(VmArgs p) {
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[pt][s], acc[pt], 0, 0, 0);
                 }
-                // maximum over the planes of each of the APH angles a lane holds, then over the angles: strict, so the first angle
-                // that reaches the maximum keeps it (a NaN compares false and leaves the best alone, like valley.hip's)
-                const int first = tile * APT + h * APH;
+                // the maxima over the planes of the APH angles a lane holds against the running best (struct Best)
 #pragma unroll
-                for (int pt = 0; pt < P; ++pt)
-#pragma unroll
-                    for (int s = 0; s < APH; ++s) {
-                        const float m = max_planes(acc[pt], s * NP, NP);
-                        const bool better = m > best[pt];
-                        best[pt] = __builtin_fmaxf(best[pt], m);
-                        bidx[pt] = better ? first + s : bidx[pt];
-                    }
+                for (int pt = 0; pt < P; ++pt) best[pt].take(acc[pt], tile * APT + h * APH);
             }
         }
         // lanes l and l + 32 hold different angles of the same pixel: the larger one, the earlier angle on a tie
         bool unfinished = false;
 #pragma unroll
         for (int pt = 0; pt < P; ++pt) {
-            const float ob = __shfl_xor(best[pt], 32);
-            const int oi = __shfl_xor(bidx[pt], 32);
-            const bool take = ob > best[pt] || (ob == best[pt] && oi < bidx[pt]);
-            const float b = take ? ob : best[pt];
-            const int bi = min(take ? oi : bidx[pt], p.n_angles - 1);  // (the last tile is filled up with copies of the last angle)
+            const float mine = best[pt].value;
+            const int mi = best[pt].position();
+            const float ob = __shfl_xor(mine, 32);
+            const int oi = __shfl_xor(mi, 32);
+            const bool take = ob > mine || (ob == mine && oi < mi);
+            const float b = take ? ob : mine;
+            const int bi = min(take ? oi : mi, p.n_angles - 1);  // (the last tile is filled up with copies of the last angle)
             const int q = u * P + pt;
             const int ox = ox0 + 32 * (q & 1) + n;
             const int oy = oy0 + wave + kWaves * (q >> 1);
@@ -341,13 +382,9 @@ __global__ __launch_bounds__(kThreads, 2) void valley_fold_kernel(VfArgs p) {
             const int ng = p.class_groups[cls];
             if (ng == 0) continue;  // (wave-uniform)
             f16x8 bh[P][KS], bl[P][KS];
-            float best[P];
-            int bpos[P];
+            Best<NP> best[P];
 #pragma unroll
-            for (int pt = 0; pt < P; ++pt) {
-                best[pt] = -INFINITY;
-                bpos[pt] = g0 * GT * APT;
-            }
+            for (int pt = 0; pt < P; ++pt) best[pt].reset(g0 * GT * APT);
             {
                 const int* ko = koff + (cls * KS * 16 + 8 * h) * 2;
 #pragma unroll
@@ -391,25 +428,18 @@ __global__ __launch_bounds__(kThreads, 2) void valley_fold_kernel(VfArgs p) {
 #pragma unroll
                         for (int pt = 0; pt < P; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[pt][s], acc[pt], 0, 0, 0);
                     }
-                    const int first = (g * GT + tt) * APT + h * APH;
 #pragma unroll
-                    for (int pt = 0; pt < P; ++pt)
-#pragma unroll
-                        for (int s = 0; s < APH; ++s) {
-                            const float m = max_planes(acc[pt], s * NP, NP);
-                            const bool better = m > best[pt];
-                            best[pt] = __builtin_fmaxf(best[pt], m);
-                            bpos[pt] = better ? first + s : bpos[pt];
-                        }
+                    for (int pt = 0; pt < P; ++pt) best[pt].take(acc[pt], (g * GT + tt) * APT + h * APH);
                 }
             }
             g0 += ng;
 #pragma unroll
             for (int pt = 0; pt < P; ++pt) {
-                const int ai = p.pos_angle[bpos[pt]];
-                bad[pt] = bad[pt] || !(fabsf(best[pt]) < INFINITY);
-                const bool take = best[pt] > rv[pt] || (best[pt] == rv[pt] && ai < ri[pt]);
-                rv[pt] = take ? best[pt] : rv[pt];
+                const float bv = best[pt].value;
+                const int ai = p.pos_angle[best[pt].position()];
+                bad[pt] = bad[pt] || !(fabsf(bv) < INFINITY);
+                const bool take = bv > rv[pt] || (bv == rv[pt] && ai < ri[pt]);
+                rv[pt] = take ? bv : rv[pt];
                 ri[pt] = take ? ai : ri[pt];
             }
         }
