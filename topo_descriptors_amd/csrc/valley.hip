@@ -20,6 +20,10 @@
 // change a sum.
 // Direct float32 evaluation on the vector ALU; cost ~ taps x angles x planes per pixel, so kernels of
 // 64 px and more are handed to the FFT route (valley_fft.hip), as are those too large for the LDS tile.
+// Round 6: kernels of up to 17 px (25 cells a side rotated) run as a dense product on the matrix pipe (valley_mfma.hip,
+// 5 x as fast); this kernel then follows it in "repair" mode over the tiles that one flagged and rewrites exactly the pixels
+// it marked (norm = -1: a non-finite sample in the kernel footprint) - and remains the evaluation of everything between 19
+// and 63 px, and the reference of the matrix-pipe kernels' tests (TOPO_AMD_VALLEY_MFMA_MAX_KERNEL=0).
 #include "common.hpp"
 
 #include <algorithm>
