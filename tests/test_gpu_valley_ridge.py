@@ -333,3 +333,60 @@ def test_tables_that_are_not_point_symmetric_take_the_unfolded_form(monkeypatch)
     scale = float(norm_d.max())
     assert np.max(np.abs(norm_b - norm_d)) <= 1e-5 * scale and np.mean(dir_b == dir_d) >= 0.99
     assert np.max(np.abs(norm_b - norm_f)) > 1e-4 * scale   # and the changed tap shows
+
+
+@pytest.mark.parametrize("size,planes", [(19, 3), (21, 1), (25, 3), (33, 2), (41, 3), (43, 4)])
+def test_streamed_matrix_pipe_form_for_kernels_of_19_to_45_px(size, planes, monkeypatch):
+    """Kernels whose pairs of cells no longer fit a wave's registers (more than 15 K steps) stream their pixel operands chunk by
+    chunk (valley_fold_stream_kernel): against the float64 oracle and the tap-by-tap kernel, row blocks bit-identical, non-finite
+    samples handed over pixel by pixel."""
+    flats = [0, 0.1, 0.2, 0.3][:planes]
+    dem = (orc.synthetic_dem(120, 150, seed=size) + np.random.default_rng(size).uniform(0, 1, (120, 150))).astype(np.float32)
+    angles = np.arange(0, 178, 7, dtype=np.float32)
+    taps, ksize, ang = topo._valley_ridge_tables(topo._valley_kernels(size, flats), angles)
+    assert 25 < ksize.max() < 64 or size == 19
+    _set_route(monkeypatch, "direct")
+    norm_d, dir_d = _block_run(dem, taps, ksize, ang, planes, 1)
+    assert d.valley_route() == 0
+    _set_route(monkeypatch, "folded")
+    norm_m, dir_m = _block_run(dem, taps, ksize, ang, planes, 1)
+    assert d.valley_route() == 1 + 4 + 8 + 16
+    (norm_ex, _), maps = orc.valley_ridge_exact(dem, size, "valley", flats, angles=angles, return_maps=True)
+    scale = float(np.max(norm_ex))
+    err_m, err_d = float(np.max(np.abs(norm_m - norm_ex))), float(np.max(np.abs(norm_d - norm_ex)))
+    assert err_m <= 3e-6 * scale and err_m <= 1.5 * err_d + 1e-7 * scale, (err_m, err_d, scale)
+    index = np.searchsorted(angles, dir_m)
+    assert np.all(angles[index] == dir_m)
+    assert np.max(np.max(maps, axis=0) - np.take_along_axis(maps, index[None], axis=0)[0]) <= 1e-5 * scale
+    assert np.mean(dir_m == dir_d) >= 0.99
+    for nb in (2, 3):
+        norm_b, dir_b = _block_run(dem, taps, ksize, ang, planes, nb)
+        assert np.array_equal(norm_b, norm_m) and np.array_equal(dir_b, dir_m), nb
+    # a NaN and an infinity: the pixels they reach take the tap-by-tap kernel's bits, nothing stays marked
+    holed = dem.copy()
+    holed[60, 70] = np.nan
+    holed[5, 140] = np.inf
+    mean, stdev = float(dem.mean()), float(dem.std())
+
+    def run(route):
+        _set_route(monkeypatch, route)
+        dev = d.DeviceArray.from_host(holed)
+        n, a = d.DeviceArray(*holed.shape), d.DeviceArray(*holed.shape)
+        d.Block(dev).valley_ridge(taps, ksize, ang, planes, mean, stdev, n, a)
+        d.sync()
+        out = n.to_host(), a.to_host()
+        for x in (dev, n, a):
+            x.free()
+        return out
+
+    nh_d, dh_d = run("direct")
+    nh_m, dh_m = run("folded")
+    assert not np.any(nh_m == -1.0)
+    reach = int(ksize.max()) // 2 + 1
+    near = np.zeros(dem.shape, bool)
+    near[max(0, 60 - reach):60 + reach + 1, max(0, 70 - reach):70 + reach + 1] = True
+    near[0:5 + reach + 1, max(0, 140 - reach):] = True
+    differs = ~((nh_m == nh_d) | (np.isnan(nh_m) & np.isnan(nh_d)))
+    touched = ~((nh_m == norm_m) | (np.isnan(nh_m) & np.isnan(norm_m)))      # pixels the two samples changed at all
+    assert not np.any(differs & touched)                                     # ... carry the tap-by-tap kernel's bits
+    assert not np.any(touched & ~near)

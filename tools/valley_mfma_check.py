@@ -94,8 +94,10 @@ def timing():
             print(f"lab {lab}: {min(ts[1:]):8.2f} ms", flush=True)
         return
     dem = orc.synthetic_dem(side, side, seed=1)
-    for size in (5, 7, 9, 11, 13, 15, 17):
+    for size in (5, 7, 9, 11, 13, 15, 17, 19, 21, 33, 41, 45):
         for route in ("direct", "mfma", "folded"):
+            if route == "mfma" and size > 13:
+                continue   # (more than 240 cells with taps: that form hands the call to the tap-by-tap kernel)
             kernels = topo._valley_kernels(size, [0, 0.15, 0.3])
             taps, ksize, ang = topo._valley_ridge_tables(kernels, np.arange(0, 180, dtype=np.float32))
             os.environ["TOPO_AMD_VALLEY_MFMA_MAX_KERNEL"] = "0" if route == "direct" else "64"

@@ -213,7 +213,8 @@ void note_valley_route(int route);  // what topo_amd_valley_route reports for th
 // the same on the matrix pipe for rotated kernels of up to kValleyMfmaMaxKernel cells a side with at most 240 cells that hold a
 // tap at any angle (valley_mfma.hip; *done = 0: not such a case, nothing launched); leaves the pixels it cannot do marked
 // norm = -1 and their tiles (kValleyMfmaTileRows x 64, anchored at out_row0) flagged
-constexpr int kValleyMfmaMaxKernel = 25;
+constexpr int kValleyMfmaMaxKernel = 25;     // ... with a pixel tile's operands in registers
+constexpr int kValleyStreamMaxKernel = 63;   // ... folded with the operands streamed (point-symmetric tables)
 constexpr int kValleyMfmaTileRows = 32;
 int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles,
                              int n_planes, int kmax, double mean, double stdev, float* norm_out, float* dir_out,

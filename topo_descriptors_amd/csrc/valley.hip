@@ -274,13 +274,13 @@ int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize,
     // small kernels: the dense product on the matrix pipe (valley_mfma.hip); this kernel then only visits the tiles in which
     // that one met a non-finite sample
     e = std::getenv("TOPO_AMD_VALLEY_MFMA_MAX_KERNEL");
-    const int mfma_upto = e && *e ? std::min(std::atoi(e), kValleyMfmaMaxKernel) : kValleyMfmaMaxKernel;
+    const int mfma_upto = e && *e ? std::min(std::atoi(e), kValleyStreamMaxKernel) : kValleyStreamMaxKernel;
     if (kmax <= mfma_upto) {
         int done = 0;
         TOPO_TRY(launch_valley_ridge_mfma(b, taps, ksize, angles, n_angles, n_planes, kmax, mean, stdev, norm_out, dir_out,
                                           &a.repair, &a.repair_cols, &done));
         if (!done) a.repair = nullptr;
-        if (done) note_valley_route(1 + 4 + (done == 2 ? 8 : 0));
+        if (done) note_valley_route(1 + 4 + (done >= 2 ? 8 : 0) + (done == 3 ? 16 : 0));
     }
     // compress: the non-zero taps of each angle, with their offset in the LDS tile (smaller kernels
     // sit centred inside the reach staged for the largest one)

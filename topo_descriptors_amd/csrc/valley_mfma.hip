@@ -468,6 +468,207 @@ __global__ __launch_bounds__(kThreads, 2) void valley_fold_kernel(VfArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- the folded form for larger kernels: the pixel operands streamed too ----------------------------------------------
+// Beyond 15 K steps (kernels of 19 px and more) a pixel tile's operands no longer fit the registers.  Here a wave works on
+// kSTG filter tiles x kSP pixel tiles at a time (kSTG * kSP accumulators) and walks the K steps in chunks of kSKC: it builds the
+// chunk's pixel operands (the fold and the split, as above), multiplies them into the kSTG tiles' accumulators, and moves on - the
+// operands are rebuilt for every group of kSTG filter tiles.  The tap stream's stage is one (tile group, chunk).  One block of
+// eight waves a CU (the float32 image of the DEM tile with the reach of a 63-cell canvas, the pair offsets and two stages are
+// ~90 KB).  Per 32 pixels, filter tile and K step: 3 MFMAs (96 cycles) + a third of ~11 vector instructions' 44: about 5 x the
+// tap-by-tap kernel at 21 px, 8 x at 41 px (profiles/r06_valley_mfma.txt).
+constexpr int kSWaves = 8;
+constexpr int kSThreads = 64 * kSWaves;
+constexpr int kSP = 2;    // pixel tiles a wave holds at a time
+constexpr int kSTG = 3;   // filter tiles it accumulates at a time
+constexpr int kSKC = 2;   // K steps per chunk = per stage of the tap stream
+constexpr int kStageBytes = kSTG * kSKC * 2 * kFragBytes;
+constexpr int kStreamMaxSteps = 96;  // K steps (multiple of kSKC): 1536 live pairs a class (kernels of up to ~45 px)
+
+struct VsArgs {
+    const float* in;
+    float* norm;
+    float* dir;
+    const unsigned char* atab;  // [class][tile group][chunk][tile in group][K step in chunk][hi, lo][64 lanes x 16 bytes]
+    const int* koff;            // [class][K step][16][2]: the LDS distances (floats) of a pair's two cells from the window's first cell
+    const int* pos_angle;       // [class][tile group][tile][row position] -> index of the angle
+    const float* angles;
+    int* flags;
+    int class_tiles[2];
+    int ks;                     // K steps (a multiple of kSKC)
+    int w, pitch;               // window side; floats a row of the LDS image
+    int in_rows, in_row0, gny, nx;
+    int out_row0, out_rows;
+    float mean, stdev;
+};
+
+__host__ __device__ inline int stream_image_bytes(int w, int pitch, int ks) {
+    return ((kTH + w - 1) * pitch * 4 + 2 * ks * 16 * 2 * 4 + kFragBytes - 1) / kFragBytes * kFragBytes;
+}
+
+template <int NP>
+__global__ __launch_bounds__(kSThreads, 1) void valley_fold_stream_kernel(VsArgs p) {
+    constexpr int P = kSP;
+    constexpr int UNITS = (kTH / kSWaves) * 2 / P;
+    constexpr int APH = 16 / NP;
+    constexpr int APT = 2 * APH;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int rows_l = kTH + p.w - 1, cols_l = kTW + p.w - 1;
+    float* img = reinterpret_cast<float*>(lds);
+    int* koff = reinterpret_cast<int*>(lds + (size_t)rows_l * p.pitch * 4);
+    unsigned char* abuf = lds + stream_image_bytes(p.w, p.pitch, p.ks);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = lane & 31;
+    const int h = lane >> 5;
+    const int ox0 = blockIdx.x * kTW;
+    const int oy0 = p.out_row0 + blockIdx.y * kTH;
+    const int reach = p.w / 2;
+    const int n_chunks = p.ks / kSKC;
+    const int groups0 = (p.class_tiles[0] + kSTG - 1) / kSTG, groups1 = (p.class_tiles[1] + kSTG - 1) / kSTG;
+    const int n_stages = (groups0 + groups1) * n_chunks;
+
+    auto issue_stage = [&](int stage, int buf) {
+        const unsigned char* src = p.atab + (size_t)stage * kStageBytes + lane * 16;
+        unsigned char* dst = abuf + buf * kStageBytes;
+#pragma unroll
+        for (int f = wave; f < kSTG * kSKC * 2; f += kSWaves)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * kFragBytes),
+                                             (__attribute__((address_space(3))) void*)(dst + f * kFragBytes + lane * 16), 16, 0,
+                                             0);
+    };
+    issue_stage(0, 0);
+
+    for (int r = wave; r < rows_l; r += kSWaves) {
+        const int gy = oy0 - reach + r;
+        const int by = gy - p.in_row0;
+        const bool row_ok = gy >= 0 && gy < p.gny && by >= 0 && by < p.in_rows;
+        for (int c = lane; c < cols_l; c += 64) {
+            const int gx = ox0 - reach + c;
+            float v = 0.0f;
+            if (row_ok && gx >= 0 && gx < p.nx) v = (p.in[(size_t)by * p.nx + gx] - p.mean) / p.stdev;
+            img[r * p.pitch + c] = v;
+        }
+    }
+    for (int i = threadIdx.x; i < 2 * p.ks * 16 * 2; i += kSThreads) koff[i] = p.koff[i];
+
+    int it = 0;  // position in the stream: buffer it & 1 holds stage it % n_stages
+#pragma unroll 1
+    for (int u = 0; u < UNITS; ++u) {
+        float rv[P];
+        int ri[P];
+        bool bad[P];
+        const float* at[P];
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            rv[pt] = -INFINITY;
+            ri[pt] = 0x7fffffff;
+            bad[pt] = false;
+            const int q = u * P + pt;  // the wave's pixel tile: row wave + 8 (q / 2), columns 32 (q % 2) ...
+            at[pt] = img + (wave + kSWaves * (q >> 1)) * p.pitch + 32 * (q & 1) + n;
+        }
+        if (u == 0) __syncthreads();
+        int stage = 0, tile0 = 0;
+#pragma unroll 1
+        for (int cls = 0; cls < 2; ++cls) {
+            const int tiles = p.class_tiles[cls];
+            Best<NP> best[P];
+#pragma unroll
+            for (int pt = 0; pt < P; ++pt) best[pt].reset(tile0 * APT);
+#pragma unroll 1
+            for (int tg = 0; tg * kSTG < tiles; ++tg) {
+                f32x16 acc[kSTG][P];
+#pragma unroll
+                for (int t = 0; t < kSTG; ++t)
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) acc[t][pt][v] = 0.0f;
+#pragma unroll 1
+                for (int c = 0; c < n_chunks; ++c, ++stage, ++it) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    issue_stage(stage + 1 == n_stages ? 0 : stage + 1, (it + 1) & 1);
+                    // the chunk's pixel operands: z(c) + z(c*) in float32, split into two f16
+                    f16x8 bh[P][kSKC], bl[P][kSKC];
+                    const int* ko = koff + ((cls * p.ks + c * kSKC) * 16 + 8 * h) * 2;
+#pragma unroll
+                    for (int s = 0; s < kSKC; ++s)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int o1 = ko[(s * 16 + e) * 2], o2 = ko[(s * 16 + e) * 2 + 1];
+#pragma unroll
+                            for (int pt = 0; pt < P; ++pt) {
+                                const float zf = at[pt][o1] + at[pt][o2];
+                                const _Float16 hi = (_Float16)zf;
+                                bh[pt][s][e] = hi;
+                                bl[pt][s][e] = (_Float16)(zf - (float)hi);
+                            }
+                        }
+                    const unsigned char* ab = abuf + (it & 1) * kStageBytes + lane * 16;
+#pragma unroll
+                    for (int t = 0; t < kSTG; ++t) {
+                        if (tg * kSTG + t >= tiles) break;  // (wave-uniform: the class's last group is not full)
+#pragma unroll
+                        for (int s = 0; s < kSKC; ++s) {
+                            const f16x8 ah = *reinterpret_cast<const f16x8*>(ab + ((t * kSKC + s) * 2) * kFragBytes);
+                            const f16x8 al = *reinterpret_cast<const f16x8*>(ab + ((t * kSKC + s) * 2 + 1) * kFragBytes);
+#pragma unroll
+                            for (int pt = 0; pt < P; ++pt)
+                                acc[t][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[pt][s], acc[t][pt], 0, 0, 0);
+#pragma unroll
+                            for (int pt = 0; pt < P; ++pt)
+                                acc[t][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[pt][s], acc[t][pt], 0, 0, 0);
+#pragma unroll
+                            for (int pt = 0; pt < P; ++pt)
+                                acc[t][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[pt][s], acc[t][pt], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < kSTG; ++t) {
+                    if (tg * kSTG + t >= tiles) break;
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) best[pt].take(acc[t][pt], (tile0 + tg * kSTG + t) * APT + h * APH);
+                }
+            }
+            if (tiles > 0) {
+#pragma unroll
+                for (int pt = 0; pt < P; ++pt) {
+                    const float bv = best[pt].value;
+                    const int ai = p.pos_angle[best[pt].position()];
+                    bad[pt] = bad[pt] || !(fabsf(bv) < INFINITY);
+                    const bool take = bv > rv[pt] || (bv == rv[pt] && ai < ri[pt]);
+                    rv[pt] = take ? bv : rv[pt];
+                    ri[pt] = take ? ai : ri[pt];
+                }
+            }
+            tile0 += (tiles + kSTG - 1) / kSTG * kSTG;
+        }
+        bool unfinished = false;
+#pragma unroll
+        for (int pt = 0; pt < P; ++pt) {
+            const float ob = __shfl_xor(rv[pt], 32);
+            const int oi = __shfl_xor(ri[pt], 32);
+            const bool take = ob > rv[pt] || (ob == rv[pt] && oi < ri[pt]);
+            const float b = take ? ob : rv[pt];
+            const int bi = take ? oi : ri[pt];
+            const int q = u * P + pt;
+            const int ox = ox0 + 32 * (q & 1) + n;
+            const int oy = oy0 + wave + kSWaves * (q >> 1);
+            if (ox >= p.nx || oy >= p.out_row0 + p.out_rows) continue;
+            const bool finite = !bad[pt] && fabsf(b) < INFINITY;
+            unfinished = unfinished || !finite;
+            const size_t o = (size_t)(oy - p.out_row0) * p.nx + ox;
+            if (h == 0)
+                p.norm[o] = finite ? fmaxf(b, 0.0f) : -1.0f;
+            else
+                p.dir[o] = finite ? p.angles[bi] : 0.0f;
+        }
+        if (unfinished) p.flags[blockIdx.y * gridDim.x + blockIdx.x] = 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // float -> f16 bits, round to nearest even (the host builds the tap operands; no _Float16 arithmetic in host code)
 uint16_t f16_bits(float f) {
     uint32_t x;
@@ -535,6 +736,130 @@ int launch_fold_np(const VfArgs& a, dim3 grid, int n_planes) {
     }
 }
 
+template <int NP>
+int launch_stream_np(const VsArgs& a, dim3 grid) {
+    const int lds = stream_image_bytes(a.w, a.pitch, a.ks) + 2 * kStageBytes;
+    TOPO_HIP(hipFuncSetAttribute((const void*)valley_fold_stream_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((valley_fold_stream_kernel<NP>), grid, dim3(kSThreads), lds, ctx().compute, a);
+    TOPO_HIP(hipGetLastError());
+    return TOPO_AMD_OK;
+}
+
+// The streamed folded form (launch_fold's classes and pairs): more than 15 K steps, or a window wider than the register-resident
+// kernels' LDS image.
+int launch_fold_stream(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles, int n_planes, int W,
+                       double mean, double stdev, float* norm_out, float* dir_out, const int** flags_out, int* flag_cols, int* folded,
+                       int n_cls, const std::vector<int>& cls_of, const std::vector<int>& centre, const std::vector<int>* pair_of,
+                       const std::vector<int>* pair_cell) {
+    int KS = 0;
+    for (int c = 0; c < n_cls; ++c) KS = std::max(KS, ((int)pair_cell[c].size() + 15) / 16);
+    KS = (KS + kSKC - 1) / kSKC * kSKC;
+    const int pitch = (kTW + W - 1 + 1) & ~1;
+    if (KS > kStreamMaxSteps || W > kValleyStreamMaxKernel ||
+        stream_image_bytes(W, pitch, KS) + 2 * kStageBytes > 160 * 1024)
+        return TOPO_AMD_OK;
+    const int aph = 16 / n_planes, apt = 2 * aph, n_chunks = KS / kSKC;
+    std::vector<int> pos_angle;
+    int class_tiles[2] = {0, 0}, class_groups[2] = {0, 0}, first_group[2] = {0, 0};
+    for (int c = 0; c < n_cls; ++c) {
+        std::vector<int> mine;
+        for (int ang = 0; ang < n_angles; ++ang)
+            if (cls_of[ang] == c) mine.push_back(ang);
+        class_tiles[c] = ((int)mine.size() + apt - 1) / apt;
+        class_groups[c] = (class_tiles[c] + kSTG - 1) / kSTG;
+        first_group[c] = c == 0 ? 0 : class_groups[0];
+        for (int k = 0; k < class_groups[c] * kSTG * apt; ++k) pos_angle.push_back(mine[std::min(k, (int)mine.size() - 1)]);
+    }
+    const int n_groups = class_groups[0] + class_groups[1];
+    const size_t frag_halfs = kFragBytes / 2;
+    std::vector<uint16_t> atab((size_t)n_groups * n_chunks * kSTG * kSKC * 2 * frag_halfs, 0);
+    std::vector<size_t> first_tap((size_t)n_angles);
+    {
+        size_t at = 0;
+        for (int ang = 0; ang < n_angles; ++ang) {
+            first_tap[ang] = at;
+            at += (size_t)ksize[ang] * ksize[ang] * 4;
+        }
+    }
+    for (size_t pos = 0; pos < pos_angle.size(); ++pos) {
+        const int ang = pos_angle[pos], c = cls_of[ang], C = centre[c];
+        const int ks = ksize[ang], sh = W / 2 - ks / 2;
+        const int tile = (int)pos / apt, hrow = ((int)pos % apt) / aph, slot = ((int)pos % apt) % aph;
+        const int group = tile / kSTG, t_in = tile % kSTG;  // (groups run through both classes: a class's tiles fill whole groups)
+        const float* t = taps + first_tap[ang];
+        for (int ky = 0; ky < ks; ++ky)
+            for (int kx = 0; kx < ks; ++kx) {
+                const int wy = ky + sh, wx = kx + sh, cell = wy * W + wx, other = (C - wy) * W + (C - wx);
+                if (cell > other) continue;
+                const int k = pair_of[c][cell];
+                if (k < 0) continue;
+                for (int q = 0; q < n_planes; ++q) {
+                    float v = t[((size_t)ky * ks + kx) * 4 + q];
+                    if (v == 0.0f) continue;
+                    if (cell == other) v *= 0.5f;
+                    const uint16_t hi = f16_bits(v);
+                    const uint16_t lo = f16_bits(v - f16_value(hi));
+                    const int r = slot * n_planes + q, m = 8 * (r / 4) + 4 * hrow + r % 4;
+                    const int s = k / 16, kh = (k % 16) / 8, e = k % 8;
+                    const size_t stage = (size_t)group * n_chunks + s / kSKC;
+                    const size_t frag = (stage * kSTG * kSKC + (size_t)t_in * kSKC + s % kSKC) * 2;
+                    const size_t at = (size_t)(m + 32 * kh) * 8 + e;
+                    atab[frag * frag_halfs + at] = hi;
+                    atab[(frag + 1) * frag_halfs + at] = lo;
+                }
+            }
+    }
+    std::vector<int> ints((size_t)2 * KS * 16 * 2, 0);
+    for (int c = 0; c < n_cls; ++c)
+        for (int k = 0; k < KS * 16; ++k) {
+            const int cell = pair_cell[c][k < (int)pair_cell[c].size() ? k : 0];
+            const int wy = cell / W, wx = cell % W;
+            ints[((size_t)c * KS * 16 + k) * 2] = wy * pitch + wx;
+            ints[((size_t)c * KS * 16 + k) * 2 + 1] = (centre[c] - wy) * pitch + (centre[c] - wx);
+        }
+    const size_t koff_ints = ints.size();
+    ints.insert(ints.end(), pos_angle.begin(), pos_angle.end());
+    void *d_atab = nullptr, *d_koff = nullptr, *d_angles = nullptr, *d_flags = nullptr;
+    TOPO_TRY(upload_table(4, atab.data(), atab.size() * sizeof(uint16_t), &d_atab));
+    TOPO_TRY(upload_table(5, ints.data(), ints.size() * sizeof(int), &d_koff));
+    TOPO_TRY(upload_table(2, angles, (size_t)n_angles * sizeof(float), &d_angles));
+    dim3 grid((b.nx + kTW - 1) / kTW, (b.out_rows + kTH - 1) / kTH);
+    const size_t flag_bytes = (size_t)grid.x * grid.y * sizeof(int);
+    TOPO_TRY(workspace(3, flag_bytes, &d_flags));
+    TOPO_HIP(hipMemsetAsync(d_flags, 0, flag_bytes, ctx().compute));
+    VsArgs a{};
+    a.in = b.in;
+    a.norm = norm_out;
+    a.dir = dir_out;
+    a.atab = (const unsigned char*)d_atab;
+    a.koff = (const int*)d_koff;
+    a.pos_angle = (const int*)d_koff + koff_ints;
+    a.angles = (const float*)d_angles;
+    a.flags = (int*)d_flags;
+    a.class_tiles[0] = class_tiles[0];
+    a.class_tiles[1] = class_tiles[1];
+    a.ks = KS;
+    a.w = W;
+    a.pitch = pitch;
+    a.in_rows = b.in_rows;
+    a.in_row0 = b.in_row0;
+    a.gny = b.gny;
+    a.nx = b.nx;
+    a.out_row0 = b.out_row0;
+    a.out_rows = b.out_rows;
+    a.mean = (float)mean;
+    a.stdev = (float)stdev;
+    *flags_out = (const int*)d_flags;
+    *flag_cols = (int)grid.x;
+    *folded = 2;
+    switch (n_planes) {
+        case 1: return launch_stream_np<1>(a, grid);
+        case 2: return launch_stream_np<2>(a, grid);
+        case 3: return launch_stream_np<3>(a, grid);
+        default: return launch_stream_np<4>(a, grid);
+    }
+}
+
 // The folded form, if the tables allow it: every kernel bit for bit point-symmetric, at most two canvas centres in the common
 // window, at most 15 K steps of live pairs (kernels of up to 17 px).  *folded = 0: not such a case, nothing launched.
 int launch_fold(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles, int n_planes, int W,
@@ -586,7 +911,10 @@ int launch_fold(const Block& b, const float* taps, const int32_t* ksize, const f
             }
         KS = std::max(KS, ((int)pair_cell[c].size() + 15) / 16);
     }
-    if (KS < 1 || KS > kMaxSteps) return TOPO_AMD_OK;
+    if (KS < 1) return TOPO_AMD_OK;
+    if (KS > kMaxSteps || W > kValleyMfmaMaxKernel)
+        return launch_fold_stream(b, taps, ksize, angles, n_angles, n_planes, W, mean, stdev, norm_out, dir_out, flags_out, flag_cols,
+                                  folded, n_cls, cls_of, centre, pair_of, pair_cell);
     const int aph = 16 / n_planes, apt = 2 * aph, gt = group_tiles(KS);
     // the stream: the tiles of class 0 (its angles in rising order, the last group filled with copies of its last angle), then class 1
     std::vector<int> pos_angle;
@@ -700,7 +1028,7 @@ int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* k
                              int n_planes, int kmax, double mean, double stdev, float* norm_out, float* dir_out,
                              const int** flags_out, int* flag_cols, int* done) {
     *done = 0;
-    TOPO_REQUIRE(kmax >= 1 && kmax <= kValleyMfmaMaxKernel, "valley_ridge (matrix pipe): kernel side %d", kmax);
+    TOPO_REQUIRE(kmax >= 1 && kmax <= kValleyStreamMaxKernel, "valley_ridge (matrix pipe): kernel side %d", kmax);
     const int W = kmax;  // the window = the largest canvas (a smaller one sits inside it: it starts ks / 2 before the pixel)
     {
         const char* e = std::getenv("TOPO_AMD_VALLEY_FOLD");  // 0: never the folded form (read at every launch; tests)
@@ -709,11 +1037,12 @@ int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* k
             TOPO_TRY(launch_fold(b, taps, ksize, angles, n_angles, n_planes, W, mean, stdev, norm_out, dir_out, flags_out, flag_cols,
                                  &folded));
             if (folded) {
-                *done = 2;
+                *done = 1 + folded;  // 2: the operands in registers, 3: streamed
                 return TOPO_AMD_OK;
             }
         }
     }
+    if (W > kValleyMfmaMaxKernel) return TOPO_AMD_OK;  // (the form over the cells keeps a pixel tile's operands in registers)
     // the canvases of all (angle, plane) filters in the common window, and the cells in which any of them has a tap
     std::vector<float> canvas((size_t)n_angles * n_planes * W * W, 0.0f);
     std::vector<char> live_cell((size_t)W * W, 0);
