@@ -254,9 +254,10 @@ int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, in
  * rotated kernels of up to 25 cells a side run as a dense product on the matrix pipe
  * (split-f16 operands, float32 accumulation: closer to float64 than the float32 chain;
  * TOPO_AMD_VALLEY_MFMA_MAX_KERNEL, 0 = never) - over PAIRS of opposite cells when every
- * table is point-symmetric bit by bit, as the reference's are (at most 240 pairs with taps:
- * kernels of up to 17 px; TOPO_AMD_VALLEY_FOLD=0: never), over the cells otherwise (at most
- * 240 cells with taps: up to 13 px); larger ones tap by tap in float32; kernels of 64 px and more
+ * table is point-symmetric bit by bit, as the reference's are (rotated kernels of up to 63
+ * cells a side: kernels of up to ~45 px; TOPO_AMD_VALLEY_FOLD=0: never), over the cells
+ * otherwise (at most 240 cells with taps: up to 13 px); what neither takes tap by tap in
+ * float32; rotated kernels of 64 cells a side and more
  * (TOPO_AMD_VALLEY_FFT_MIN_KERNEL), and any too large for that kernel, by FFT like the
  * reference's signal.convolve.  The first two: a pixel whose kernel footprint holds a
  * non-finite sample is evaluated tap by tap in both, row blocks give the single block's bits.
@@ -269,7 +270,8 @@ int topo_amd_valley_ridge_dev(const float* in, int in_rows, int in_row0, int gny
 /* Which evaluation the calling thread's last valley / ridge call took (for tests and diagnostics): 0 tap by tap,
  * 1 matrix pipe, 2 FFT; + 4: the matrix-pipe pass was followed by the tap-by-tap kernel over the tiles in which it met
  * non-finite samples (launched whenever the matrix pipe is used; it returns at once in tiles that are not flagged);
- * + 8: the matrix pipe ran over pairs of opposite cells (point-symmetric tables).                                        */
+ * + 8: the matrix pipe ran over pairs of opposite cells (point-symmetric tables); + 16: with the pixel operands streamed
+ * in chunks (more than 240 pairs: kernels of 19 px and more).                                                            */
 int topo_amd_valley_route(int* route);
 /* Mean and population standard deviation (numpy's default ddof = 0) of count device floats,
  * accumulated in float64.                                                                */

@@ -335,16 +335,16 @@ def test_tables_that_are_not_point_symmetric_take_the_unfolded_form(monkeypatch)
     assert np.max(np.abs(norm_b - norm_f)) > 1e-4 * scale   # and the changed tap shows
 
 
-@pytest.mark.parametrize("size,planes", [(19, 3), (21, 1), (25, 3), (33, 2), (41, 3), (43, 4)])
-def test_streamed_matrix_pipe_form_for_kernels_of_19_to_45_px(size, planes, monkeypatch):
+@pytest.mark.parametrize("size,planes", [(19, 3), (21, 1), (25, 3), (33, 2), (41, 3), (43, 4), (47, 3), (65, 3), (83, 2)])
+def test_streamed_matrix_pipe_form_for_kernels_of_19_to_85_px(size, planes, monkeypatch):
     """Kernels whose pairs of cells no longer fit a wave's registers (more than 15 K steps) stream their pixel operands chunk by
     chunk (valley_fold_stream_kernel): against the float64 oracle and the tap-by-tap kernel, row blocks bit-identical, non-finite
     samples handed over pixel by pixel."""
     flats = [0, 0.1, 0.2, 0.3][:planes]
     dem = (orc.synthetic_dem(120, 150, seed=size) + np.random.default_rng(size).uniform(0, 1, (120, 150))).astype(np.float32)
-    angles = np.arange(0, 178, 7, dtype=np.float32)
+    angles = np.arange(0, 178, 7 if size < 47 else 19, dtype=np.float32)
     taps, ksize, ang = topo._valley_ridge_tables(topo._valley_kernels(size, flats), angles)
-    assert 25 < ksize.max() < 64 or size == 19
+    assert 25 < ksize.max() <= 120
     _set_route(monkeypatch, "direct")
     norm_d, dir_d = _block_run(dem, taps, ksize, ang, planes, 1)
     assert d.valley_route() == 0
@@ -390,3 +390,20 @@ def test_streamed_matrix_pipe_form_for_kernels_of_19_to_45_px(size, planes, monk
     touched = ~((nh_m == norm_m) | (np.isnan(nh_m) & np.isnan(norm_m)))      # pixels the two samples changed at all
     assert not np.any(differs & touched)                                     # ... carry the tap-by-tap kernel's bits
     assert not np.any(touched & ~near)
+
+
+def test_default_routes(monkeypatch):
+    """Nothing set: point-symmetric tables run on the matrix pipe up to rotated kernels of 120 cells a side (registers up to 17 px,
+    streamed beyond), by FFT above; TOPO_AMD_VALLEY_FFT_MIN_KERNEL, when set, takes its sizes away from the matrix pipe."""
+    for name in ("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "TOPO_AMD_VALLEY_MFMA_MAX_KERNEL", "TOPO_AMD_VALLEY_FOLD"):
+        monkeypatch.delenv(name, raising=False)
+    dem = orc.synthetic_dem(140, 160, seed=3)
+    angles = np.array([0, 30, 45, 100], dtype=np.float32)
+    for size, want in ((7, 13), (21, 29), (65, 29), (151, 2)):
+        taps, ksize, ang = topo._valley_ridge_tables(topo._valley_kernels(size, [0, 0.15, 0.3]), angles)
+        _block_run(dem, taps, ksize, ang, 3, 1)
+        assert d.valley_route() == want, (size, int(ksize.max()))
+    monkeypatch.setenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL", "64")
+    taps, ksize, ang = topo._valley_ridge_tables(topo._valley_kernels(65, [0, 0.15, 0.3]), angles)
+    _block_run(dem, taps, ksize, ang, 3, 1)
+    assert d.valley_route() == 2

@@ -94,13 +94,15 @@ def timing():
             print(f"lab {lab}: {min(ts[1:]):8.2f} ms", flush=True)
         return
     dem = orc.synthetic_dem(side, side, seed=1)
-    for size in (5, 7, 9, 11, 13, 15, 17, 19, 21, 33, 41, 45):
+    for size in (5, 7, 9, 11, 13, 15, 17, 19, 21, 33, 41, 45, 65, 81, 85):
         for route in ("direct", "mfma", "folded"):
             if route == "mfma" and size > 13:
                 continue   # (more than 240 cells with taps: that form hands the call to the tap-by-tap kernel)
+            if route == "direct" and size >= 45:
+                route = "fft"   # (what such kernels took before the streamed form: rotated kernels of 64 cells a side and more)
             kernels = topo._valley_kernels(size, [0, 0.15, 0.3])
             taps, ksize, ang = topo._valley_ridge_tables(kernels, np.arange(0, 180, dtype=np.float32))
-            os.environ["TOPO_AMD_VALLEY_MFMA_MAX_KERNEL"] = "0" if route == "direct" else "64"
+            os.environ["TOPO_AMD_VALLEY_MFMA_MAX_KERNEL"] = "0" if route in ("direct", "fft") else "1000"
             os.environ["TOPO_AMD_VALLEY_FOLD"] = "1" if route == "folded" else "0"
             dev = d.DeviceArray.from_host(dem)
             n, a = d.DeviceArray(side, side), d.DeviceArray(side, side)

@@ -214,7 +214,7 @@ void note_valley_route(int route);  // what topo_amd_valley_route reports for th
 // tap at any angle (valley_mfma.hip; *done = 0: not such a case, nothing launched); leaves the pixels it cannot do marked
 // norm = -1 and their tiles (kValleyMfmaTileRows x 64, anchored at out_row0) flagged
 constexpr int kValleyMfmaMaxKernel = 25;     // ... with a pixel tile's operands in registers
-constexpr int kValleyStreamMaxKernel = 63;   // ... folded with the operands streamed (point-symmetric tables)
+constexpr int kValleyStreamMaxKernel = 120;  // ... folded with the operands streamed (point-symmetric tables)
 constexpr int kValleyMfmaTileRows = 32;
 int launch_valley_ridge_mfma(const Block& b, const float* taps, const int32_t* ksize, const float* angles, int n_angles,
                              int n_planes, int kmax, double mean, double stdev, float* norm_out, float* dir_out,

@@ -264,24 +264,27 @@ int launch_valley_ridge(const Block& b, const float* taps, const int32_t* ksize,
     a.mean = (float)mean;
     a.stdev = (float)stdev;
     const size_t lds = (size_t)a.rows_l * a.stride * sizeof(float);
-    // large kernels: by FFT (valley_fft.hip), whose cost does not depend on the kernel size
+    // Which evaluation.  The matrix pipe (valley_mfma.hip) for everything it takes: rotated kernels of up to 120 cells a side when
+    // the tables are point-symmetric, of up to 25 otherwise - this kernel then only visits the tiles in which that one met a
+    // non-finite sample.  Else, large kernels by FFT (valley_fft.hip), whose cost does not depend on the kernel size: from 64
+    // cells a side, or from TOPO_AMD_VALLEY_FFT_MIN_KERNEL - which, when set, also takes those kernels away from the matrix pipe
+    // (the tests' way to the FFT route) - and whatever this kernel cannot stage.
     const char* e = std::getenv("TOPO_AMD_VALLEY_FFT_MIN_KERNEL");
-    const int fft_from = e && *e ? std::atoi(e) : kValleyFftFrom;
-    note_valley_route(kmax >= fft_from || lds > 160 * 1024 ? 2 : 0);
-    if (kmax >= fft_from || lds > 160 * 1024)
-        return launch_valley_ridge_fft(b, taps, ksize, angles, n_angles, n_planes, kmax, mean, stdev, norm_out,
-                                       dir_out);
-    // small kernels: the dense product on the matrix pipe (valley_mfma.hip); this kernel then only visits the tiles in which
-    // that one met a non-finite sample
+    const bool fft_pinned = e && *e;
+    const int fft_from = fft_pinned ? std::atoi(e) : kValleyFftFrom;
+    const bool stageable = lds <= 160 * 1024;
     e = std::getenv("TOPO_AMD_VALLEY_MFMA_MAX_KERNEL");
     const int mfma_upto = e && *e ? std::min(std::atoi(e), kValleyStreamMaxKernel) : kValleyStreamMaxKernel;
-    if (kmax <= mfma_upto) {
-        int done = 0;
+    int done = 0;
+    if (kmax <= mfma_upto && stageable && !(fft_pinned && kmax >= fft_from))
         TOPO_TRY(launch_valley_ridge_mfma(b, taps, ksize, angles, n_angles, n_planes, kmax, mean, stdev, norm_out, dir_out,
                                           &a.repair, &a.repair_cols, &done));
-        if (!done) a.repair = nullptr;
-        if (done) note_valley_route(1 + 4 + (done >= 2 ? 8 : 0) + (done == 3 ? 16 : 0));
+    if (!done) a.repair = nullptr;
+    if (!done && (kmax >= fft_from || !stageable)) {
+        note_valley_route(2);
+        return launch_valley_ridge_fft(b, taps, ksize, angles, n_angles, n_planes, kmax, mean, stdev, norm_out, dir_out);
     }
+    note_valley_route(done ? 1 + 4 + (done >= 2 ? 8 : 0) + (done == 3 ? 16 : 0) : 0);
     // compress: the non-zero taps of each angle, with their offset in the LDS tile (smaller kernels
     // sit centred inside the reach staged for the largest one)
     std::vector<int> meta((size_t)2 * n_angles);

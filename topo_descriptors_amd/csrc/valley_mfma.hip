@@ -473,8 +473,8 @@ __global__ __launch_bounds__(kThreads, 2) void valley_fold_kernel(VfArgs p) {
 // kSTG filter tiles x kSP pixel tiles at a time (kSTG * kSP accumulators) and walks the K steps in chunks of kSKC: it builds the
 // chunk's pixel operands (the fold and the split, as above), multiplies them into the kSTG tiles' accumulators, and moves on - the
 // operands are rebuilt for every group of kSTG filter tiles.  The tap stream's stage is one (tile group, chunk).  One block of
-// eight waves a CU (the float32 image of the DEM tile with the reach of a 63-cell canvas, the pair offsets and two stages are
-// ~90 KB).  Per 32 pixels, filter tile and K step: 3 MFMAs (96 cycles) + a third of ~11 vector instructions' 44: about 5 x the
+// eight waves a CU (the float32 image of the DEM tile with the reach of a 120-cell canvas, the pairs' offsets and two stages are
+// ~150 KB).  Per 32 pixels, filter tile and K step: 3 MFMAs (96 cycles) + a third of ~11 vector instructions' 44: about 5 x the
 // tap-by-tap kernel at 21 px, 8 x at 41 px (profiles/r06_valley_mfma.txt).
 constexpr int kSWaves = 8;
 constexpr int kSThreads = 64 * kSWaves;
@@ -482,14 +482,15 @@ constexpr int kSP = 2;    // pixel tiles a wave holds at a time
 constexpr int kSTG = 3;   // filter tiles it accumulates at a time
 constexpr int kSKC = 2;   // K steps per chunk = per stage of the tap stream
 constexpr int kStageBytes = kSTG * kSKC * 2 * kFragBytes;
-constexpr int kStreamMaxSteps = 96;  // K steps (multiple of kSKC): 1536 live pairs a class (kernels of up to ~45 px)
+constexpr int kStreamMaxSteps = 352;  // K steps (multiple of kSKC): 5632 live pairs a class (rotated kernels of up to ~120 cells a side)
 
 struct VsArgs {
     const float* in;
     float* norm;
     float* dir;
     const unsigned char* atab;  // [class][tile group][chunk][tile in group][K step in chunk][hi, lo][64 lanes x 16 bytes]
-    const int* koff;            // [class][K step][16][2]: the LDS distances (floats) of a pair's two cells from the window's first cell
+    const unsigned short* koff; // [class][K step][16]: the LDS distance (floats) of a pair's first cell from the window's first cell ...
+    int pair_sum[2];            // ... and of the two cells together (opposite cells: their distances add up to the same for a class)
     const int* pos_angle;       // [class][tile group][tile][row position] -> index of the angle
     const float* angles;
     int* flags;
@@ -502,7 +503,7 @@ struct VsArgs {
 };
 
 __host__ __device__ inline int stream_image_bytes(int w, int pitch, int ks) {
-    return ((kTH + w - 1) * pitch * 4 + 2 * ks * 16 * 2 * 4 + kFragBytes - 1) / kFragBytes * kFragBytes;
+    return ((kTH + w - 1) * pitch * 4 + 2 * ks * 16 * 2 + kFragBytes - 1) / kFragBytes * kFragBytes;
 }
 
 template <int NP>
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(kSThreads, 1) void valley_fold_stream_kernel(VsArgs
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int rows_l = kTH + p.w - 1, cols_l = kTW + p.w - 1;
     float* img = reinterpret_cast<float*>(lds);
-    int* koff = reinterpret_cast<int*>(lds + (size_t)rows_l * p.pitch * 4);
+    unsigned short* koff = reinterpret_cast<unsigned short*>(lds + (size_t)rows_l * p.pitch * 4);
     unsigned char* abuf = lds + stream_image_bytes(p.w, p.pitch, p.ks);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(kSThreads, 1) void valley_fold_stream_kernel(VsArgs
             img[r * p.pitch + c] = v;
         }
     }
-    for (int i = threadIdx.x; i < 2 * p.ks * 16 * 2; i += kSThreads) koff[i] = p.koff[i];
+    for (int i = threadIdx.x; i < 2 * p.ks * 16; i += kSThreads) koff[i] = p.koff[i];
 
     int it = 0;  // position in the stream: buffer it & 1 holds stage it % n_stages
 #pragma unroll 1
@@ -590,12 +591,13 @@ __global__ __launch_bounds__(kSThreads, 1) void valley_fold_stream_kernel(VsArgs
                     issue_stage(stage + 1 == n_stages ? 0 : stage + 1, (it + 1) & 1);
                     // the chunk's pixel operands: z(c) + z(c*) in float32, split into two f16
                     f16x8 bh[P][kSKC], bl[P][kSKC];
-                    const int* ko = koff + ((cls * p.ks + c * kSKC) * 16 + 8 * h) * 2;
+                    const unsigned short* ko = koff + (cls * p.ks + c * kSKC) * 16 + 8 * h;
+                    const int pair_sum = p.pair_sum[cls];
 #pragma unroll
                     for (int s = 0; s < kSKC; ++s)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const int o1 = ko[(s * 16 + e) * 2], o2 = ko[(s * 16 + e) * 2 + 1];
+                            const int o1 = ko[s * 16 + e], o2 = pair_sum - o1;
 #pragma unroll
                             for (int pt = 0; pt < P; ++pt) {
                                 const float zf = at[pt][o1] + at[pt][o2];
@@ -809,15 +811,17 @@ int launch_fold_stream(const Block& b, const float* taps, const int32_t* ksize, 
                 }
             }
     }
-    std::vector<int> ints((size_t)2 * KS * 16 * 2, 0);
-    for (int c = 0; c < n_cls; ++c)
-        for (int k = 0; k < KS * 16; ++k) {
-            const int cell = pair_cell[c][k < (int)pair_cell[c].size() ? k : 0];
-            const int wy = cell / W, wx = cell % W;
-            ints[((size_t)c * KS * 16 + k) * 2] = wy * pitch + wx;
-            ints[((size_t)c * KS * 16 + k) * 2 + 1] = (centre[c] - wy) * pitch + (centre[c] - wx);
-        }
-    const size_t koff_ints = ints.size();
+    // one table of ints: the pairs' first cells (16 bits each, two to an int), then the positions' angles
+    const size_t koff_ints = (size_t)2 * KS * 16 / 2;
+    std::vector<int> ints(koff_ints, 0);
+    {
+        unsigned short* k16 = reinterpret_cast<unsigned short*>(ints.data());
+        for (int c = 0; c < n_cls; ++c)
+            for (int k = 0; k < KS * 16; ++k) {
+                const int cell = pair_cell[c][k < (int)pair_cell[c].size() ? k : 0];
+                k16[(size_t)c * KS * 16 + k] = (unsigned short)((cell / W) * pitch + cell % W);
+            }
+    }
     ints.insert(ints.end(), pos_angle.begin(), pos_angle.end());
     void *d_atab = nullptr, *d_koff = nullptr, *d_angles = nullptr, *d_flags = nullptr;
     TOPO_TRY(upload_table(4, atab.data(), atab.size() * sizeof(uint16_t), &d_atab));
@@ -832,7 +836,9 @@ int launch_fold_stream(const Block& b, const float* taps, const int32_t* ksize, 
     a.norm = norm_out;
     a.dir = dir_out;
     a.atab = (const unsigned char*)d_atab;
-    a.koff = (const int*)d_koff;
+    a.koff = (const unsigned short*)d_koff;
+    a.pair_sum[0] = centre[0] * pitch + centre[0];
+    a.pair_sum[1] = n_cls > 1 ? centre[1] * pitch + centre[1] : 0;
     a.pos_angle = (const int*)d_koff + koff_ints;
     a.angles = (const float*)d_angles;
     a.flags = (int*)d_flags;

@@ -125,7 +125,8 @@ def host_chunks():
 def valley_route():
     """The evaluation the calling thread's last valley / ridge call took: 0 tap by tap (``csrc/valley.hip``), 1 matrix pipe
     (``csrc/valley_mfma.hip``), 2 FFT; + 4 when the tap-by-tap kernel followed the matrix pipe over its flagged tiles; + 8 when the
-    matrix pipe ran its folded form (point-symmetric tables: pairs of opposite window cells)."""
+    matrix pipe ran its folded form (point-symmetric tables: pairs of opposite window cells); + 16 when that form streamed its pixel
+    operands (kernels of 19 px and more)."""
     n = C.c_int32()
     _lib.check(_lib.lib().topo_amd_valley_route(C.byref(n)), "valley_route")
     return n.value
