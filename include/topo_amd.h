@@ -254,10 +254,10 @@ int topo_amd_sx_multi_dev(const float* in, int in_rows, int in_row0, int gny, in
  * rotated kernels of up to 25 cells a side run as a dense product on the matrix pipe
  * (split-f16 operands, float32 accumulation: closer to float64 than the float32 chain;
  * TOPO_AMD_VALLEY_MFMA_MAX_KERNEL, 0 = never) - over PAIRS of opposite cells when every
- * table is point-symmetric bit by bit, as the reference's are (rotated kernels of up to 63
- * cells a side: kernels of up to ~45 px; TOPO_AMD_VALLEY_FOLD=0: never), over the cells
+ * table is point-symmetric bit by bit, as the reference's are (rotated kernels of up to 120
+ * cells a side: kernels of up to ~85 px; TOPO_AMD_VALLEY_FOLD=0: never), over the cells
  * otherwise (at most 240 cells with taps: up to 13 px); what neither takes tap by tap in
- * float32; rotated kernels of 64 cells a side and more
+ * float32; of that, rotated kernels of 64 cells a side and more
  * (TOPO_AMD_VALLEY_FFT_MIN_KERNEL), and any too large for that kernel, by FFT like the
  * reference's signal.convolve.  The first two: a pixel whose kernel footprint holds a
  * non-finite sample is evaluated tap by tap in both, row blocks give the single block's bits.

@@ -131,7 +131,7 @@ while time.time() < t_end:
         else:
             if ny < 3 or nx < 3 or ny * nx > 40000:
                 continue
-            size = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17]))
+            size = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 19, 25, 33]))   # (from 19 px on: the streamed form)
             flats = [[0, 0.15, 0.3], [0], [0.2, 0.4], [0, 0.1, 0.2, 0.3]][int(rng.integers(4))]
             mode = str(rng.choice(["valley", "ridge"]))
             angles = np.sort(rng.choice(np.arange(180, dtype=np.float32), int(rng.integers(1, 40)), replace=False))
