@@ -1,4 +1,5 @@
-// K7m: valley / ridge index on the matrix pipe, for rotated kernels of up to kValleyMfmaMaxKernel cells a side.
+// K7m: valley / ridge index on the matrix pipe, for rotated kernels of up to kValleyStreamMaxKernel cells a side (kernels of up to
+// ~85 px) when the tables are point-symmetric, of up to kValleyMfmaMaxKernel otherwise.
 //
 // The same quantity as valley.hip (reference topo.py:431-447; the host's tables are the plane sums of the rotated
 // kernels, flipped: a correlation): per pixel, the largest response over the angles of the maximum over the planes,
@@ -42,8 +43,9 @@
 // (the norm proper is clipped at 0) and raises its tile's flag; the launcher then runs the direct kernel over the
 // flagged tiles, which rewrites exactly the marked pixels.  Which pixels those are depends on their own window alone.
 //
-// Two kernels: valley_mfma_kernel over the live cells (any tables), and valley_fold_kernel over PAIRS of opposite cells, which
-// tables that are point-symmetric bit by bit - the reference's - take: half the K steps (further down, "the folded form").
+// Three kernels: valley_mfma_kernel over the live cells (any tables), valley_fold_kernel over PAIRS of opposite cells, which
+// tables that are point-symmetric bit by bit - the reference's - take: half the K steps (further down, "the folded form"), and
+// valley_fold_stream_kernel, the folded form for kernels of 19 px and more, whose pixel operands no longer fit the registers.
 #include "common.hpp"
 
 #include <algorithm>
@@ -474,8 +476,10 @@ __global__ __launch_bounds__(kThreads, 2) void valley_fold_kernel(VfArgs p) {
 // chunk's pixel operands (the fold and the split, as above), multiplies them into the kSTG tiles' accumulators, and moves on - the
 // operands are rebuilt for every group of kSTG filter tiles.  The tap stream's stage is one (tile group, chunk).  One block of
 // eight waves a CU (the float32 image of the DEM tile with the reach of a 120-cell canvas, the pairs' offsets and two stages are
-// ~150 KB).  Per 32 pixels, filter tile and K step: 3 MFMAs (96 cycles) + a third of ~11 vector instructions' 44: about 5 x the
-// tap-by-tap kernel at 21 px, 8 x at 41 px (profiles/r06_valley_mfma.txt).
+// ~150 KB).  Per 32 pixels, filter tile and K step: 3 MFMAs (96 cycles) + a third of ~11 vector instructions' 44.  8192^2, 180
+// angles x 3 planes: 3.6 - 3.9 ms per K step of pairs = 5 x the tap-by-tap kernel from 19 to 41 px (41 px: 1523 -> 291 ms), and
+// faster than the FFT route's 2.05 s up to the 120-cell windows the LDS image holds (45 px 350 ms, 65 px 732, 85 px 1252;
+// profiles/r06_valley_mfma.txt section 7).
 constexpr int kSWaves = 8;
 constexpr int kSThreads = 64 * kSWaves;
 constexpr int kSP = 2;    // pixel tiles a wave holds at a time
