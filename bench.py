@@ -361,6 +361,13 @@ def extras(dev, lib_mod, args, block_cls, dem, ny, nx):
     entry("valley_ridge_s7_tap_by_tap", st, 12, "valley_ridge_kernel<3> (the float32 chain on the non-zero taps: rounds 2 - 5)")
     nonzero = int(np.any(taps.reshape(-1, 4)[:, :3] != 0, axis=1).sum())  # the taps the kernel evaluates
     out["valley_ridge_s7_tap_by_tap"]["GFMA_per_s_executed"] = round(px * nonzero * 3 / st["median"] / 1e6, 0)
+    # a mid-size kernel (21 px: rotated kernels of 30 cells a side, ~290 pairs of cells a class): the streamed form of the matrix-pipe
+    # kernel (round 6; the tap-by-tap kernel takes 358 ms for this on 8192^2, i.e. ~5.7 s here)
+    taps21, ksize21, angles21 = topo._valley_ridge_tables(topo._valley_kernels(21, [0, 0.15, 0.3]), np.arange(0, 180, dtype=np.float32))
+    st = time_kernel(lambda: blk.valley_ridge(taps21, ksize21, angles21, 3, mean, stdev, o1, o2), 3, d)
+    entry("valley_ridge_s21", st, 12, "valley_fold_stream_kernel<3> (the folded product with the pixel operands streamed in chunks of 2 K steps, "
+          "3 filter tiles x 2 pixel tiles of accumulators a wave)" if d.valley_route() & 16 else "valley_ridge_kernel<3>")
+    out["valley_ridge_s21"]["route"] = d.valley_route()
 
     # the same TPI on fractional elevations: every tile runs the integer pass plus the float
     # chain on the fractional parts and goes through the per-row scratch planes (two passes)
